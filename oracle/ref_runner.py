@@ -1,0 +1,153 @@
+"""TEST INFRASTRUCTURE ONLY - runs the *real* reference (kxhit/vMAP) hot path on CPU.
+
+This module imports ``model.py``, ``embedding.py``, ``render_rays.py`` and ``loss.py`` unmodified from
+``/root/reference`` (read-only, present only in the authoring container - never on the GPU box) and
+drives them exactly the way the reference does:
+
+* ``utils.update_vmap``   (utils.py:30-34)  -> ``combine_state_for_ensemble`` + ``requires_grad_``
+* ``train.py:293-294``    -> ``vmap(pe_model)(...)``, ``vmap(fc_model)(...)``
+* ``train.py:303-306``    -> ``loss.step_batch_loss``
+* ``train.py:324-326``    -> ``backward()``, ``AdamW.step()``, ``zero_grad``
+
+It is used only by ``tests/golden/make_goldens.py`` to produce the committed fixtures that pin the
+oracle (``oracle/vmap_oracle.py``).  Nothing in the product, the gpu tests, ``smoke()`` or ``bench.py``
+may import it.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+
+REFERENCE_ROOT = os.environ.get("VMAP_REFERENCE_ROOT", "/root/reference")
+
+
+def _import_reference():
+    if not os.path.isdir(REFERENCE_ROOT):
+        raise RuntimeError(f"reference tree not found at {REFERENCE_ROOT}")
+    sys.dont_write_bytecode = True
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, REFERENCE_ROOT)
+    import importlib
+    mods = {}
+    for name in ("model", "embedding", "render_rays", "loss"):
+        mods[name] = importlib.import_module(name)
+        assert os.path.dirname(mods[name].__file__) == REFERENCE_ROOT, mods[name].__file__
+    return mods
+
+
+def build_reference_models(fc_np, B_np, scale_np, H, dtype=torch.float32):
+    """One ``OccupancyMap`` + ``UniDirsEmbed`` per object (trainer.py:26-33) loaded with given values."""
+    mods = _import_reference()
+    from vmap_amd import layout
+    n = B_np.shape[0]
+    fc_models, pe_models = [], []
+    for k in range(n):
+        m = mods["model"].OccupancyMap(layout.EMB1, layout.EMB2, hidden_size=H)
+        with torch.no_grad():
+            for p, a in zip(m.parameters(), fc_np):
+                p.copy_(torch.from_numpy(a[k]))
+        pe = mods["embedding"].UniDirsEmbed(max_deg=5, scale=float(scale_np[k]))
+        with torch.no_grad():
+            pe.B_layer.weight.copy_(torch.from_numpy(B_np[k]))
+        fc_models.append(m.to(dtype))
+        pe_models.append(pe.to(dtype))
+    return fc_models, pe_models
+
+
+def reference_step(fc_np, B_np, scale_np, batch, H, dtype=torch.float32, strategy="vmap",
+                   adamw_steps=0, lr=1e-3, weight_decay=0.013):
+    """Run the reference training step; returns dict of numpy arrays.
+
+    ``adamw_steps`` > 0 additionally runs that many full optimisation steps (same batch each step)
+    with ``torch.optim.AdamW`` the way train.py:67,324-326 does and returns the final parameters.
+    """
+    mods = _import_reference()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        from functorch import combine_state_for_ensemble, vmap
+    render_rays, loss_mod = mods["render_rays"], mods["loss"]
+
+    fc_models, pe_models = build_reference_models(fc_np, B_np, scale_np, H, dtype)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        fc_model, fc_param, fc_buffer = combine_state_for_ensemble(fc_models)
+        pe_model, pe_param, pe_buffer = combine_state_for_ensemble(pe_models)
+    [p.requires_grad_() for p in fc_param]
+    [p.requires_grad_() for p in pe_param]
+
+    pcs = torch.from_numpy(batch["pcs"]).to(dtype)
+    z = torch.from_numpy(batch["z"]).to(dtype)
+    gt_depth = torch.from_numpy(batch["gt_depth"]).to(dtype)
+    gt_rgb = torch.from_numpy(batch["gt_rgb"]).to(dtype)
+    sem = torch.from_numpy(batch["sem"])
+    dmask = torch.from_numpy(batch["depth_mask"]).bool()
+
+    def forward():
+        if strategy == "vmap":
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                emb = vmap(pe_model)(pe_param, pe_buffer, pcs)
+                alpha, color = vmap(fc_model)(fc_param, fc_buffer, emb)
+        else:  # "forloop", train.py:278-290
+            al, co = [], []
+            for k in range(len(fc_models)):
+                e = pe_model([p[k] for p in pe_param], [b[k] for b in pe_buffer], pcs[k])
+                a, c = fc_model([p[k] for p in fc_param], [b[k] for b in fc_buffer], e)
+                al.append(a)
+                co.append(c)
+            alpha, color = torch.stack(al), torch.stack(co)
+        return alpha, color
+
+    alpha, color = forward()
+    # re-derive the rendered quantities the way loss.py:24-31 does (it does not return them)
+    a2 = alpha.squeeze(-1)
+    occ = render_rays.occupancy_activation(a2)
+    term = render_rays.occupancy_to_termination(occ, is_batch=True)
+    r_depth = render_rays.render(term, z)
+    var = render_rays.render(term, (z - r_depth[..., None]) ** 2)
+    r_color = render_rays.render(term[..., None], color, dim=-2)
+    r_opacity = term.sum(-1)
+
+    loss, _ = loss_mod.step_batch_loss(alpha, color, gt_depth, gt_rgb, sem, dmask, z)
+    out = {
+        "loss": loss.detach().numpy().astype(np.float64),
+        "alpha": a2.detach().numpy(), "color": color.detach().numpy(),
+        "render_depth": r_depth.detach().numpy(), "render_color": r_color.detach().numpy(),
+        "opacity": r_opacity.detach().numpy(), "var": var.detach().numpy(),
+    }
+    if loss.requires_grad:
+        loss.backward()
+        for t, p in enumerate(fc_param):
+            out[f"g_fc{t}"] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy().copy()
+        pB = pe_param[0]
+        out["g_B"] = (pB.grad if pB.grad is not None else torch.zeros_like(pB)).numpy().copy()
+    else:  # every loss term dropped (render_rays.py:68-73): no graph, all gradients are zero/None
+        for t, p in enumerate(fc_param):
+            out[f"g_fc{t}"] = torch.zeros_like(p).numpy()
+        out["g_B"] = torch.zeros_like(pe_param[0]).numpy()
+
+    if adamw_steps > 0:
+        # train.py:67 builds the optimiser on a dummy variable and adds groups (utils.py:33)
+        opt = torch.optim.AdamW([torch.autograd.Variable(torch.tensor(0.0))], lr=lr, weight_decay=weight_decay)
+        opt.add_param_group({"params": fc_param})
+        opt.add_param_group({"params": pe_param})
+        for p in list(fc_param) + list(pe_param):
+            p.grad = None
+        losses = []
+        for _ in range(adamw_steps):
+            alpha, color = forward()
+            l, _ = loss_mod.step_batch_loss(alpha, color, gt_depth, gt_rgb, sem, dmask, z)
+            if l.requires_grad:
+                l.backward()
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+            losses.append(float(l))
+        out["adamw_losses"] = np.array(losses, dtype=np.float64)
+        for t, p in enumerate(fc_param):
+            out[f"p_fc{t}"] = p.detach().numpy().copy()
+        out["p_B"] = pe_param[0].detach().numpy().copy()
+    return out

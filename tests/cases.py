@@ -1,0 +1,56 @@
+"""Named, seeded parity cases shared by the golden generator and the tests.
+
+Each case is (parameters, batch) built by ``vmap_amd.synth`` plus, for the quirk cases, a
+deterministic edit that forces one of the reference's data-dependent branches
+(SURVEY.md section 8(c) known-answer list).
+"""
+from __future__ import annotations
+
+import hashlib
+
+import numpy as np
+
+from vmap_amd import synth
+
+CASES = {
+    # name: (n_obj, R, S, H, scale, param_seed, batch_seed, gain, edit)
+    "tiny":          (3, 12, 10, 32, 2.0, 10, 11, 1.0, None),
+    "ragged":        (5, 17, 10, 32, 2.0, 12, 13, 1.0, None),        # R*S not a multiple of 32
+    "cfg2":          (20, 120, 10, 32, 2.0, 20, 21, 1.0, None),      # BASELINE configs[1]
+    "drop_depth":    (4, 24, 10, 32, 2.0, 30, 31, 1.0, "no_depth"),  # one object without valid depth
+    "drop_opacity":  (4, 24, 10, 32, 2.0, 32, 33, 1.0, "all_unknown"),
+    "drop_colour":   (4, 24, 10, 32, 2.0, 34, 35, 1.0, "all_other"),
+    "saturated":     (3, 24, 10, 32, 2.0, 40, 41, 4.0, None),        # |alpha| >> 17: occupancy == 1.0f
+    "exact_hit":     (2, 12, 10, 32, 2.0, 42, 43, 1.0, "no_valid_surface"),
+    "h64":           (4, 32, 10, 64, 2.0, 50, 51, 1.0, None),
+    "bg_h128_s14":   (1, 48, 14, 128, 5.0, 60, 61, 1.0, None),       # train.py:308-316 shapes (fewer rays)
+    "imap_h256":     (1, 100, 14, 256, 10.0, 70, 71, 1.0, None),     # BASELINE configs[0]
+    "scannet_scale": (6, 120, 10, 32, 3.0, 80, 81, 1.0, None),       # configs[3] obj_scale
+}
+
+
+def build_case(name):
+    n, R, S, H, scale, ps, bs, gain, edit = CASES[name]
+    fc, B, pe_scale = synth.make_params(n, H, scale=scale, seed=ps, gain=gain)
+    batch = synth.make_batch(n, R, S, seed=bs)
+    if edit == "no_depth":
+        batch["depth_mask"][2, :] = 0
+    elif edit == "all_unknown":
+        batch["sem"][1, :] = 2
+    elif edit == "all_other":
+        batch["sem"][3, :] = 0
+    elif edit == "no_valid_surface":
+        # every ray of object 0 is 'other object' with invalid depth: depth term has an empty mask
+        batch["sem"][0, :] = 0
+    return dict(name=name, n=n, R=R, S=S, H=H, fc=fc, B=B, scale=pe_scale, batch=batch)
+
+
+def input_digest(case) -> str:
+    h = hashlib.sha256()
+    for a in case["fc"]:
+        h.update(np.ascontiguousarray(a).tobytes())
+    h.update(case["B"].tobytes())
+    h.update(case["scale"].tobytes())
+    for k in ("pcs", "z", "gt_depth", "gt_rgb", "sem", "depth_mask"):
+        h.update(np.ascontiguousarray(case["batch"][k]).tobytes())
+    return h.hexdigest()

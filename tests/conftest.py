@@ -1,0 +1,33 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run through gpurun / the driver's GPU tier)")
+    config.addinivalue_line("markers", "slow: CPU test that takes more than a few seconds")
+
+
+def relerr(a, b):
+    """max-norm relative error: max|a-b| / max|b| (b = reference)."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN_DIR, f"{name}.npz"))
+
+
+GRAD_KEYS = [f"g_fc{t}" for t in range(14)] + ["g_B"]
+RENDER_KEYS = ["render_depth", "render_color", "opacity"]

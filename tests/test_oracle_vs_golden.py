@@ -1,0 +1,110 @@
+"""Pins the CPU oracle (oracle/vmap_oracle.py) against fixtures produced by the real reference.
+
+The reference has no tests of its own; ``tests/golden/*.npz`` were produced by
+``tests/golden/make_goldens.py`` running the reference's model.py / embedding.py / render_rays.py /
+loss.py through functorch on CPU, in float32 and float64.
+"""
+import numpy as np
+import pytest
+
+import cases
+from conftest import GRAD_KEYS, RENDER_KEYS, load_golden, relerr
+from oracle import vmap_oracle as vo
+
+# fp32-vs-fp32 noise floor between two CPU implementations (numpy vs ATen): different exp/sin and
+# summation order.  'saturated' drives occupancy to exactly 1.0f where var -> 0 and the
+# 1/(sqrt(var)+1e-4) weight amplifies rounding noise; its floor is measured, not chosen.
+F32_TOL = {"default": dict(render=2e-5, grad=1e-4), "saturated": dict(render=2e-3, grad=2e-3)}
+
+
+@pytest.mark.parametrize("name", list(cases.CASES))
+def test_inputs_are_reproducible(name):
+    c = cases.build_case(name)
+    g = load_golden(name)
+    assert cases.input_digest(c) == str(g["input_sha256"]), "synthetic generator drifted from the goldens"
+
+
+@pytest.mark.parametrize("name", list(cases.CASES))
+def test_oracle_f64_matches_reference_f64(name):
+    c = cases.build_case(name)
+    g = load_golden(name)
+    o = vo.training_step(c["fc"], c["B"], c["scale"], c["batch"], dtype=np.float64)
+    assert abs(o["loss"] - float(g["f64_loss"])) <= 1e-9 * max(1.0, abs(float(g["f64_loss"])))
+    for k in RENDER_KEYS + ["var"] + GRAD_KEYS:
+        assert relerr(o[k], g["f64_" + k]) < 3e-7, k   # goldens are stored as float32
+
+
+@pytest.mark.parametrize("name", list(cases.CASES))
+def test_oracle_f32_matches_reference_f32(name):
+    c = cases.build_case(name)
+    g = load_golden(name)
+    tol = F32_TOL.get(name, F32_TOL["default"])
+    o = vo.training_step(c["fc"], c["B"], c["scale"], c["batch"], dtype=np.float32)
+    assert abs(o["loss"] - float(g["loss"])) <= 2e-5 * abs(float(g["loss"]))
+    for k in RENDER_KEYS:
+        assert relerr(o[k], g[k]) < tol["render"], k
+    for k in GRAD_KEYS:
+        assert relerr(o[k], g[k]) < tol["grad"], k
+
+
+def test_any_empty_mask_quirk_is_global():
+    """render_rays.py:68-73: one object without valid depth drops the depth term for EVERY object."""
+    c = cases.build_case("drop_depth")
+    o = vo.training_step(c["fc"], c["B"], c["scale"], c["batch"], dtype=np.float32)
+    assert o["drop"].tolist() == [True, False, False]
+    assert np.all(o["l_d"] == 0)
+    c2 = cases.build_case("drop_depth")
+    c2["batch"]["depth_mask"][2, 0] = 1
+    c2["batch"]["sem"][2, 0] = 1
+    o2 = vo.training_step(c2["fc"], c2["B"], c2["scale"], c2["batch"], dtype=np.float32)
+    assert o2["drop"].tolist() == [False, False, False] and np.all(o2["l_d"] > 0)
+
+
+def test_reference_forloop_equals_vmap_noise_floor():
+    """train.py:278-290 vs :291-294: the reference's two strategies agree to ~1e-6 (its own noise floor)."""
+    for name in ("tiny", "drop_depth"):
+        g = load_golden(name)
+        assert abs(float(g["forloop_loss"]) - float(g["loss"])) <= 1e-6 * abs(float(g["loss"]))
+        assert relerr(g["forloop_g_fc4"], g["g_fc4"]) < 5e-6
+
+
+@pytest.mark.parametrize("name", ["tiny", "scannet_scale"])
+def test_oracle_adamw_tracks_reference(name):
+    """Three full steps (train.py:324-326 with AdamW lr 1e-3, wd 0.013) on a fixed batch."""
+    c = cases.build_case(name)
+    g = load_golden(name)
+    fc = [a.copy() for a in c["fc"]]
+    B = c["B"].copy()
+    params = fc + [B]
+    m = [np.zeros_like(p) for p in params]
+    v = [np.zeros_like(p) for p in params]
+    for step in range(1, 4):
+        o = vo.training_step(params[:14], params[14], c["scale"], c["batch"], dtype=np.float32)
+        assert abs(o["loss"] - g["adamw_losses"][step - 1]) <= 2e-4 * abs(g["adamw_losses"][step - 1])
+        grads = [o[k] for k in GRAD_KEYS]
+        for i in range(15):
+            params[i], m[i], v[i] = vo.adamw_update(params[i], grads[i], m[i], v[i], step)
+    # Adam normalises every element by sqrt(v): where a gradient element is ~0 its rounding noise decides
+    # the sign of a full lr-sized update, so a handful of elements may differ by up to steps*lr; the bulk
+    # must agree to float32 rounding.
+    ref = [g[f"adamw_p_fc{t}"] for t in range(14)] + [g["adamw_p_B"]]
+    diff = np.concatenate([np.abs(p.astype(np.float64) - r).ravel() for p, r in zip(params, ref)])
+    assert diff.max() <= 3 * 1e-3 * 1.05
+    assert np.quantile(diff, 0.99) < 2e-5
+    assert np.median(diff) < 1e-6
+
+
+def test_oracle_adamw_update_equals_torch_adamw():
+    """adamw_update restates torch.optim.AdamW (the third-party optimiser train.py:67 constructs)."""
+    import torch
+    rng = np.random.default_rng(0)
+    p0 = rng.standard_normal((7, 33)).astype(np.float32)
+    p = torch.nn.Parameter(torch.from_numpy(p0.copy()))
+    opt = torch.optim.AdamW([p], lr=1e-3, weight_decay=0.013)
+    q, m, v = p0.copy(), np.zeros_like(p0), np.zeros_like(p0)
+    for step in range(1, 6):
+        gnp = (rng.standard_normal(p0.shape) * 10.0 ** rng.integers(-6, 2)).astype(np.float32)
+        p.grad = torch.from_numpy(gnp.copy())
+        opt.step()
+        q, m, v = vo.adamw_update(q, gnp, m, v, step)
+        assert relerr(q, p.detach().numpy()) < 5e-7
