@@ -1,0 +1,28 @@
+// TEST INFRASTRUCTURE: stand-in for <hip/hip_runtime.h> when the kernel headers are compiled for the CPU
+// SIMT executor (tests/sim).  Only what vmap_amd/csrc/step_kernels.h uses.
+#pragma once
+#include <cmath>
+#include <cstdint>
+
+#include "sim_runtime.h"
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __restrict__
+
+struct sim_tid_proxy { unsigned x, y, z; };
+#define threadIdx (sim_tid_proxy{sim::tid(), 0u, 0u})
+#define blockIdx (sim::g_blockIdx)
+#define blockDim (sim::g_blockDim)
+#define gridDim (sim::g_gridDim)
+
+inline void __syncthreads() { sim::barrier_wait(sim::g_block->block_bar); }
+inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
+inline int atomicOr(int* p, int v) { int o = *p; *p = o | v; return o; }
+inline int atomicMax(int* p, int v) { int o = *p; if (v > o) *p = v; return o; }
+inline void sincosf_sim(float x, float* s, float* c) { *s = sinf(x); *c = cosf(x); }
+inline int min(int a, int b) { return a < b ? a : b; }
+inline int max(int a, int b) { return a > b ? a : b; }

@@ -1,0 +1,81 @@
+// TEST INFRASTRUCTURE: runs the kernels of vmap_amd/csrc/step_kernels.h on the CPU SIMT executor.
+// Host pointers in, host pointers out; mirrors the launch sequence of vmap_amd/csrc/vmapstep.hip.
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "step_kernels.h"
+
+namespace {
+void fc_sizes(int H, int* sz) {
+    const int s[14] = {H * 87, H, H * H, H, H * (H + 87), H, H * H, H, H, 1, H * (H + 42), H, 3 * H, 3};
+    for (int i = 0; i < 14; ++i) sz[i] = s[i];
+}
+}  // namespace
+
+extern "C" int vmsim_lds_bytes() { return vk::Lds32::BYTES; }
+
+// fc[t]: [n][size_t] contiguous; grads: flat slab [n][P] in natural order (14 field tensors then B).
+extern "C" int vmsim_step(int n, int R, int S, int H, int G,
+                          const float* const* fc, const float* B, const float* scale,
+                          const float* pcs, const float* z, const float* gt_depth, const float* gt_rgb,
+                          const uint8_t* sem, const uint8_t* dmask, float color_w, float opac_w,
+                          float* grads, float* loss, float* dbg_depth, float* dbg_rgb, float* dbg_opacity,
+                          float* dbg_var, int* flags, int bwd,
+                          // optional fused AdamW (params updated in copies p_out [n][P], moments m, v [n][PP])
+                          int do_adam, float* p_out, float* m, float* v, int step, float lr, float wd) {
+    if (H != 32) return -1;
+    if (G * S > vk::kMaxPts || G < 1) return -2;
+    int sz[14], offs[16];
+    fc_sizes(H, sz);
+    int P = 0;
+    for (int t = 0; t < 14; ++t) { offs[t] = P; P += sz[t]; }
+    offs[14] = P; P += 63; offs[15] = P;
+    const int PP = (P + 63) / 64 * 64;
+    const int NG = (R + G - 1) / G;
+
+    std::vector<float> stats(n * 4, NAN), part_grad((size_t)n * NG * PP, NAN), part_loss((size_t)n * NG * 4, NAN);
+    std::vector<int> fl(4, -1);
+
+    vk::StepArgs a{};
+    a.n_obj = n; a.R = R; a.S = S; a.G = G; a.NG = NG; a.PP = PP;
+    for (int t = 0; t < 14; ++t) a.fc[t] = {const_cast<float*>(fc[t]), sz[t]};
+    a.pe_B = {const_cast<float*>(B), 63};
+    a.pe_scale = {const_cast<float*>(scale), 1};
+    a.pcs = pcs; a.pcs_so = (long long)R * S * 3; a.pcs_sr = S * 3; a.pcs_ss = 3; a.pcs_sc = 1;
+    a.z = z; a.z_so = (long long)R * S; a.z_sr = S; a.z_ss = 1;
+    a.gt_depth = gt_depth; a.gd_so = R; a.gd_sr = 1;
+    a.gt_rgb = gt_rgb; a.rgb_so = R * 3; a.rgb_sr = 3; a.rgb_sc = 1;
+    a.sem = sem; a.sem_so = R; a.sem_sr = 1;
+    a.dmask = dmask; a.dm_so = R; a.dm_sr = 1;
+    a.color_w = color_w; a.opac_w = opac_w;
+    a.stats = stats.data(); a.flags = fl.data();
+    a.part_grad = part_grad.data(); a.part_loss = part_loss.data();
+    a.dbg_depth = dbg_depth; a.dbg_rgb = dbg_rgb; a.dbg_opacity = dbg_opacity; a.dbg_var = dbg_var;
+
+    sim::launch(1, vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep(a); });
+    if (bwd) sim::launch(n * NG, vk::kWG, vk::Lds32::BYTES, [&] { vk::step_main_h32<true>(a); });
+    else     sim::launch(n * NG, vk::kWG, vk::Lds32::BYTES, [&] { vk::step_main_h32<false>(a); });
+
+    vk::FinalizeArgs f{};
+    f.n_obj = n; f.NG = NG; f.PP = PP; f.P = P;
+    for (int t = 0; t < 16; ++t) f.offs[t] = offs[t];
+    std::vector<float> zero_part;
+    if (!bwd) { zero_part.assign(part_grad.size(), 0.0f); }
+    for (int t = 0; t < 15; ++t) {
+        f.grad[t] = {grads ? grads + offs[t] : nullptr, P};
+        f.param[t] = {p_out ? p_out + offs[t] : nullptr, P};
+    }
+    f.m = m; f.v = v;
+    f.part_grad = bwd ? part_grad.data() : zero_part.data();
+    f.part_loss = part_loss.data();
+    f.flags_in = fl.data(); f.flags_out = flags; f.loss_out = loss;
+    f.color_w = color_w; f.opac_w = opac_w;
+    f.do_adam = do_adam;
+    f.lr = lr; f.beta1 = 0.9f; f.beta2 = 0.999f; f.eps = 1e-8f; f.weight_decay = wd;
+    f.bias_corr1 = (float)(1.0 - std::pow(0.9, step));
+    f.bias_corr2_sqrt = (float)std::sqrt(1.0 - std::pow(0.999, step));
+    const int bpo = (P + vk::kWG - 1) / vk::kWG;
+    sim::launch(n * bpo, vk::kWG, 0, [&] { vk::step_finalize(f); });
+    return 0;
+}

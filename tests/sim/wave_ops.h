@@ -1,0 +1,47 @@
+// TEST INFRASTRUCTURE: CPU model of vmap_amd/csrc/wave_ops.h (same interface, fibers instead of lanes).
+// Selected by include-path order when tests/sim builds the kernel headers for the host.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace wv {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// v_mfma_f32_32x32x2_f32 lane maps (cdna_hip_programming.md section 3):
+//   A[i][k]: lane = 32*k + i;  B[k][j]: lane = 32*k + j;  D[i][j]: lane = j + 32*((i>>2)&1), reg = (i&3) + 4*(i>>3)
+inline f32x16 mfma32(float a, float b, f32x16 c) {
+    const int w = sim::wave_id(), l = sim::lane_id();
+    sim::Block* B = sim::g_block;
+    B->xa[w][l] = a;
+    B->xb[w][l] = b;
+    sim::wave_barrier();
+    const int j = l & 31, hi = l >> 5;
+    f32x16 d = c;
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float acc = c[r];
+        acc = fmaf(B->xa[w][i], B->xb[w][j], acc);             // k = 0
+        acc = fmaf(B->xa[w][32 + i], B->xb[w][32 + j], acc);   // k = 1
+        d[r] = acc;
+    }
+    sim::wave_barrier();
+    return d;
+}
+
+inline float swap_half(float x) {
+    const int w = sim::wave_id(), l = sim::lane_id();
+    sim::g_block->xa[w][l] = x;
+    sim::wave_barrier();
+    float y = sim::g_block->xa[w][l ^ 32];
+    sim::wave_barrier();
+    return y;
+}
+
+inline void wave_lds_fence() { sim::wave_barrier(); }
+
+inline float* lds_base() { return reinterpret_cast<float*>(sim::g_block->lds.data()); }
+
+inline void lds_add(float* p, float v) { *p += v; }
+
+}  // namespace wv

@@ -1,0 +1,96 @@
+"""TEST INFRASTRUCTURE: builds and loads the CPU SIMT executor build of the kernel headers (tests/sim)."""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SIM = os.path.join(HERE, "sim")
+OUT = os.path.join(SIM, "_build", "libvmsim.so")
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+
+
+def build(force=False):
+    srcs = [os.path.join(SIM, "sim_abi.cpp"), os.path.join(SIM, "sim_runtime.cpp")]
+    deps = srcs + [os.path.join(SIM, "sim_runtime.h"), os.path.join(SIM, "wave_ops.h"),
+                   os.path.join(SIM, "include", "hip", "hip_runtime.h"),
+                   os.path.join(ROOT, "vmap_amd", "csrc", "step_kernels.h")]
+    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
+        return OUT
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    cxx = CLANG if os.path.exists(CLANG) else "clang++"
+    # include order: the sim's wave_ops.h and fake <hip/hip_runtime.h> shadow the device ones
+    cmd = [cxx, "-std=c++17", "-O2", "-mfma", "-ffp-contract=fast", "-fPIC", "-shared",
+           "-I", SIM, "-I", os.path.join(SIM, "include"), "-I", os.path.join(ROOT, "vmap_amd", "csrc"),
+           "-Wno-unused-value", "-o", OUT] + srcs
+    subprocess.run(cmd, check=True)
+    return OUT
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = ctypes.CDLL(build())
+    return _lib
+
+
+def _p(a, ty=ctypes.c_float):
+    return a.ctypes.data_as(ctypes.POINTER(ty)) if a is not None else None
+
+
+def sim_step(case_or_fc, B=None, scale=None, batch=None, G=None, bwd=True, adam=None):
+    """Run prep + main + finalize on the simulator. Returns dict like oracle.training_step."""
+    if isinstance(case_or_fc, dict):
+        c = case_or_fc
+        fc, B, scale, batch = c["fc"], c["B"], c["scale"], c["batch"]
+    else:
+        fc = case_or_fc
+    n, R, S = batch["z"].shape
+    H = fc[2].shape[-1]
+    if G is None:
+        G = max(1, 128 // S)
+    fc_c = [np.ascontiguousarray(a, dtype=np.float32) for a in fc]
+    sizes = [a[0].size for a in fc_c]
+    P = sum(sizes) + 63
+    PP = (P + 63) // 64 * 64
+    arr = (ctypes.POINTER(ctypes.c_float) * 14)(*[_p(a) for a in fc_c])
+    Bc = np.ascontiguousarray(B, dtype=np.float32)
+    sc = np.ascontiguousarray(scale, dtype=np.float32)
+    pcs = np.ascontiguousarray(batch["pcs"], dtype=np.float32)
+    z = np.ascontiguousarray(batch["z"], dtype=np.float32)
+    gd = np.ascontiguousarray(batch["gt_depth"], dtype=np.float32)
+    rgb = np.ascontiguousarray(batch["gt_rgb"], dtype=np.float32)
+    sem = np.ascontiguousarray(batch["sem"], dtype=np.uint8)
+    dm = np.ascontiguousarray(batch["depth_mask"], dtype=np.uint8)
+    grads = np.full((n, P), np.nan, dtype=np.float32)
+    loss = np.full((1,), np.nan, dtype=np.float32)
+    dD = np.full((n, R), np.nan, dtype=np.float32)
+    dC = np.full((n, R, 3), np.nan, dtype=np.float32)
+    dO = np.full((n, R), np.nan, dtype=np.float32)
+    dV = np.full((n, R), np.nan, dtype=np.float32)
+    flags = np.full((4,), -1, dtype=np.int32)
+    do_adam, p_out, m, v, step, lr, wd = 0, None, None, None, 1, 1e-3, 0.013
+    if adam is not None:
+        do_adam = 1
+        p_out, m, v, step = adam["p"], adam["m"], adam["v"], adam["step"]
+    rc = lib().vmsim_step(
+        n, R, S, H, G, arr, _p(Bc), _p(sc), _p(pcs), _p(z), _p(gd), _p(rgb),
+        _p(sem, ctypes.c_uint8), _p(dm, ctypes.c_uint8), ctypes.c_float(5.0), ctypes.c_float(10.0),
+        _p(grads), _p(loss), _p(dD), _p(dC), _p(dO), _p(dV), _p(flags, ctypes.c_int), int(bool(bwd)),
+        do_adam, _p(p_out), _p(m), _p(v), int(step), ctypes.c_float(lr), ctypes.c_float(wd))
+    if rc != 0:
+        raise RuntimeError(f"vmsim_step failed: {rc}")
+    out = dict(loss=float(loss[0]), render_depth=dD, render_color=dC, opacity=dO, var=dV, flags=flags, grads_flat=grads)
+    o = 0
+    for t, a in enumerate(fc_c):
+        out[f"g_fc{t}"] = grads[:, o:o + sizes[t]].reshape(a.shape)
+        o += sizes[t]
+    out["g_B"] = grads[:, o:o + 63].reshape(n, 21, 3)
+    return out

@@ -1,0 +1,737 @@
+// step_kernels.h - fused per-object training step of the vectorised object fields (gfx950 / CDNA4).
+//
+// Replaces, for one optimisation step, the ATen op stream the reference emits at
+//   train.py:293-294  vmap(pe_model) / vmap(fc_model)      (embedding.py:82-91, model.py:54-85)
+//   train.py:303-306  loss.step_batch_loss                  (loss.py:5-62, render_rays.py:4-8,26-96)
+//   train.py:324      batch_loss.backward()                 (autograd transpose of all of the above)
+// with three launches:  step_prep  ->  step_main_h32  ->  step_finalize.
+//
+// step_main_h32 (the dominant kernel): one workgroup = 4 waves = up to 128 sample points (whole rays) of
+// ONE object.  The object's weights are staged once into LDS; every wave owns one 32-point tile and runs
+//   encoding -> 4 hidden layers + 2 heads -> [workgroup: alpha-compositing, loss, d/d(raw)] -> backward
+// entirely out of registers + LDS.  All contractions run on the exact-fp32 matrix instruction
+// v_mfma_f32_32x32x2_f32 in a "points-on-lanes" form that chains layer to layer without transposes:
+//
+//   P-form of X[point][feature] (32 features):  lane (p = l&31, hi = l>>5), register r  <->  X[p][phi(r,hi)],
+//                                               phi(r,hi) = (r&3) + 8*(r>>2) + 4*hi   (the MFMA C/D row map)
+//   forward   Y^T = W * X^T      : A = W[j][k] from LDS (lane = j), B = X in P-form  ->  Y in P-form
+//   d-prop    dX^T = W^T * dY^T  : A = W[j][k] from LDS (lane = k), B = dY in P-form ->  dX in P-form
+//   dW        dW = dY^T * X      : A = dY in F-form, B = X in F-form  (F-form: lane = feature, register r
+//                                  <-> point r + 16*hi; obtained from P-form through a 32x33 LDS transpose)
+//
+// Numerics: fp32 throughout, accurate sincosf/expf/division/sqrt; the only reorderings w.r.t. the reference
+// are summation orders.  Cross-workgroup reduction of the weight gradients is a plain store of per-workgroup
+// partials followed by an ordered sum in step_finalize (no global atomics).
+#pragma once
+#include <wave_ops.h>   // resolved through -I: csrc/ (device) or tests/sim/ (CPU SIMT executor)
+
+namespace vk {
+
+using wv::f32x16;
+
+constexpr int kEmb1 = 87;      // trainer.py:16  xyz + octaves 0..3
+constexpr int kEmb2 = 42;      // trainer.py:17  octaves 4..5
+constexpr int kDirs = 21;      // embedding.py:51-73
+constexpr int kNFc = 14;
+constexpr int kWG = 256;
+constexpr int kWaves = 4;
+constexpr int kMaxPts = 128;   // sample points per workgroup (4 tiles of 32)
+constexpr float kPi = 3.14159274101257324f;   // float32(np.pi), embedding.py:88
+
+struct TensorRef {
+    float* p;
+    long long stride;   // elements between consecutive objects
+};
+
+// Everything one launch needs.  Passed by value as the kernel argument.
+struct StepArgs {
+    int n_obj, R, S, G, NG, PP;        // G rays per workgroup, NG workgroups per object, PP padded params/object
+    TensorRef fc[kNFc];                // the 14 field tensors, nn.Module.parameters() order (model.py:28-49)
+    TensorRef pe_B;                    // B_layer.weight [n,21,3] (embedding.py:75-76)
+    TensorRef pe_scale;                // scale buffer [n] (embedding.py:80)
+    const float* pcs; long long pcs_so, pcs_sr, pcs_ss, pcs_sc;
+    const float* z; long long z_so, z_sr, z_ss;
+    const float* gt_depth; long long gd_so, gd_sr;
+    const float* gt_rgb; long long rgb_so, rgb_sr, rgb_sc;
+    const unsigned char* sem; long long sem_so, sem_sr;
+    const unsigned char* dmask; long long dm_so, dm_sr;
+    float color_w, opac_w;             // loss.py:6 defaults 5.0 / 10.0
+    float* stats;                      // [n][4]   1/(N_depth+1e-10), 1/(N_obj+1e-10), 1/(N_sem+1e-10), unused
+    int* flags;                        // [4]      drop_depth, drop_colour, drop_opacity, explode
+    float* part_grad;                  // [n][NG][PP]
+    float* part_loss;                  // [n][NG][4]
+    float* dbg_depth; float* dbg_rgb; float* dbg_opacity; float* dbg_var;   // [n][R](,3) or null
+};
+
+__device__ __forceinline__ constexpr int phi(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+// ---------------------------------------------------------------------------------------------------------
+// LDS map for H = 32 (floats).  Weight images are row-major [out][ld] with odd ld (conflict-free for both
+// "lane = row" and "lane = column" reads) and zeroed padding columns.
+// ---------------------------------------------------------------------------------------------------------
+struct Lds32 {
+    static constexpr int H = 32;
+    static constexpr int LD_IN = 89;             // 87 data + zero cols 87, 88
+    static constexpr int LD_M = 33;
+    static constexpr int LD_CAT = H + 89;        // h2 part | e1 part (87) | zero cols
+    static constexpr int LD_C = H + 47;          // h4 part | e2 part (42) | zero cols up to +46
+    static constexpr int W_IN = 0;
+    static constexpr int W_M1 = W_IN + H * LD_IN;
+    static constexpr int W_CAT = W_M1 + H * LD_M;
+    static constexpr int W_M2 = W_CAT + H * LD_CAT;
+    static constexpr int W_C = W_M2 + H * LD_M;
+    static constexpr int B_IN = W_C + H * LD_C;
+    static constexpr int B_M1 = B_IN + H;
+    static constexpr int B_CAT = B_M1 + H;
+    static constexpr int B_M2 = B_CAT + H;
+    static constexpr int B_C = B_M2 + H;
+    static constexpr int W_A = B_C + H;
+    static constexpr int W_OC = W_A + H;          // [3][H]
+    static constexpr int B_A = W_OC + 3 * H;      // 1 (+3 pad)
+    static constexpr int B_OC = B_A + 4;          // 3 (+1 pad)
+    static constexpr int PE_B = B_OC + 4;         // [21][3] (+1 pad)
+    static constexpr int IMG = PE_B + 64;         // floats in one parameter image
+    static constexpr int WGT = 0;                 // weight image
+    static constexpr int GRD = IMG;               // gradient image (same map)
+    static constexpr int SCR = 2 * IMG;           // per-wave transpose scratch: kWaves x 2 x [32][33]
+    static constexpr int SCR_WAVE = 2 * 32 * 33;
+    static constexpr int CB = SCR + kWaves * SCR_WAVE;      // composite buffer [kMaxPts][8]
+    static constexpr int LOSS = CB + kMaxPts * 8;           // 4 floats
+    static constexpr int TOTAL = LOSS + 4;
+    static constexpr int BYTES = TOTAL * 4;
+};
+
+// natural (row-major, unpadded) -> LDS image copy of one matrix, zero-filling the padding columns
+template <int ROWS, int COLS, int LD>
+__device__ __forceinline__ void stage_matrix(float* dst, const float* src, int tid) {
+    for (int i = tid; i < ROWS * LD; i += kWG) {
+        const int row = i / LD, col = i - row * LD;
+        dst[i] = col < COLS ? src[row * COLS + col] : 0.0f;
+    }
+}
+template <int ROWS, int COLS, int LD>
+__device__ __forceinline__ void unstage_matrix(float* dst, const float* img, int tid) {
+    for (int i = tid; i < ROWS * COLS; i += kWG) {
+        const int row = i / COLS, col = i - row * COLS;
+        dst[i] = img[row * LD + col];
+    }
+}
+
+__device__ __forceinline__ void load_bias(f32x16& acc, const float* b, int hi) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = b[phi(r, hi)];
+}
+__device__ __forceinline__ void relu_to(float (&h)[16], const f32x16& acc) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) h[r] = acc[r] > 0.0f ? acc[r] : 0.0f;
+}
+__device__ __forceinline__ void zero_acc(f32x16& acc) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+}
+
+// forward: acc[p][j] += sum_k W[j][k0 + phi(r,hi)] * x[p][phi(r,hi)];  wrow = &W[j = lane&31][k0 + 4*hi]
+template <int NSTEPS>
+__device__ __forceinline__ void fwd_mm(f32x16& acc, const float* wrow, const float (&x)[16]) {
+#pragma unroll
+    for (int r = 0; r < NSTEPS; ++r) acc = wv::mfma32(wrow[(r & 3) + 8 * (r >> 2)], x[r], acc);
+}
+// d-prop: acc[p][k] += sum_j W[phi(r,hi)][k] * dy[p][phi(r,hi)];  wcol = &W[4*hi][k = column of this lane]
+template <int LD>
+__device__ __forceinline__ void bwd_mm(f32x16& acc, const float* wcol, const float (&dy)[16]) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc = wv::mfma32(wcol[((r & 3) + 8 * (r >> 2)) * LD], dy[r], acc);
+}
+// dW: acc[j][k] += sum_q dyF[q][j] * xF[q][k]
+__device__ __forceinline__ void dw_mm(f32x16& acc, const float (&dyF)[16], const float (&xF)[16]) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc = wv::mfma32(dyF[r], xF[r], acc);
+}
+// P-form -> F-form through a wave-private [32][33] LDS tile
+__device__ __forceinline__ void to_F(float (&F)[16], const float (&P)[16], float* scr, int p31, int hi) {
+    wv::wave_lds_fence();   // earlier reads of this tile are done
+#pragma unroll
+    for (int r = 0; r < 16; ++r) scr[p31 * 33 + phi(r, hi)] = P[r];
+    wv::wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) F[r] = scr[(r + 16 * hi) * 33 + p31];
+}
+// accumulate a dW block (lane = column k, register r <-> row phi(r,hi)) into the LDS gradient image
+template <int LD>
+__device__ __forceinline__ void add_dw(float* img, const f32x16& acc, int col, bool col_ok, int hi) {
+    if (col_ok) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) wv::lds_add(img + phi(r, hi) * LD + col, acc[r]);
+    }
+}
+// bias gradient: sum over the 32 points of a tile of dY (F-form), lane = feature
+__device__ __forceinline__ void add_db(float* gb, const float (&dyF)[16], int p31, int hi) {
+    float s = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += dyF[r];
+    s += wv::swap_half(s);
+    if (hi == 0) wv::lds_add(gb + p31, s);
+}
+
+// One embedding slot.  c = index into the 129-wide encoding (embedding.py:85-89: 3 + f*21 + d), or -1 = padding.
+__device__ __forceinline__ void pe_slot(int c, const float (&t)[3], const float (&proj)[kDirs],
+                                        float& pre, float& tv, float& fac) {
+    pre = 0.0f; tv = 0.0f; fac = 0.0f;
+    if (c >= 0 && c < 3) {
+        tv = t[c];
+    } else if (c >= 3) {
+        const int f = (c - 3) / kDirs, d = (c - 3) % kDirs;
+        const float band = (float)(1 << f);
+        pre = proj[d] * band;          // exact (power of two)
+        fac = kPi * band;              // d sin(x*pi*band)/dx = cos(.) * pi * band
+    }
+}
+// One 32-feature block of the encoding in P-form (+ cos * pi * 2^f for the backward).  base = first encoding
+// index of this group (0 for e1, 87 for e2), limit = width of the group, kb = block within the group.
+template <int NSTEPS>
+__device__ __forceinline__ void pe_block(float (&e)[16], float (&cf)[16], int base, int limit, int kb,
+                                         const float (&t)[3], const float (&proj)[kDirs], int hi) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        e[r] = 0.0f;
+        cf[r] = 0.0f;
+        if (r < NSTEPS) {
+            const int l0 = 32 * kb + phi(r, 0), l1 = 32 * kb + phi(r, 1);
+            const int c0 = l0 < limit ? base + l0 : -1, c1 = l1 < limit ? base + l1 : -1;
+            float pre0, tv0, fac0, pre1, tv1, fac1;
+            pe_slot(c0, t, proj, pre0, tv0, fac0);
+            pe_slot(c1, t, proj, pre1, tv1, fac1);
+            if (c0 >= 3 || c1 >= 3) {
+                const float arg = (hi ? pre1 : pre0) * kPi;    // fl32(xb * fl32(pi)), embedding.py:88
+                float s, c;
+                sincosf(arg, &s, &c);
+                const float v0 = c0 >= 3 ? s : tv0, v1 = c1 >= 3 ? s : tv1;
+                e[r] = hi ? v1 : v0;
+                cf[r] = c * (hi ? fac1 : fac0);
+            } else {
+                e[r] = hi ? tv1 : tv0;
+            }
+        }
+    }
+}
+// gradient w.r.t. the 21 projections from one block of d(encoding)
+template <int NSTEPS>
+__device__ __forceinline__ void pe_block_bwd(float (&dproj)[kDirs], const f32x16& de, const float (&cf)[16],
+                                             int base, int limit, int kb, int hi) {
+#pragma unroll
+    for (int r = 0; r < NSTEPS; ++r) {
+        const int l0 = 32 * kb + phi(r, 0), l1 = 32 * kb + phi(r, 1);
+        const int c0 = l0 < limit ? base + l0 : -1, c1 = l1 < limit ? base + l1 : -1;
+        const float g = de[r] * cf[r];
+        if (c0 >= 3) dproj[(c0 - 3) % kDirs] += hi ? 0.0f : g;
+        if (c1 >= 3) dproj[(c1 - 3) % kDirs] += hi ? g : 0.0f;
+    }
+}
+
+__device__ __forceinline__ float sigmoidf_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float sgnf(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
+
+// ---------------------------------------------------------------------------------------------------------
+// step_prep: per-object mask counts and the batch-wide "any object has an empty mask" switches
+// (loss.py:16-19,38,46,56; render_rays.py:68-73).  One workgroup, no atomics.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kWG) void step_prep(const StepArgs a) {
+    float* lds = wv::lds_base();   // 3 * kWG ints worth
+    int* cnt = reinterpret_cast<int*>(lds);
+    const int tid = threadIdx.x;
+    int drop_d = 0, drop_c = 0, drop_o = 0;
+    for (int k = 0; k < a.n_obj; ++k) {
+        int nd = 0, no = 0, ns = 0;
+        for (int r = tid; r < a.R; r += kWG) {
+            const unsigned char s = a.sem[k * a.sem_so + r * a.sem_sr];
+            const unsigned char dm = a.dmask[k * a.dm_so + r * a.dm_sr];
+            const int mo = s != 0, ms = s != 2;
+            nd += (dm != 0) && mo;
+            no += mo;
+            ns += ms;
+        }
+        cnt[tid] = nd; cnt[kWG + tid] = no; cnt[2 * kWG + tid] = ns;
+        __syncthreads();
+        for (int w = kWG / 2; w > 0; w >>= 1) {
+            if (tid < w) {
+                cnt[tid] += cnt[tid + w];
+                cnt[kWG + tid] += cnt[kWG + tid + w];
+                cnt[2 * kWG + tid] += cnt[2 * kWG + tid + w];
+            }
+            __syncthreads();
+        }
+        nd = cnt[0]; no = cnt[kWG]; ns = cnt[2 * kWG];
+        __syncthreads();
+        if (tid == 0) {
+            a.stats[k * 4 + 0] = 1.0f / ((float)nd + 1e-10f);   // render_rays.py:87
+            a.stats[k * 4 + 1] = 1.0f / ((float)no + 1e-10f);
+            a.stats[k * 4 + 2] = 1.0f / ((float)ns + 1e-10f);
+            a.stats[k * 4 + 3] = 0.0f;
+        }
+        drop_d |= nd == 0; drop_c |= no == 0; drop_o |= ns == 0;
+    }
+    if (tid == 0) {
+        a.flags[0] = drop_d; a.flags[1] = drop_c; a.flags[2] = drop_o; a.flags[3] = 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// step_main_h32
+// ---------------------------------------------------------------------------------------------------------
+template <bool BWD>
+__global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
+    using L = Lds32;
+    constexpr int H = 32;
+    float* lds = wv::lds_base();
+    float* W = lds + L::WGT;
+    float* Gd = lds + L::GRD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p31 = lane & 31, hi = lane >> 5;
+    const int obj = blockIdx.x / a.NG, grp = blockIdx.x - obj * a.NG;
+
+    // ---- stage this object's parameters into LDS, clear the gradient image and the composite buffer ----
+    stage_matrix<H, kEmb1, L::LD_IN>(W + L::W_IN, a.fc[0].p + obj * a.fc[0].stride, tid);
+    stage_matrix<H, H, L::LD_M>(W + L::W_M1, a.fc[2].p + obj * a.fc[2].stride, tid);
+    stage_matrix<H, H + kEmb1, L::LD_CAT>(W + L::W_CAT, a.fc[4].p + obj * a.fc[4].stride, tid);
+    stage_matrix<H, H, L::LD_M>(W + L::W_M2, a.fc[6].p + obj * a.fc[6].stride, tid);
+    stage_matrix<H, H + kEmb2, L::LD_C>(W + L::W_C, a.fc[10].p + obj * a.fc[10].stride, tid);
+    if (tid < H) {
+        W[L::B_IN + tid] = a.fc[1].p[obj * a.fc[1].stride + tid];
+        W[L::B_M1 + tid] = a.fc[3].p[obj * a.fc[3].stride + tid];
+        W[L::B_CAT + tid] = a.fc[5].p[obj * a.fc[5].stride + tid];
+        W[L::B_M2 + tid] = a.fc[7].p[obj * a.fc[7].stride + tid];
+        W[L::B_C + tid] = a.fc[11].p[obj * a.fc[11].stride + tid];
+        W[L::W_A + tid] = a.fc[8].p[obj * a.fc[8].stride + tid];
+    } else if (tid < H + 3 * H) {
+        W[L::W_OC + tid - H] = a.fc[12].p[obj * a.fc[12].stride + tid - H];
+    } else if (tid < 4 * H + 8) {
+        const int i = tid - 4 * H;   // 0..7: b_a, pad x3, b_oc x3, pad
+        float v = 0.0f;
+        if (i == 0) v = a.fc[9].p[obj * a.fc[9].stride];
+        if (i >= 4 && i < 7) v = a.fc[13].p[obj * a.fc[13].stride + i - 4];
+        W[L::B_A + i] = v;
+    } else if (tid < 4 * H + 8 + 64) {
+        const int i = tid - (4 * H + 8);
+        W[L::PE_B + i] = i < 63 ? a.pe_B.p[obj * a.pe_B.stride + i] : 0.0f;
+    }
+    if (BWD) {
+        for (int i = tid; i < L::IMG; i += kWG) Gd[i] = 0.0f;
+    }
+    for (int i = tid; i < kMaxPts * 8 + 4; i += kWG) lds[L::CB + i] = 0.0f;   // composite buffer + loss cell
+    __syncthreads();
+
+    // ---- this lane's sample point ----
+    const int ray0 = grp * a.G;
+    const int nrays = min(a.G, a.R - ray0);
+    const int npts = nrays * a.S;
+    const int pt = wave * 32 + p31;
+    const bool valid = pt < npts;
+    const int lray = valid ? pt / a.S : 0;
+    const int smp = valid ? pt - lray * a.S : 0;
+    const int ray = ray0 + lray;
+    float t[3] = {0.0f, 0.0f, 0.0f};
+    {
+        const float scale = a.pe_scale.p[obj * a.pe_scale.stride];
+        if (valid) {
+            const float* px = a.pcs + obj * a.pcs_so + ray * a.pcs_sr + smp * a.pcs_ss;
+            t[0] = px[0] / scale;              // embedding.py:83  x / self.scale
+            t[1] = px[a.pcs_sc] / scale;
+            t[2] = px[2 * a.pcs_sc] / scale;
+        }
+    }
+
+    // ---- encoding (embedding.py:82-91), P-form blocks ----
+    float e1a[16], e1b[16], e1c[16], e2a[16], e2b[16];          // sin / xyz values
+    float c1a[16], c1b[16], c1c[16], c2a[16], c2b[16];          // cos * pi * 2^f
+    {
+        float proj[kDirs];
+#pragma unroll
+        for (int d = 0; d < kDirs; ++d) {
+            const float* b = W + L::PE_B + 3 * d;
+            proj[d] = fmaf(t[2], b[2], fmaf(t[1], b[1], t[0] * b[0]));   // embedding.py:84 B_layer(tensor)
+        }
+        pe_block<16>(e1a, c1a, 0, kEmb1, 0, t, proj, hi);
+        pe_block<16>(e1b, c1b, 0, kEmb1, 1, t, proj, hi);
+        pe_block<12>(e1c, c1c, 0, kEmb1, 2, t, proj, hi);
+        pe_block<16>(e2a, c2a, kEmb1, kEmb2, 0, t, proj, hi);
+        pe_block<6>(e2b, c2b, kEmb1, kEmb2, 1, t, proj, hi);
+    }
+
+    // ---- field MLP forward (model.py:59-83) ----
+    float h1[16], h2[16], h3[16], h4[16], hc[16];
+    f32x16 acc;
+    {
+        const float* w = W + L::W_IN + p31 * L::LD_IN + 4 * hi;
+        load_bias(acc, W + L::B_IN, hi);
+        fwd_mm<16>(acc, w, e1a);
+        fwd_mm<16>(acc, w + 32, e1b);
+        fwd_mm<12>(acc, w + 64, e1c);
+        relu_to(h1, acc);                                        // :59 in_layer
+    }
+    {
+        load_bias(acc, W + L::B_M1, hi);
+        fwd_mm<16>(acc, W + L::W_M1 + p31 * L::LD_M + 4 * hi, h1);
+        relu_to(h2, acc);                                        // :60 mid1
+    }
+    {
+        const float* w = W + L::W_CAT + p31 * L::LD_CAT + 4 * hi;
+        load_bias(acc, W + L::B_CAT, hi);
+        fwd_mm<16>(acc, w, h2);                                  // :63 cat((fc2, x[:emb1]))
+        fwd_mm<16>(acc, w + H, e1a);
+        fwd_mm<16>(acc, w + H + 32, e1b);
+        fwd_mm<12>(acc, w + H + 64, e1c);
+        relu_to(h3, acc);                                        // :64 cat_layer
+    }
+    {
+        load_bias(acc, W + L::B_M2, hi);
+        fwd_mm<16>(acc, W + L::W_M2 + p31 * L::LD_M + 4 * hi, h3);
+        relu_to(h4, acc);                                        // :67 mid2
+    }
+    {
+        const float* w = W + L::W_C + p31 * L::LD_C + 4 * hi;
+        load_bias(acc, W + L::B_C, hi);
+        fwd_mm<16>(acc, w, h4);                                  // :81 cat((fc4, x[emb1:]))
+        fwd_mm<16>(acc, w + H, e2a);
+        fwd_mm<6>(acc, w + H + 32, e2b);
+        relu_to(hc, acc);                                        // :81 color_linear
+    }
+    float* cb = lds + L::CB;
+    {
+        float ra = 0.0f, r0 = 0.0f, r1 = 0.0f, r2 = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = phi(r, hi);
+            ra = fmaf(W[L::W_A + j], h4[r], ra);                 // :71 out_alpha
+            r0 = fmaf(W[L::W_OC + j], hc[r], r0);                // :82 out_color
+            r1 = fmaf(W[L::W_OC + H + j], hc[r], r1);
+            r2 = fmaf(W[L::W_OC + 2 * H + j], hc[r], r2);
+        }
+        ra += wv::swap_half(ra); r0 += wv::swap_half(r0); r1 += wv::swap_half(r1); r2 += wv::swap_half(r2);
+        ra += W[L::B_A]; r0 += W[L::B_OC]; r1 += W[L::B_OC + 1]; r2 += W[L::B_OC + 2];
+        if (valid && hi == 0) {
+            float* row = cb + pt * 8;
+            row[0] = sigmoidf_acc(ra * 10.0f);                   // :77 raw*10 ; render_rays.py:6 sigmoid
+            row[1] = sigmoidf_acc(r0);                           // :83 sigmoid(raw_color)
+            row[2] = sigmoidf_acc(r1);
+            row[3] = sigmoidf_acc(r2);
+        }
+    }
+    __syncthreads();
+
+    // ---- per-ray compositing, loss and d loss / d raw  (loss.py:24-60, render_rays.py:26-96) ----
+    if (tid < nrays) {
+        const int g = tid, rr = ray0 + g;
+        float* rows = cb + g * a.S * 8;
+        const float* zp = a.z + obj * a.z_so + rr * a.z_sr;
+        float T = 1.0f, D = 0.0f, O = 0.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
+        for (int i = 0; i < a.S; ++i) {
+            float* row = rows + i * 8;
+            const float o = row[0];
+            const float w = o * T;                               // render_rays.py:32 occupancy * cumprod
+            const float zi = zp[i * a.z_ss];
+            row[4] = T; row[5] = w; row[6] = zi;
+            D += w * zi; O += w;                                 // loss.py:27,31
+            C0 += w * row[1]; C1 += w * row[2]; C2 += w * row[3];   // loss.py:30
+            T *= (1.0f - o) + 1e-10f;                            // render_rays.py:29
+        }
+        float V = 0.0f;
+        for (int i = 0; i < a.S; ++i) {
+            const float* row = rows + i * 8;
+            const float d = row[6] - D;
+            V += row[5] * (d * d);                               // loss.py:28-29 (detached)
+        }
+        const unsigned char s = a.sem[obj * a.sem_so + rr * a.sem_sr];
+        const unsigned char dm = a.dmask[obj * a.dm_so + rr * a.dm_sr];
+        const float m_o = s != 0 ? 1.0f : 0.0f, m_s = s != 2 ? 1.0f : 0.0f;      // loss.py:16-19
+        const float m_dd = (dm != 0 && s != 0) ? 1.0f : 0.0f;                     // loss.py:37
+        const float gtd = a.gt_depth[obj * a.gd_so + rr * a.gd_sr];
+        const float* rgb = a.gt_rgb + obj * a.rgb_so + rr * a.rgb_sr;
+        const float g0 = rgb[0], g1 = rgb[a.rgb_sc], g2 = rgb[2 * a.rgb_sc];
+        const float inv_dd = a.flags[0] ? 0.0f : a.stats[obj * 4 + 0];            // render_rays.py:68-73
+        const float inv_o = a.flags[1] ? 0.0f : a.stats[obj * 4 + 1];
+        const float inv_s = a.flags[2] ? 0.0f : a.stats[obj * 4 + 2];
+        const float info = 1.0f / (sqrtf(V) + 1e-4f);                             // render_rays.py:75-79
+        const float rd = D - gtd, rc0 = C0 - g0, rc1 = C1 - g1, rc2 = C2 - g2, ro = O - m_o;
+        wv::lds_add(lds + L::LOSS + 0, fabsf(rd) * m_dd * info * inv_dd);
+        wv::lds_add(lds + L::LOSS + 1, (fabsf(rc0) + fabsf(rc1) + fabsf(rc2)) * m_o * inv_o);
+        wv::lds_add(lds + L::LOSS + 2, fabsf(ro) * m_s * inv_s);
+        if (a.dbg_depth) a.dbg_depth[obj * a.R + rr] = D;
+        if (a.dbg_opacity) a.dbg_opacity[obj * a.R + rr] = O;
+        if (a.dbg_var) a.dbg_var[obj * a.R + rr] = V;
+        if (a.dbg_rgb) {
+            float* q = a.dbg_rgb + (obj * a.R + rr) * 3;
+            q[0] = C0; q[1] = C1; q[2] = C2;
+        }
+        if (BWD) {
+            const float gD = sgnf(rd) * m_dd * info * inv_dd;
+            const float gO = a.opac_w * sgnf(ro) * m_s * inv_s;
+            const float k_c = a.color_w * m_o * inv_o;
+            const float gC0 = k_c * sgnf(rc0), gC1 = k_c * sgnf(rc1), gC2 = k_c * sgnf(rc2);
+            float suffix = 0.0f;                                   // sum_{k>i} g_w_k * w_k
+            for (int i = a.S - 1; i >= 0; --i) {
+                float* row = rows + i * 8;
+                const float o = row[0], c0 = row[1], c1 = row[2], c2 = row[3];
+                const float Ti = row[4], w = row[5], zi = row[6];
+                const float gw = gD * zi + gC0 * c0 + gC1 * c1 + gC2 * c2 + gO;
+                const float f = (1.0f - o) + 1e-10f;
+                const float d_occ = gw * Ti - suffix / f;          // cumprod backward: reverse-cumsum / input
+                suffix += gw * w;
+                row[0] = 10.0f * (d_occ * o * (1.0f - o));         // through sigmoid and the *10 (model.py:77)
+                row[1] = w * gC0 * c0 * (1.0f - c0);               // through the colour sigmoid (model.py:83)
+                row[2] = w * gC1 * c1 * (1.0f - c1);
+                row[3] = w * gC2 * c2 * (1.0f - c2);
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float* pl = a.part_loss + (obj * a.NG + grp) * 4;
+        pl[0] = lds[L::LOSS + 0]; pl[1] = lds[L::LOSS + 1]; pl[2] = lds[L::LOSS + 2]; pl[3] = 0.0f;
+    }
+    if (!BWD) return;
+
+    // ---- backward ----
+    float* scrX = lds + L::SCR + wave * L::SCR_WAVE;
+    float* scrD = scrX + 32 * 33;
+    const float* cbw = cb + wave * 32 * 8;       // this wave's 32 rows of d raw (pad rows are zero)
+    float d_raw = 0.0f, d_c0 = 0.0f, d_c1 = 0.0f, d_c2 = 0.0f;
+    {
+        const float* row = cb + pt * 8;          // pt < kMaxPts always
+        d_raw = row[0]; d_c0 = row[1]; d_c1 = row[2]; d_c2 = row[3];
+    }
+    float xF[16], dF[16];
+    float dproj[kDirs];
+#pragma unroll
+    for (int d = 0; d < kDirs; ++d) dproj[d] = 0.0f;
+
+    // heads: out_alpha / out_color weight + bias gradients (lane = hidden feature)
+    float dcp[16];   // d hc (pre-activation), P-form
+    {
+        float h4F[16];
+        to_F(h4F, h4, scrX, p31, hi);
+        to_F(xF, hc, scrD, p31, hi);             // hcF
+        float ga = 0.0f, g0 = 0.0f, g1 = 0.0f, g2 = 0.0f, sa = 0.0f, s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float* row = cbw + (r + 16 * hi) * 8;
+            const float da = row[0], q0 = row[1], q1 = row[2], q2 = row[3];
+            ga = fmaf(da, h4F[r], ga);
+            g0 = fmaf(q0, xF[r], g0); g1 = fmaf(q1, xF[r], g1); g2 = fmaf(q2, xF[r], g2);
+            sa += da; s0 += q0; s1 += q1; s2 += q2;
+        }
+        ga += wv::swap_half(ga); g0 += wv::swap_half(g0); g1 += wv::swap_half(g1); g2 += wv::swap_half(g2);
+        sa += wv::swap_half(sa); s0 += wv::swap_half(s0); s1 += wv::swap_half(s1); s2 += wv::swap_half(s2);
+        if (hi == 0) {
+            wv::lds_add(Gd + L::W_A + p31, ga);
+            wv::lds_add(Gd + L::W_OC + p31, g0);
+            wv::lds_add(Gd + L::W_OC + H + p31, g1);
+            wv::lds_add(Gd + L::W_OC + 2 * H + p31, g2);
+            if (p31 == 0) {
+                wv::lds_add(Gd + L::B_A, sa);
+                wv::lds_add(Gd + L::B_OC + 0, s0);
+                wv::lds_add(Gd + L::B_OC + 1, s1);
+                wv::lds_add(Gd + L::B_OC + 2, s2);
+            }
+        }
+        // d hc = W_oc^T d rawc, through the ReLU
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = phi(r, hi);
+            const float v = W[L::W_OC + j] * d_c0 + W[L::W_OC + H + j] * d_c1 + W[L::W_OC + 2 * H + j] * d_c2;
+            dcp[r] = hc[r] > 0.0f ? v : 0.0f;
+        }
+        // color_linear weight gradient: [d hc]^T [h4 | e2]
+        to_F(dF, dcp, scrD, p31, hi);
+        add_db(Gd + L::B_C, dF, p31, hi);
+        zero_acc(acc); dw_mm(acc, dF, h4F); add_dw<L::LD_C>(Gd + L::W_C, acc, p31, true, hi);
+        to_F(xF, e2a, scrX, p31, hi);
+        zero_acc(acc); dw_mm(acc, dF, xF); add_dw<L::LD_C>(Gd + L::W_C, acc, H + p31, true, hi);
+        to_F(xF, e2b, scrX, p31, hi);
+        zero_acc(acc); dw_mm(acc, dF, xF); add_dw<L::LD_C>(Gd + L::W_C, acc, H + 32 + p31, 32 + p31 < kEmb2, hi);
+    }
+    // d h4 = W_a d raw + W_c[:, :H]^T d hc ; d e2 = W_c[:, H:]^T d hc
+    float d4[16];
+    {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = W[L::W_A + phi(r, hi)] * d_raw;
+        bwd_mm<L::LD_C>(acc, W + L::W_C + 4 * hi * L::LD_C + p31, dcp);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d4[r] = h4[r] > 0.0f ? acc[r] : 0.0f;
+        zero_acc(acc);
+        bwd_mm<L::LD_C>(acc, W + L::W_C + 4 * hi * L::LD_C + H + p31, dcp);
+        pe_block_bwd<16>(dproj, acc, c2a, kEmb1, kEmb2, 0, hi);
+        zero_acc(acc);
+        bwd_mm<L::LD_C>(acc, W + L::W_C + 4 * hi * L::LD_C + H + min(32 + p31, 46), dcp);
+        pe_block_bwd<6>(dproj, acc, c2b, kEmb1, kEmb2, 1, hi);
+    }
+    // mid2
+    float d3[16];
+    {
+        to_F(dF, d4, scrD, p31, hi);
+        to_F(xF, h3, scrX, p31, hi);
+        add_db(Gd + L::B_M2, dF, p31, hi);
+        zero_acc(acc); dw_mm(acc, dF, xF); add_dw<L::LD_M>(Gd + L::W_M2, acc, p31, true, hi);
+        zero_acc(acc);
+        bwd_mm<L::LD_M>(acc, W + L::W_M2 + 4 * hi * L::LD_M + p31, d4);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d3[r] = h3[r] > 0.0f ? acc[r] : 0.0f;
+    }
+    // cat_layer
+    float d2[16];
+    f32x16 de1a, de1b, de1c;
+    {
+        to_F(dF, d3, scrD, p31, hi);
+        add_db(Gd + L::B_CAT, dF, p31, hi);
+        to_F(xF, h2, scrX, p31, hi);
+        zero_acc(acc); dw_mm(acc, dF, xF); add_dw<L::LD_CAT>(Gd + L::W_CAT, acc, p31, true, hi);
+        to_F(xF, e1a, scrX, p31, hi);
+        zero_acc(acc); dw_mm(acc, dF, xF); add_dw<L::LD_CAT>(Gd + L::W_CAT, acc, H + p31, true, hi);
+        to_F(xF, e1b, scrX, p31, hi);
+        zero_acc(acc); dw_mm(acc, dF, xF); add_dw<L::LD_CAT>(Gd + L::W_CAT, acc, H + 32 + p31, true, hi);
+        to_F(xF, e1c, scrX, p31, hi);
+        zero_acc(acc); dw_mm(acc, dF, xF); add_dw<L::LD_CAT>(Gd + L::W_CAT, acc, H + 64 + p31, 64 + p31 < kEmb1, hi);
+        const float* wc = W + L::W_CAT + 4 * hi * L::LD_CAT;
+        zero_acc(acc);
+        bwd_mm<L::LD_CAT>(acc, wc + p31, d3);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d2[r] = h2[r] > 0.0f ? acc[r] : 0.0f;
+        zero_acc(de1a); bwd_mm<L::LD_CAT>(de1a, wc + H + p31, d3);
+        zero_acc(de1b); bwd_mm<L::LD_CAT>(de1b, wc + H + 32 + p31, d3);
+        zero_acc(de1c); bwd_mm<L::LD_CAT>(de1c, wc + H + min(64 + p31, 88), d3);
+    }
+    // mid1
+    float d1[16];
+    {
+        to_F(dF, d2, scrD, p31, hi);
+        to_F(xF, h1, scrX, p31, hi);
+        add_db(Gd + L::B_M1, dF, p31, hi);
+        zero_acc(acc); dw_mm(acc, dF, xF); add_dw<L::LD_M>(Gd + L::W_M1, acc, p31, true, hi);
+        zero_acc(acc);
+        bwd_mm<L::LD_M>(acc, W + L::W_M1 + 4 * hi * L::LD_M + p31, d2);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d1[r] = h1[r] > 0.0f ? acc[r] : 0.0f;
+    }
+    // in_layer + encoding backward
+    float e1aF[16];
+    {
+        to_F(dF, d1, scrD, p31, hi);
+        add_db(Gd + L::B_IN, dF, p31, hi);
+        to_F(e1aF, e1a, scrX, p31, hi);
+        zero_acc(acc); dw_mm(acc, dF, e1aF); add_dw<L::LD_IN>(Gd + L::W_IN, acc, p31, true, hi);
+        to_F(xF, e1b, scrX, p31, hi);
+        zero_acc(acc); dw_mm(acc, dF, xF); add_dw<L::LD_IN>(Gd + L::W_IN, acc, 32 + p31, true, hi);
+        to_F(xF, e1c, scrX, p31, hi);
+        zero_acc(acc); dw_mm(acc, dF, xF); add_dw<L::LD_IN>(Gd + L::W_IN, acc, 64 + p31, 64 + p31 < kEmb1, hi);
+        const float* wi = W + L::W_IN + 4 * hi * L::LD_IN;
+        bwd_mm<L::LD_IN>(de1a, wi + p31, d1);
+        bwd_mm<L::LD_IN>(de1b, wi + 32 + p31, d1);
+        bwd_mm<L::LD_IN>(de1c, wi + min(64 + p31, 88), d1);
+        pe_block_bwd<16>(dproj, de1a, c1a, 0, kEmb1, 0, hi);
+        pe_block_bwd<16>(dproj, de1b, c1b, 0, kEmb1, 1, hi);
+        pe_block_bwd<12>(dproj, de1c, c1c, 0, kEmb1, 2, hi);
+    }
+    // B_layer.weight gradient: dB[d][j] = sum_points dproj[d] * t[j]  (t = encoding columns 0..2)
+    {
+        float dpP[16];
+#pragma unroll
+        for (int d = 0; d < kDirs; ++d) dproj[d] += wv::swap_half(dproj[d]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int f0 = phi(r, 0), f1 = phi(r, 1);
+            const float v0 = f0 < kDirs ? dproj[f0 < kDirs ? f0 : 0] : 0.0f;
+            const float v1 = f1 < kDirs ? dproj[f1 < kDirs ? f1 : 0] : 0.0f;
+            dpP[r] = hi ? v1 : v0;
+        }
+        to_F(dF, dpP, scrD, p31, hi);
+        zero_acc(acc); dw_mm(acc, dF, e1aF);
+        if (p31 < 3) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int d = phi(r, hi);
+                if (d < kDirs) wv::lds_add(Gd + L::PE_B + 3 * d + p31, acc[r]);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- write this workgroup's partial gradients in the natural flat order ----
+    float* out = a.part_grad + ((long long)(obj * a.NG + grp)) * a.PP;
+    unstage_matrix<H, kEmb1, L::LD_IN>(out, Gd + L::W_IN, tid);            out += H * kEmb1;
+    if (tid < H) out[tid] = Gd[L::B_IN + tid];                             out += H;
+    unstage_matrix<H, H, L::LD_M>(out, Gd + L::W_M1, tid);                 out += H * H;
+    if (tid < H) out[tid] = Gd[L::B_M1 + tid];                             out += H;
+    unstage_matrix<H, H + kEmb1, L::LD_CAT>(out, Gd + L::W_CAT, tid);      out += H * (H + kEmb1);
+    if (tid < H) out[tid] = Gd[L::B_CAT + tid];                            out += H;
+    unstage_matrix<H, H, L::LD_M>(out, Gd + L::W_M2, tid);                 out += H * H;
+    if (tid < H) out[tid] = Gd[L::B_M2 + tid];                             out += H;
+    if (tid < H) out[tid] = Gd[L::W_A + tid];                              out += H;
+    if (tid == 0) out[0] = Gd[L::B_A];                                     out += 1;
+    unstage_matrix<H, H + kEmb2, L::LD_C>(out, Gd + L::W_C, tid);          out += H * (H + kEmb2);
+    if (tid < H) out[tid] = Gd[L::B_C + tid];                              out += H;
+    if (tid < 3 * H) out[tid] = Gd[L::W_OC + tid];                         out += 3 * H;
+    if (tid < 3) out[tid] = Gd[L::B_OC + tid];                             out += 3;
+    if (tid < 63) out[tid] = Gd[L::PE_B + tid];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// step_finalize: ordered sum of the per-workgroup partials -> gradients (and, fused, torch.optim.AdamW's
+// single-tensor update: decoupled decay, lerp first moment, bias-corrected denominator), the scalar loss
+// (loss.py:59-60) and the "loss explode" flag (render_rays.py:88-90).
+// ---------------------------------------------------------------------------------------------------------
+struct FinalizeArgs {
+    int n_obj, NG, PP, P;              // P = real parameter count per object (flat order: 14 field tensors, then B)
+    int offs[kNFc + 2];                // flat start offset of each tensor, offs[15] = P
+    TensorRef param[kNFc + 1];         // parameters (updated in place when do_adam)
+    TensorRef grad[kNFc + 1];          // gradient outputs (p may be null: skip)
+    float* m; float* v;                // Adam moments, [n][PP] slabs (when do_adam)
+    const float* part_grad; const float* part_loss;
+    const int* flags_in; int* flags_out;
+    float* loss_out;                   // [1]
+    float color_w, opac_w;
+    int do_adam;
+    float lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2_sqrt;
+};
+
+__global__ __launch_bounds__(kWG) void step_finalize(const FinalizeArgs a) {
+    const int blocks_per_obj = (a.P + kWG - 1) / kWG;
+    const int obj = blockIdx.x / blocks_per_obj;
+    const int i = (blockIdx.x - obj * blocks_per_obj) * kWG + threadIdx.x;
+    if (obj < a.n_obj && i < a.P) {
+        const float* pg = a.part_grad + (long long)obj * a.NG * a.PP + i;
+        float g = 0.0f;
+        for (int q = 0; q < a.NG; ++q) g += pg[(long long)q * a.PP];
+        int t = 0;
+#pragma unroll
+        for (int k = 1; k <= kNFc; ++k) t += i >= a.offs[k];
+        const int o = i - a.offs[t];
+        if (a.grad[t].p) a.grad[t].p[obj * a.grad[t].stride + o] = g;
+        if (a.do_adam) {
+            float* pp = a.param[t].p + obj * a.param[t].stride + o;
+            const long long s = (long long)obj * a.PP + i;
+            float p = *pp, m = a.m[s], v = a.v[s];
+            p = p * (1.0f - a.lr * a.weight_decay);                       // param.mul_(1 - lr * wd)
+            m = m + (g - m) * (1.0f - a.beta1);                           // exp_avg.lerp_(grad, 1 - beta1)
+            v = v * a.beta2 + (g * g) * (1.0f - a.beta2);                 // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
+            const float denom = sqrtf(v) / a.bias_corr2_sqrt + a.eps;
+            p = p - (a.lr / a.bias_corr1) * (m / denom);                  // param.addcdiv_(exp_avg, denom, -step_size)
+            *pp = p; a.m[s] = m; a.v[s] = v;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        float loss = 0.0f;
+        int explode = 0;
+        for (int k = 0; k < a.n_obj; ++k) {
+            float ld = 0.0f, lc = 0.0f, lo = 0.0f;
+            for (int q = 0; q < a.NG; ++q) {
+                const float* pl = a.part_loss + ((long long)k * a.NG + q) * 4;
+                ld += pl[0]; lc += pl[1]; lo += pl[2];
+            }
+            explode |= (ld > 100000.0f) || (lc > 100000.0f) || (lo > 100000.0f);   // render_rays.py:88
+            loss += ld + lc * a.color_w + lo * a.opac_w;                            // loss.py:59
+        }
+        a.loss_out[0] = loss;                                                       // loss.py:60
+        a.flags_out[0] = a.flags_in[0]; a.flags_out[1] = a.flags_in[1]; a.flags_out[2] = a.flags_in[2];
+        a.flags_out[3] = explode;
+    }
+}
+
+}  // namespace vk

@@ -1,0 +1,41 @@
+// wave_ops.h - the handful of gfx950 wave-level primitives the step kernels are written against.
+//
+// Device implementation (CDNA4, wave64).  Everything the kernels need from the hardware beyond plain
+// per-lane arithmetic goes through this header: the fp32 matrix instruction, the half-wave exchange,
+// the intra-wave LDS ordering point and the dynamic LDS base.  tests/sim/ provides a host-side model of
+// exactly this interface so that the kernel source can be executed lane-by-lane on a CPU in the
+// `-m "not gpu"` tier; the product never uses that model.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace wv {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// D = A(32x2) * B(2x32) + C, exact fp32 (bitwise an fmaf chain over k), 64 cycles per SIMD.
+//   a: lane l supplies A[i = l & 31][k = l >> 5]
+//   b: lane l supplies B[k = l >> 5][j = l & 31]
+//   c/d: lane l, register r holds D[i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)][j = l & 31]
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// value held by the partner lane in the other 32-lane half of the wave (lane ^ 32)
+__device__ __forceinline__ float swap_half(float x) { return __shfl_xor(x, 32); }
+
+// Orders this wave's earlier LDS writes before its later LDS reads (data exchanged between lanes of ONE
+// wave through a wave-private LDS region).  A wave's DS instructions execute in order, so no hardware
+// barrier is needed - only the compiler must not move accesses across this point.
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds_bytes[];
+__device__ __forceinline__ float* lds_base() { return reinterpret_cast<float*>(dyn_lds_bytes); }
+
+__device__ __forceinline__ void lds_add(float* p, float v) { atomicAdd(p, v); }   // ds_add_f32
+
+}  // namespace wv
