@@ -1,0 +1,141 @@
+/* vmapstep.h - C ABI of the MI355X-native per-object training step (libvmapstep.so).
+ *
+ * The reference (kxhit/vMAP) has no plugin/FFI interface: the hot path is inlined in train.py.  The
+ * de-facto operator boundary this library replaces is
+ *
+ *   state      utils.py:30-34   update_vmap -> stacked parameters (leading object dimension)
+ *   forward    train.py:293-294 vmap(pe_model)(...), vmap(fc_model)(...)
+ *   loss       train.py:303-306 loss.step_batch_loss(...)                (loss.py:5-62)
+ *   backward   train.py:324     batch_loss.backward()
+ *   optimiser  train.py:325     optimiser.step()  (torch.optim.AdamW built at train.py:67)
+ *   step loop  train.py:270-277 data_idx = slice(i*R, (i+1)*R) over the per-frame sample tensors
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch tensors in the Python host code);
+ *     the library never allocates, frees or synchronises: it only enqueues kernels on `stream`
+ *     (a hipStream_t passed as void*; NULL = the default stream);
+ *   - strides are in ELEMENTS; tensors may be the non-contiguous slices train.py:271-277 produces;
+ *   - return value 0 = ok, negative = error; vmapstep_last_error() describes the last failure of the
+ *     calling thread; no C++ exception crosses the ABI;
+ *   - data-dependent decisions the reference takes with host syncs (render_rays.py:68-73 "any object has
+ *     an empty mask", :88-90 "loss explode -> exit(-1)") are reported through `flags`, on the device.
+ */
+#ifndef VMAPSTEP_H
+#define VMAPSTEP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VMAPSTEP_ABI_VERSION 1
+#define VMAPSTEP_NUM_FC 14 /* field-MLP tensors per object, nn.Module.parameters() order (model.py:28-49) */
+
+#define VMAPSTEP_OK 0
+#define VMAPSTEP_ERR_ARGUMENT (-1)    /* null pointer / inconsistent shape */
+#define VMAPSTEP_ERR_UNSUPPORTED (-2) /* shape the device kernels do not implement */
+#define VMAPSTEP_ERR_WORKSPACE (-3)   /* workspace too small / misaligned */
+#define VMAPSTEP_ERR_DEVICE (-4)      /* HIP runtime error while enqueueing */
+
+/* flags[4] written per step */
+#define VMAPSTEP_FLAG_DROP_DEPTH 0   /* render_rays.py:68-73 fired for the depth term (whole batch) */
+#define VMAPSTEP_FLAG_DROP_COLOUR 1
+#define VMAPSTEP_FLAG_DROP_OPACITY 2
+#define VMAPSTEP_FLAG_EXPLODE 3      /* render_rays.py:88-90: a per-object loss term exceeded 1e5 */
+
+typedef struct vmapstep_shape {
+    int32_t n_obj;   /* objects in the stack                         (len(obj_dict))        */
+    int32_t rays;    /* rays per object per step, R                  (cfg.n_per_optim)      */
+    int32_t samples; /* samples per ray, S = n_bins_cam2surface+n_bins                      */
+    int32_t hidden;  /* hidden width H                               (hidden_feature_size)  */
+} vmapstep_shape;
+
+/* One stacked tensor: object k starts at ptr + k * obj_stride (elements); each object's block is dense. */
+typedef struct vmapstep_tensor {
+    float* ptr;
+    int64_t obj_stride;
+} vmapstep_tensor;
+
+/* The 15 trainable stacked tensors (or same-shaped gradients): fc_param of utils.py:31 + B_layer.weight. */
+typedef struct vmapstep_params {
+    vmapstep_tensor fc[VMAPSTEP_NUM_FC]; /* [n,H,87] [n,H] [n,H,H] [n,H] [n,H,H+87] [n,H] [n,H,H] [n,H]
+                                            [n,1,H] [n,1] [n,H,H+42] [n,H] [n,3,H] [n,3]             */
+    vmapstep_tensor pe_B;                /* [n,21,3]  embedding.py:75-76 */
+} vmapstep_params;
+
+/* One step's ray batch: the six tensors of train.py:271-277 (strides in elements, outermost first). */
+typedef struct vmapstep_batch {
+    const float* pcs;          int64_t pcs_stride[4];        /* [n,R,S,3]  sample points, object frame  */
+    const float* z;            int64_t z_stride[3];          /* [n,R,S]    sample depths                */
+    const float* gt_depth;     int64_t gt_depth_stride[2];   /* [n,R]                                   */
+    const float* gt_rgb;       int64_t gt_rgb_stride[3];     /* [n,R,3]    already divided by 255       */
+    const uint8_t* sem;        int64_t sem_stride[2];        /* [n,R]      0 other, 1 this, 2 unknown   */
+    const uint8_t* depth_mask; int64_t depth_mask_stride[2]; /* [n,R]      bool as bytes                */
+} vmapstep_batch;
+
+typedef struct vmapstep_outputs {
+    float* loss;          /* [n_steps]     required: batch loss (loss.py:60)                      */
+    int32_t* flags;       /* [n_steps][4]  required                                               */
+    float* render_depth;  /* [n,R]    optional (NULL = skip): loss.py:27, last step only          */
+    float* render_color;  /* [n,R,3]  optional: loss.py:30                                        */
+    float* opacity;       /* [n,R]    optional: loss.py:31                                        */
+    float* var;           /* [n,R]    optional: loss.py:28-29                                     */
+} vmapstep_outputs;
+
+/* torch.optim.AdamW hyper-parameters + state for the fused update (train.py:67, :325). */
+typedef struct vmapstep_adamw {
+    float lr, beta1, beta2, eps, weight_decay;
+    int32_t step;        /* number of updates already applied to this stack (0 for a fresh update_vmap) */
+    float* exp_avg;      /* [n][padded_params] first moments  (see vmapstep_param_layout)               */
+    float* exp_avg_sq;   /* [n][padded_params] second moments                                           */
+} vmapstep_adamw;
+
+const char* vmapstep_last_error(void);
+int vmapstep_abi_version(void);
+
+/* sizes[15]: element count per object of the 14 field tensors then B_layer.weight; their sum -> *params;
+ * *padded_params = row length of the optimiser-state slabs. */
+int vmapstep_param_layout(int32_t hidden, int64_t sizes[VMAPSTEP_NUM_FC + 1], int64_t* params, int64_t* padded_params);
+
+/* Bytes of scratch the calls below need for `shape` and up to `max_steps` steps per call (256-byte aligned). */
+int vmapstep_workspace_bytes(const vmapstep_shape* shape, int32_t max_steps, size_t* bytes);
+
+/* One step of train.py:293-306 + :324: loss and the gradients of all 15 stacked tensors (written to `grads`,
+ * which has the layout of `params`; replaces loss.backward() populating p.grad). */
+int vmapstep_fwd_bwd(const vmapstep_shape* shape, const vmapstep_params* params, const vmapstep_tensor* pe_scale,
+                     const vmapstep_batch* batch, float color_scaling, float opacity_scaling,
+                     const vmapstep_params* grads, const vmapstep_outputs* out,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* Forward + loss only (no gradients): rendered depth / colour / opacity / variance and the batch loss. */
+int vmapstep_render(const vmapstep_shape* shape, const vmapstep_params* params, const vmapstep_tensor* pe_scale,
+                    const vmapstep_batch* batch, float color_scaling, float opacity_scaling,
+                    const vmapstep_outputs* out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* The step loop of train.py:270-326 for one frame: for i in [0, n_steps): batch rays [i*ray_step, i*ray_step+R)
+ * of the per-frame tensors described by `frame` -> forward, loss, backward, fused AdamW update of `params` in
+ * place (opt->step is the count BEFORE the first of these steps; the caller adds n_steps afterwards).
+ * `grads` may be NULL (gradients are then consumed by the fused update only); if given it receives the
+ * gradients of the LAST step. out->loss / out->flags receive one entry per step. */
+int vmapstep_train_steps(const vmapstep_shape* shape, const vmapstep_params* params, const vmapstep_tensor* pe_scale,
+                         const vmapstep_batch* frame, int64_t ray_step, int32_t n_steps,
+                         float color_scaling, float opacity_scaling, const vmapstep_adamw* opt,
+                         const vmapstep_params* grads, const vmapstep_outputs* out,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* Measurement hook: step_prep once, then the dominant kernel (step_main, forward+backward) `reps` times back to
+ * back on `stream` with nothing in between, so that events recorded around the call give its average launch
+ * duration (bench.py's roofline figure).  Writes only to the workspace. */
+int vmapstep_profile_main_kernel(const vmapstep_shape* shape, const vmapstep_params* params,
+                                 const vmapstep_tensor* pe_scale, const vmapstep_batch* batch, int32_t reps,
+                                 void* workspace, size_t workspace_bytes, void* stream);
+
+/* Tuning knob (0 = automatic): workgroups per object of the fused kernel. Returns the previous value. */
+int vmapstep_set_workgroups_per_object(int32_t nw);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VMAPSTEP_H */

@@ -23,6 +23,6 @@ inline void __syncthreads() { sim::barrier_wait(sim::g_block->block_bar); }
 inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
 inline int atomicOr(int* p, int v) { int o = *p; *p = o | v; return o; }
 inline int atomicMax(int* p, int v) { int o = *p; if (v > o) *p = v; return o; }
-inline void sincosf_sim(float x, float* s, float* c) { *s = sinf(x); *c = cosf(x); }
+
 inline int min(int a, int b) { return a < b ? a : b; }
 inline int max(int a, int b) { return a > b ? a : b; }

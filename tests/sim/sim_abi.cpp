@@ -16,7 +16,7 @@ void fc_sizes(int H, int* sz) {
 extern "C" int vmsim_lds_bytes() { return vk::Lds32::BYTES; }
 
 // fc[t]: [n][size_t] contiguous; grads: flat slab [n][P] in natural order (14 field tensors then B).
-extern "C" int vmsim_step(int n, int R, int S, int H, int G,
+extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req,
                           const float* const* fc, const float* B, const float* scale,
                           const float* pcs, const float* z, const float* gt_depth, const float* gt_rgb,
                           const uint8_t* sem, const uint8_t* dmask, float color_w, float opac_w,
@@ -33,12 +33,13 @@ extern "C" int vmsim_step(int n, int R, int S, int H, int G,
     offs[14] = P; P += 63; offs[15] = P;
     const int PP = (P + 63) / 64 * 64;
     const int NG = (R + G - 1) / G;
+    const int NW = NW_req > 0 && NW_req < NG ? NW_req : NG;
 
-    std::vector<float> stats(n * 4, NAN), part_grad((size_t)n * NG * PP, NAN), part_loss((size_t)n * NG * 4, NAN);
+    std::vector<float> stats(n * 4, NAN), part_grad((size_t)n * NW * PP, NAN), part_loss((size_t)n * NW * 4, NAN);
     std::vector<int> fl(4, -1);
 
     vk::StepArgs a{};
-    a.n_obj = n; a.R = R; a.S = S; a.G = G; a.NG = NG; a.PP = PP;
+    a.n_obj = n; a.R = R; a.S = S; a.G = G; a.NG = NG; a.NW = NW; a.PP = PP; a.prep_steps = 1; a.prep_ray_step = 0;
     for (int t = 0; t < 14; ++t) a.fc[t] = {const_cast<float*>(fc[t]), sz[t]};
     a.pe_B = {const_cast<float*>(B), 63};
     a.pe_scale = {const_cast<float*>(scale), 1};
@@ -54,26 +55,26 @@ extern "C" int vmsim_step(int n, int R, int S, int H, int G,
     a.dbg_depth = dbg_depth; a.dbg_rgb = dbg_rgb; a.dbg_opacity = dbg_opacity; a.dbg_var = dbg_var;
 
     sim::launch(1, vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep(a); });
-    if (bwd) sim::launch(n * NG, vk::kWG, vk::Lds32::BYTES, [&] { vk::step_main_h32<true>(a); });
-    else     sim::launch(n * NG, vk::kWG, vk::Lds32::BYTES, [&] { vk::step_main_h32<false>(a); });
+    if (bwd) sim::launch(n * NW, vk::kWG, vk::Lds32::BYTES, [&] { vk::step_main_h32<true>(a); });
+    else     sim::launch(n * NW, vk::kWG, vk::Lds32::BYTES, [&] { vk::step_main_h32<false>(a); });
 
     vk::FinalizeArgs f{};
-    f.n_obj = n; f.NG = NG; f.PP = PP; f.P = P;
+    f.n_obj = n; f.NW = NW; f.PP = PP; f.P = P;
     for (int t = 0; t < 16; ++t) f.offs[t] = offs[t];
-    std::vector<float> zero_part;
-    if (!bwd) { zero_part.assign(part_grad.size(), 0.0f); }
     for (int t = 0; t < 15; ++t) {
         f.grad[t] = {grads ? grads + offs[t] : nullptr, P};
         f.param[t] = {p_out ? p_out + offs[t] : nullptr, P};
     }
     f.m = m; f.v = v;
-    f.part_grad = bwd ? part_grad.data() : zero_part.data();
+    f.part_grad = part_grad.data(); f.have_grad = bwd;
     f.part_loss = part_loss.data();
     f.flags_in = fl.data(); f.flags_out = flags; f.loss_out = loss;
     f.color_w = color_w; f.opac_w = opac_w;
     f.do_adam = do_adam;
-    f.lr = lr; f.beta1 = 0.9f; f.beta2 = 0.999f; f.eps = 1e-8f; f.weight_decay = wd;
-    f.bias_corr1 = (float)(1.0 - std::pow(0.9, step));
+    f.decay = (float)(1.0 - (double)lr * (double)wd);
+    f.one_minus_beta1 = (float)(1.0 - 0.9); f.beta2 = 0.999f; f.one_minus_beta2 = (float)(1.0 - 0.999);
+    f.eps = 1e-8f;
+    f.step_size = (float)((double)lr / (1.0 - std::pow(0.9, step)));
     f.bias_corr2_sqrt = (float)std::sqrt(1.0 - std::pow(0.999, step));
     const int bpo = (P + vk::kWG - 1) / vk::kWG;
     sim::launch(n * bpo, vk::kWG, 0, [&] { vk::step_finalize(f); });

@@ -38,6 +38,16 @@ inline float swap_half(float x) {
     return y;
 }
 
+inline bool wave_any(bool pred) {
+    const int w = sim::wave_id(), l = sim::lane_id();
+    sim::g_block->xa[w][l] = pred ? 1.0f : 0.0f;
+    sim::wave_barrier();
+    bool any = false;
+    for (int i = 0; i < sim::kWave; ++i) any |= sim::g_block->xa[w][i] != 0.0f;
+    sim::wave_barrier();
+    return any;
+}
+
 inline void wave_lds_fence() { sim::wave_barrier(); }
 
 inline float* lds_base() { return reinterpret_cast<float*>(sim::g_block->lds.data()); }

@@ -1,0 +1,60 @@
+"""CPU tier: libvmapstep.so loads, exports every symbol include/vmapstep.h declares, and its argument checks work
+without a GPU (no kernel is launched here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+from vmap_amd import _lib, layout
+
+
+def _declared_functions():
+    src = open(os.path.join(ROOT, "include", "vmapstep.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(vmapstep_[a-z_]+)\s*\(", src)))
+
+
+def test_header_and_binding_agree():
+    assert _declared_functions() == sorted(_lib.EXPORTS)
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    for name in _declared_functions():
+        assert hasattr(lib, name), name
+    assert lib.vmapstep_abi_version() == 1
+
+
+@pytest.mark.parametrize("H", [32, 64, 128, 256])
+def test_param_layout_matches_reference_shapes(H):
+    lib = _lib.load()
+    sizes = (ctypes.c_int64 * 15)()
+    P, PP = ctypes.c_int64(), ctypes.c_int64()
+    assert lib.vmapstep_param_layout(H, sizes, ctypes.byref(P), ctypes.byref(PP)) == 0
+    assert list(sizes)[:14] == list(layout.fc_sizes(H)) and sizes[14] == 63
+    assert P.value == layout.param_count(H) == H * (4 * H + 225) + 4 + 63
+    assert PP.value % 64 == 0 and PP.value >= P.value
+
+
+def test_workspace_and_error_reporting():
+    lib = _lib.load()
+    nbytes = ctypes.c_size_t()
+    sh = _lib.Shape(20, 120, 10, 32)
+    assert lib.vmapstep_workspace_bytes(ctypes.byref(sh), 20, ctypes.byref(nbytes)) == 0
+    assert nbytes.value > 20 * 10 * layout.param_count(32) * 4
+    bad = _lib.Shape(20, 120, 10, 48)
+    assert lib.vmapstep_workspace_bytes(ctypes.byref(bad), 1, ctypes.byref(nbytes)) == -2
+    assert b"hidden=48" in lib.vmapstep_last_error()
+    assert lib.vmapstep_workspace_bytes(ctypes.byref(_lib.Shape(0, 1, 1, 32)), 1, ctypes.byref(nbytes)) == -1
+    # null arguments are rejected before anything touches the device
+    assert lib.vmapstep_fwd_bwd(ctypes.byref(sh), None, None, None, 5.0, 10.0, None, None, None, 0, None) == -1
+    with pytest.raises(_lib.VmapStepError):
+        _lib.check(-1)
+
+
+def test_step_operator_refuses_cpu():
+    from vmap_amd import step
+    with pytest.raises(_lib.VmapStepError):
+        step.VmapStep(2, 12, 10, 32, device="cpu")

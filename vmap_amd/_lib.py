@@ -1,0 +1,108 @@
+"""ctypes binding of libvmapstep.so (C ABI in include/vmapstep.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` (hipcc, gfx950).  There is NO fallback: if the
+shared object is missing or a call fails, the product path raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvmapstep.so")
+
+NUM_FC = 14
+ABI_VERSION = 1
+
+
+class Shape(ctypes.Structure):
+    _fields_ = [("n_obj", ctypes.c_int32), ("rays", ctypes.c_int32), ("samples", ctypes.c_int32),
+                ("hidden", ctypes.c_int32)]
+
+
+class Tensor(ctypes.Structure):
+    _fields_ = [("ptr", ctypes.c_void_p), ("obj_stride", ctypes.c_int64)]
+
+
+class Params(ctypes.Structure):
+    _fields_ = [("fc", Tensor * NUM_FC), ("pe_B", Tensor)]
+
+
+class Batch(ctypes.Structure):
+    _fields_ = [
+        ("pcs", ctypes.c_void_p), ("pcs_stride", ctypes.c_int64 * 4),
+        ("z", ctypes.c_void_p), ("z_stride", ctypes.c_int64 * 3),
+        ("gt_depth", ctypes.c_void_p), ("gt_depth_stride", ctypes.c_int64 * 2),
+        ("gt_rgb", ctypes.c_void_p), ("gt_rgb_stride", ctypes.c_int64 * 3),
+        ("sem", ctypes.c_void_p), ("sem_stride", ctypes.c_int64 * 2),
+        ("depth_mask", ctypes.c_void_p), ("depth_mask_stride", ctypes.c_int64 * 2),
+    ]
+
+
+class Outputs(ctypes.Structure):
+    _fields_ = [("loss", ctypes.c_void_p), ("flags", ctypes.c_void_p), ("render_depth", ctypes.c_void_p),
+                ("render_color", ctypes.c_void_p), ("opacity", ctypes.c_void_p), ("var", ctypes.c_void_p)]
+
+
+class AdamW(ctypes.Structure):
+    _fields_ = [("lr", ctypes.c_float), ("beta1", ctypes.c_float), ("beta2", ctypes.c_float),
+                ("eps", ctypes.c_float), ("weight_decay", ctypes.c_float), ("step", ctypes.c_int32),
+                ("exp_avg", ctypes.c_void_p), ("exp_avg_sq", ctypes.c_void_p)]
+
+
+EXPORTS = (
+    "vmapstep_last_error", "vmapstep_abi_version", "vmapstep_param_layout", "vmapstep_workspace_bytes",
+    "vmapstep_fwd_bwd", "vmapstep_render", "vmapstep_train_steps", "vmapstep_set_workgroups_per_object",
+    "vmapstep_profile_main_kernel",
+)
+
+_lib = None
+
+
+class VmapStepError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library. Import torch first so that its libamdhip64 is the one both sides share."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    import torch  # noqa: F401  (maps torch/lib/libamdhip64.so before our NEEDED entry is resolved)
+    if not os.path.exists(LIB_PATH):
+        raise VmapStepError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback for the training step.")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.vmapstep_last_error.restype = ctypes.c_char_p
+    lib.vmapstep_abi_version.restype = ctypes.c_int
+    lib.vmapstep_param_layout.argtypes = [ctypes.c_int32, ctypes.POINTER(ctypes.c_int64),
+                                          ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
+    lib.vmapstep_workspace_bytes.argtypes = [ctypes.POINTER(Shape), ctypes.c_int32, ctypes.POINTER(ctypes.c_size_t)]
+    lib.vmapstep_fwd_bwd.argtypes = [ctypes.POINTER(Shape), ctypes.POINTER(Params), ctypes.POINTER(Tensor),
+                                     ctypes.POINTER(Batch), ctypes.c_float, ctypes.c_float, ctypes.POINTER(Params),
+                                     ctypes.POINTER(Outputs), ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    lib.vmapstep_render.argtypes = [ctypes.POINTER(Shape), ctypes.POINTER(Params), ctypes.POINTER(Tensor),
+                                    ctypes.POINTER(Batch), ctypes.c_float, ctypes.c_float,
+                                    ctypes.POINTER(Outputs), ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    lib.vmapstep_train_steps.argtypes = [ctypes.POINTER(Shape), ctypes.POINTER(Params), ctypes.POINTER(Tensor),
+                                         ctypes.POINTER(Batch), ctypes.c_int64, ctypes.c_int32, ctypes.c_float,
+                                         ctypes.c_float, ctypes.POINTER(AdamW), ctypes.POINTER(Params),
+                                         ctypes.POINTER(Outputs), ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    lib.vmapstep_profile_main_kernel.argtypes = [ctypes.POINTER(Shape), ctypes.POINTER(Params), ctypes.POINTER(Tensor),
+                                                 ctypes.POINTER(Batch), ctypes.c_int32, ctypes.c_void_p,
+                                                 ctypes.c_size_t, ctypes.c_void_p]
+    lib.vmapstep_set_workgroups_per_object.argtypes = [ctypes.c_int32]
+    for fn in ("vmapstep_param_layout", "vmapstep_workspace_bytes", "vmapstep_fwd_bwd", "vmapstep_render",
+               "vmapstep_train_steps", "vmapstep_set_workgroups_per_object", "vmapstep_profile_main_kernel"):
+        getattr(lib, fn).restype = ctypes.c_int
+    if lib.vmapstep_abi_version() != ABI_VERSION:
+        raise VmapStepError(f"ABI mismatch: library {lib.vmapstep_abi_version()} != binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int):
+    if rc != 0:
+        msg = load().vmapstep_last_error().decode("utf-8", "replace")
+        raise VmapStepError(f"vmapstep error {rc}: {msg}")

@@ -45,7 +45,9 @@ struct TensorRef {
 
 // Everything one launch needs.  Passed by value as the kernel argument.
 struct StepArgs {
-    int n_obj, R, S, G, NG, PP;        // G rays per workgroup, NG workgroups per object, PP padded params/object
+    int n_obj, R, S, G, NG, NW, PP;    // G rays per pass, NG ray groups per object, NW workgroups per object
+                                       // (workgroup w takes groups w, w+NW, ...), PP padded params per object
+    int prep_steps; long long prep_ray_step;   // step_prep only: block b handles rays [b*ray_step, b*ray_step+R)
     TensorRef fc[kNFc];                // the 14 field tensors, nn.Module.parameters() order (model.py:28-49)
     TensorRef pe_B;                    // B_layer.weight [n,21,3] (embedding.py:75-76)
     TensorRef pe_scale;                // scale buffer [n] (embedding.py:80)
@@ -58,8 +60,8 @@ struct StepArgs {
     float color_w, opac_w;             // loss.py:6 defaults 5.0 / 10.0
     float* stats;                      // [n][4]   1/(N_depth+1e-10), 1/(N_obj+1e-10), 1/(N_sem+1e-10), unused
     int* flags;                        // [4]      drop_depth, drop_colour, drop_opacity, explode
-    float* part_grad;                  // [n][NG][PP]
-    float* part_loss;                  // [n][NG][4]
+    float* part_grad;                  // [n][NW][PP]
+    float* part_loss;                  // [n][NW][4]
     float* dbg_depth; float* dbg_rgb; float* dbg_opacity; float* dbg_var;   // [n][R](,3) or null
 };
 
@@ -173,6 +175,28 @@ __device__ __forceinline__ void add_db(float* gb, const float (&dyF)[16], int p3
     if (hi == 0) wv::lds_add(gb + p31, s);
 }
 
+// sin and cos of a float32 argument, ~1.5 ulp, branch-free; valid for |x| < 2^20 (the encoding's arguments are
+// 2^f * pi * proj with |proj| of a few units).  Cody-Waite reduction by pi/2 in three float32 pieces with FMAs,
+// then the classic degree-7/8 minimax polynomials on [-pi/4, pi/4].  Replaces the library sincosf, whose
+// inlined Payne-Hanek path costs ~100 instructions per call site; tiles that do hold a larger argument take
+// the library path instead (decided once per wave, see kSinCosFastLimit).
+constexpr float kSinCosFastLimit = 1048576.0f;
+__device__ __forceinline__ void sincos_f32(float x, float& s, float& c) {
+    const float n = rintf(x * 0.636619772367581343f);              // x * 2/pi
+    float r = fmaf(-n, 1.57079637050628662109375f, x);             // pi/2 = C1 + C2 + C3
+    r = fmaf(-n, -4.37113900018624283e-8f, r);
+    r = fmaf(-n, -1.71512449026012451e-15f, r);
+    const int q = (int)n & 3;
+    const float r2 = r * r;
+    const float sp = fmaf(r * r2, fmaf(r2, fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f), r);
+    const float cp = fmaf(r2 * r2, fmaf(r2, fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f),
+                                        4.166664568298827e-2f), fmaf(r2, -0.5f, 1.0f));
+    const float ss = (q & 1) ? cp : sp;
+    const float cc = (q & 1) ? sp : cp;
+    s = (q & 2) ? -ss : ss;
+    c = ((q + 1) & 2) ? -cc : cc;
+}
+
 // One embedding slot.  c = index into the 129-wide encoding (embedding.py:85-89: 3 + f*21 + d), or -1 = padding.
 __device__ __forceinline__ void pe_slot(int c, const float (&t)[3], const float (&proj)[kDirs],
                                         float& pre, float& tv, float& fac) {
@@ -188,7 +212,7 @@ __device__ __forceinline__ void pe_slot(int c, const float (&t)[3], const float 
 }
 // One 32-feature block of the encoding in P-form (+ cos * pi * 2^f for the backward).  base = first encoding
 // index of this group (0 for e1, 87 for e2), limit = width of the group, kb = block within the group.
-template <int NSTEPS>
+template <int NSTEPS, bool BIG>
 __device__ __forceinline__ void pe_block(float (&e)[16], float (&cf)[16], int base, int limit, int kb,
                                          const float (&t)[3], const float (&proj)[kDirs], int hi) {
 #pragma unroll
@@ -204,7 +228,7 @@ __device__ __forceinline__ void pe_block(float (&e)[16], float (&cf)[16], int ba
             if (c0 >= 3 || c1 >= 3) {
                 const float arg = (hi ? pre1 : pre0) * kPi;    // fl32(xb * fl32(pi)), embedding.py:88
                 float s, c;
-                sincosf(arg, &s, &c);
+                if (BIG) sincosf(arg, &s, &c); else sincos_f32(arg, s, c);
                 const float v0 = c0 >= 3 ? s : tv0, v1 = c1 >= 3 ? s : tv1;
                 e[r] = hi ? v1 : v0;
                 cf[r] = c * (hi ? fac1 : fac0);
@@ -239,12 +263,17 @@ __global__ __launch_bounds__(kWG) void step_prep(const StepArgs a) {
     float* lds = wv::lds_base();   // 3 * kWG ints worth
     int* cnt = reinterpret_cast<int*>(lds);
     const int tid = threadIdx.x;
+    const int step = blockIdx.x;                       // one workgroup per optimisation step of the frame
+    const unsigned char* sem = a.sem + step * a.prep_ray_step * a.sem_sr;
+    const unsigned char* dmask = a.dmask + step * a.prep_ray_step * a.dm_sr;
+    float* stats = a.stats + (long long)step * a.n_obj * 4;
+    int* flags = a.flags + step * 4;
     int drop_d = 0, drop_c = 0, drop_o = 0;
     for (int k = 0; k < a.n_obj; ++k) {
         int nd = 0, no = 0, ns = 0;
         for (int r = tid; r < a.R; r += kWG) {
-            const unsigned char s = a.sem[k * a.sem_so + r * a.sem_sr];
-            const unsigned char dm = a.dmask[k * a.dm_so + r * a.dm_sr];
+            const unsigned char s = sem[k * a.sem_so + r * a.sem_sr];
+            const unsigned char dm = dmask[k * a.dm_so + r * a.dm_sr];
             const int mo = s != 0, ms = s != 2;
             nd += (dm != 0) && mo;
             no += mo;
@@ -263,15 +292,15 @@ __global__ __launch_bounds__(kWG) void step_prep(const StepArgs a) {
         nd = cnt[0]; no = cnt[kWG]; ns = cnt[2 * kWG];
         __syncthreads();
         if (tid == 0) {
-            a.stats[k * 4 + 0] = 1.0f / ((float)nd + 1e-10f);   // render_rays.py:87
-            a.stats[k * 4 + 1] = 1.0f / ((float)no + 1e-10f);
-            a.stats[k * 4 + 2] = 1.0f / ((float)ns + 1e-10f);
-            a.stats[k * 4 + 3] = 0.0f;
+            stats[k * 4 + 0] = 1.0f / ((float)nd + 1e-10f);   // render_rays.py:87
+            stats[k * 4 + 1] = 1.0f / ((float)no + 1e-10f);
+            stats[k * 4 + 2] = 1.0f / ((float)ns + 1e-10f);
+            stats[k * 4 + 3] = 0.0f;
         }
         drop_d |= nd == 0; drop_c |= no == 0; drop_o |= ns == 0;
     }
     if (tid == 0) {
-        a.flags[0] = drop_d; a.flags[1] = drop_c; a.flags[2] = drop_o; a.flags[3] = 0;
+        flags[0] = drop_d; flags[1] = drop_c; flags[2] = drop_o; flags[3] = 0;
     }
 }
 
@@ -286,7 +315,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
     float* W = lds + L::WGT;
     float* Gd = lds + L::GRD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p31 = lane & 31, hi = lane >> 5;
-    const int obj = blockIdx.x / a.NG, grp = blockIdx.x - obj * a.NG;
+    const int obj = blockIdx.x / a.NW, wgo = blockIdx.x - obj * a.NW;
 
     // ---- stage this object's parameters into LDS, clear the gradient image and the composite buffer ----
     stage_matrix<H, kEmb1, L::LD_IN>(W + L::W_IN, a.fc[0].p + obj * a.fc[0].stride, tid);
@@ -316,7 +345,15 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
     if (BWD) {
         for (int i = tid; i < L::IMG; i += kWG) Gd[i] = 0.0f;
     }
-    for (int i = tid; i < kMaxPts * 8 + 4; i += kWG) lds[L::CB + i] = 0.0f;   // composite buffer + loss cell
+    if (tid < 4) lds[L::LOSS + tid] = 0.0f;
+    float* scrX = lds + L::SCR + wave * L::SCR_WAVE;
+    float* scrD = scrX + 32 * 33;
+    float* cb = lds + L::CB;
+    const float* cbw = cb + wave * 32 * 8;       // this wave's 32 rows of the composite buffer
+
+    for (int grp = wgo; grp < a.NG; grp += a.NW) {   // ---- one pass = up to kMaxPts points (whole rays) ----
+    __syncthreads();                                 // previous pass finished reading the composite buffer
+    for (int i = tid; i < kMaxPts * 8; i += kWG) cb[i] = 0.0f;   // padding rows must read as zero
     __syncthreads();
 
     // ---- this lane's sample point ----
@@ -349,11 +386,22 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
             const float* b = W + L::PE_B + 3 * d;
             proj[d] = fmaf(t[2], b[2], fmaf(t[1], b[1], t[0] * b[0]));   // embedding.py:84 B_layer(tensor)
         }
-        pe_block<16>(e1a, c1a, 0, kEmb1, 0, t, proj, hi);
-        pe_block<16>(e1b, c1b, 0, kEmb1, 1, t, proj, hi);
-        pe_block<12>(e1c, c1c, 0, kEmb1, 2, t, proj, hi);
-        pe_block<16>(e2a, c2a, kEmb1, kEmb2, 0, t, proj, hi);
-        pe_block<6>(e2b, c2b, kEmb1, kEmb2, 1, t, proj, hi);
+        float amax = 0.0f;
+#pragma unroll
+        for (int d = 0; d < kDirs; ++d) amax = fmaxf(amax, fabsf(proj[d]));
+        if (!wv::wave_any(!(amax * (32.0f * kPi) < kSinCosFastLimit))) {
+            pe_block<16, false>(e1a, c1a, 0, kEmb1, 0, t, proj, hi);
+            pe_block<16, false>(e1b, c1b, 0, kEmb1, 1, t, proj, hi);
+            pe_block<12, false>(e1c, c1c, 0, kEmb1, 2, t, proj, hi);
+            pe_block<16, false>(e2a, c2a, kEmb1, kEmb2, 0, t, proj, hi);
+            pe_block<6, false>(e2b, c2b, kEmb1, kEmb2, 1, t, proj, hi);
+        } else {   // cold: some point of this tile is absurdly far from its object (or not finite)
+            pe_block<16, true>(e1a, c1a, 0, kEmb1, 0, t, proj, hi);
+            pe_block<16, true>(e1b, c1b, 0, kEmb1, 1, t, proj, hi);
+            pe_block<12, true>(e1c, c1c, 0, kEmb1, 2, t, proj, hi);
+            pe_block<16, true>(e2a, c2a, kEmb1, kEmb2, 0, t, proj, hi);
+            pe_block<6, true>(e2b, c2b, kEmb1, kEmb2, 1, t, proj, hi);
+        }
     }
 
     // ---- field MLP forward (model.py:59-83) ----
@@ -394,7 +442,6 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
         fwd_mm<6>(acc, w + H + 32, e2b);
         relu_to(hc, acc);                                        // :81 color_linear
     }
-    float* cb = lds + L::CB;
     {
         float ra = 0.0f, r0 = 0.0f, r1 = 0.0f, r2 = 0.0f;
 #pragma unroll
@@ -483,16 +530,8 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
         }
     }
     __syncthreads();
-    if (tid == 0) {
-        float* pl = a.part_loss + (obj * a.NG + grp) * 4;
-        pl[0] = lds[L::LOSS + 0]; pl[1] = lds[L::LOSS + 1]; pl[2] = lds[L::LOSS + 2]; pl[3] = 0.0f;
-    }
-    if (!BWD) return;
-
+    if (BWD) {
     // ---- backward ----
-    float* scrX = lds + L::SCR + wave * L::SCR_WAVE;
-    float* scrD = scrX + 32 * 33;
-    const float* cbw = cb + wave * 32 * 8;       // this wave's 32 rows of d raw (pad rows are zero)
     float d_raw = 0.0f, d_c0 = 0.0f, d_c1 = 0.0f, d_c2 = 0.0f;
     {
         const float* row = cb + pt * 8;          // pt < kMaxPts always
@@ -651,10 +690,17 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
             }
         }
     }
+    }   // BWD
+    }   // pass loop
     __syncthreads();
+    if (tid == 0) {
+        float* pl = a.part_loss + (obj * a.NW + wgo) * 4;
+        pl[0] = lds[L::LOSS + 0]; pl[1] = lds[L::LOSS + 1]; pl[2] = lds[L::LOSS + 2]; pl[3] = 0.0f;
+    }
+    if (!BWD) return;
 
     // ---- write this workgroup's partial gradients in the natural flat order ----
-    float* out = a.part_grad + ((long long)(obj * a.NG + grp)) * a.PP;
+    float* out = a.part_grad + ((long long)(obj * a.NW + wgo)) * a.PP;
     unstage_matrix<H, kEmb1, L::LD_IN>(out, Gd + L::W_IN, tid);            out += H * kEmb1;
     if (tid < H) out[tid] = Gd[L::B_IN + tid];                             out += H;
     unstage_matrix<H, H, L::LD_M>(out, Gd + L::W_M1, tid);                 out += H * H;
@@ -678,7 +724,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
 // (loss.py:59-60) and the "loss explode" flag (render_rays.py:88-90).
 // ---------------------------------------------------------------------------------------------------------
 struct FinalizeArgs {
-    int n_obj, NG, PP, P;              // P = real parameter count per object (flat order: 14 field tensors, then B)
+    int n_obj, NW, PP, P;              // NW partials per object; P = real parameter count per object (flat order: 14 field tensors, then B)
     int offs[kNFc + 2];                // flat start offset of each tensor, offs[15] = P
     TensorRef param[kNFc + 1];         // parameters (updated in place when do_adam)
     TensorRef grad[kNFc + 1];          // gradient outputs (p may be null: skip)
@@ -688,17 +734,19 @@ struct FinalizeArgs {
     float* loss_out;                   // [1]
     float color_w, opac_w;
     int do_adam;
-    float lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2_sqrt;
+    int have_grad;                     // 0: forward-only call, skip the gradient/optimiser part
+    // AdamW constants, evaluated by the host in double and rounded once (as torch's Python-side scalars are)
+    float decay, one_minus_beta1, beta2, one_minus_beta2, eps, step_size, bias_corr2_sqrt;
 };
 
 __global__ __launch_bounds__(kWG) void step_finalize(const FinalizeArgs a) {
     const int blocks_per_obj = (a.P + kWG - 1) / kWG;
     const int obj = blockIdx.x / blocks_per_obj;
     const int i = (blockIdx.x - obj * blocks_per_obj) * kWG + threadIdx.x;
-    if (obj < a.n_obj && i < a.P) {
-        const float* pg = a.part_grad + (long long)obj * a.NG * a.PP + i;
+    if (a.have_grad && obj < a.n_obj && i < a.P) {
+        const float* pg = a.part_grad + (long long)obj * a.NW * a.PP + i;
         float g = 0.0f;
-        for (int q = 0; q < a.NG; ++q) g += pg[(long long)q * a.PP];
+        for (int q = 0; q < a.NW; ++q) g += pg[(long long)q * a.PP];
         int t = 0;
 #pragma unroll
         for (int k = 1; k <= kNFc; ++k) t += i >= a.offs[k];
@@ -708,11 +756,11 @@ __global__ __launch_bounds__(kWG) void step_finalize(const FinalizeArgs a) {
             float* pp = a.param[t].p + obj * a.param[t].stride + o;
             const long long s = (long long)obj * a.PP + i;
             float p = *pp, m = a.m[s], v = a.v[s];
-            p = p * (1.0f - a.lr * a.weight_decay);                       // param.mul_(1 - lr * wd)
-            m = m + (g - m) * (1.0f - a.beta1);                           // exp_avg.lerp_(grad, 1 - beta1)
-            v = v * a.beta2 + (g * g) * (1.0f - a.beta2);                 // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
+            p = p * a.decay;                                              // param.mul_(1 - lr * wd)
+            m = m + (g - m) * a.one_minus_beta1;                          // exp_avg.lerp_(grad, 1 - beta1)
+            v = v * a.beta2 + (g * g) * a.one_minus_beta2;                // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
             const float denom = sqrtf(v) / a.bias_corr2_sqrt + a.eps;
-            p = p - (a.lr / a.bias_corr1) * (m / denom);                  // param.addcdiv_(exp_avg, denom, -step_size)
+            p = p - a.step_size * (m / denom);                            // param.addcdiv_(exp_avg, denom, -lr / bc1)
             *pp = p; a.m[s] = m; a.v[s] = v;
         }
     }
@@ -721,8 +769,8 @@ __global__ __launch_bounds__(kWG) void step_finalize(const FinalizeArgs a) {
         int explode = 0;
         for (int k = 0; k < a.n_obj; ++k) {
             float ld = 0.0f, lc = 0.0f, lo = 0.0f;
-            for (int q = 0; q < a.NG; ++q) {
-                const float* pl = a.part_loss + ((long long)k * a.NG + q) * 4;
+            for (int q = 0; q < a.NW; ++q) {
+                const float* pl = a.part_loss + ((long long)k * a.NW + q) * 4;
                 ld += pl[0]; lc += pl[1]; lo += pl[2];
             }
             explode |= (ld > 100000.0f) || (lc > 100000.0f) || (lo > 100000.0f);   // render_rays.py:88

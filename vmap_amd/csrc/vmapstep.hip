@@ -1,0 +1,334 @@
+// vmapstep.hip - C ABI (include/vmapstep.h) over the fused step kernels; gfx950 only.
+//
+// Host side of the drop-in boundary: validates shapes, lays out the caller-provided workspace, fills the
+// kernel argument blocks and enqueues   step_prep -> (step_main_h32 -> step_finalize) x n_steps   on the
+// caller's stream.  Never allocates, never synchronises.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/vmapstep.h"
+#include "step_kernels.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+int g_nw_override = 0;
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+constexpr size_t kAlign = 256;
+size_t align_up(size_t x) { return (x + kAlign - 1) / kAlign * kAlign; }
+
+struct Layout {
+    int64_t sizes[15];
+    int offs[16];
+    int P, PP;
+};
+void make_layout(int H, Layout& L) {
+    const int64_t s[15] = {(int64_t)H * 87, H, (int64_t)H * H, H, (int64_t)H * (H + 87), H, (int64_t)H * H, H,
+                           H, 1, (int64_t)H * (H + 42), H, 3 * H, 3, 63};
+    int o = 0;
+    for (int t = 0; t < 15; ++t) { L.sizes[t] = s[t]; L.offs[t] = o; o += (int)s[t]; }
+    L.offs[15] = o;
+    L.P = o;
+    L.PP = (o + 63) / 64 * 64;
+}
+
+struct Plan {
+    int G, NG, NW;
+    size_t off_stats, off_flags, off_ploss, off_pgrad, total;
+};
+
+int make_plan(const vmapstep_shape* sh, int max_steps, Plan& pl, const Layout& L) {
+    if (!sh) return fail(VMAPSTEP_ERR_ARGUMENT, "shape is null");
+    if (sh->n_obj < 1 || sh->rays < 1 || sh->samples < 1 || max_steps < 1)
+        return fail(VMAPSTEP_ERR_ARGUMENT, "bad shape n=%d R=%d S=%d steps=%d", sh->n_obj, sh->rays, sh->samples, max_steps);
+    if (sh->hidden != 32)
+        return fail(VMAPSTEP_ERR_UNSUPPORTED, "hidden=%d: the fused kernel implements hidden=32", sh->hidden);
+    if (sh->samples > vk::kMaxPts)
+        return fail(VMAPSTEP_ERR_UNSUPPORTED, "samples=%d > %d", sh->samples, vk::kMaxPts);
+    pl.G = vk::kMaxPts / sh->samples;
+    if (pl.G > sh->rays) pl.G = sh->rays;
+    pl.NG = (sh->rays + pl.G - 1) / pl.G;
+    int nw = g_nw_override > 0 ? g_nw_override : 256 / sh->n_obj;
+    if (nw < 1) nw = 1;
+    if (nw > pl.NG) nw = pl.NG;
+    pl.NW = nw;
+    size_t o = 0;
+    pl.off_stats = o; o += align_up((size_t)max_steps * sh->n_obj * 4 * sizeof(float));
+    pl.off_flags = o; o += align_up((size_t)max_steps * 4 * sizeof(int));
+    pl.off_ploss = o; o += align_up((size_t)sh->n_obj * pl.NG * 4 * sizeof(float));     // sized for NW = NG
+    pl.off_pgrad = o; o += align_up((size_t)sh->n_obj * pl.NG * L.PP * sizeof(float));
+    pl.total = o;
+    return VMAPSTEP_OK;
+}
+
+int check_params(const vmapstep_params* p, const char* what, bool allow_null_entries) {
+    if (!p) return fail(VMAPSTEP_ERR_ARGUMENT, "%s is null", what);
+    for (int t = 0; t < VMAPSTEP_NUM_FC; ++t)
+        if (!p->fc[t].ptr && !allow_null_entries) return fail(VMAPSTEP_ERR_ARGUMENT, "%s.fc[%d] is null", what, t);
+    if (!p->pe_B.ptr && !allow_null_entries) return fail(VMAPSTEP_ERR_ARGUMENT, "%s.pe_B is null", what);
+    return VMAPSTEP_OK;
+}
+
+int check_batch(const vmapstep_batch* b) {
+    if (!b) return fail(VMAPSTEP_ERR_ARGUMENT, "batch is null");
+    if (!b->pcs || !b->z || !b->gt_depth || !b->gt_rgb || !b->sem || !b->depth_mask)
+        return fail(VMAPSTEP_ERR_ARGUMENT, "batch has a null tensor");
+    return VMAPSTEP_OK;
+}
+
+void fill_step_args(vk::StepArgs& a, const vmapstep_shape* sh, const Plan& pl, const Layout& L,
+                    const vmapstep_params* params, const vmapstep_tensor* pe_scale, const vmapstep_batch* b,
+                    int64_t ray0, float cw, float ow, char* ws) {
+    std::memset(&a, 0, sizeof(a));
+    a.n_obj = sh->n_obj; a.R = sh->rays; a.S = sh->samples;
+    a.G = pl.G; a.NG = pl.NG; a.NW = pl.NW; a.PP = L.PP;
+    for (int t = 0; t < VMAPSTEP_NUM_FC; ++t) a.fc[t] = {params->fc[t].ptr, params->fc[t].obj_stride};
+    a.pe_B = {params->pe_B.ptr, params->pe_B.obj_stride};
+    a.pe_scale = {pe_scale->ptr, pe_scale->obj_stride};
+    a.pcs = b->pcs + ray0 * b->pcs_stride[1];
+    a.pcs_so = b->pcs_stride[0]; a.pcs_sr = b->pcs_stride[1]; a.pcs_ss = b->pcs_stride[2]; a.pcs_sc = b->pcs_stride[3];
+    a.z = b->z + ray0 * b->z_stride[1];
+    a.z_so = b->z_stride[0]; a.z_sr = b->z_stride[1]; a.z_ss = b->z_stride[2];
+    a.gt_depth = b->gt_depth + ray0 * b->gt_depth_stride[1];
+    a.gd_so = b->gt_depth_stride[0]; a.gd_sr = b->gt_depth_stride[1];
+    a.gt_rgb = b->gt_rgb + ray0 * b->gt_rgb_stride[1];
+    a.rgb_so = b->gt_rgb_stride[0]; a.rgb_sr = b->gt_rgb_stride[1]; a.rgb_sc = b->gt_rgb_stride[2];
+    a.sem = b->sem + ray0 * b->sem_stride[1];
+    a.sem_so = b->sem_stride[0]; a.sem_sr = b->sem_stride[1];
+    a.dmask = b->depth_mask + ray0 * b->depth_mask_stride[1];
+    a.dm_so = b->depth_mask_stride[0]; a.dm_sr = b->depth_mask_stride[1];
+    a.color_w = cw; a.opac_w = ow;
+    a.stats = reinterpret_cast<float*>(ws + pl.off_stats);
+    a.flags = reinterpret_cast<int*>(ws + pl.off_flags);
+    a.part_loss = reinterpret_cast<float*>(ws + pl.off_ploss);
+    a.part_grad = reinterpret_cast<float*>(ws + pl.off_pgrad);
+}
+
+template <bool BWD>
+int launch_main(const vk::StepArgs& a, hipStream_t st) {
+    static bool attr_set = false;
+    auto kern = vk::step_main_h32<BWD>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, vk::Lds32::BYTES);
+        if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.n_obj * a.NW), dim3(vk::kWG), vk::Lds32::BYTES, st, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "step_main launch: %s", hipGetErrorString(e));
+    return VMAPSTEP_OK;
+}
+
+int launch_prep(const vk::StepArgs& a, int n_steps, hipStream_t st) {
+    hipLaunchKernelGGL(vk::step_prep, dim3(n_steps), dim3(vk::kWG), 3 * vk::kWG * sizeof(int), st, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "step_prep launch: %s", hipGetErrorString(e));
+    return VMAPSTEP_OK;
+}
+
+int launch_finalize(const vk::StepArgs& a, const Layout& L, const vmapstep_params* params, const vmapstep_params* grads,
+                    const vmapstep_adamw* opt, int step_after, bool have_grad, float* loss_out, int* flags_out,
+                    hipStream_t st) {
+    vk::FinalizeArgs f;
+    std::memset(&f, 0, sizeof(f));
+    f.n_obj = a.n_obj; f.NW = a.NW; f.PP = L.PP; f.P = L.P;
+    for (int t = 0; t < 16; ++t) f.offs[t] = L.offs[t];
+    for (int t = 0; t < 15; ++t) {
+        const vmapstep_tensor* pt = t < 14 ? &params->fc[t] : &params->pe_B;
+        f.param[t] = {pt->ptr, pt->obj_stride};
+        if (grads) {
+            const vmapstep_tensor* gt = t < 14 ? &grads->fc[t] : &grads->pe_B;
+            f.grad[t] = {gt->ptr, gt->obj_stride};
+        }
+    }
+    f.part_grad = a.part_grad; f.part_loss = a.part_loss;
+    f.flags_in = a.flags; f.flags_out = flags_out; f.loss_out = loss_out;
+    f.color_w = a.color_w; f.opac_w = a.opac_w;
+    f.have_grad = have_grad ? 1 : 0;
+    f.do_adam = (opt && have_grad) ? 1 : 0;
+    if (f.do_adam) {
+        f.m = opt->exp_avg; f.v = opt->exp_avg_sq;
+        const double lr = opt->lr, b1 = opt->beta1, b2 = opt->beta2, wd = opt->weight_decay;
+        f.decay = (float)(1.0 - lr * wd);
+        f.one_minus_beta1 = (float)(1.0 - b1);
+        f.beta2 = opt->beta2;
+        f.one_minus_beta2 = (float)(1.0 - b2);
+        f.eps = opt->eps;
+        f.step_size = (float)(lr / (1.0 - std::pow(b1, (double)step_after)));
+        f.bias_corr2_sqrt = (float)std::sqrt(1.0 - std::pow(b2, (double)step_after));
+    }
+    const int bpo = (L.P + vk::kWG - 1) / vk::kWG;
+    const int grid = have_grad ? a.n_obj * bpo : 1;
+    hipLaunchKernelGGL(vk::step_finalize, dim3(grid), dim3(vk::kWG), 0, st, f);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "step_finalize launch: %s", hipGetErrorString(e));
+    return VMAPSTEP_OK;
+}
+
+int check_ws(void* ws, size_t bytes, const Plan& pl) {
+    if (!ws) return fail(VMAPSTEP_ERR_WORKSPACE, "workspace is null");
+    if (reinterpret_cast<uintptr_t>(ws) % kAlign) return fail(VMAPSTEP_ERR_WORKSPACE, "workspace not 256-byte aligned");
+    if (bytes < pl.total) return fail(VMAPSTEP_ERR_WORKSPACE, "workspace %zu < required %zu bytes", bytes, pl.total);
+    return VMAPSTEP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* vmapstep_last_error(void) { return g_err; }
+int vmapstep_abi_version(void) { return VMAPSTEP_ABI_VERSION; }
+
+int vmapstep_set_workgroups_per_object(int32_t nw) {
+    int old = g_nw_override;
+    g_nw_override = nw > 0 ? nw : 0;
+    return old;
+}
+
+int vmapstep_param_layout(int32_t hidden, int64_t sizes[VMAPSTEP_NUM_FC + 1], int64_t* params, int64_t* padded_params) {
+    if (hidden < 1) return fail(VMAPSTEP_ERR_ARGUMENT, "hidden=%d", hidden);
+    Layout L;
+    make_layout(hidden, L);
+    if (sizes) for (int t = 0; t < 15; ++t) sizes[t] = L.sizes[t];
+    if (params) *params = L.P;
+    if (padded_params) *padded_params = L.PP;
+    return VMAPSTEP_OK;
+}
+
+int vmapstep_workspace_bytes(const vmapstep_shape* shape, int32_t max_steps, size_t* bytes) {
+    if (!bytes) return fail(VMAPSTEP_ERR_ARGUMENT, "bytes is null");
+    if (!shape) return fail(VMAPSTEP_ERR_ARGUMENT, "shape is null");
+    Layout L;
+    make_layout(shape->hidden, L);
+    Plan pl;
+    int rc = make_plan(shape, max_steps, pl, L);
+    if (rc) return rc;
+    *bytes = pl.total;
+    return VMAPSTEP_OK;
+}
+
+int vmapstep_fwd_bwd(const vmapstep_shape* shape, const vmapstep_params* params, const vmapstep_tensor* pe_scale,
+                     const vmapstep_batch* batch, float color_scaling, float opacity_scaling,
+                     const vmapstep_params* grads, const vmapstep_outputs* out,
+                     void* workspace, size_t workspace_bytes, void* stream) {
+    int rc;
+    if (!shape) return fail(VMAPSTEP_ERR_ARGUMENT, "shape is null");
+    Layout L;
+    make_layout(shape->hidden, L);
+    Plan pl;
+    if ((rc = make_plan(shape, 1, pl, L))) return rc;
+    if ((rc = check_params(params, "params", false))) return rc;
+    if ((rc = check_params(grads, "grads", true))) return rc;
+    if ((rc = check_batch(batch))) return rc;
+    if (!pe_scale || !pe_scale->ptr) return fail(VMAPSTEP_ERR_ARGUMENT, "pe_scale is null");
+    if (!out || !out->loss || !out->flags) return fail(VMAPSTEP_ERR_ARGUMENT, "outputs.loss / outputs.flags are required");
+    if ((rc = check_ws(workspace, workspace_bytes, pl))) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    vk::StepArgs a;
+    fill_step_args(a, shape, pl, L, params, pe_scale, batch, 0, color_scaling, opacity_scaling, static_cast<char*>(workspace));
+    a.prep_steps = 1; a.prep_ray_step = 0;
+    a.dbg_depth = out->render_depth; a.dbg_rgb = out->render_color; a.dbg_opacity = out->opacity; a.dbg_var = out->var;
+    if ((rc = launch_prep(a, 1, st))) return rc;
+    if ((rc = launch_main<true>(a, st))) return rc;
+    return launch_finalize(a, L, params, grads, nullptr, 0, true, out->loss, out->flags, st);
+}
+
+int vmapstep_render(const vmapstep_shape* shape, const vmapstep_params* params, const vmapstep_tensor* pe_scale,
+                    const vmapstep_batch* batch, float color_scaling, float opacity_scaling,
+                    const vmapstep_outputs* out, void* workspace, size_t workspace_bytes, void* stream) {
+    int rc;
+    if (!shape) return fail(VMAPSTEP_ERR_ARGUMENT, "shape is null");
+    Layout L;
+    make_layout(shape->hidden, L);
+    Plan pl;
+    if ((rc = make_plan(shape, 1, pl, L))) return rc;
+    if ((rc = check_params(params, "params", false))) return rc;
+    if ((rc = check_batch(batch))) return rc;
+    if (!pe_scale || !pe_scale->ptr) return fail(VMAPSTEP_ERR_ARGUMENT, "pe_scale is null");
+    if (!out || !out->loss || !out->flags) return fail(VMAPSTEP_ERR_ARGUMENT, "outputs.loss / outputs.flags are required");
+    if ((rc = check_ws(workspace, workspace_bytes, pl))) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    vk::StepArgs a;
+    fill_step_args(a, shape, pl, L, params, pe_scale, batch, 0, color_scaling, opacity_scaling, static_cast<char*>(workspace));
+    a.prep_steps = 1; a.prep_ray_step = 0;
+    a.dbg_depth = out->render_depth; a.dbg_rgb = out->render_color; a.dbg_opacity = out->opacity; a.dbg_var = out->var;
+    if ((rc = launch_prep(a, 1, st))) return rc;
+    if ((rc = launch_main<false>(a, st))) return rc;
+    return launch_finalize(a, L, params, nullptr, nullptr, 0, false, out->loss, out->flags, st);
+}
+
+int vmapstep_train_steps(const vmapstep_shape* shape, const vmapstep_params* params, const vmapstep_tensor* pe_scale,
+                         const vmapstep_batch* frame, int64_t ray_step, int32_t n_steps,
+                         float color_scaling, float opacity_scaling, const vmapstep_adamw* opt,
+                         const vmapstep_params* grads, const vmapstep_outputs* out,
+                         void* workspace, size_t workspace_bytes, void* stream) {
+    int rc;
+    if (!shape) return fail(VMAPSTEP_ERR_ARGUMENT, "shape is null");
+    if (n_steps < 1) return fail(VMAPSTEP_ERR_ARGUMENT, "n_steps=%d", n_steps);
+    Layout L;
+    make_layout(shape->hidden, L);
+    Plan pl;
+    if ((rc = make_plan(shape, n_steps, pl, L))) return rc;
+    if ((rc = check_params(params, "params", false))) return rc;
+    if (grads && (rc = check_params(grads, "grads", true))) return rc;
+    if ((rc = check_batch(frame))) return rc;
+    if (!pe_scale || !pe_scale->ptr) return fail(VMAPSTEP_ERR_ARGUMENT, "pe_scale is null");
+    if (!opt || !opt->exp_avg || !opt->exp_avg_sq) return fail(VMAPSTEP_ERR_ARGUMENT, "optimiser state is required");
+    if (!out || !out->loss || !out->flags) return fail(VMAPSTEP_ERR_ARGUMENT, "outputs.loss / outputs.flags are required");
+    if ((rc = check_ws(workspace, workspace_bytes, pl))) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    char* ws = static_cast<char*>(workspace);
+    vk::StepArgs a;
+    fill_step_args(a, shape, pl, L, params, pe_scale, frame, 0, color_scaling, opacity_scaling, ws);
+    a.prep_steps = n_steps; a.prep_ray_step = ray_step;
+    if ((rc = launch_prep(a, n_steps, st))) return rc;
+    for (int i = 0; i < n_steps; ++i) {
+        fill_step_args(a, shape, pl, L, params, pe_scale, frame, (int64_t)i * ray_step, color_scaling, opacity_scaling, ws);
+        a.stats += (size_t)i * shape->n_obj * 4;
+        a.flags += (size_t)i * 4;
+        const bool last = i == n_steps - 1;
+        if (last) { a.dbg_depth = out->render_depth; a.dbg_rgb = out->render_color; a.dbg_opacity = out->opacity; a.dbg_var = out->var; }
+        if ((rc = launch_main<true>(a, st))) return rc;
+        if ((rc = launch_finalize(a, L, params, last ? grads : nullptr, opt, opt->step + i + 1, true,
+                                  out->loss + i, out->flags + 4 * i, st))) return rc;
+    }
+    return VMAPSTEP_OK;
+}
+
+int vmapstep_profile_main_kernel(const vmapstep_shape* shape, const vmapstep_params* params,
+                                 const vmapstep_tensor* pe_scale, const vmapstep_batch* batch, int32_t reps,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+    int rc;
+    if (!shape) return fail(VMAPSTEP_ERR_ARGUMENT, "shape is null");
+    Layout L;
+    make_layout(shape->hidden, L);
+    Plan pl;
+    if ((rc = make_plan(shape, 1, pl, L))) return rc;
+    if ((rc = check_params(params, "params", false))) return rc;
+    if ((rc = check_batch(batch))) return rc;
+    if (!pe_scale || !pe_scale->ptr) return fail(VMAPSTEP_ERR_ARGUMENT, "pe_scale is null");
+    if ((rc = check_ws(workspace, workspace_bytes, pl))) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    vk::StepArgs a;
+    fill_step_args(a, shape, pl, L, params, pe_scale, batch, 0, 5.0f, 10.0f, static_cast<char*>(workspace));
+    a.prep_steps = 1; a.prep_ray_step = 0;
+    if ((rc = launch_prep(a, 1, st))) return rc;
+    for (int i = 0; i < reps; ++i)
+        if ((rc = launch_main<true>(a, st))) return rc;
+    return VMAPSTEP_OK;
+}
+
+}  // extern "C"

@@ -24,6 +24,9 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 // value held by the partner lane in the other 32-lane half of the wave (lane ^ 32)
 __device__ __forceinline__ float swap_half(float x) { return __shfl_xor(x, 32); }
 
+// true on every lane iff pred holds on at least one lane of the wave (wave-uniform result)
+__device__ __forceinline__ bool wave_any(bool pred) { return __any(pred) != 0; }
+
 // Orders this wave's earlier LDS writes before its later LDS reads (data exchanged between lanes of ONE
 // wave through a wave-private LDS region).  A wave's DS instructions execute in order, so no hardware
 // barrier is needed - only the compiler must not move accesses across this point.

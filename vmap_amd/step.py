@@ -1,0 +1,206 @@
+"""Host side of the fused per-object training step: PyTorch tensors in, HIP kernels via the C ABI.
+
+Drop-in for the call triple of the reference step loop (train.py:293-294 forward, :303-306 loss, :324
+backward) and, through ``train_steps``, for the whole 20-iteration loop of one frame including the AdamW
+update (train.py:270-326).  PyTorch is plumbing here (device memory, current stream); all arithmetic runs in
+``libvmapstep.so``.  There is no fallback path: a missing library or an unsupported shape raises.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib, layout
+
+
+def _obj_dense(t: torch.Tensor) -> bool:
+    return t.dim() == 1 or t[0].is_contiguous()
+
+
+class StepResult:
+    """What one fused step produced (device tensors; nothing is synchronised)."""
+
+    def __init__(self, loss, flags, render_depth=None, render_color=None, opacity=None, var=None):
+        self.loss = loss                # [n_steps] float32
+        self.flags = flags              # [n_steps, 4] int32: drop_depth, drop_colour, drop_opacity, explode
+        self.render_depth, self.render_color, self.opacity, self.var = render_depth, render_color, opacity, var
+
+
+class FusedAdamWState:
+    """Optimiser state of one stacked ensemble: moments as [n, padded_params] slabs + the step count.
+
+    A fresh state (zeros, step 0) is what the reference gets whenever ``update_vmap`` re-stacks the objects
+    and adds a new param group (utils.py:33): Adam moments restart - preserved here on purpose.
+    """
+
+    def __init__(self, n_obj: int, hidden: int, device, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.013):
+        self.padded = (layout.param_count(hidden) + 63) // 64 * 64
+        self.exp_avg = torch.zeros(n_obj, self.padded, dtype=torch.float32, device=device)
+        self.exp_avg_sq = torch.zeros_like(self.exp_avg)
+        self.step = 0
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+
+    def c_struct(self) -> _lib.AdamW:
+        return _lib.AdamW(self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step,
+                          self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr())
+
+
+class VmapStep:
+    """The fused step operator for a fixed (n_obj, rays, samples, hidden) problem shape."""
+
+    def __init__(self, n_obj: int, rays: int, samples: int, hidden: int, device="cuda:0", max_steps: int = 32,
+                 color_scaling: float = 5.0, opacity_scaling: float = 10.0):
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.VmapStepError("VmapStep runs on the GPU only (no CPU fallback)")
+        self.shape = _lib.Shape(n_obj, rays, samples, hidden)
+        self.n_obj, self.rays, self.samples, self.hidden = n_obj, rays, samples, hidden
+        self.max_steps = max_steps
+        self.color_scaling, self.opacity_scaling = float(color_scaling), float(opacity_scaling)
+        nbytes = ctypes.c_size_t(0)
+        _lib.check(self.lib.vmapstep_workspace_bytes(ctypes.byref(self.shape), max_steps, ctypes.byref(nbytes)))
+        self.workspace = torch.empty(nbytes.value + 256, dtype=torch.uint8, device=self.device)
+        off = (-self.workspace.data_ptr()) % 256
+        self._ws_ptr = self.workspace.data_ptr() + off
+        self._ws_bytes = nbytes.value
+        self._shapes = layout.fc_shapes(hidden)
+
+    # ---- argument marshalling -------------------------------------------------------------------------
+    def _params(self, fc: Sequence[torch.Tensor], B: torch.Tensor, what="params") -> _lib.Params:
+        if len(fc) != _lib.NUM_FC:
+            raise ValueError(f"{what}: expected {_lib.NUM_FC} field tensors, got {len(fc)}")
+        p = _lib.Params()
+        for t, (x, shp) in enumerate(zip(fc, self._shapes)):
+            self._check(x, (self.n_obj,) + tuple(shp), f"{what}.fc[{t}]")
+            p.fc[t] = _lib.Tensor(x.data_ptr(), x.stride(0))
+        self._check(B, (self.n_obj,) + layout.PE_B_SHAPE, f"{what}.B")
+        p.pe_B = _lib.Tensor(B.data_ptr(), B.stride(0))
+        return p
+
+    def _check(self, x: torch.Tensor, shape, name: str):
+        if tuple(x.shape) != tuple(shape):
+            raise ValueError(f"{name}: shape {tuple(x.shape)} != {tuple(shape)}")
+        if x.dtype != torch.float32 or x.device != self.device:
+            raise ValueError(f"{name}: need float32 on {self.device}, got {x.dtype} on {x.device}")
+        if not _obj_dense(x):
+            raise ValueError(f"{name}: each object's block must be dense")
+
+    def _batch(self, pcs, z, gt_depth, gt_rgb, sem, depth_mask, rays_total: Optional[int] = None) -> _lib.Batch:
+        n, R, S = self.n_obj, (rays_total or self.rays), self.samples
+        for name, x, shp, dt in (("pcs", pcs, (n, R, S, 3), torch.float32), ("z", z, (n, R, S), torch.float32),
+                                 ("gt_depth", gt_depth, (n, R), torch.float32), ("gt_rgb", gt_rgb, (n, R, 3), torch.float32)):
+            if tuple(x.shape) != shp or x.dtype != dt or x.device != self.device:
+                raise ValueError(f"{name}: need {dt} {shp} on {self.device}, got {x.dtype} {tuple(x.shape)} on {x.device}")
+        if sem.dtype != torch.uint8 or tuple(sem.shape) != (n, R):
+            raise ValueError(f"sem: need uint8 {(n, R)}, got {sem.dtype} {tuple(sem.shape)}")
+        if depth_mask.dtype == torch.bool:
+            depth_mask = depth_mask.view(torch.uint8)      # same bytes (vmap.py:376 bool mask)
+        if depth_mask.dtype != torch.uint8 or tuple(depth_mask.shape) != (n, R):
+            raise ValueError(f"depth_mask: need bool/uint8 {(n, R)}")
+        b = _lib.Batch()
+        b.pcs, b.z, b.gt_depth, b.gt_rgb = pcs.data_ptr(), z.data_ptr(), gt_depth.data_ptr(), gt_rgb.data_ptr()
+        b.sem, b.depth_mask = sem.data_ptr(), depth_mask.data_ptr()
+        b.pcs_stride[:] = pcs.stride()
+        b.z_stride[:] = z.stride()
+        b.gt_depth_stride[:] = gt_depth.stride()
+        b.gt_rgb_stride[:] = gt_rgb.stride()
+        b.sem_stride[:] = sem.stride()
+        b.depth_mask_stride[:] = depth_mask.stride()
+        return b
+
+    def _outputs(self, n_steps: int, render: bool):
+        dev = self.device
+        loss = torch.empty(n_steps, dtype=torch.float32, device=dev)
+        flags = torch.empty(n_steps, 4, dtype=torch.int32, device=dev)
+        res = StepResult(loss, flags)
+        o = _lib.Outputs(loss.data_ptr(), flags.data_ptr(), None, None, None, None)
+        if render:
+            n, R = self.n_obj, self.rays
+            res.render_depth = torch.empty(n, R, dtype=torch.float32, device=dev)
+            res.render_color = torch.empty(n, R, 3, dtype=torch.float32, device=dev)
+            res.opacity = torch.empty(n, R, dtype=torch.float32, device=dev)
+            res.var = torch.empty(n, R, dtype=torch.float32, device=dev)
+            o.render_depth, o.render_color = res.render_depth.data_ptr(), res.render_color.data_ptr()
+            o.opacity, o.var = res.opacity.data_ptr(), res.var.data_ptr()
+        return res, o
+
+    @staticmethod
+    def _stream() -> int:
+        return torch.cuda.current_stream().cuda_stream
+
+    # ---- operators ------------------------------------------------------------------------------------
+    def fwd_bwd(self, fc, B, pe_scale, pcs, z, gt_depth, gt_rgb, sem, depth_mask, grads_fc=None, grad_B=None,
+                render: bool = False) -> StepResult:
+        """Loss + gradients of all 15 stacked tensors (train.py:293-306 + :324). Gradients are written to
+        ``grads_fc``/``grad_B`` if given, else into freshly allocated ``p.grad`` of the parameters."""
+        if grads_fc is None:
+            grads_fc = []
+            for p in list(fc) + [B]:
+                if p.grad is None:
+                    p.grad = torch.empty_like(p)
+                grads_fc.append(p.grad)
+            grad_B = grads_fc.pop()
+        pp = self._params(fc, B)
+        gp = self._params(grads_fc, grad_B, "grads")
+        sc = _lib.Tensor(pe_scale.data_ptr(), pe_scale.stride(0) if pe_scale.dim() else 0)
+        bt = self._batch(pcs, z, gt_depth, gt_rgb, sem, depth_mask)
+        res, out = self._outputs(1, render)
+        _lib.check(self.lib.vmapstep_fwd_bwd(ctypes.byref(self.shape), ctypes.byref(pp), ctypes.byref(sc),
+                                             ctypes.byref(bt), self.color_scaling, self.opacity_scaling,
+                                             ctypes.byref(gp), ctypes.byref(out), self._ws_ptr, self._ws_bytes,
+                                             self._stream()))
+        return res
+
+    def render(self, fc, B, pe_scale, pcs, z, gt_depth, gt_rgb, sem, depth_mask) -> StepResult:
+        """Forward + loss only: rendered depth / colour / opacity / variance (loss.py:24-31)."""
+        pp = self._params(fc, B)
+        sc = _lib.Tensor(pe_scale.data_ptr(), pe_scale.stride(0) if pe_scale.dim() else 0)
+        bt = self._batch(pcs, z, gt_depth, gt_rgb, sem, depth_mask)
+        res, out = self._outputs(1, True)
+        _lib.check(self.lib.vmapstep_render(ctypes.byref(self.shape), ctypes.byref(pp), ctypes.byref(sc),
+                                            ctypes.byref(bt), self.color_scaling, self.opacity_scaling,
+                                            ctypes.byref(out), self._ws_ptr, self._ws_bytes, self._stream()))
+        return res
+
+    def profile_main_kernel(self, fc, B, pe_scale, pcs, z, gt_depth, gt_rgb, sem, depth_mask, reps: int) -> float:
+        """Average duration (ms) of one launch of the dominant kernel, timed with events on the current stream."""
+        pp = self._params(fc, B)
+        sc = _lib.Tensor(pe_scale.data_ptr(), pe_scale.stride(0) if pe_scale.dim() else 0)
+        bt = self._batch(pcs, z, gt_depth, gt_rgb, sem, depth_mask)
+        args = (ctypes.byref(self.shape), ctypes.byref(pp), ctypes.byref(sc), ctypes.byref(bt))
+        _lib.check(self.lib.vmapstep_profile_main_kernel(*args, 3, self._ws_ptr, self._ws_bytes, self._stream()))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        _lib.check(self.lib.vmapstep_profile_main_kernel(*args, reps, self._ws_ptr, self._ws_bytes, self._stream()))
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    def train_steps(self, fc, B, pe_scale, pcs, z, gt_depth, gt_rgb, sem, depth_mask, opt: FusedAdamWState,
+                    n_steps: int, ray_step: Optional[int] = None, grads_fc=None, grad_B=None,
+                    render: bool = False) -> StepResult:
+        """The step loop of one frame (train.py:270-326): step i trains on rays [i*ray_step, i*ray_step+R) of the
+        per-frame tensors ([n, rays_total, ...]) and applies the fused AdamW update in place."""
+        if n_steps > self.max_steps:
+            raise ValueError(f"n_steps={n_steps} > max_steps={self.max_steps} this operator was sized for")
+        ray_step = self.rays if ray_step is None else int(ray_step)
+        rays_total = pcs.shape[1]
+        if (n_steps - 1) * ray_step + self.rays > rays_total:
+            raise ValueError(f"frame tensors hold {rays_total} rays, need {(n_steps - 1) * ray_step + self.rays}")
+        pp = self._params(fc, B)
+        gp = self._params(grads_fc, grad_B, "grads") if grads_fc is not None else None
+        sc = _lib.Tensor(pe_scale.data_ptr(), pe_scale.stride(0) if pe_scale.dim() else 0)
+        bt = self._batch(pcs, z, gt_depth, gt_rgb, sem, depth_mask, rays_total=rays_total)
+        res, out = self._outputs(n_steps, render)
+        oc = opt.c_struct()
+        _lib.check(self.lib.vmapstep_train_steps(ctypes.byref(self.shape), ctypes.byref(pp), ctypes.byref(sc),
+                                                 ctypes.byref(bt), ray_step, n_steps, self.color_scaling,
+                                                 self.opacity_scaling, ctypes.byref(oc),
+                                                 ctypes.byref(gp) if gp is not None else None, ctypes.byref(out),
+                                                 self._ws_ptr, self._ws_bytes, self._stream()))
+        opt.step += n_steps
+        return res

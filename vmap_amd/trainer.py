@@ -1,0 +1,71 @@
+"""Per-object model holder with the reference's attribute surface (trainer.py:9-33).
+
+``Trainer(cfg)`` exposes ``fc_occ_map``, ``pe``, ``obj_scale``, ``device``, ``hidden_feature_size``, ``obj_id``
+and ``bound_extent`` so that code written against the reference's ``sceneObject.trainer`` keeps working.
+``cfg`` is any object with the attributes the reference's ``cfg.Config`` provides (cfg.py:6-91).
+Mesh extraction (trainer.py:35-75) is outside the hot path and not provided; ``eval_points`` is.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import fields, layout
+
+
+class Trainer:
+    def __init__(self, cfg):
+        self.obj_id = cfg.obj_id
+        self.device = cfg.training_device
+        self.hidden_feature_size = cfg.hidden_feature_size
+        self.obj_scale = cfg.obj_scale
+        self.n_unidir_funcs = cfg.n_unidir_funcs
+        self.emb_size1 = layout.EMB1
+        self.emb_size2 = layout.EMB2
+        self.load_network()
+        self.bound_extent = 0.995 if self.obj_id == 0 else 0.9      # trainer.py:21-24
+
+    def load_network(self):
+        self.fc_occ_map = fields.OccupancyMap(self.emb_size1, self.emb_size2, hidden_size=self.hidden_feature_size)
+        self.fc_occ_map.apply(fields.init_weights).to(self.device)
+        self.pe = fields.UniDirsEmbed(max_deg=self.n_unidir_funcs, scale=self.obj_scale).to(self.device)
+
+    @torch.no_grad()
+    def eval_points(self, points: torch.Tensor, chunk_size: int = 100000):
+        """Occupancy and colour at arbitrary points of this object's frame (trainer.py:77-95)."""
+        alphas, colors = [], []
+        for k in range(0, points.shape[0], chunk_size):
+            a, c = self.fc_occ_map(self.pe(points[k:k + chunk_size]))
+            alphas.append(a.squeeze(-1))
+            colors.append(c)
+        occ = torch.sigmoid(torch.cat(alphas))
+        if occ.max() == 0:
+            return None
+        return occ, torch.cat(colors)
+
+
+class SimpleConfig:
+    """The subset of cfg.Config (cfg.py) the hot path reads, with the Replica room0 vMAP values as defaults."""
+
+    def __init__(self, **kw):
+        self.obj_id = -1
+        self.training_device = "cuda:0"
+        self.data_device = "cuda:0"
+        self.training_strategy = "hip"        # third option next to the reference's "vmap" / "forloop" (cfg.py:20)
+        self.hidden_feature_size = 32
+        self.hidden_feature_size_bg = 128
+        self.obj_scale = 2.0
+        self.bg_scale = 5.0
+        self.n_unidir_funcs = 5
+        self.n_per_optim = 120
+        self.n_per_optim_bg = 1200
+        self.n_iter_per_frame = 20
+        self.win_size = 5
+        self.n_samples_per_frame = self.n_per_optim // self.win_size
+        self.n_bins_cam2surface = 1
+        self.n_bins_cam2surface_bg = 5
+        self.n_bins = 9
+        self.learning_rate = 1e-3
+        self.weight_decay = 0.013
+        self.do_bg = False
+        for k, v in kw.items():
+            setattr(self, k, v)
