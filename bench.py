@@ -1,0 +1,176 @@
+"""bench.py - training rays/sec of the fused per-object step on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path over one synthetic batch already resident in HBM: encoding + field MLP
+forward + compositing + loss + backward + fused AdamW for every object (train.py:293-326 without the data
+plumbing).  Workload at N=1: BASELINE configs[1] (20 objects x 4-layer/32-hidden MLP, 120 rays/object, 10
+samples/ray, fp32).  N>1: weak scaling - every rank owns its own 20 objects (objects are independent units,
+no data-path collective); value = rays of all ranks / max-over-ranks time.
+
+Rank 0 prints ONE JSON line with the contract fields plus
+  roofline     - the dominant kernel (step_main_h32) against the fp32 MFMA peak, timed live with events
+  cpu_baseline - the PyTorch-CPU port of the oracle timed on this host's cores (reported, not a target)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+from vmap_amd import layout, step, synth
+
+FP32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(cfg, budget_s=18.0):
+    """Oracle port (PyTorch CPU) on the same workload; ~budget_s of CPU work in total.  The step is ~400 small
+    ATen ops, so it does not scale with the host's core count: a few thread counts are tried and the best kept."""
+    from oracle import vmap_oracle_torch as vt          # checker/baseline only - never on the product path
+    ncpu = os.cpu_count() or 1
+    fc, B, sc = synth.make_params(cfg["n_obj"], cfg["H"], scale=cfg["scale"], seed=0)
+    batch = synth.make_batch(cfg["n_obj"], cfg["R"], cfg["S"], seed=1)
+    rays = cfg["n_obj"] * cfg["R"]
+    best = None
+    cands = sorted({min(ncpu, t) for t in (8, 16, 32)})
+    for threads in cands:
+        torch.set_num_threads(threads)
+        tr = vt.CpuTrainer(fc, B, sc)
+        for _ in range(2):
+            tr.step(batch)
+        t0 = time.perf_counter()
+        n = 0
+        while True:
+            tr.step(batch)
+            n += 1
+            el = time.perf_counter() - t0
+            if el > budget_s / len(cands) or n >= 1000:
+                break
+        r = {"value": rays * n / el, "unit": "rays/s", "cores": threads, "kind": "port",
+             "sample": f"{n} full steps (fwd+loss+bwd+AdamW) of the same workload, torch CPU {threads} threads of "
+                       f"{ncpu} host CPUs, {el / n * 1e3:.2f} ms/step"}
+        if best is None or r["value"] > best["value"]:
+            best = r
+    return best
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--config", default="replica_room0_vmap", choices=list(synth.CONFIGS))
+    ap.add_argument("--iters-per-frame", type=int, default=20)       # config: render.iters_per_frame
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-reps", type=int, default=200)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+    dist = world > 1
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if dist:
+        import torch.distributed as td
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        td.init_process_group("nccl", device_id=dev)
+
+    cfg = synth.CONFIGS[args.config]
+    n, R, S, H = cfg["n_obj"], cfg["R"], cfg["S"], cfg["H"]
+    ipf = args.iters_per_frame
+    # every rank owns its own objects (weak scaling): different seeds per rank, same shapes
+    fc, B, sc = synth.make_params(n, H, scale=cfg["scale"], seed=1000 * rank)
+    frame = synth.make_batch(n, R * ipf, S, seed=1000 * rank + 1)        # [n, iters*R, ...] like train.py:255-260
+    tfc = [torch.from_numpy(a).to(dev) for a in fc]
+    tB, tsc = torch.from_numpy(B).to(dev), torch.from_numpy(sc).to(dev)
+    fr = {k: torch.from_numpy(v).to(dev) for k, v in frame.items()}
+    op = step.VmapStep(n, R, S, H, device=dev, max_steps=ipf)
+    opt = step.FusedAdamWState(n, H, dev, lr=1e-3, weight_decay=0.013)
+    fargs = (fr["pcs"], fr["z"], fr["gt_depth"], fr["gt_rgb"], fr["sem"], fr["depth_mask"])
+
+    def run(n_steps):
+        done = 0
+        while done < n_steps:
+            k = min(ipf, n_steps - done)
+            op.train_steps(tfc, tB, tsc, *fargs, opt=opt, n_steps=k)
+            done += k
+
+    def barrier():
+        if dist:
+            td.barrier()
+        torch.cuda.synchronize()
+
+    run(args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    run(args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    rays_per_step = n * R * world
+    value = rays_per_step / (elapsed / args.steps)
+
+    out = None
+    if rank == 0:
+        # ---- dominant kernel, timed live on the launch stream ----
+        b0 = tuple(x[:, :R] for x in fargs)
+        k_ms = op.profile_main_kernel(tfc, tB, tsc, *b0, reps=args.profile_reps)
+        flops = layout.step_flops(n, R, S, H)
+        abytes = layout.step_bytes(n, R, S, H)
+        achieved = flops / (k_ms * 1e-3) / 1e12
+        # forward+backward only (no optimiser), same loop structure
+        gfc = [torch.zeros_like(t) for t in tfc]
+        gB = torch.zeros_like(tB)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(100):
+            op.fwd_bwd(tfc, tB, tsc, *b0, grads_fc=gfc, grad_B=gB)
+        torch.cuda.synchronize()
+        fb_ms = (time.perf_counter() - t1) / 100 * 1e3
+        out = {
+            "metric": "training rays/sec (all objects) per step", "value": value, "unit": "rays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config}: {n} objects/GPU x 4-layer/{H}-hidden MLP, {R} rays/object, "
+                                   f"{S} samples/ray, fwd+loss+bwd+fused AdamW, {ipf} steps per frame call",
+                       "objects_per_gpu": n, "rays_per_object": R, "samples_per_ray": S, "hidden": H,
+                       "parallelism": f"objects sharded over {world} GPU(s), no data-path collective"},
+            "roofline": {"bound": "mfma", "kernel": "step_main_h32<true>", "achieved": achieved,
+                         "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
+                         "traffic": None, "kernel_ms": k_ms, "algorithmic_flops_per_launch": flops,
+                         "algorithmic_bytes_per_launch": abytes,
+                         "hbm_achieved_GBs": abytes / (k_ms * 1e-3) / 1e9,
+                         "hbm_frac": abytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "fwd_bwd_only": {"ms_per_step_host_launched": fb_ms, "rays_per_s": n * R / (fb_ms * 1e-3)},
+        }
+    if dist:
+        td.barrier()
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(out), flush=True)
+    if dist:
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

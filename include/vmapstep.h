@@ -132,6 +132,14 @@ int vmapstep_profile_main_kernel(const vmapstep_shape* shape, const vmapstep_par
                                  const vmapstep_tensor* pe_scale, const vmapstep_batch* batch, int32_t reps,
                                  void* workspace, size_t workspace_bytes, void* stream);
 
+/* Diagnostics: one forward+backward launch with in-kernel shader-clock stamps. timing receives
+ * [workgroups][4 waves][16 marks] uint32 (s_memtime low word) and *n_workgroups the launch's grid size;
+ * timing_elems is the capacity of the buffer in uint32 elements. */
+int vmapstep_profile_phases(const vmapstep_shape* shape, const vmapstep_params* params,
+                            const vmapstep_tensor* pe_scale, const vmapstep_batch* batch,
+                            uint32_t* timing, size_t timing_elems, int32_t* n_workgroups,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
 /* Tuning knob (0 = automatic): workgroups per object of the fused kernel. Returns the previous value. */
 int vmapstep_set_workgroups_per_object(int32_t nw);
 

@@ -23,7 +23,7 @@ def forward_loss(fc, B, scale, pcs, z, gt_depth, gt_rgb, sem, depth_mask, color_
     n, R, S, _ = pcs.shape
     t = (pcs / scale.view(n, 1, 1, 1)).reshape(n, R * S, 3)
     proj = torch.bmm(t, B.transpose(1, 2))                                   # [n,M,21]
-    bands = 2.0 ** torch.arange(6, dtype=pcs.dtype)
+    bands = 2.0 ** torch.arange(6, dtype=pcs.dtype, device=pcs.device)
     xb = (proj.unsqueeze(-2) * bands.view(1, 1, 6, 1)).reshape(n, R * S, 126)
     emb = torch.cat((t, torch.sin(xb * math.pi)), dim=-1)
     e1, e2 = emb[..., :87], emb[..., 87:]
@@ -36,7 +36,7 @@ def forward_loss(fc, B, scale, pcs, z, gt_depth, gt_rgb, sem, depth_mask, color_
     color = torch.sigmoid(_lin(hc, fc[12], fc[13])).reshape(n, R, S, 3)
     occ = torch.sigmoid(alpha)
     free = (1.0 - occ + 1e-10)[..., :-1]
-    T = torch.cumprod(torch.cat((torch.ones(n, R, 1, dtype=pcs.dtype), free), -1), -1)
+    T = torch.cumprod(torch.cat((torch.ones(n, R, 1, dtype=pcs.dtype, device=pcs.device), free), -1), -1)
     w = occ * T
     D = (w * z).sum(-1)
     V = (w * (z - D.unsqueeze(-1)) ** 2).sum(-1).detach()
@@ -48,7 +48,7 @@ def forward_loss(fc, B, scale, pcs, z, gt_depth, gt_rgb, sem, depth_mask, color_
     def reduce(mat, mask, var=None):                                         # render_rays.py:67-96
         cnt = mask.sum(-1)
         if (cnt == 0).any():
-            return torch.zeros(n, dtype=pcs.dtype)
+            return torch.zeros(n, dtype=pcs.dtype, device=pcs.device)
         if var is not None:
             mat = mat * (1.0 / (torch.sqrt(var) + 1e-4))
         return mat.sum(-1) / (cnt + 1e-10)
@@ -63,14 +63,16 @@ def forward_loss(fc, B, scale, pcs, z, gt_depth, gt_rgb, sem, depth_mask, color_
 class CpuTrainer:
     """fwd + loss + backward + AdamW on CPU tensors (train.py:293-326 without the data plumbing)."""
 
-    def __init__(self, fc_np, B_np, scale_np, lr=1e-3, weight_decay=0.013):
-        self.fc = [torch.from_numpy(a.copy()).requires_grad_() for a in fc_np]
-        self.B = torch.from_numpy(B_np.copy()).requires_grad_()
-        self.scale = torch.from_numpy(scale_np.copy())
+    def __init__(self, fc_np, B_np, scale_np, lr=1e-3, weight_decay=0.013, device="cpu"):
+        self.device = torch.device(device)
+        self.fc = [torch.from_numpy(a.copy()).to(self.device).requires_grad_() for a in fc_np]
+        self.B = torch.from_numpy(B_np.copy()).to(self.device).requires_grad_()
+        self.scale = torch.from_numpy(scale_np.copy()).to(self.device)
         self.opt = torch.optim.AdamW(self.fc + [self.B], lr=lr, weight_decay=weight_decay)
 
     def step(self, batch, update=True):
-        args = [torch.from_numpy(batch[k]) for k in ("pcs", "z", "gt_depth", "gt_rgb", "sem", "depth_mask")]
+        args = [batch[k] if torch.is_tensor(batch[k]) else torch.from_numpy(batch[k]).to(self.device)
+                for k in ("pcs", "z", "gt_depth", "gt_rgb", "sem", "depth_mask")]
         loss, rend = forward_loss(self.fc, self.B, self.scale, *args)
         if loss.requires_grad:
             loss.backward()
@@ -78,4 +80,4 @@ class CpuTrainer:
         if update:
             self.opt.step()
         self.opt.zero_grad(set_to_none=True)
-        return float(loss), rend, grads
+        return loss.detach(), rend, grads

@@ -52,6 +52,8 @@ inline void wave_lds_fence() { sim::wave_barrier(); }
 
 inline float* lds_base() { return reinterpret_cast<float*>(sim::g_block->lds.data()); }
 
+inline unsigned clock32() { return (unsigned)sim::g_yields; }
+
 inline void lds_add(float* p, float v) { *p += v; }
 
 }  // namespace wv

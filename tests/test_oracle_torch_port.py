@@ -13,6 +13,7 @@ def test_torch_port_matches_reference(name):
     g = load_golden(name)
     tr = vt.CpuTrainer(c["fc"], c["B"], c["scale"])
     loss, rend, grads = tr.step(c["batch"], update=False)
+    loss = float(loss)
     assert abs(loss - float(g["loss"])) <= 2e-5 * abs(float(g["loss"]))
     for k in RENDER_KEYS:
         assert relerr(rend[k].detach().numpy(), g[k]) < 2e-5, k

@@ -1,0 +1,40 @@
+"""Measurement tool: in-kernel phase breakdown of step_main_h32 (shader clocks) for a BASELINE config."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from vmap_amd import step, synth  # noqa: E402
+
+NAMES = ["start", "staged+cb zeroed", "encoding", "mlp fwd (5 layers)", "heads+cb write", "barrier B", "composite+barrier C",
+         "bwd heads + dW colour", "bwd d4 + d e2", "bwd mid2", "bwd cat", "bwd mid1", "bwd in + enc", "bwd dB",
+         "final barrier", "partials written"]
+name = sys.argv[1] if len(sys.argv) > 1 else "replica_room0_vmap"
+cfg = synth.CONFIGS[name]
+n, R, S, H = cfg["n_obj"], cfg["R"], cfg["S"], cfg["H"]
+fc, B, sc = synth.make_params(n, H, scale=cfg["scale"], seed=0)
+batch = synth.make_batch(n, R, S, seed=1)
+dev = "cuda:0"
+tfc = [torch.from_numpy(a).to(dev) for a in fc]
+tB, tsc = torch.from_numpy(B).to(dev), torch.from_numpy(sc).to(dev)
+tb = {k: torch.from_numpy(v).to(dev) for k, v in batch.items()}
+op = step.VmapStep(n, R, S, H, device=dev)
+args = (tfc, tB, tsc, tb["pcs"], tb["z"], tb["gt_depth"], tb["gt_rgb"], tb["sem"], tb["depth_mask"])
+for _ in range(3):
+    t = op.profile_phases(*args)
+t = op.profile_phases(*args).astype(np.float64)          # [WG, 4 waves, 16]
+d = np.diff(t, axis=-1)
+print(f"config {name}: {t.shape[0]} workgroups; kernel span {t.max():.0f} clocks; per-phase clocks (median / p90 / max over waves)")
+tot = 0.0
+for i in range(15):
+    x = d[:, :, i].ravel()
+    print(f"  {i:2d}->{i+1:2d} {NAMES[i+1]:26s} {np.median(x):9.0f} {np.quantile(x, 0.9):9.0f} {x.max():9.0f}")
+    tot += np.median(x)
+print(f"  sum of medians {tot:.0f}; wave-0 first stamp spread across WGs {np.ptp(t[:, 0, 0]):.0f}; "
+      f"last stamp median {np.median(t[:, :, 15]):.0f} max {t[:, :, 15].max():.0f}")
+json.dump({"config": name, "median": np.median(d.reshape(-1, 15), axis=0).tolist(), "names": NAMES[1:]},
+          open(os.path.join(ROOT, "gpurun_out", f"phases_{name}.json"), "w"))

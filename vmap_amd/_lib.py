@@ -53,7 +53,7 @@ class AdamW(ctypes.Structure):
 EXPORTS = (
     "vmapstep_last_error", "vmapstep_abi_version", "vmapstep_param_layout", "vmapstep_workspace_bytes",
     "vmapstep_fwd_bwd", "vmapstep_render", "vmapstep_train_steps", "vmapstep_set_workgroups_per_object",
-    "vmapstep_profile_main_kernel",
+    "vmapstep_profile_main_kernel", "vmapstep_profile_phases",
 )
 
 _lib = None
@@ -92,9 +92,14 @@ def load():
     lib.vmapstep_profile_main_kernel.argtypes = [ctypes.POINTER(Shape), ctypes.POINTER(Params), ctypes.POINTER(Tensor),
                                                  ctypes.POINTER(Batch), ctypes.c_int32, ctypes.c_void_p,
                                                  ctypes.c_size_t, ctypes.c_void_p]
+    lib.vmapstep_profile_phases.argtypes = [ctypes.POINTER(Shape), ctypes.POINTER(Params), ctypes.POINTER(Tensor),
+                                            ctypes.POINTER(Batch), ctypes.c_void_p, ctypes.c_size_t,
+                                            ctypes.POINTER(ctypes.c_int32), ctypes.c_void_p, ctypes.c_size_t,
+                                            ctypes.c_void_p]
     lib.vmapstep_set_workgroups_per_object.argtypes = [ctypes.c_int32]
     for fn in ("vmapstep_param_layout", "vmapstep_workspace_bytes", "vmapstep_fwd_bwd", "vmapstep_render",
-               "vmapstep_train_steps", "vmapstep_set_workgroups_per_object", "vmapstep_profile_main_kernel"):
+               "vmapstep_train_steps", "vmapstep_set_workgroups_per_object", "vmapstep_profile_main_kernel",
+               "vmapstep_profile_phases"):
         getattr(lib, fn).restype = ctypes.c_int
     if lib.vmapstep_abi_version() != ABI_VERSION:
         raise VmapStepError(f"ABI mismatch: library {lib.vmapstep_abi_version()} != binding {ABI_VERSION}")

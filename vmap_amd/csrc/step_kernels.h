@@ -36,6 +36,7 @@ constexpr int kNFc = 14;
 constexpr int kWG = 256;
 constexpr int kWaves = 4;
 constexpr int kMaxPts = 128;   // sample points per workgroup (4 tiles of 32)
+constexpr int kMarks = 16;     // phase timestamps per wave when StepArgs::timing is set
 constexpr float kPi = 3.14159274101257324f;   // float32(np.pi), embedding.py:88
 
 struct TensorRef {
@@ -63,6 +64,7 @@ struct StepArgs {
     float* part_grad;                  // [n][NW][PP]
     float* part_loss;                  // [n][NW][4]
     float* dbg_depth; float* dbg_rgb; float* dbg_opacity; float* dbg_var;   // [n][R](,3) or null
+    unsigned* timing;                  // optional [workgroups][kWaves][kMarks] shader-clock stamps (diagnostics)
 };
 
 __device__ __forceinline__ constexpr int phi(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
@@ -316,6 +318,9 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
     float* Gd = lds + L::GRD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p31 = lane & 31, hi = lane >> 5;
     const int obj = blockIdx.x / a.NW, wgo = blockIdx.x - obj * a.NW;
+    unsigned* tmark = a.timing ? a.timing + ((long long)blockIdx.x * kWaves + wave) * kMarks : nullptr;
+#define VK_MARK(i) do { if (tmark && lane == 0) tmark[i] = wv::clock32(); } while (0)
+    VK_MARK(0);
 
     // ---- stage this object's parameters into LDS, clear the gradient image and the composite buffer ----
     stage_matrix<H, kEmb1, L::LD_IN>(W + L::W_IN, a.fc[0].p + obj * a.fc[0].stride, tid);
@@ -355,6 +360,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
     __syncthreads();                                 // previous pass finished reading the composite buffer
     for (int i = tid; i < kMaxPts * 8; i += kWG) cb[i] = 0.0f;   // padding rows must read as zero
     __syncthreads();
+    VK_MARK(1);
 
     // ---- this lane's sample point ----
     const int ray0 = grp * a.G;
@@ -404,6 +410,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
         }
     }
 
+    VK_MARK(2);
     // ---- field MLP forward (model.py:59-83) ----
     float h1[16], h2[16], h3[16], h4[16], hc[16];
     f32x16 acc;
@@ -442,6 +449,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
         fwd_mm<6>(acc, w + H + 32, e2b);
         relu_to(hc, acc);                                        // :81 color_linear
     }
+    VK_MARK(3);
     {
         float ra = 0.0f, r0 = 0.0f, r1 = 0.0f, r2 = 0.0f;
 #pragma unroll
@@ -462,7 +470,9 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
             row[3] = sigmoidf_acc(r2);
         }
     }
+    VK_MARK(4);
     __syncthreads();
+    VK_MARK(5);
 
     // ---- per-ray compositing, loss and d loss / d raw  (loss.py:24-60, render_rays.py:26-96) ----
     if (tid < nrays) {
@@ -530,6 +540,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
         }
     }
     __syncthreads();
+    VK_MARK(6);
     if (BWD) {
     // ---- backward ----
     float d_raw = 0.0f, d_c0 = 0.0f, d_c1 = 0.0f, d_c2 = 0.0f;
@@ -587,6 +598,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
         to_F(xF, e2b, scrX, p31, hi);
         zero_acc(acc); dw_mm(acc, dF, xF); add_dw<L::LD_C>(Gd + L::W_C, acc, H + 32 + p31, 32 + p31 < kEmb2, hi);
     }
+    VK_MARK(7);
     // d h4 = W_a d raw + W_c[:, :H]^T d hc ; d e2 = W_c[:, H:]^T d hc
     float d4[16];
     {
@@ -602,6 +614,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
         bwd_mm<L::LD_C>(acc, W + L::W_C + 4 * hi * L::LD_C + H + min(32 + p31, 46), dcp);
         pe_block_bwd<6>(dproj, acc, c2b, kEmb1, kEmb2, 1, hi);
     }
+    VK_MARK(8);
     // mid2
     float d3[16];
     {
@@ -614,6 +627,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) d3[r] = h3[r] > 0.0f ? acc[r] : 0.0f;
     }
+    VK_MARK(9);
     // cat_layer
     float d2[16];
     f32x16 de1a, de1b, de1c;
@@ -637,6 +651,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
         zero_acc(de1b); bwd_mm<L::LD_CAT>(de1b, wc + H + 32 + p31, d3);
         zero_acc(de1c); bwd_mm<L::LD_CAT>(de1c, wc + H + min(64 + p31, 88), d3);
     }
+    VK_MARK(10);
     // mid1
     float d1[16];
     {
@@ -649,6 +664,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) d1[r] = h1[r] > 0.0f ? acc[r] : 0.0f;
     }
+    VK_MARK(11);
     // in_layer + encoding backward
     float e1aF[16];
     {
@@ -668,6 +684,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
         pe_block_bwd<16>(dproj, de1b, c1b, 0, kEmb1, 1, hi);
         pe_block_bwd<12>(dproj, de1c, c1c, 0, kEmb1, 2, hi);
     }
+    VK_MARK(12);
     // B_layer.weight gradient: dB[d][j] = sum_points dproj[d] * t[j]  (t = encoding columns 0..2)
     {
         float dpP[16];
@@ -690,9 +707,11 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
             }
         }
     }
+    VK_MARK(13);
     }   // BWD
     }   // pass loop
     __syncthreads();
+    VK_MARK(14);
     if (tid == 0) {
         float* pl = a.part_loss + (obj * a.NW + wgo) * 4;
         pl[0] = lds[L::LOSS + 0]; pl[1] = lds[L::LOSS + 1]; pl[2] = lds[L::LOSS + 2]; pl[3] = 0.0f;
@@ -716,6 +735,8 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
     if (tid < 3 * H) out[tid] = Gd[L::W_OC + tid];                         out += 3 * H;
     if (tid < 3) out[tid] = Gd[L::B_OC + tid];                             out += 3;
     if (tid < 63) out[tid] = Gd[L::PE_B + tid];
+    VK_MARK(15);
+#undef VK_MARK
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -764,10 +785,13 @@ __global__ __launch_bounds__(kWG) void step_finalize(const FinalizeArgs a) {
             *pp = p; a.m[s] = m; a.v[s] = v;
         }
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (blockIdx.x == 0) {
+        // per-object loss terms: thread q sums object q, q+256, ... ; then a block reduction (loss.py:59-60)
+        float* red = wv::lds_base();       // kWG floats + kWG ints
+        int* redi = reinterpret_cast<int*>(red + kWG);
         float loss = 0.0f;
         int explode = 0;
-        for (int k = 0; k < a.n_obj; ++k) {
+        for (int k = threadIdx.x; k < a.n_obj; k += kWG) {
             float ld = 0.0f, lc = 0.0f, lo = 0.0f;
             for (int q = 0; q < a.NW; ++q) {
                 const float* pl = a.part_loss + ((long long)k * a.NW + q) * 4;
@@ -776,9 +800,21 @@ __global__ __launch_bounds__(kWG) void step_finalize(const FinalizeArgs a) {
             explode |= (ld > 100000.0f) || (lc > 100000.0f) || (lo > 100000.0f);   // render_rays.py:88
             loss += ld + lc * a.color_w + lo * a.opac_w;                            // loss.py:59
         }
-        a.loss_out[0] = loss;                                                       // loss.py:60
-        a.flags_out[0] = a.flags_in[0]; a.flags_out[1] = a.flags_in[1]; a.flags_out[2] = a.flags_in[2];
-        a.flags_out[3] = explode;
+        red[threadIdx.x] = loss;
+        redi[threadIdx.x] = explode;
+        __syncthreads();
+        for (int w = kWG / 2; w > 0; w >>= 1) {
+            if ((int)threadIdx.x < w) {
+                red[threadIdx.x] += red[threadIdx.x + w];
+                redi[threadIdx.x] |= redi[threadIdx.x + w];
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            a.loss_out[0] = red[0];                                                 // loss.py:60
+            a.flags_out[0] = a.flags_in[0]; a.flags_out[1] = a.flags_in[1]; a.flags_out[2] = a.flags_in[2];
+            a.flags_out[3] = redi[0];
+        }
     }
 }
 

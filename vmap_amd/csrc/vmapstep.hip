@@ -172,7 +172,7 @@ int launch_finalize(const vk::StepArgs& a, const Layout& L, const vmapstep_param
     }
     const int bpo = (L.P + vk::kWG - 1) / vk::kWG;
     const int grid = have_grad ? a.n_obj * bpo : 1;
-    hipLaunchKernelGGL(vk::step_finalize, dim3(grid), dim3(vk::kWG), 0, st, f);
+    hipLaunchKernelGGL(vk::step_finalize, dim3(grid), dim3(vk::kWG), 2 * vk::kWG * sizeof(float), st, f);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "step_finalize launch: %s", hipGetErrorString(e));
     return VMAPSTEP_OK;
@@ -329,6 +329,33 @@ int vmapstep_profile_main_kernel(const vmapstep_shape* shape, const vmapstep_par
     for (int i = 0; i < reps; ++i)
         if ((rc = launch_main<true>(a, st))) return rc;
     return VMAPSTEP_OK;
+}
+
+int vmapstep_profile_phases(const vmapstep_shape* shape, const vmapstep_params* params,
+                            const vmapstep_tensor* pe_scale, const vmapstep_batch* batch,
+                            uint32_t* timing, size_t timing_elems, int32_t* n_workgroups,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+    int rc;
+    if (!shape) return fail(VMAPSTEP_ERR_ARGUMENT, "shape is null");
+    Layout L;
+    make_layout(shape->hidden, L);
+    Plan pl;
+    if ((rc = make_plan(shape, 1, pl, L))) return rc;
+    if ((rc = check_params(params, "params", false))) return rc;
+    if ((rc = check_batch(batch))) return rc;
+    if (!pe_scale || !pe_scale->ptr) return fail(VMAPSTEP_ERR_ARGUMENT, "pe_scale is null");
+    if (!timing || !n_workgroups) return fail(VMAPSTEP_ERR_ARGUMENT, "timing / n_workgroups is null");
+    const size_t need = (size_t)shape->n_obj * pl.NW * vk::kWaves * vk::kMarks;
+    if (timing_elems < need) return fail(VMAPSTEP_ERR_ARGUMENT, "timing buffer %zu < %zu elements", timing_elems, need);
+    if ((rc = check_ws(workspace, workspace_bytes, pl))) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    vk::StepArgs a;
+    fill_step_args(a, shape, pl, L, params, pe_scale, batch, 0, 5.0f, 10.0f, static_cast<char*>(workspace));
+    a.prep_steps = 1; a.prep_ray_step = 0;
+    a.timing = timing;
+    *n_workgroups = shape->n_obj * pl.NW;
+    if ((rc = launch_prep(a, 1, st))) return rc;
+    return launch_main<true>(a, st);
 }
 
 }  // extern "C"

@@ -39,6 +39,9 @@ __device__ __forceinline__ void wave_lds_fence() {
 extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds_bytes[];
 __device__ __forceinline__ float* lds_base() { return reinterpret_cast<float*>(dyn_lds_bytes); }
 
+// shader-clock timestamp (low 32 bits of s_memtime)
+__device__ __forceinline__ unsigned clock32() { return (unsigned)__builtin_amdgcn_s_memtime(); }
+
 __device__ __forceinline__ void lds_add(float* p, float v) { atomicAdd(p, v); }   // ds_add_f32
 
 }  // namespace wv

@@ -180,6 +180,23 @@ class VmapStep:
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps
 
+    def profile_phases(self, fc, B, pe_scale, pcs, z, gt_depth, gt_rgb, sem, depth_mask):
+        """In-kernel phase timestamps of one forward+backward launch: int64 array [workgroups, 4, 16] (shader clocks,
+        relative to the earliest stamp)."""
+        pp = self._params(fc, B)
+        sc = _lib.Tensor(pe_scale.data_ptr(), pe_scale.stride(0) if pe_scale.dim() else 0)
+        bt = self._batch(pcs, z, gt_depth, gt_rgb, sem, depth_mask)
+        cap = self.n_obj * 64 * 4 * 16
+        buf = torch.zeros(cap, dtype=torch.int32, device=self.device)
+        nwg = ctypes.c_int32(0)
+        _lib.check(self.lib.vmapstep_profile_phases(ctypes.byref(self.shape), ctypes.byref(pp), ctypes.byref(sc),
+                                                    ctypes.byref(bt), buf.data_ptr(), cap, ctypes.byref(nwg),
+                                                    self._ws_ptr, self._ws_bytes, self._stream()))
+        torch.cuda.synchronize()
+        t = buf[: nwg.value * 64].cpu().numpy().astype("int64") & 0xFFFFFFFF
+        t = t.reshape(nwg.value, 4, 16)
+        return t - t[:, :, 0].min()
+
     def train_steps(self, fc, B, pe_scale, pcs, z, gt_depth, gt_rgb, sem, depth_mask, opt: FusedAdamWState,
                     n_steps: int, ray_step: Optional[int] = None, grads_fc=None, grad_B=None,
                     render: bool = False) -> StepResult:
