@@ -55,8 +55,10 @@ extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req,
     a.dbg_depth = dbg_depth; a.dbg_rgb = dbg_rgb; a.dbg_opacity = dbg_opacity; a.dbg_var = dbg_var;
 
     sim::launch(1, vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep(a); });
-    if (bwd) sim::launch(n * NW, vk::kWG, vk::Lds32::BYTES, [&] { vk::step_main_h32<true>(a); });
-    else     sim::launch(n * NW, vk::kWG, vk::Lds32::BYTES, [&] { vk::step_main_h32<false>(a); });
+    const bool multi = NW < NG;
+    if (bwd && multi)  sim::launch(n * NW, vk::kWG, vk::Lds32::BYTES, [&] { vk::step_main_h32<true, true>(a); });
+    if (bwd && !multi) sim::launch(n * NW, vk::kWG, vk::Lds32::BYTES, [&] { vk::step_main_h32<true, false>(a); });
+    if (!bwd)          sim::launch(n * NW, vk::kWG, vk::Lds32::BYTES, [&] { vk::step_main_h32<false, false>(a); });
 
     vk::FinalizeArgs f{};
     f.n_obj = n; f.NW = NW; f.PP = PP; f.P = P;

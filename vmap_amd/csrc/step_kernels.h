@@ -20,8 +20,8 @@
 //                                  <-> point r + 16*hi; obtained from P-form through a 32x33 LDS transpose)
 //
 // Numerics: fp32 throughout, accurate sincosf/expf/division/sqrt; the only reorderings w.r.t. the reference
-// are summation orders.  Cross-workgroup reduction of the weight gradients is a plain store of per-workgroup
-// partials followed by an ordered sum in step_finalize (no global atomics).
+// are summation orders.  Weight gradients are reduced without atomics: across the 4 waves through staged LDS
+// tiles (reduce_block), across workgroups by plain stores of partials + an ordered sum in step_finalize.
 #pragma once
 #include <wave_ops.h>   // resolved through -I: csrc/ (device) or tests/sim/ (CPU SIMT executor)
 
@@ -96,21 +96,56 @@ struct Lds32 {
     static constexpr int PE_B = B_OC + 4;         // [21][3] (+1 pad)
     static constexpr int IMG = PE_B + 64;         // floats in one parameter image
     static constexpr int WGT = 0;                 // weight image
-    static constexpr int GRD = IMG;               // gradient image (same map)
-    static constexpr int SCR = 2 * IMG;           // per-wave transpose scratch: kWaves x 2 x [32][33]
+    static constexpr int SMALL0 = B_IN;           // small vectors of the image: biases, heads, B
+    static constexpr int SMALL_N = IMG - B_IN;
+    static constexpr int SCR = IMG;               // per-wave transpose scratch: kWaves x 2 x [32][33]
     static constexpr int SCR_WAVE = 2 * 32 * 33;
-    static constexpr int CB = SCR + kWaves * SCR_WAVE;      // composite buffer [kMaxPts][8]
-    static constexpr int LOSS = CB + kMaxPts * 8;           // 4 floats
+    static constexpr int STG_TILE = 32 * 33;      // one staged 32x32 weight-gradient block
+    static constexpr int STG = SCR + kWaves * SCR_WAVE;       // 2 buffers x kWaves tiles
+    static constexpr int VEC = STG + 2 * kWaves * STG_TILE;   // per-wave private small-vector gradient accumulators
+    static constexpr int CB = VEC + kWaves * SMALL_N;         // composite buffer [kMaxPts][8]
+    static constexpr int LOSS = CB + kMaxPts * 8;             // 4 floats
     static constexpr int TOTAL = LOSS + 4;
     static constexpr int BYTES = TOTAL * 4;
 };
 
-// natural (row-major, unpadded) -> LDS image copy of one matrix, zero-filling the padding columns
+// start offsets of the tensors in the natural flat per-object order (14 field tensors, then B)
+struct Flat32 {
+    static constexpr int H = 32;
+    static constexpr int W_IN = 0, B_IN = W_IN + H * kEmb1, W_M1 = B_IN + H, B_M1 = W_M1 + H * H;
+    static constexpr int W_CAT = B_M1 + H, B_CAT = W_CAT + H * (H + kEmb1), W_M2 = B_CAT + H, B_M2 = W_M2 + H * H;
+    static constexpr int W_A = B_M2 + H, B_A = W_A + H, W_C = B_A + 1, B_C = W_C + H * (H + kEmb2);
+    static constexpr int W_OC = B_C + H, B_OC = W_OC + 3 * H, PE_B = B_OC + 3, P = PE_B + 63;
+};
+
+// natural (row-major, unpadded) -> LDS image copy of one matrix, in two halves so that the global loads of ALL
+// matrices are in flight before the first LDS store waits on one: stage_load (coalesced, fully unrolled, values
+// parked in registers) ... stage_store (scatter to the padded image, zero the padding columns).
+template <int ROWS, int COLS>
+struct StageRegs { static constexpr int IT = (ROWS * COLS + kWG - 1) / kWG; float v[IT]; };
+
+template <int ROWS, int COLS>
+__device__ __forceinline__ void stage_load(StageRegs<ROWS, COLS>& r, const float* src, int tid) {
+#pragma unroll
+    for (int k = 0; k < StageRegs<ROWS, COLS>::IT; ++k) {
+        const int i = tid + k * kWG;
+        r.v[k] = i < ROWS * COLS ? src[i] : 0.0f;
+    }
+}
 template <int ROWS, int COLS, int LD>
-__device__ __forceinline__ void stage_matrix(float* dst, const float* src, int tid) {
-    for (int i = tid; i < ROWS * LD; i += kWG) {
-        const int row = i / LD, col = i - row * LD;
-        dst[i] = col < COLS ? src[row * COLS + col] : 0.0f;
+__device__ __forceinline__ void stage_store(float* dst, const StageRegs<ROWS, COLS>& r, int tid) {
+#pragma unroll
+    for (int k = 0; k < StageRegs<ROWS, COLS>::IT; ++k) {
+        const int i = tid + k * kWG;
+        if (i < ROWS * COLS) {
+            const int row = i / COLS, col = i - row * COLS;
+            dst[row * LD + col] = r.v[k];
+        }
+    }
+    constexpr int PADC = LD - COLS;
+    for (int i = tid; i < ROWS * PADC; i += kWG) {
+        const int row = i / PADC;
+        dst[row * LD + COLS + (i - row * PADC)] = 0.0f;
     }
 }
 template <int ROWS, int COLS, int LD>
@@ -160,21 +195,48 @@ __device__ __forceinline__ void to_F(float (&F)[16], const float (&P)[16], float
 #pragma unroll
     for (int r = 0; r < 16; ++r) F[r] = scr[(r + 16 * hi) * 33 + p31];
 }
-// accumulate a dW block (lane = column k, register r <-> row phi(r,hi)) into the LDS gradient image
-template <int LD>
-__device__ __forceinline__ void add_dw(float* img, const f32x16& acc, int col, bool col_ok, int hi) {
-    if (col_ok) {
+// Cross-wave sum of one 32x32 weight-gradient block without atomics: every wave stages its partial tile
+// (lane = column k, register r <-> row phi(r,hi)), one workgroup barrier, then wave w adds rows 8w..8w+7 of the
+// four tiles (its quarter: lane (k, hi), i -> row 8w + 4hi + i) into its persistent register accumulator.
+// Consecutive blocks alternate between two staging buffers, so one barrier per block suffices.
+__device__ __forceinline__ void reduce_block(float (&q)[4], const f32x16& acc, float* stage, int wave, int p31, int hi) {
+    float* mine = stage + wave * Lds32::STG_TILE + p31;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) wv::lds_add(img + phi(r, hi) * LD + col, acc[r]);
-    }
+    for (int r = 0; r < 16; ++r) mine[phi(r, hi) * 33] = acc[r];
+    __syncthreads();
+    const float* rd = stage + (8 * wave + 4 * hi) * 33 + p31;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        q[i] += (rd[i * 33] + rd[Lds32::STG_TILE + i * 33]) + (rd[2 * Lds32::STG_TILE + i * 33] + rd[3 * Lds32::STG_TILE + i * 33]);
 }
-// bias gradient: sum over the 32 points of a tile of dY (F-form), lane = feature
+// bias gradient: sum over the 32 points of a tile of dY (F-form), lane = feature; accumulated in the wave's
+// private small-vector area (single owner lane per address -> plain read-modify-write)
 __device__ __forceinline__ void add_db(float* gb, const float (&dyF)[16], int p31, int hi) {
     float s = 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) s += dyF[r];
     s += wv::swap_half(s);
-    if (hi == 0) wv::lds_add(gb + p31, s);
+    if (hi == 0) gb[p31] += s;
+}
+// this wave's quarter of a reduced block -> natural row-major tensor (row length K), columns col0 .. col0+ncols-1
+template <int K>
+__device__ __forceinline__ void store_quarter(float* out, const float (&q)[4], int col0, int ncols, int wave, int p31, int hi) {
+    if (p31 < ncols) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) out[(8 * wave + 4 * hi + i) * K + col0 + p31] = q[i];
+    }
+}
+
+template <bool MULTI, int K>
+__device__ __forceinline__ void emit_block(float (&qp)[4], const f32x16& acc, float* stage, float* out, int col0, int ncols,
+                                           int wave, int p31, int hi) {
+    if (MULTI) {
+        reduce_block(qp, acc, stage, wave, p31, hi);
+    } else {
+        float q[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        reduce_block(q, acc, stage, wave, p31, hi);
+        store_quarter<K>(out, q, col0, ncols, wave, p31, hi);
+    }
 }
 
 // sin and cos of a float32 argument, ~1.5 ulp, branch-free; valid for |x| < 2^20 (the encoding's arguments are
@@ -309,25 +371,32 @@ __global__ __launch_bounds__(kWG) void step_prep(const StepArgs a) {
 // ---------------------------------------------------------------------------------------------------------
 // step_main_h32
 // ---------------------------------------------------------------------------------------------------------
-template <bool BWD>
+// MULTI = a workgroup covers several ray groups (NW < NG): reduced gradient quarters persist in registers over the
+// passes and are stored once at the end; otherwise (one pass per workgroup) each quarter is stored as soon as it is
+// reduced and no accumulator registers are held.
+template <bool BWD, bool MULTI>
 __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
     using L = Lds32;
     constexpr int H = 32;
     float* lds = wv::lds_base();
     float* W = lds + L::WGT;
-    float* Gd = lds + L::GRD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p31 = lane & 31, hi = lane >> 5;
+    float* Gv = lds + L::VEC + wave * L::SMALL_N - L::SMALL0;   // this wave's private small-vector gradients
     const int obj = blockIdx.x / a.NW, wgo = blockIdx.x - obj * a.NW;
     unsigned* tmark = a.timing ? a.timing + ((long long)blockIdx.x * kWaves + wave) * kMarks : nullptr;
 #define VK_MARK(i) do { if (tmark && lane == 0) tmark[i] = wv::clock32(); } while (0)
     VK_MARK(0);
 
     // ---- stage this object's parameters into LDS, clear the gradient image and the composite buffer ----
-    stage_matrix<H, kEmb1, L::LD_IN>(W + L::W_IN, a.fc[0].p + obj * a.fc[0].stride, tid);
-    stage_matrix<H, H, L::LD_M>(W + L::W_M1, a.fc[2].p + obj * a.fc[2].stride, tid);
-    stage_matrix<H, H + kEmb1, L::LD_CAT>(W + L::W_CAT, a.fc[4].p + obj * a.fc[4].stride, tid);
-    stage_matrix<H, H, L::LD_M>(W + L::W_M2, a.fc[6].p + obj * a.fc[6].stride, tid);
-    stage_matrix<H, H + kEmb2, L::LD_C>(W + L::W_C, a.fc[10].p + obj * a.fc[10].stride, tid);
+    StageRegs<H, kEmb1> rg_in;
+    StageRegs<H, H> rg_m1, rg_m2;
+    StageRegs<H, H + kEmb1> rg_cat;
+    StageRegs<H, H + kEmb2> rg_c;
+    stage_load(rg_in, a.fc[0].p + obj * a.fc[0].stride, tid);
+    stage_load(rg_m1, a.fc[2].p + obj * a.fc[2].stride, tid);
+    stage_load(rg_cat, a.fc[4].p + obj * a.fc[4].stride, tid);
+    stage_load(rg_m2, a.fc[6].p + obj * a.fc[6].stride, tid);
+    stage_load(rg_c, a.fc[10].p + obj * a.fc[10].stride, tid);
     if (tid < H) {
         W[L::B_IN + tid] = a.fc[1].p[obj * a.fc[1].stride + tid];
         W[L::B_M1 + tid] = a.fc[3].p[obj * a.fc[3].stride + tid];
@@ -347,9 +416,24 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
         const int i = tid - (4 * H + 8);
         W[L::PE_B + i] = i < 63 ? a.pe_B.p[obj * a.pe_B.stride + i] : 0.0f;
     }
+    stage_store<H, kEmb1, L::LD_IN>(W + L::W_IN, rg_in, tid);
+    stage_store<H, H, L::LD_M>(W + L::W_M1, rg_m1, tid);
+    stage_store<H, H + kEmb1, L::LD_CAT>(W + L::W_CAT, rg_cat, tid);
+    stage_store<H, H, L::LD_M>(W + L::W_M2, rg_m2, tid);
+    stage_store<H, H + kEmb2, L::LD_C>(W + L::W_C, rg_c, tid);
     if (BWD) {
-        for (int i = tid; i < L::IMG; i += kWG) Gd[i] = 0.0f;
+        for (int i = tid; i < kWaves * L::SMALL_N; i += kWG) lds[L::VEC + i] = 0.0f;
     }
+    using F = Flat32;
+    float* out = a.part_grad + ((long long)(obj * a.NW + wgo)) * a.PP;   // this workgroup's partial gradients
+    float qacc[13][4];      // MULTI only: this wave's quarter of every reduced weight-gradient block
+#pragma unroll
+    for (int b = 0; b < 13; ++b) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) qacc[b][i] = 0.0f;
+    }
+    float* stg0 = lds + L::STG;
+    float* stg1 = stg0 + kWaves * L::STG_TILE;
     if (tid < 4) lds[L::LOSS + tid] = 0.0f;
     float* scrX = lds + L::SCR + wave * L::SCR_WAVE;
     float* scrD = scrX + 32 * 33;
@@ -464,6 +548,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
         ra += W[L::B_A]; r0 += W[L::B_OC]; r1 += W[L::B_OC + 1]; r2 += W[L::B_OC + 2];
         if (valid && hi == 0) {
             float* row = cb + pt * 8;
+            row[6] = a.z[obj * a.z_so + ray * a.z_sr + smp * a.z_ss];
             row[0] = sigmoidf_acc(ra * 10.0f);                   // :77 raw*10 ; render_rays.py:6 sigmoid
             row[1] = sigmoidf_acc(r0);                           // :83 sigmoid(raw_color)
             row[2] = sigmoidf_acc(r1);
@@ -478,14 +563,13 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
     if (tid < nrays) {
         const int g = tid, rr = ray0 + g;
         float* rows = cb + g * a.S * 8;
-        const float* zp = a.z + obj * a.z_so + rr * a.z_sr;
         float T = 1.0f, D = 0.0f, O = 0.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
         for (int i = 0; i < a.S; ++i) {
             float* row = rows + i * 8;
             const float o = row[0];
             const float w = o * T;                               // render_rays.py:32 occupancy * cumprod
-            const float zi = zp[i * a.z_ss];
-            row[4] = T; row[5] = w; row[6] = zi;
+            const float zi = row[6];
+            row[4] = T; row[5] = w;
             D += w * zi; O += w;                                 // loss.py:27,31
             C0 += w * row[1]; C1 += w * row[2]; C2 += w * row[3];   // loss.py:30
             T *= (1.0f - o) + 1e-10f;                            // render_rays.py:29
@@ -571,15 +655,15 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
         ga += wv::swap_half(ga); g0 += wv::swap_half(g0); g1 += wv::swap_half(g1); g2 += wv::swap_half(g2);
         sa += wv::swap_half(sa); s0 += wv::swap_half(s0); s1 += wv::swap_half(s1); s2 += wv::swap_half(s2);
         if (hi == 0) {
-            wv::lds_add(Gd + L::W_A + p31, ga);
-            wv::lds_add(Gd + L::W_OC + p31, g0);
-            wv::lds_add(Gd + L::W_OC + H + p31, g1);
-            wv::lds_add(Gd + L::W_OC + 2 * H + p31, g2);
+            Gv[L::W_A + p31] += ga;
+            Gv[L::W_OC + p31] += g0;
+            Gv[L::W_OC + H + p31] += g1;
+            Gv[L::W_OC + 2 * H + p31] += g2;
             if (p31 == 0) {
-                wv::lds_add(Gd + L::B_A, sa);
-                wv::lds_add(Gd + L::B_OC + 0, s0);
-                wv::lds_add(Gd + L::B_OC + 1, s1);
-                wv::lds_add(Gd + L::B_OC + 2, s2);
+                Gv[L::B_A] += sa;
+                Gv[L::B_OC + 0] += s0;
+                Gv[L::B_OC + 1] += s1;
+                Gv[L::B_OC + 2] += s2;
             }
         }
         // d hc = W_oc^T d rawc, through the ReLU
@@ -591,12 +675,12 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
         }
         // color_linear weight gradient: [d hc]^T [h4 | e2]
         to_F(dF, dcp, scrD, p31, hi);
-        add_db(Gd + L::B_C, dF, p31, hi);
-        zero_acc(acc); dw_mm(acc, dF, h4F); add_dw<L::LD_C>(Gd + L::W_C, acc, p31, true, hi);
+        add_db(Gv + L::B_C, dF, p31, hi);
+        zero_acc(acc); dw_mm(acc, dF, h4F); emit_block<MULTI, H + kEmb2>(qacc[0], acc, stg0, out + F::W_C, 0, 32, wave, p31, hi);
         to_F(xF, e2a, scrX, p31, hi);
-        zero_acc(acc); dw_mm(acc, dF, xF); add_dw<L::LD_C>(Gd + L::W_C, acc, H + p31, true, hi);
+        zero_acc(acc); dw_mm(acc, dF, xF); emit_block<MULTI, H + kEmb2>(qacc[1], acc, stg1, out + F::W_C, H, 32, wave, p31, hi);
         to_F(xF, e2b, scrX, p31, hi);
-        zero_acc(acc); dw_mm(acc, dF, xF); add_dw<L::LD_C>(Gd + L::W_C, acc, H + 32 + p31, 32 + p31 < kEmb2, hi);
+        zero_acc(acc); dw_mm(acc, dF, xF); emit_block<MULTI, H + kEmb2>(qacc[2], acc, stg0, out + F::W_C, H + 32, kEmb2 - 32, wave, p31, hi);
     }
     VK_MARK(7);
     // d h4 = W_a d raw + W_c[:, :H]^T d hc ; d e2 = W_c[:, H:]^T d hc
@@ -620,8 +704,8 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
     {
         to_F(dF, d4, scrD, p31, hi);
         to_F(xF, h3, scrX, p31, hi);
-        add_db(Gd + L::B_M2, dF, p31, hi);
-        zero_acc(acc); dw_mm(acc, dF, xF); add_dw<L::LD_M>(Gd + L::W_M2, acc, p31, true, hi);
+        add_db(Gv + L::B_M2, dF, p31, hi);
+        zero_acc(acc); dw_mm(acc, dF, xF); emit_block<MULTI, H>(qacc[3], acc, stg1, out + F::W_M2, 0, 32, wave, p31, hi);
         zero_acc(acc);
         bwd_mm<L::LD_M>(acc, W + L::W_M2 + 4 * hi * L::LD_M + p31, d4);
 #pragma unroll
@@ -633,15 +717,15 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
     f32x16 de1a, de1b, de1c;
     {
         to_F(dF, d3, scrD, p31, hi);
-        add_db(Gd + L::B_CAT, dF, p31, hi);
+        add_db(Gv + L::B_CAT, dF, p31, hi);
         to_F(xF, h2, scrX, p31, hi);
-        zero_acc(acc); dw_mm(acc, dF, xF); add_dw<L::LD_CAT>(Gd + L::W_CAT, acc, p31, true, hi);
+        zero_acc(acc); dw_mm(acc, dF, xF); emit_block<MULTI, H + kEmb1>(qacc[4], acc, stg0, out + F::W_CAT, 0, 32, wave, p31, hi);
         to_F(xF, e1a, scrX, p31, hi);
-        zero_acc(acc); dw_mm(acc, dF, xF); add_dw<L::LD_CAT>(Gd + L::W_CAT, acc, H + p31, true, hi);
+        zero_acc(acc); dw_mm(acc, dF, xF); emit_block<MULTI, H + kEmb1>(qacc[5], acc, stg1, out + F::W_CAT, H, 32, wave, p31, hi);
         to_F(xF, e1b, scrX, p31, hi);
-        zero_acc(acc); dw_mm(acc, dF, xF); add_dw<L::LD_CAT>(Gd + L::W_CAT, acc, H + 32 + p31, true, hi);
+        zero_acc(acc); dw_mm(acc, dF, xF); emit_block<MULTI, H + kEmb1>(qacc[6], acc, stg0, out + F::W_CAT, H + 32, 32, wave, p31, hi);
         to_F(xF, e1c, scrX, p31, hi);
-        zero_acc(acc); dw_mm(acc, dF, xF); add_dw<L::LD_CAT>(Gd + L::W_CAT, acc, H + 64 + p31, 64 + p31 < kEmb1, hi);
+        zero_acc(acc); dw_mm(acc, dF, xF); emit_block<MULTI, H + kEmb1>(qacc[7], acc, stg1, out + F::W_CAT, H + 64, kEmb1 - 64, wave, p31, hi);
         const float* wc = W + L::W_CAT + 4 * hi * L::LD_CAT;
         zero_acc(acc);
         bwd_mm<L::LD_CAT>(acc, wc + p31, d3);
@@ -657,8 +741,8 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
     {
         to_F(dF, d2, scrD, p31, hi);
         to_F(xF, h1, scrX, p31, hi);
-        add_db(Gd + L::B_M1, dF, p31, hi);
-        zero_acc(acc); dw_mm(acc, dF, xF); add_dw<L::LD_M>(Gd + L::W_M1, acc, p31, true, hi);
+        add_db(Gv + L::B_M1, dF, p31, hi);
+        zero_acc(acc); dw_mm(acc, dF, xF); emit_block<MULTI, H>(qacc[8], acc, stg0, out + F::W_M1, 0, 32, wave, p31, hi);
         zero_acc(acc);
         bwd_mm<L::LD_M>(acc, W + L::W_M1 + 4 * hi * L::LD_M + p31, d2);
 #pragma unroll
@@ -669,13 +753,13 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
     float e1aF[16];
     {
         to_F(dF, d1, scrD, p31, hi);
-        add_db(Gd + L::B_IN, dF, p31, hi);
+        add_db(Gv + L::B_IN, dF, p31, hi);
         to_F(e1aF, e1a, scrX, p31, hi);
-        zero_acc(acc); dw_mm(acc, dF, e1aF); add_dw<L::LD_IN>(Gd + L::W_IN, acc, p31, true, hi);
+        zero_acc(acc); dw_mm(acc, dF, e1aF); emit_block<MULTI, kEmb1>(qacc[9], acc, stg1, out + F::W_IN, 0, 32, wave, p31, hi);
         to_F(xF, e1b, scrX, p31, hi);
-        zero_acc(acc); dw_mm(acc, dF, xF); add_dw<L::LD_IN>(Gd + L::W_IN, acc, 32 + p31, true, hi);
+        zero_acc(acc); dw_mm(acc, dF, xF); emit_block<MULTI, kEmb1>(qacc[10], acc, stg0, out + F::W_IN, 32, 32, wave, p31, hi);
         to_F(xF, e1c, scrX, p31, hi);
-        zero_acc(acc); dw_mm(acc, dF, xF); add_dw<L::LD_IN>(Gd + L::W_IN, acc, 64 + p31, 64 + p31 < kEmb1, hi);
+        zero_acc(acc); dw_mm(acc, dF, xF); emit_block<MULTI, kEmb1>(qacc[11], acc, stg1, out + F::W_IN, 64, kEmb1 - 64, wave, p31, hi);
         const float* wi = W + L::W_IN + 4 * hi * L::LD_IN;
         bwd_mm<L::LD_IN>(de1a, wi + p31, d1);
         bwd_mm<L::LD_IN>(de1b, wi + 32 + p31, d1);
@@ -699,11 +783,17 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
         }
         to_F(dF, dpP, scrD, p31, hi);
         zero_acc(acc); dw_mm(acc, dF, e1aF);
-        if (p31 < 3) {
+        if (MULTI) {
+            reduce_block(qacc[12], acc, stg0, wave, p31, hi);   // rows = direction d (21 valid), cols 0..2 = xyz
+        } else {
+            float q[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            reduce_block(q, acc, stg0, wave, p31, hi);
+            if (p31 < 3) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int d = phi(r, hi);
-                if (d < kDirs) wv::lds_add(Gd + L::PE_B + 3 * d + p31, acc[r]);
+                for (int i = 0; i < 4; ++i) {
+                    const int d = 8 * wave + 4 * hi + i;
+                    if (d < kDirs) out[F::PE_B + 3 * d + p31] = q[i];
+                }
             }
         }
     }
@@ -719,22 +809,44 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
     if (!BWD) return;
 
     // ---- write this workgroup's partial gradients in the natural flat order ----
-    float* out = a.part_grad + ((long long)(obj * a.NW + wgo)) * a.PP;
-    unstage_matrix<H, kEmb1, L::LD_IN>(out, Gd + L::W_IN, tid);            out += H * kEmb1;
-    if (tid < H) out[tid] = Gd[L::B_IN + tid];                             out += H;
-    unstage_matrix<H, H, L::LD_M>(out, Gd + L::W_M1, tid);                 out += H * H;
-    if (tid < H) out[tid] = Gd[L::B_M1 + tid];                             out += H;
-    unstage_matrix<H, H + kEmb1, L::LD_CAT>(out, Gd + L::W_CAT, tid);      out += H * (H + kEmb1);
-    if (tid < H) out[tid] = Gd[L::B_CAT + tid];                            out += H;
-    unstage_matrix<H, H, L::LD_M>(out, Gd + L::W_M2, tid);                 out += H * H;
-    if (tid < H) out[tid] = Gd[L::B_M2 + tid];                             out += H;
-    if (tid < H) out[tid] = Gd[L::W_A + tid];                              out += H;
-    if (tid == 0) out[0] = Gd[L::B_A];                                     out += 1;
-    unstage_matrix<H, H + kEmb2, L::LD_C>(out, Gd + L::W_C, tid);          out += H * (H + kEmb2);
-    if (tid < H) out[tid] = Gd[L::B_C + tid];                              out += H;
-    if (tid < 3 * H) out[tid] = Gd[L::W_OC + tid];                         out += 3 * H;
-    if (tid < 3) out[tid] = Gd[L::B_OC + tid];                             out += 3;
-    if (tid < 63) out[tid] = Gd[L::PE_B + tid];
+    if (MULTI) {
+        store_quarter<H + kEmb2>(out + F::W_C, qacc[0], 0, 32, wave, p31, hi);
+        store_quarter<H + kEmb2>(out + F::W_C, qacc[1], H, 32, wave, p31, hi);
+        store_quarter<H + kEmb2>(out + F::W_C, qacc[2], H + 32, kEmb2 - 32, wave, p31, hi);
+        store_quarter<H>(out + F::W_M2, qacc[3], 0, 32, wave, p31, hi);
+        store_quarter<H + kEmb1>(out + F::W_CAT, qacc[4], 0, 32, wave, p31, hi);
+        store_quarter<H + kEmb1>(out + F::W_CAT, qacc[5], H, 32, wave, p31, hi);
+        store_quarter<H + kEmb1>(out + F::W_CAT, qacc[6], H + 32, 32, wave, p31, hi);
+        store_quarter<H + kEmb1>(out + F::W_CAT, qacc[7], H + 64, kEmb1 - 64, wave, p31, hi);
+        store_quarter<H>(out + F::W_M1, qacc[8], 0, 32, wave, p31, hi);
+        store_quarter<kEmb1>(out + F::W_IN, qacc[9], 0, 32, wave, p31, hi);
+        store_quarter<kEmb1>(out + F::W_IN, qacc[10], 32, 32, wave, p31, hi);
+        store_quarter<kEmb1>(out + F::W_IN, qacc[11], 64, kEmb1 - 64, wave, p31, hi);
+        if (p31 < 3) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int d = 8 * wave + 4 * hi + i;
+                if (d < kDirs) out[F::PE_B + 3 * d + p31] = qacc[12][i];
+            }
+        }
+    }
+    // small vectors: sum of the four waves' private accumulators
+    for (int sv = tid; sv < L::SMALL_N; sv += kWG) {
+        const float* v = lds + L::VEC + sv;
+        const float g = (v[0] + v[L::SMALL_N]) + (v[2 * L::SMALL_N] + v[3 * L::SMALL_N]);
+        const int i = L::SMALL0 + sv;         // position in the LDS image map
+        int o = -1;
+        if (i < L::B_M1) o = F::B_IN + (i - L::B_IN);
+        else if (i < L::B_CAT) o = F::B_M1 + (i - L::B_M1);
+        else if (i < L::B_M2) o = F::B_CAT + (i - L::B_CAT);
+        else if (i < L::B_C) o = F::B_M2 + (i - L::B_M2);
+        else if (i < L::W_A) o = F::B_C + (i - L::B_C);
+        else if (i < L::W_OC) o = F::W_A + (i - L::W_A);
+        else if (i < L::B_A) o = F::W_OC + (i - L::W_OC);
+        else if (i == L::B_A) o = F::B_A;
+        else if (i >= L::B_OC && i < L::B_OC + 3) o = F::B_OC + (i - L::B_OC);
+        if (o >= 0) out[o] = g;
+    }
     VK_MARK(15);
 #undef VK_MARK
 }

@@ -116,10 +116,10 @@ void fill_step_args(vk::StepArgs& a, const vmapstep_shape* sh, const Plan& pl, c
     a.part_grad = reinterpret_cast<float*>(ws + pl.off_pgrad);
 }
 
-template <bool BWD>
-int launch_main(const vk::StepArgs& a, hipStream_t st) {
+template <bool BWD, bool MULTI>
+int launch_main_v(const vk::StepArgs& a, hipStream_t st) {
     static bool attr_set = false;
-    auto kern = vk::step_main_h32<BWD>;
+    auto kern = vk::step_main_h32<BWD, MULTI>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, vk::Lds32::BYTES);
@@ -130,6 +130,11 @@ int launch_main(const vk::StepArgs& a, hipStream_t st) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "step_main launch: %s", hipGetErrorString(e));
     return VMAPSTEP_OK;
+}
+
+template <bool BWD>
+int launch_main(const vk::StepArgs& a, hipStream_t st) {
+    return a.NW < a.NG ? launch_main_v<BWD, true>(a, st) : launch_main_v<BWD, false>(a, st);
 }
 
 int launch_prep(const vk::StepArgs& a, int n_steps, hipStream_t st) {
