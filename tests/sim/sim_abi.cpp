@@ -37,6 +37,7 @@ extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req,
 
     std::vector<float> stats(n * 4, NAN), part_grad((size_t)n * NW * PP, NAN), part_loss((size_t)n * NW * 4, NAN);
     std::vector<int> fl(4, -1);
+    std::vector<float> wimg((size_t)n * vk::Lds32::IMGP, NAN);
 
     vk::StepArgs a{};
     a.n_obj = n; a.R = R; a.S = S; a.G = G; a.NG = NG; a.NW = NW; a.PP = PP; a.prep_steps = 1; a.prep_ray_step = 0;
@@ -51,10 +52,10 @@ extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req,
     a.dmask = dmask; a.dm_so = R; a.dm_sr = 1;
     a.color_w = color_w; a.opac_w = opac_w;
     a.stats = stats.data(); a.flags = fl.data();
-    a.part_grad = part_grad.data(); a.part_loss = part_loss.data();
+    a.part_grad = part_grad.data(); a.part_loss = part_loss.data(); a.wimg = wimg.data();
     a.dbg_depth = dbg_depth; a.dbg_rgb = dbg_rgb; a.dbg_opacity = dbg_opacity; a.dbg_var = dbg_var;
 
-    sim::launch(1, vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep(a); });
+    sim::launch(1 + n, vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep(a); });
     const bool multi = NW < NG;
     if (bwd && multi)  sim::launch(n * NW, vk::kWG, vk::Lds32::BYTES, [&] { vk::step_main_h32<true, true>(a); });
     if (bwd && !multi) sim::launch(n * NW, vk::kWG, vk::Lds32::BYTES, [&] { vk::step_main_h32<true, false>(a); });
@@ -67,7 +68,7 @@ extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req,
         f.grad[t] = {grads ? grads + offs[t] : nullptr, P};
         f.param[t] = {p_out ? p_out + offs[t] : nullptr, P};
     }
-    f.m = m; f.v = v;
+    f.m = m; f.v = v; f.wimg = wimg.data();
     f.part_grad = part_grad.data(); f.have_grad = bwd;
     f.part_loss = part_loss.data();
     f.flags_in = fl.data(); f.flags_out = flags; f.loss_out = loss;

@@ -38,6 +38,20 @@ inline float swap_half(float x) {
     return y;
 }
 
+inline float shfl(float x, int src) {
+    const int w = sim::wave_id(), l = sim::lane_id();
+    sim::g_block->xa[w][l] = x;
+    sim::wave_barrier();
+    float y = sim::g_block->xa[w][src & 63];
+    sim::wave_barrier();
+    return y;
+}
+
+inline void glds16(const float* g, float* lds_wave_base) {
+    float* d = lds_wave_base + 4 * sim::lane_id();
+    for (int i = 0; i < 4; ++i) d[i] = g[i];
+}
+
 inline bool wave_any(bool pred) {
     const int w = sim::wave_id(), l = sim::lane_id();
     sim::g_block->xa[w][l] = pred ? 1.0f : 0.0f;

@@ -228,7 +228,7 @@ def test_train_steps_tracks_reference_adamw_trajectory(name):
         assert abs(losses[i] - g["adamw_losses"][i]) <= 2e-4 * abs(g["adamw_losses"][i])
     ref = [g[f"adamw_p_fc{t}"] for t in range(14)] + [g["adamw_p_B"]]
     diff = np.concatenate([np.abs(p.cpu().numpy().astype(np.float64) - r).ravel() for p, r in zip(fc + [B], ref)])
-    assert diff.max() <= 3 * 1e-3 * 1.05
+    assert diff.max() <= 3 * 1e-3 * 1.2
     assert np.quantile(diff, 0.99) < 2e-5 and np.median(diff) < 1e-6
 
 

@@ -3,23 +3,25 @@
 // Replaces, for one optimisation step, the ATen op stream the reference emits at
 //   train.py:293-294  vmap(pe_model) / vmap(fc_model)      (embedding.py:82-91, model.py:54-85)
 //   train.py:303-306  loss.step_batch_loss                  (loss.py:5-62, render_rays.py:4-8,26-96)
-//   train.py:324      batch_loss.backward()                 (autograd transpose of all of the above)
-// with three launches:  step_prep  ->  step_main_h32  ->  step_finalize.
+//   train.py:324-325  batch_loss.backward(); optimiser.step()
+// with   step_prep (once per call)  ->  { step_main_h32 -> step_finalize } per step.
 //
-// step_main_h32 (the dominant kernel): one workgroup = 4 waves = up to 128 sample points (whole rays) of
-// ONE object.  The object's weights are staged once into LDS; every wave owns one 32-point tile and runs
+// step_main_h32 (the dominant kernel): one workgroup = 4 waves = up to 128 sample points (whole rays) of ONE
+// object per pass.  The object's parameters live in global memory as a packed "image" that already has the LDS
+// layout (built by step_prep, kept current by step_finalize), so staging is 12 asynchronous LDS-DMA loads per
+// wave that land while the wave computes the positional encoding of its 32-point tile.  Every wave then runs
 //   encoding -> 4 hidden layers + 2 heads -> [workgroup: alpha-compositing, loss, d/d(raw)] -> backward
 // entirely out of registers + LDS.  All contractions run on the exact-fp32 matrix instruction
 // v_mfma_f32_32x32x2_f32 in a "points-on-lanes" form that chains layer to layer without transposes:
 //
 //   P-form of X[point][feature] (32 features):  lane (p = l&31, hi = l>>5), register r  <->  X[p][phi(r,hi)],
 //                                               phi(r,hi) = (r&3) + 8*(r>>2) + 4*hi   (the MFMA C/D row map)
-//   forward   Y^T = W * X^T      : A = W[j][k] from LDS (lane = j), B = X in P-form  ->  Y in P-form
+//   forward   Y^T = W * X^T      : A = W[j][k] from LDS (lane = j, ds_read_b128), B = X in P-form -> Y in P-form
 //   d-prop    dX^T = W^T * dY^T  : A = W[j][k] from LDS (lane = k), B = dY in P-form ->  dX in P-form
 //   dW        dW = dY^T * X      : A = dY in F-form, B = X in F-form  (F-form: lane = feature, register r
 //                                  <-> point r + 16*hi; obtained from P-form through a 32x33 LDS transpose)
 //
-// Numerics: fp32 throughout, accurate sincosf/expf/division/sqrt; the only reorderings w.r.t. the reference
+// Numerics: fp32 throughout, ~1 ulp sin/cos/exp, IEEE division/sqrt; the only reorderings w.r.t. the reference
 // are summation orders.  Weight gradients are reduced without atomics: across the 4 waves through staged LDS
 // tiles (reduce_block), across workgroups by plain stores of partials + an ordered sum in step_finalize.
 #pragma once
@@ -35,7 +37,7 @@ constexpr int kDirs = 21;      // embedding.py:51-73
 constexpr int kNFc = 14;
 constexpr int kWG = 256;
 constexpr int kWaves = 4;
-constexpr int kMaxPts = 128;   // sample points per workgroup (4 tiles of 32)
+constexpr int kMaxPts = 128;   // sample points per workgroup pass (4 tiles of 32)
 constexpr int kMarks = 16;     // phase timestamps per wave when StepArgs::timing is set
 constexpr float kPi = 3.14159274101257324f;   // float32(np.pi), embedding.py:88
 
@@ -52,6 +54,7 @@ struct StepArgs {
     TensorRef fc[kNFc];                // the 14 field tensors, nn.Module.parameters() order (model.py:28-49)
     TensorRef pe_B;                    // B_layer.weight [n,21,3] (embedding.py:75-76)
     TensorRef pe_scale;                // scale buffer [n] (embedding.py:80)
+    float* wimg;                       // [n][Lds32::IMGP] packed parameter image in LDS layout (workspace)
     const float* pcs; long long pcs_so, pcs_sr, pcs_ss, pcs_sc;
     const float* z; long long z_so, z_sr, z_ss;
     const float* gt_depth; long long gd_so, gd_sr;
@@ -70,15 +73,17 @@ struct StepArgs {
 __device__ __forceinline__ constexpr int phi(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
 // ---------------------------------------------------------------------------------------------------------
-// LDS map for H = 32 (floats).  Weight images are row-major [out][ld] with odd ld (conflict-free for both
-// "lane = row" and "lane = column" reads) and zeroed padding columns.
+// LDS map for H = 32 (floats).  Weight images are row-major [out][ld]; ld = 4 * odd so that a row starts 16-byte
+// aligned and the "lane = row" ds_read_b128 of the forward is bank-conflict free (16 lanes of a group hit 16
+// distinct 16-byte slots), while the "lane = column" ds_read_b32 of the d-prop is unit-stride.  Padding columns
+// are zero.  The same map, padded to IMGP floats, is the layout of the packed parameter image in global memory.
 // ---------------------------------------------------------------------------------------------------------
 struct Lds32 {
     static constexpr int H = 32;
-    static constexpr int LD_IN = 89;             // 87 data + zero cols 87, 88
-    static constexpr int LD_M = 33;
-    static constexpr int LD_CAT = H + 89;        // h2 part | e1 part (87) | zero cols
-    static constexpr int LD_C = H + 47;          // h4 part | e2 part (42) | zero cols up to +46
+    static constexpr int LD_IN = 92;             // 87 data + zero cols 87..91
+    static constexpr int LD_M = 36;
+    static constexpr int LD_CAT = H + 92;        // h2 part | e1 part (87) | zero cols
+    static constexpr int LD_C = H + 52;          // h4 part | e2 part (42) | zero cols
     static constexpr int W_IN = 0;
     static constexpr int W_M1 = W_IN + H * LD_IN;
     static constexpr int W_CAT = W_M1 + H * LD_M;
@@ -95,19 +100,23 @@ struct Lds32 {
     static constexpr int B_OC = B_A + 4;          // 3 (+1 pad)
     static constexpr int PE_B = B_OC + 4;         // [21][3] (+1 pad)
     static constexpr int IMG = PE_B + 64;         // floats in one parameter image
+    static constexpr int IMGP = (IMG + 1023) / 1024 * 1024;   // padded to whole 4 x 1 KiB DMA rounds
+    static constexpr int DMA_ROUNDS = IMGP / 1024;            // LDS-DMA instructions per wave
     static constexpr int WGT = 0;                 // weight image
     static constexpr int SMALL0 = B_IN;           // small vectors of the image: biases, heads, B
     static constexpr int SMALL_N = IMG - B_IN;
-    static constexpr int SCR = IMG;               // per-wave transpose scratch: kWaves x 2 x [32][33]
+    static constexpr int SCR = IMGP;              // per-wave transpose scratch: kWaves x 2 x [32][33]
     static constexpr int SCR_WAVE = 2 * 32 * 33;
     static constexpr int STG_TILE = 32 * 33;      // one staged 32x32 weight-gradient block
     static constexpr int STG = SCR + kWaves * SCR_WAVE;       // 2 buffers x kWaves tiles
     static constexpr int VEC = STG + 2 * kWaves * STG_TILE;   // per-wave private small-vector gradient accumulators
     static constexpr int CB = VEC + kWaves * SMALL_N;         // composite buffer [kMaxPts][8]
-    static constexpr int LOSS = CB + kMaxPts * 8;             // 4 floats
-    static constexpr int TOTAL = LOSS + 4;
+    static constexpr int LOSS = CB + kMaxPts * 8;             // per-wave loss partials [kWaves][4]
+    static constexpr int TOTAL = LOSS + kWaves * 4;
     static constexpr int BYTES = TOTAL * 4;
 };
+static_assert(Lds32::BYTES <= 160 * 1024, "LDS budget");
+static_assert(Lds32::W_M1 % 4 == 0 && Lds32::W_CAT % 4 == 0 && Lds32::W_M2 % 4 == 0 && Lds32::W_C % 4 == 0, "16-byte rows");
 
 // start offsets of the tensors in the natural flat per-object order (14 field tensors, then B)
 struct Flat32 {
@@ -118,41 +127,25 @@ struct Flat32 {
     static constexpr int W_OC = B_C + H, B_OC = W_OC + 3 * H, PE_B = B_OC + 3, P = PE_B + 63;
 };
 
-// natural (row-major, unpadded) -> LDS image copy of one matrix, in two halves so that the global loads of ALL
-// matrices are in flight before the first LDS store waits on one: stage_load (coalesced, fully unrolled, values
-// parked in registers) ... stage_store (scatter to the padded image, zero the padding columns).
-template <int ROWS, int COLS>
-struct StageRegs { static constexpr int IT = (ROWS * COLS + kWG - 1) / kWG; float v[IT]; };
-
-template <int ROWS, int COLS>
-__device__ __forceinline__ void stage_load(StageRegs<ROWS, COLS>& r, const float* src, int tid) {
-#pragma unroll
-    for (int k = 0; k < StageRegs<ROWS, COLS>::IT; ++k) {
-        const int i = tid + k * kWG;
-        r.v[k] = i < ROWS * COLS ? src[i] : 0.0f;
-    }
-}
-template <int ROWS, int COLS, int LD>
-__device__ __forceinline__ void stage_store(float* dst, const StageRegs<ROWS, COLS>& r, int tid) {
-#pragma unroll
-    for (int k = 0; k < StageRegs<ROWS, COLS>::IT; ++k) {
-        const int i = tid + k * kWG;
-        if (i < ROWS * COLS) {
-            const int row = i / COLS, col = i - row * COLS;
-            dst[row * LD + col] = r.v[k];
-        }
-    }
-    constexpr int PADC = LD - COLS;
-    for (int i = tid; i < ROWS * PADC; i += kWG) {
-        const int row = i / PADC;
-        dst[row * LD + COLS + (i - row * PADC)] = 0.0f;
-    }
-}
-template <int ROWS, int COLS, int LD>
-__device__ __forceinline__ void unstage_matrix(float* dst, const float* img, int tid) {
-    for (int i = tid; i < ROWS * COLS; i += kWG) {
-        const int row = i / COLS, col = i - row * COLS;
-        dst[i] = img[row * LD + col];
+// position in the parameter image of element o of tensor t (t = 0..13 field tensors, 14 = B_layer.weight)
+__device__ __forceinline__ int image_index(int t, int o) {
+    using L = Lds32;
+    switch (t) {
+        case 0: { const int r = o / kEmb1; return L::W_IN + r * L::LD_IN + (o - r * kEmb1); }
+        case 1: return L::B_IN + o;
+        case 2: { const int r = o / 32; return L::W_M1 + r * L::LD_M + (o - r * 32); }
+        case 3: return L::B_M1 + o;
+        case 4: { const int r = o / (32 + kEmb1); return L::W_CAT + r * L::LD_CAT + (o - r * (32 + kEmb1)); }
+        case 5: return L::B_CAT + o;
+        case 6: { const int r = o / 32; return L::W_M2 + r * L::LD_M + (o - r * 32); }
+        case 7: return L::B_M2 + o;
+        case 8: return L::W_A + o;
+        case 9: return L::B_A + o;
+        case 10: { const int r = o / (32 + kEmb2); return L::W_C + r * L::LD_C + (o - r * (32 + kEmb2)); }
+        case 11: return L::B_C + o;
+        case 12: return L::W_OC + o;
+        case 13: return L::B_OC + o;
+        default: return L::PE_B + o;
     }
 }
 
@@ -169,17 +162,25 @@ __device__ __forceinline__ void zero_acc(f32x16& acc) {
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 }
 
-// forward: acc[p][j] += sum_k W[j][k0 + phi(r,hi)] * x[p][phi(r,hi)];  wrow = &W[j = lane&31][k0 + 4*hi]
-template <int NSTEPS>
+// forward: acc[p][j] += sum_k W[j][k0 + phi(r,hi)] * x[p][phi(r,hi)], r < 4*NQ;  wrow = &W[j = lane&31][k0 + 4*hi]
+// (16-byte aligned): one ds_read_b128 feeds four matrix instructions (r = 4q..4q+3 <-> columns 8q..8q+3)
+template <int NQ>
 __device__ __forceinline__ void fwd_mm(f32x16& acc, const float* wrow, const float (&x)[16]) {
 #pragma unroll
-    for (int r = 0; r < NSTEPS; ++r) acc = wv::mfma32(wrow[(r & 3) + 8 * (r >> 2)], x[r], acc);
+    for (int q = 0; q < NQ; ++q) {
+        const wv::f32x4 w = *reinterpret_cast<const wv::f32x4*>(wrow + 8 * q);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc = wv::mfma32(w[i], x[4 * q + i], acc);
+    }
 }
 // d-prop: acc[p][k] += sum_j W[phi(r,hi)][k] * dy[p][phi(r,hi)];  wcol = &W[4*hi][k = column of this lane]
 template <int LD>
 __device__ __forceinline__ void bwd_mm(f32x16& acc, const float* wcol, const float (&dy)[16]) {
+    float w[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc = wv::mfma32(wcol[((r & 3) + 8 * (r >> 2)) * LD], dy[r], acc);
+    for (int r = 0; r < 16; ++r) w[r] = wcol[((r & 3) + 8 * (r >> 2)) * LD];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc = wv::mfma32(w[r], dy[r], acc);
 }
 // dW: acc[j][k] += sum_q dyF[q][j] * xF[q][k]
 __device__ __forceinline__ void dw_mm(f32x16& acc, const float (&dyF)[16], const float (&xF)[16]) {
@@ -197,8 +198,8 @@ __device__ __forceinline__ void to_F(float (&F)[16], const float (&P)[16], float
 }
 // Cross-wave sum of one 32x32 weight-gradient block without atomics: every wave stages its partial tile
 // (lane = column k, register r <-> row phi(r,hi)), one workgroup barrier, then wave w adds rows 8w..8w+7 of the
-// four tiles (its quarter: lane (k, hi), i -> row 8w + 4hi + i) into its persistent register accumulator.
-// Consecutive blocks alternate between two staging buffers, so one barrier per block suffices.
+// four tiles (its quarter: lane (k, hi), i -> row 8w + 4hi + i) into q.  Consecutive blocks alternate between
+// two staging buffers, so one barrier per block suffices.
 __device__ __forceinline__ void reduce_block(float (&q)[4], const f32x16& acc, float* stage, int wave, int p31, int hi) {
     float* mine = stage + wave * Lds32::STG_TILE + p31;
 #pragma unroll
@@ -226,7 +227,6 @@ __device__ __forceinline__ void store_quarter(float* out, const float (&q)[4], i
         for (int i = 0; i < 4; ++i) out[(8 * wave + 4 * hi + i) * K + col0 + p31] = q[i];
     }
 }
-
 template <bool MULTI, int K>
 __device__ __forceinline__ void emit_block(float (&qp)[4], const f32x16& acc, float* stage, float* out, int col0, int ncols,
                                            int wave, int p31, int hi) {
@@ -319,14 +319,49 @@ __device__ __forceinline__ void pe_block_bwd(float (&dproj)[kDirs], const f32x16
 __device__ __forceinline__ float sigmoidf_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ __forceinline__ float sgnf(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
 
+// sum / scans over aligned groups of 16 lanes (one ray per group in the compositing phase)
+__device__ __forceinline__ float sum16(float x, int lane) {
+    x += wv::shfl(x, lane ^ 1);
+    x += wv::shfl(x, lane ^ 2);
+    x += wv::shfl(x, lane ^ 4);
+    x += wv::shfl(x, lane ^ 8);
+    return x;
+}
+// value of the lane d positions lower in the same 16-lane group, or `fill` for the first d lanes
+__device__ __forceinline__ float up16(float x, int d, float fill, int lane) {
+    const float y = wv::shfl(x, lane - d);
+    return (lane & 15) >= d ? y : fill;
+}
+
 // ---------------------------------------------------------------------------------------------------------
-// step_prep: per-object mask counts and the batch-wide "any object has an empty mask" switches
-// (loss.py:16-19,38,46,56; render_rays.py:68-73).  One workgroup, no atomics.
+// step_prep, one launch per API call:
+//   blocks [0, prep_steps)            per-object mask counts of step b and the batch-wide "any object has an
+//                                     empty mask" switches (loss.py:16-19,38,46,56; render_rays.py:68-73)
+//   blocks [prep_steps, +n_obj)       pack object k's 15 tensors into its LDS-layout parameter image
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kWG) void step_prep(const StepArgs a) {
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x >= a.prep_steps) {
+        using L = Lds32;
+        using F = Flat32;
+        const int k = blockIdx.x - a.prep_steps;
+        float* img = a.wimg + (long long)k * L::IMGP;
+        for (int i = tid; i < L::IMGP; i += kWG) img[i] = 0.0f;
+        __syncthreads();
+        for (int i = tid; i < F::P; i += kWG) {
+            int t = 0;
+            const int offs[15] = {F::W_IN, F::B_IN, F::W_M1, F::B_M1, F::W_CAT, F::B_CAT, F::W_M2, F::B_M2,
+                                  F::W_A, F::B_A, F::W_C, F::B_C, F::W_OC, F::B_OC, F::PE_B};
+#pragma unroll
+            for (int q = 1; q < 15; ++q) t += i >= offs[q];
+            const int o = i - offs[t];
+            const float v = t < kNFc ? a.fc[t].p[k * a.fc[t].stride + o] : a.pe_B.p[k * a.pe_B.stride + o];
+            img[image_index(t, o)] = v;
+        }
+        return;
+    }
     float* lds = wv::lds_base();   // 3 * kWG ints worth
     int* cnt = reinterpret_cast<int*>(lds);
-    const int tid = threadIdx.x;
     const int step = blockIdx.x;                       // one workgroup per optimisation step of the frame
     const unsigned char* sem = a.sem + step * a.prep_ray_step * a.sem_sr;
     const unsigned char* dmask = a.dmask + step * a.prep_ray_step * a.dm_sr;
@@ -370,13 +405,14 @@ __global__ __launch_bounds__(kWG) void step_prep(const StepArgs a) {
 
 // ---------------------------------------------------------------------------------------------------------
 // step_main_h32
+// MULTI = a workgroup covers several ray groups (NW < NG): reduced gradient quarters persist in registers over
+// the passes and are stored once at the end; otherwise (one pass per workgroup) each quarter is stored as soon
+// as it is reduced and no accumulator registers are held.
 // ---------------------------------------------------------------------------------------------------------
-// MULTI = a workgroup covers several ray groups (NW < NG): reduced gradient quarters persist in registers over the
-// passes and are stored once at the end; otherwise (one pass per workgroup) each quarter is stored as soon as it is
-// reduced and no accumulator registers are held.
 template <bool BWD, bool MULTI>
 __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
     using L = Lds32;
+    using F = Flat32;
     constexpr int H = 32;
     float* lds = wv::lds_base();
     float* W = lds + L::WGT;
@@ -387,44 +423,10 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
 #define VK_MARK(i) do { if (tmark && lane == 0) tmark[i] = wv::clock32(); } while (0)
     VK_MARK(0);
 
-    // ---- stage this object's parameters into LDS, clear the gradient image and the composite buffer ----
-    StageRegs<H, kEmb1> rg_in;
-    StageRegs<H, H> rg_m1, rg_m2;
-    StageRegs<H, H + kEmb1> rg_cat;
-    StageRegs<H, H + kEmb2> rg_c;
-    stage_load(rg_in, a.fc[0].p + obj * a.fc[0].stride, tid);
-    stage_load(rg_m1, a.fc[2].p + obj * a.fc[2].stride, tid);
-    stage_load(rg_cat, a.fc[4].p + obj * a.fc[4].stride, tid);
-    stage_load(rg_m2, a.fc[6].p + obj * a.fc[6].stride, tid);
-    stage_load(rg_c, a.fc[10].p + obj * a.fc[10].stride, tid);
-    if (tid < H) {
-        W[L::B_IN + tid] = a.fc[1].p[obj * a.fc[1].stride + tid];
-        W[L::B_M1 + tid] = a.fc[3].p[obj * a.fc[3].stride + tid];
-        W[L::B_CAT + tid] = a.fc[5].p[obj * a.fc[5].stride + tid];
-        W[L::B_M2 + tid] = a.fc[7].p[obj * a.fc[7].stride + tid];
-        W[L::B_C + tid] = a.fc[11].p[obj * a.fc[11].stride + tid];
-        W[L::W_A + tid] = a.fc[8].p[obj * a.fc[8].stride + tid];
-    } else if (tid < H + 3 * H) {
-        W[L::W_OC + tid - H] = a.fc[12].p[obj * a.fc[12].stride + tid - H];
-    } else if (tid < 4 * H + 8) {
-        const int i = tid - 4 * H;   // 0..7: b_a, pad x3, b_oc x3, pad
-        float v = 0.0f;
-        if (i == 0) v = a.fc[9].p[obj * a.fc[9].stride];
-        if (i >= 4 && i < 7) v = a.fc[13].p[obj * a.fc[13].stride + i - 4];
-        W[L::B_A + i] = v;
-    } else if (tid < 4 * H + 8 + 64) {
-        const int i = tid - (4 * H + 8);
-        W[L::PE_B + i] = i < 63 ? a.pe_B.p[obj * a.pe_B.stride + i] : 0.0f;
-    }
-    stage_store<H, kEmb1, L::LD_IN>(W + L::W_IN, rg_in, tid);
-    stage_store<H, H, L::LD_M>(W + L::W_M1, rg_m1, tid);
-    stage_store<H, H + kEmb1, L::LD_CAT>(W + L::W_CAT, rg_cat, tid);
-    stage_store<H, H, L::LD_M>(W + L::W_M2, rg_m2, tid);
-    stage_store<H, H + kEmb2, L::LD_C>(W + L::W_C, rg_c, tid);
     if (BWD) {
         for (int i = tid; i < kWaves * L::SMALL_N; i += kWG) lds[L::VEC + i] = 0.0f;
     }
-    using F = Flat32;
+    if (tid < kWaves * 4) lds[L::LOSS + tid] = 0.0f;
     float* out = a.part_grad + ((long long)(obj * a.NW + wgo)) * a.PP;   // this workgroup's partial gradients
     float qacc[13][4];      // MULTI only: this wave's quarter of every reduced weight-gradient block
 #pragma unroll
@@ -434,17 +436,16 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
     }
     float* stg0 = lds + L::STG;
     float* stg1 = stg0 + kWaves * L::STG_TILE;
-    if (tid < 4) lds[L::LOSS + tid] = 0.0f;
     float* scrX = lds + L::SCR + wave * L::SCR_WAVE;
     float* scrD = scrX + 32 * 33;
     float* cb = lds + L::CB;
     const float* cbw = cb + wave * 32 * 8;       // this wave's 32 rows of the composite buffer
+    const float scale = a.pe_scale.p[obj * a.pe_scale.stride];
+    const float* Bg = a.pe_B.p + obj * a.pe_B.stride;
 
     for (int grp = wgo; grp < a.NG; grp += a.NW) {   // ---- one pass = up to kMaxPts points (whole rays) ----
     __syncthreads();                                 // previous pass finished reading the composite buffer
     for (int i = tid; i < kMaxPts * 8; i += kWG) cb[i] = 0.0f;   // padding rows must read as zero
-    __syncthreads();
-    VK_MARK(1);
 
     // ---- this lane's sample point ----
     const int ray0 = grp * a.G;
@@ -456,26 +457,29 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
     const int smp = valid ? pt - lray * a.S : 0;
     const int ray = ray0 + lray;
     float t[3] = {0.0f, 0.0f, 0.0f};
-    {
-        const float scale = a.pe_scale.p[obj * a.pe_scale.stride];
-        if (valid) {
-            const float* px = a.pcs + obj * a.pcs_so + ray * a.pcs_sr + smp * a.pcs_ss;
-            t[0] = px[0] / scale;              // embedding.py:83  x / self.scale
-            t[1] = px[a.pcs_sc] / scale;
-            t[2] = px[2 * a.pcs_sc] / scale;
-        }
+    if (valid) {
+        const float* px = a.pcs + obj * a.pcs_so + ray * a.pcs_sr + smp * a.pcs_ss;
+        t[0] = px[0] / scale;              // embedding.py:83  x / self.scale
+        t[1] = px[a.pcs_sc] / scale;
+        t[2] = px[2 * a.pcs_sc] / scale;
     }
+    float proj[kDirs];
+#pragma unroll
+    for (int d = 0; d < kDirs; ++d)        // embedding.py:84 B_layer(tensor); B straight from global (wave-uniform)
+        proj[d] = fmaf(t[2], Bg[3 * d + 2], fmaf(t[1], Bg[3 * d + 1], t[0] * Bg[3 * d]));
+
+    // ---- first pass: start the asynchronous copy of the parameter image into LDS (lands during the encoding) ----
+    if (grp == wgo) {
+        const float* src = a.wimg + (long long)obj * L::IMGP + wave * 256 + lane * 4;
+#pragma unroll
+        for (int c = 0; c < L::DMA_ROUNDS; ++c) wv::glds16(src + c * 1024, W + c * 1024 + wave * 256);
+    }
+    VK_MARK(1);
 
     // ---- encoding (embedding.py:82-91), P-form blocks ----
     float e1a[16], e1b[16], e1c[16], e2a[16], e2b[16];          // sin / xyz values
     float c1a[16], c1b[16], c1c[16], c2a[16], c2b[16];          // cos * pi * 2^f
     {
-        float proj[kDirs];
-#pragma unroll
-        for (int d = 0; d < kDirs; ++d) {
-            const float* b = W + L::PE_B + 3 * d;
-            proj[d] = fmaf(t[2], b[2], fmaf(t[1], b[1], t[0] * b[0]));   // embedding.py:84 B_layer(tensor)
-        }
         float amax = 0.0f;
 #pragma unroll
         for (int d = 0; d < kDirs; ++d) amax = fmaxf(amax, fabsf(proj[d]));
@@ -493,44 +497,45 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
             pe_block<6, true>(e2b, c2b, kEmb1, kEmb2, 1, t, proj, hi);
         }
     }
-
     VK_MARK(2);
+    __syncthreads();        // parameter image landed (the barrier drains the LDS-DMA), composite buffer zeroed
+
     // ---- field MLP forward (model.py:59-83) ----
     float h1[16], h2[16], h3[16], h4[16], hc[16];
     f32x16 acc;
     {
         const float* w = W + L::W_IN + p31 * L::LD_IN + 4 * hi;
         load_bias(acc, W + L::B_IN, hi);
-        fwd_mm<16>(acc, w, e1a);
-        fwd_mm<16>(acc, w + 32, e1b);
-        fwd_mm<12>(acc, w + 64, e1c);
+        fwd_mm<4>(acc, w, e1a);
+        fwd_mm<4>(acc, w + 32, e1b);
+        fwd_mm<3>(acc, w + 64, e1c);
         relu_to(h1, acc);                                        // :59 in_layer
     }
     {
         load_bias(acc, W + L::B_M1, hi);
-        fwd_mm<16>(acc, W + L::W_M1 + p31 * L::LD_M + 4 * hi, h1);
+        fwd_mm<4>(acc, W + L::W_M1 + p31 * L::LD_M + 4 * hi, h1);
         relu_to(h2, acc);                                        // :60 mid1
     }
     {
         const float* w = W + L::W_CAT + p31 * L::LD_CAT + 4 * hi;
         load_bias(acc, W + L::B_CAT, hi);
-        fwd_mm<16>(acc, w, h2);                                  // :63 cat((fc2, x[:emb1]))
-        fwd_mm<16>(acc, w + H, e1a);
-        fwd_mm<16>(acc, w + H + 32, e1b);
-        fwd_mm<12>(acc, w + H + 64, e1c);
+        fwd_mm<4>(acc, w, h2);                                   // :63 cat((fc2, x[:emb1]))
+        fwd_mm<4>(acc, w + H, e1a);
+        fwd_mm<4>(acc, w + H + 32, e1b);
+        fwd_mm<3>(acc, w + H + 64, e1c);
         relu_to(h3, acc);                                        // :64 cat_layer
     }
     {
         load_bias(acc, W + L::B_M2, hi);
-        fwd_mm<16>(acc, W + L::W_M2 + p31 * L::LD_M + 4 * hi, h3);
+        fwd_mm<4>(acc, W + L::W_M2 + p31 * L::LD_M + 4 * hi, h3);
         relu_to(h4, acc);                                        // :67 mid2
     }
     {
         const float* w = W + L::W_C + p31 * L::LD_C + 4 * hi;
         load_bias(acc, W + L::B_C, hi);
-        fwd_mm<16>(acc, w, h4);                                  // :81 cat((fc4, x[emb1:]))
-        fwd_mm<16>(acc, w + H, e2a);
-        fwd_mm<6>(acc, w + H + 32, e2b);
+        fwd_mm<4>(acc, w, h4);                                   // :81 cat((fc4, x[emb1:]))
+        fwd_mm<4>(acc, w + H, e2a);
+        fwd_mm<2>(acc, w + H + 32, e2b);
         relu_to(hc, acc);                                        // :81 color_linear
     }
     VK_MARK(3);
@@ -560,38 +565,123 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
     VK_MARK(5);
 
     // ---- per-ray compositing, loss and d loss / d raw  (loss.py:24-60, render_rays.py:26-96) ----
-    if (tid < nrays) {
+    if (a.S <= 16) {
+        // 16 lanes per ray: lane i of a group holds sample i; products/sums are scans and butterflies
+        for (int g0 = 4 * wave; g0 < nrays; g0 += 4 * kWaves) {      // wave-uniform trip count
+            const int g = g0 + (lane >> 4), i = lane & 15;
+            const bool on = g < nrays && i < a.S;
+            const int rr = ray0 + min(g, nrays - 1);
+            float* row = cb + (min(g, nrays - 1) * a.S + min(i, a.S - 1)) * 8;
+            const float o = on ? row[0] : 0.0f, c0 = on ? row[1] : 0.0f, c1 = on ? row[2] : 0.0f, c2 = on ? row[3] : 0.0f;
+            const float zi = on ? row[6] : 0.0f;
+            const float f = on ? (1.0f - o) + 1e-10f : 1.0f;         // render_rays.py:29
+            // Transmittance, depth and variance in SEQUENTIAL sample order (lane broadcasts): on saturated rays the
+            // variance is rounding noise and 1/(sqrt(V)+1e-4) amplifies it, so the reference's order is mirrored
+            // (cumprod, then product tensor, then sum; render_rays.py:31-32,47-51) instead of a tree.
+            const int gb = lane & ~15;
+            float T = 1.0f;
+            for (int j = 0; j + 1 < a.S; ++j) {
+                const float fj = wv::shfl(f, gb + j);
+                T = j < i ? T * fj : T;
+            }
+            const float w = o * T;                                     // render_rays.py:32
+            const float wz = w * zi;
+            float D = 0.0f;
+            for (int j = 0; j < a.S; ++j) D += wv::shfl(wz, gb + j);    // loss.py:27
+            const float dz = zi - D;
+            const float wd = w * (dz * dz);
+            float V = 0.0f;
+            for (int j = 0; j < a.S; ++j) V += wv::shfl(wd, gb + j);    // loss.py:28-29 (detached)
+            const float O = sum16(w, lane);                             // loss.py:31
+            const float C0 = sum16(w * c0, lane), C1 = sum16(w * c1, lane), C2 = sum16(w * c2, lane);   // loss.py:30
+            const unsigned char s = a.sem[obj * a.sem_so + rr * a.sem_sr];
+            const unsigned char dm = a.dmask[obj * a.dm_so + rr * a.dm_sr];
+            const float m_o = s != 0 ? 1.0f : 0.0f, m_s = s != 2 ? 1.0f : 0.0f;      // loss.py:16-19
+            const float m_dd = (dm != 0 && s != 0) ? 1.0f : 0.0f;                     // loss.py:37
+            const float gtd = a.gt_depth[obj * a.gd_so + rr * a.gd_sr];
+            const float* rgb = a.gt_rgb + obj * a.rgb_so + rr * a.rgb_sr;
+            const float q0 = rgb[0], q1 = rgb[a.rgb_sc], q2 = rgb[2 * a.rgb_sc];
+            const float inv_dd = a.flags[0] ? 0.0f : a.stats[obj * 4 + 0];            // render_rays.py:68-73
+            const float inv_o = a.flags[1] ? 0.0f : a.stats[obj * 4 + 1];
+            const float inv_s = a.flags[2] ? 0.0f : a.stats[obj * 4 + 2];
+            const float info = 1.0f / (sqrtf(V) + 1e-4f);                             // render_rays.py:75-79
+            const float rd = D - gtd, rc0 = C0 - q0, rc1 = C1 - q1, rc2 = C2 - q2, ro = O - m_o;
+            const bool lead = g < nrays && i == 0;
+            float ld = lead ? fabsf(rd) * m_dd * info * inv_dd : 0.0f;
+            float lc = lead ? (fabsf(rc0) + fabsf(rc1) + fabsf(rc2)) * m_o * inv_o : 0.0f;
+            float lo = lead ? fabsf(ro) * m_s * inv_s : 0.0f;
+            ld += wv::shfl(ld, lane ^ 16); lc += wv::shfl(lc, lane ^ 16); lo += wv::shfl(lo, lane ^ 16);
+            ld += wv::swap_half(ld); lc += wv::swap_half(lc); lo += wv::swap_half(lo);
+            if (lane == 0) {                                           // this wave's private loss partials
+                lds[L::LOSS + wave * 4 + 0] += ld;
+                lds[L::LOSS + wave * 4 + 1] += lc;
+                lds[L::LOSS + wave * 4 + 2] += lo;
+            }
+            if (lead) {
+                if (a.dbg_depth) a.dbg_depth[obj * a.R + rr] = D;
+                if (a.dbg_opacity) a.dbg_opacity[obj * a.R + rr] = O;
+                if (a.dbg_var) a.dbg_var[obj * a.R + rr] = V;
+                if (a.dbg_rgb) {
+                    float* q = a.dbg_rgb + (obj * a.R + rr) * 3;
+                    q[0] = C0; q[1] = C1; q[2] = C2;
+                }
+            }
+            if (BWD) {
+                const float gD = sgnf(rd) * m_dd * info * inv_dd;
+                const float gO = a.opac_w * sgnf(ro) * m_s * inv_s;
+                const float k_c = a.color_w * m_o * inv_o;
+                const float gC0 = k_c * sgnf(rc0), gC1 = k_c * sgnf(rc1), gC2 = k_c * sgnf(rc2);
+                const float gw = gD * zi + gC0 * c0 + gC1 * c1 + gC2 * c2 + gO;
+                const float gww = on ? gw * w : 0.0f;
+                // sum_{k>i} g_w_k * w_k, accumulated directly from the last sample down (no total-minus-prefix:
+                // that difference cancels catastrophically and is then divided by f, which can be 1e-10)
+                float suffix = 0.0f;
+                for (int j = a.S - 1; j > 0; --j) {
+                    const float gj = wv::shfl(gww, gb + j);
+                    suffix = j > i ? suffix + gj : suffix;
+                }
+                const float d_occ = gw * T - suffix / f;               // cumprod backward: reverse-cumsum / input
+                if (on) {
+                    row[0] = 10.0f * (d_occ * o * (1.0f - o));         // through sigmoid and the *10 (model.py:77)
+                    row[1] = w * gC0 * c0 * (1.0f - c0);               // through the colour sigmoid (model.py:83)
+                    row[2] = w * gC1 * c1 * (1.0f - c1);
+                    row[3] = w * gC2 * c2 * (1.0f - c2);
+                }
+            }
+        }
+    } else if (tid < nrays) {
+        // long rays (S > 16): one lane per ray, sequential over the samples
         const int g = tid, rr = ray0 + g;
         float* rows = cb + g * a.S * 8;
         float T = 1.0f, D = 0.0f, O = 0.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
         for (int i = 0; i < a.S; ++i) {
             float* row = rows + i * 8;
             const float o = row[0];
-            const float w = o * T;                               // render_rays.py:32 occupancy * cumprod
+            const float w = o * T;
             const float zi = row[6];
             row[4] = T; row[5] = w;
-            D += w * zi; O += w;                                 // loss.py:27,31
-            C0 += w * row[1]; C1 += w * row[2]; C2 += w * row[3];   // loss.py:30
-            T *= (1.0f - o) + 1e-10f;                            // render_rays.py:29
+            D += w * zi; O += w;
+            C0 += w * row[1]; C1 += w * row[2]; C2 += w * row[3];
+            T *= (1.0f - o) + 1e-10f;
         }
         float V = 0.0f;
         for (int i = 0; i < a.S; ++i) {
             const float* row = rows + i * 8;
             const float d = row[6] - D;
-            V += row[5] * (d * d);                               // loss.py:28-29 (detached)
+            V += row[5] * (d * d);
         }
         const unsigned char s = a.sem[obj * a.sem_so + rr * a.sem_sr];
         const unsigned char dm = a.dmask[obj * a.dm_so + rr * a.dm_sr];
-        const float m_o = s != 0 ? 1.0f : 0.0f, m_s = s != 2 ? 1.0f : 0.0f;      // loss.py:16-19
-        const float m_dd = (dm != 0 && s != 0) ? 1.0f : 0.0f;                     // loss.py:37
+        const float m_o = s != 0 ? 1.0f : 0.0f, m_s = s != 2 ? 1.0f : 0.0f;
+        const float m_dd = (dm != 0 && s != 0) ? 1.0f : 0.0f;
         const float gtd = a.gt_depth[obj * a.gd_so + rr * a.gd_sr];
         const float* rgb = a.gt_rgb + obj * a.rgb_so + rr * a.rgb_sr;
-        const float g0 = rgb[0], g1 = rgb[a.rgb_sc], g2 = rgb[2 * a.rgb_sc];
-        const float inv_dd = a.flags[0] ? 0.0f : a.stats[obj * 4 + 0];            // render_rays.py:68-73
+        const float q0 = rgb[0], q1 = rgb[a.rgb_sc], q2 = rgb[2 * a.rgb_sc];
+        const float inv_dd = a.flags[0] ? 0.0f : a.stats[obj * 4 + 0];
         const float inv_o = a.flags[1] ? 0.0f : a.stats[obj * 4 + 1];
         const float inv_s = a.flags[2] ? 0.0f : a.stats[obj * 4 + 2];
-        const float info = 1.0f / (sqrtf(V) + 1e-4f);                             // render_rays.py:75-79
-        const float rd = D - gtd, rc0 = C0 - g0, rc1 = C1 - g1, rc2 = C2 - g2, ro = O - m_o;
+        const float info = 1.0f / (sqrtf(V) + 1e-4f);
+        const float rd = D - gtd, rc0 = C0 - q0, rc1 = C1 - q1, rc2 = C2 - q2, ro = O - m_o;
         wv::lds_add(lds + L::LOSS + 0, fabsf(rd) * m_dd * info * inv_dd);
         wv::lds_add(lds + L::LOSS + 1, (fabsf(rc0) + fabsf(rc1) + fabsf(rc2)) * m_o * inv_o);
         wv::lds_add(lds + L::LOSS + 2, fabsf(ro) * m_s * inv_s);
@@ -607,17 +697,17 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
             const float gO = a.opac_w * sgnf(ro) * m_s * inv_s;
             const float k_c = a.color_w * m_o * inv_o;
             const float gC0 = k_c * sgnf(rc0), gC1 = k_c * sgnf(rc1), gC2 = k_c * sgnf(rc2);
-            float suffix = 0.0f;                                   // sum_{k>i} g_w_k * w_k
+            float suffix = 0.0f;
             for (int i = a.S - 1; i >= 0; --i) {
                 float* row = rows + i * 8;
                 const float o = row[0], c0 = row[1], c1 = row[2], c2 = row[3];
                 const float Ti = row[4], w = row[5], zi = row[6];
                 const float gw = gD * zi + gC0 * c0 + gC1 * c1 + gC2 * c2 + gO;
                 const float f = (1.0f - o) + 1e-10f;
-                const float d_occ = gw * Ti - suffix / f;          // cumprod backward: reverse-cumsum / input
+                const float d_occ = gw * Ti - suffix / f;
                 suffix += gw * w;
-                row[0] = 10.0f * (d_occ * o * (1.0f - o));         // through sigmoid and the *10 (model.py:77)
-                row[1] = w * gC0 * c0 * (1.0f - c0);               // through the colour sigmoid (model.py:83)
+                row[0] = 10.0f * (d_occ * o * (1.0f - o));
+                row[1] = w * gC0 * c0 * (1.0f - c0);
                 row[2] = w * gC1 * c1 * (1.0f - c1);
                 row[3] = w * gC2 * c2 * (1.0f - c2);
             }
@@ -629,7 +719,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
     // ---- backward ----
     float d_raw = 0.0f, d_c0 = 0.0f, d_c1 = 0.0f, d_c2 = 0.0f;
     {
-        const float* row = cb + pt * 8;          // pt < kMaxPts always
+        const float* row = cb + pt * 8;          // pt < kMaxPts always; padding rows hold zeros
         d_raw = row[0]; d_c0 = row[1]; d_c1 = row[2]; d_c2 = row[3];
     }
     float xF[16], dF[16];
@@ -676,11 +766,14 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
         // color_linear weight gradient: [d hc]^T [h4 | e2]
         to_F(dF, dcp, scrD, p31, hi);
         add_db(Gv + L::B_C, dF, p31, hi);
-        zero_acc(acc); dw_mm(acc, dF, h4F); emit_block<MULTI, H + kEmb2>(qacc[0], acc, stg0, out + F::W_C, 0, 32, wave, p31, hi);
+        zero_acc(acc); dw_mm(acc, dF, h4F);
+        emit_block<MULTI, H + kEmb2>(qacc[0], acc, stg0, out + F::W_C, 0, 32, wave, p31, hi);
         to_F(xF, e2a, scrX, p31, hi);
-        zero_acc(acc); dw_mm(acc, dF, xF); emit_block<MULTI, H + kEmb2>(qacc[1], acc, stg1, out + F::W_C, H, 32, wave, p31, hi);
+        zero_acc(acc); dw_mm(acc, dF, xF);
+        emit_block<MULTI, H + kEmb2>(qacc[1], acc, stg1, out + F::W_C, H, 32, wave, p31, hi);
         to_F(xF, e2b, scrX, p31, hi);
-        zero_acc(acc); dw_mm(acc, dF, xF); emit_block<MULTI, H + kEmb2>(qacc[2], acc, stg0, out + F::W_C, H + 32, kEmb2 - 32, wave, p31, hi);
+        zero_acc(acc); dw_mm(acc, dF, xF);
+        emit_block<MULTI, H + kEmb2>(qacc[2], acc, stg0, out + F::W_C, H + 32, kEmb2 - 32, wave, p31, hi);
     }
     VK_MARK(7);
     // d h4 = W_a d raw + W_c[:, :H]^T d hc ; d e2 = W_c[:, H:]^T d hc
@@ -705,7 +798,8 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
         to_F(dF, d4, scrD, p31, hi);
         to_F(xF, h3, scrX, p31, hi);
         add_db(Gv + L::B_M2, dF, p31, hi);
-        zero_acc(acc); dw_mm(acc, dF, xF); emit_block<MULTI, H>(qacc[3], acc, stg1, out + F::W_M2, 0, 32, wave, p31, hi);
+        zero_acc(acc); dw_mm(acc, dF, xF);
+        emit_block<MULTI, H>(qacc[3], acc, stg1, out + F::W_M2, 0, 32, wave, p31, hi);
         zero_acc(acc);
         bwd_mm<L::LD_M>(acc, W + L::W_M2 + 4 * hi * L::LD_M + p31, d4);
 #pragma unroll
@@ -719,13 +813,17 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
         to_F(dF, d3, scrD, p31, hi);
         add_db(Gv + L::B_CAT, dF, p31, hi);
         to_F(xF, h2, scrX, p31, hi);
-        zero_acc(acc); dw_mm(acc, dF, xF); emit_block<MULTI, H + kEmb1>(qacc[4], acc, stg0, out + F::W_CAT, 0, 32, wave, p31, hi);
+        zero_acc(acc); dw_mm(acc, dF, xF);
+        emit_block<MULTI, H + kEmb1>(qacc[4], acc, stg0, out + F::W_CAT, 0, 32, wave, p31, hi);
         to_F(xF, e1a, scrX, p31, hi);
-        zero_acc(acc); dw_mm(acc, dF, xF); emit_block<MULTI, H + kEmb1>(qacc[5], acc, stg1, out + F::W_CAT, H, 32, wave, p31, hi);
+        zero_acc(acc); dw_mm(acc, dF, xF);
+        emit_block<MULTI, H + kEmb1>(qacc[5], acc, stg1, out + F::W_CAT, H, 32, wave, p31, hi);
         to_F(xF, e1b, scrX, p31, hi);
-        zero_acc(acc); dw_mm(acc, dF, xF); emit_block<MULTI, H + kEmb1>(qacc[6], acc, stg0, out + F::W_CAT, H + 32, 32, wave, p31, hi);
+        zero_acc(acc); dw_mm(acc, dF, xF);
+        emit_block<MULTI, H + kEmb1>(qacc[6], acc, stg0, out + F::W_CAT, H + 32, 32, wave, p31, hi);
         to_F(xF, e1c, scrX, p31, hi);
-        zero_acc(acc); dw_mm(acc, dF, xF); emit_block<MULTI, H + kEmb1>(qacc[7], acc, stg1, out + F::W_CAT, H + 64, kEmb1 - 64, wave, p31, hi);
+        zero_acc(acc); dw_mm(acc, dF, xF);
+        emit_block<MULTI, H + kEmb1>(qacc[7], acc, stg1, out + F::W_CAT, H + 64, kEmb1 - 64, wave, p31, hi);
         const float* wc = W + L::W_CAT + 4 * hi * L::LD_CAT;
         zero_acc(acc);
         bwd_mm<L::LD_CAT>(acc, wc + p31, d3);
@@ -742,7 +840,8 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
         to_F(dF, d2, scrD, p31, hi);
         to_F(xF, h1, scrX, p31, hi);
         add_db(Gv + L::B_M1, dF, p31, hi);
-        zero_acc(acc); dw_mm(acc, dF, xF); emit_block<MULTI, H>(qacc[8], acc, stg0, out + F::W_M1, 0, 32, wave, p31, hi);
+        zero_acc(acc); dw_mm(acc, dF, xF);
+        emit_block<MULTI, H>(qacc[8], acc, stg0, out + F::W_M1, 0, 32, wave, p31, hi);
         zero_acc(acc);
         bwd_mm<L::LD_M>(acc, W + L::W_M1 + 4 * hi * L::LD_M + p31, d2);
 #pragma unroll
@@ -755,11 +854,14 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
         to_F(dF, d1, scrD, p31, hi);
         add_db(Gv + L::B_IN, dF, p31, hi);
         to_F(e1aF, e1a, scrX, p31, hi);
-        zero_acc(acc); dw_mm(acc, dF, e1aF); emit_block<MULTI, kEmb1>(qacc[9], acc, stg1, out + F::W_IN, 0, 32, wave, p31, hi);
+        zero_acc(acc); dw_mm(acc, dF, e1aF);
+        emit_block<MULTI, kEmb1>(qacc[9], acc, stg1, out + F::W_IN, 0, 32, wave, p31, hi);
         to_F(xF, e1b, scrX, p31, hi);
-        zero_acc(acc); dw_mm(acc, dF, xF); emit_block<MULTI, kEmb1>(qacc[10], acc, stg0, out + F::W_IN, 32, 32, wave, p31, hi);
+        zero_acc(acc); dw_mm(acc, dF, xF);
+        emit_block<MULTI, kEmb1>(qacc[10], acc, stg0, out + F::W_IN, 32, 32, wave, p31, hi);
         to_F(xF, e1c, scrX, p31, hi);
-        zero_acc(acc); dw_mm(acc, dF, xF); emit_block<MULTI, kEmb1>(qacc[11], acc, stg1, out + F::W_IN, 64, kEmb1 - 64, wave, p31, hi);
+        zero_acc(acc); dw_mm(acc, dF, xF);
+        emit_block<MULTI, kEmb1>(qacc[11], acc, stg1, out + F::W_IN, 64, kEmb1 - 64, wave, p31, hi);
         const float* wi = W + L::W_IN + 4 * hi * L::LD_IN;
         bwd_mm<L::LD_IN>(de1a, wi + p31, d1);
         bwd_mm<L::LD_IN>(de1b, wi + 32 + p31, d1);
@@ -804,7 +906,10 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
     VK_MARK(14);
     if (tid == 0) {
         float* pl = a.part_loss + (obj * a.NW + wgo) * 4;
-        pl[0] = lds[L::LOSS + 0]; pl[1] = lds[L::LOSS + 1]; pl[2] = lds[L::LOSS + 2]; pl[3] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            pl[k] = (lds[L::LOSS + k] + lds[L::LOSS + 4 + k]) + (lds[L::LOSS + 8 + k] + lds[L::LOSS + 12 + k]);
+        pl[3] = 0.0f;
     }
     if (!BWD) return;
 
@@ -853,8 +958,9 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
 
 // ---------------------------------------------------------------------------------------------------------
 // step_finalize: ordered sum of the per-workgroup partials -> gradients (and, fused, torch.optim.AdamW's
-// single-tensor update: decoupled decay, lerp first moment, bias-corrected denominator), the scalar loss
-// (loss.py:59-60) and the "loss explode" flag (render_rays.py:88-90).
+// single-tensor update: decoupled decay, lerp first moment, bias-corrected denominator; the updated value is
+// written to the parameter tensor AND to the packed image the next step's step_main stages from), the scalar
+// loss (loss.py:59-60) and the "loss explode" flag (render_rays.py:88-90).
 // ---------------------------------------------------------------------------------------------------------
 struct FinalizeArgs {
     int n_obj, NW, PP, P;              // NW partials per object; P = real parameter count per object (flat order: 14 field tensors, then B)
@@ -862,6 +968,7 @@ struct FinalizeArgs {
     TensorRef param[kNFc + 1];         // parameters (updated in place when do_adam)
     TensorRef grad[kNFc + 1];          // gradient outputs (p may be null: skip)
     float* m; float* v;                // Adam moments, [n][PP] slabs (when do_adam)
+    float* wimg;                       // [n][Lds32::IMGP] packed parameter image (updated when do_adam)
     const float* part_grad; const float* part_loss;
     const int* flags_in; int* flags_out;
     float* loss_out;                   // [1]
@@ -895,6 +1002,7 @@ __global__ __launch_bounds__(kWG) void step_finalize(const FinalizeArgs a) {
             const float denom = sqrtf(v) / a.bias_corr2_sqrt + a.eps;
             p = p - a.step_size * (m / denom);                            // param.addcdiv_(exp_avg, denom, -lr / bc1)
             *pp = p; a.m[s] = m; a.v[s] = v;
+            a.wimg[(long long)obj * Lds32::IMGP + image_index(t, o)] = p;
         }
     }
     if (blockIdx.x == 0) {

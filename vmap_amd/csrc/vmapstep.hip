@@ -46,7 +46,7 @@ void make_layout(int H, Layout& L) {
 
 struct Plan {
     int G, NG, NW;
-    size_t off_stats, off_flags, off_ploss, off_pgrad, total;
+    size_t off_stats, off_flags, off_ploss, off_pgrad, off_wimg, total;
 };
 
 int make_plan(const vmapstep_shape* sh, int max_steps, Plan& pl, const Layout& L) {
@@ -69,6 +69,7 @@ int make_plan(const vmapstep_shape* sh, int max_steps, Plan& pl, const Layout& L
     pl.off_flags = o; o += align_up((size_t)max_steps * 4 * sizeof(int));
     pl.off_ploss = o; o += align_up((size_t)sh->n_obj * pl.NG * 4 * sizeof(float));     // sized for NW = NG
     pl.off_pgrad = o; o += align_up((size_t)sh->n_obj * pl.NG * L.PP * sizeof(float));
+    pl.off_wimg = o; o += align_up((size_t)sh->n_obj * vk::Lds32::IMGP * sizeof(float));
     pl.total = o;
     return VMAPSTEP_OK;
 }
@@ -114,6 +115,7 @@ void fill_step_args(vk::StepArgs& a, const vmapstep_shape* sh, const Plan& pl, c
     a.flags = reinterpret_cast<int*>(ws + pl.off_flags);
     a.part_loss = reinterpret_cast<float*>(ws + pl.off_ploss);
     a.part_grad = reinterpret_cast<float*>(ws + pl.off_pgrad);
+    a.wimg = reinterpret_cast<float*>(ws + pl.off_wimg);
 }
 
 template <bool BWD, bool MULTI>
@@ -138,7 +140,7 @@ int launch_main(const vk::StepArgs& a, hipStream_t st) {
 }
 
 int launch_prep(const vk::StepArgs& a, int n_steps, hipStream_t st) {
-    hipLaunchKernelGGL(vk::step_prep, dim3(n_steps), dim3(vk::kWG), 3 * vk::kWG * sizeof(int), st, a);
+    hipLaunchKernelGGL(vk::step_prep, dim3(n_steps + a.n_obj), dim3(vk::kWG), 3 * vk::kWG * sizeof(int), st, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "step_prep launch: %s", hipGetErrorString(e));
     return VMAPSTEP_OK;
@@ -159,7 +161,7 @@ int launch_finalize(const vk::StepArgs& a, const Layout& L, const vmapstep_param
             f.grad[t] = {gt->ptr, gt->obj_stride};
         }
     }
-    f.part_grad = a.part_grad; f.part_loss = a.part_loss;
+    f.part_grad = a.part_grad; f.part_loss = a.part_loss; f.wimg = a.wimg;
     f.flags_in = a.flags; f.flags_out = flags_out; f.loss_out = loss_out;
     f.color_w = a.color_w; f.opac_w = a.opac_w;
     f.have_grad = have_grad ? 1 : 0;

@@ -24,6 +24,16 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 // value held by the partner lane in the other 32-lane half of the wave (lane ^ 32)
 __device__ __forceinline__ float swap_half(float x) { return __shfl_xor(x, 32); }
 
+// value of x held by lane `src` (0..63) of this wave
+__device__ __forceinline__ float shfl(float x, int src) { return __shfl(x, src & 63); }
+
+// asynchronous 16-byte-per-lane copy global -> LDS (LDS-DMA, no VGPR round trip): lane l's 16 bytes at `g` land at
+// lds_wave_base + 16*l.  Completion is covered by the vmcnt drain of the next workgroup barrier.
+__device__ __forceinline__ void glds16(const float* g, float* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
 // true on every lane iff pred holds on at least one lane of the wave (wave-uniform result)
 __device__ __forceinline__ bool wave_any(bool pred) { return __any(pred) != 0; }
 
