@@ -125,6 +125,22 @@ int vmapstep_train_steps(const vmapstep_shape* shape, const vmapstep_params* par
                          const vmapstep_params* grads, const vmapstep_outputs* out,
                          void* workspace, size_t workspace_bytes, void* stream);
 
+/* Multi-GPU split of vmapstep_train_steps (objects sharded over ranks).  The only quantity of the
+ * step that couples objects is the batch-wide "any object has an empty mask" switch (render_rays.py:68-73):
+ *   1. vmapstep_prepare(...)        per-step mask statistics + switches of THIS rank's objects -> workspace;
+ *   2. the caller max-reduces the int32[n_steps][4] array at (char*)workspace + *flags_offset across ranks
+ *      (one tiny collective per frame, outside the per-step path);
+ *   3. vmapstep_train_steps_prepared(...) runs the step loop on the prepared (and reduced) workspace.
+ * Single-GPU callers just use vmapstep_train_steps. */
+int vmapstep_prepare(const vmapstep_shape* shape, const vmapstep_params* params, const vmapstep_batch* frame,
+                     int64_t ray_step, int32_t n_steps, void* workspace, size_t workspace_bytes,
+                     size_t* flags_offset, void* stream);
+int vmapstep_train_steps_prepared(const vmapstep_shape* shape, const vmapstep_params* params,
+                                  const vmapstep_tensor* pe_scale, const vmapstep_batch* frame, int64_t ray_step,
+                                  int32_t n_steps, float color_scaling, float opacity_scaling,
+                                  const vmapstep_adamw* opt, const vmapstep_params* grads,
+                                  const vmapstep_outputs* out, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Measurement hook: step_prep once, then the dominant kernel (step_main, forward+backward) `reps` times back to
  * back on `stream` with nothing in between, so that events recorded around the call give its average launch
  * duration (bench.py's roofline figure).  Writes only to the workspace. */

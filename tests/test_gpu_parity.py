@@ -266,3 +266,30 @@ def test_full_size_properties_headline_config():
 def test_unsupported_hidden_width_fails_loudly():
     with pytest.raises(_lib.VmapStepError, match="hidden=64"):
         step.VmapStep(4, 32, 10, 64, device=DEV)
+
+
+def test_prepared_split_applies_externally_reduced_flags():
+    """vmapstep_prepare -> (flag reduction across ranks) -> vmapstep_train_steps_prepared: a switch raised by ANOTHER
+    rank's objects must drop the term here too (render_rays.py:68-73 is batch-wide)."""
+    c = cases.build_case("tiny")
+    fc, B, sc, b = _to_dev(c)
+    op = step.VmapStep(c["n"], c["R"], c["S"], c["H"], device=DEV)
+    st = step.FusedAdamWState(c["n"], c["H"], DEV, lr=0.0, weight_decay=0.0)      # lr 0: parameters stay put
+    gfc = [torch.zeros_like(t) for t in fc]
+    gB = torch.zeros_like(B)
+    seen = {}
+
+    def inject(flags):                      # what ObjectShard.reduce_flags would deliver if a peer had an empty depth mask
+        seen["local"] = flags.clone()
+        flags[:, 0] = 1
+
+    res = op.train_steps(fc, B, sc, b["pcs"], b["z"], b["gt_depth"], b["gt_rgb"], b["sem"], b["depth_mask"], opt=st,
+                         n_steps=1, grads_fc=gfc, grad_B=gB, flag_reduce=inject)
+    torch.cuda.synchronize()
+    assert seen["local"][0, :3].tolist() == [0, 0, 0]
+    o = vo.training_step(c["fc"], c["B"], c["scale"], c["batch"], dtype=np.float32, drop=[True, False, False])
+    assert float(res.loss[0]) == pytest.approx(o["loss"], rel=2e-5)
+    assert res.flags[0].tolist()[:3] == [1, 0, 0]
+    for t in range(14):
+        assert relerr(gfc[t].cpu().numpy(), o[f"g_fc{t}"]) < 1e-4
+    assert relerr(gB.cpu().numpy(), o["g_B"]) < 1e-4

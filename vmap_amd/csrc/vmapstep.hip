@@ -277,11 +277,12 @@ int vmapstep_render(const vmapstep_shape* shape, const vmapstep_params* params, 
     return launch_finalize(a, L, params, nullptr, nullptr, 0, false, out->loss, out->flags, st);
 }
 
-int vmapstep_train_steps(const vmapstep_shape* shape, const vmapstep_params* params, const vmapstep_tensor* pe_scale,
-                         const vmapstep_batch* frame, int64_t ray_step, int32_t n_steps,
-                         float color_scaling, float opacity_scaling, const vmapstep_adamw* opt,
-                         const vmapstep_params* grads, const vmapstep_outputs* out,
-                         void* workspace, size_t workspace_bytes, void* stream) {
+static int train_steps_impl(const vmapstep_shape* shape, const vmapstep_params* params, const vmapstep_tensor* pe_scale,
+                            const vmapstep_batch* frame, int64_t ray_step, int32_t n_steps,
+                            float color_scaling, float opacity_scaling, const vmapstep_adamw* opt,
+                            const vmapstep_params* grads, const vmapstep_outputs* out,
+                            void* workspace, size_t workspace_bytes, void* stream, bool do_prep, bool do_steps,
+                            size_t* flags_offset) {
     int rc;
     if (!shape) return fail(VMAPSTEP_ERR_ARGUMENT, "shape is null");
     if (n_steps < 1) return fail(VMAPSTEP_ERR_ARGUMENT, "n_steps=%d", n_steps);
@@ -292,16 +293,22 @@ int vmapstep_train_steps(const vmapstep_shape* shape, const vmapstep_params* par
     if ((rc = check_params(params, "params", false))) return rc;
     if (grads && (rc = check_params(grads, "grads", true))) return rc;
     if ((rc = check_batch(frame))) return rc;
+    if ((rc = check_ws(workspace, workspace_bytes, pl))) return rc;
+    if (flags_offset) *flags_offset = pl.off_flags;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    char* ws = static_cast<char*>(workspace);
+    vmapstep_tensor dummy_scale = {params->fc[0].ptr, 0};
+    const vmapstep_tensor* sc = pe_scale ? pe_scale : &dummy_scale;
+    vk::StepArgs a;
+    if (do_prep) {
+        fill_step_args(a, shape, pl, L, params, sc, frame, 0, color_scaling, opacity_scaling, ws);
+        a.prep_steps = n_steps; a.prep_ray_step = ray_step;
+        if ((rc = launch_prep(a, n_steps, st))) return rc;
+    }
+    if (!do_steps) return VMAPSTEP_OK;
     if (!pe_scale || !pe_scale->ptr) return fail(VMAPSTEP_ERR_ARGUMENT, "pe_scale is null");
     if (!opt || !opt->exp_avg || !opt->exp_avg_sq) return fail(VMAPSTEP_ERR_ARGUMENT, "optimiser state is required");
     if (!out || !out->loss || !out->flags) return fail(VMAPSTEP_ERR_ARGUMENT, "outputs.loss / outputs.flags are required");
-    if ((rc = check_ws(workspace, workspace_bytes, pl))) return rc;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    char* ws = static_cast<char*>(workspace);
-    vk::StepArgs a;
-    fill_step_args(a, shape, pl, L, params, pe_scale, frame, 0, color_scaling, opacity_scaling, ws);
-    a.prep_steps = n_steps; a.prep_ray_step = ray_step;
-    if ((rc = launch_prep(a, n_steps, st))) return rc;
     for (int i = 0; i < n_steps; ++i) {
         fill_step_args(a, shape, pl, L, params, pe_scale, frame, (int64_t)i * ray_step, color_scaling, opacity_scaling, ws);
         a.stats += (size_t)i * shape->n_obj * 4;
@@ -313,6 +320,32 @@ int vmapstep_train_steps(const vmapstep_shape* shape, const vmapstep_params* par
                                   out->loss + i, out->flags + 4 * i, st))) return rc;
     }
     return VMAPSTEP_OK;
+}
+
+int vmapstep_train_steps(const vmapstep_shape* shape, const vmapstep_params* params, const vmapstep_tensor* pe_scale,
+                         const vmapstep_batch* frame, int64_t ray_step, int32_t n_steps,
+                         float color_scaling, float opacity_scaling, const vmapstep_adamw* opt,
+                         const vmapstep_params* grads, const vmapstep_outputs* out,
+                         void* workspace, size_t workspace_bytes, void* stream) {
+    return train_steps_impl(shape, params, pe_scale, frame, ray_step, n_steps, color_scaling, opacity_scaling, opt, grads,
+                            out, workspace, workspace_bytes, stream, true, true, nullptr);
+}
+
+int vmapstep_prepare(const vmapstep_shape* shape, const vmapstep_params* params, const vmapstep_batch* frame,
+                     int64_t ray_step, int32_t n_steps, void* workspace, size_t workspace_bytes,
+                     size_t* flags_offset, void* stream) {
+    if (!flags_offset) return fail(VMAPSTEP_ERR_ARGUMENT, "flags_offset is null");
+    return train_steps_impl(shape, params, nullptr, frame, ray_step, n_steps, 5.0f, 10.0f, nullptr, nullptr, nullptr,
+                            workspace, workspace_bytes, stream, true, false, flags_offset);
+}
+
+int vmapstep_train_steps_prepared(const vmapstep_shape* shape, const vmapstep_params* params,
+                                  const vmapstep_tensor* pe_scale, const vmapstep_batch* frame, int64_t ray_step,
+                                  int32_t n_steps, float color_scaling, float opacity_scaling,
+                                  const vmapstep_adamw* opt, const vmapstep_params* grads,
+                                  const vmapstep_outputs* out, void* workspace, size_t workspace_bytes, void* stream) {
+    return train_steps_impl(shape, params, pe_scale, frame, ray_step, n_steps, color_scaling, opacity_scaling, opt, grads,
+                            out, workspace, workspace_bytes, stream, false, true, nullptr);
 }
 
 int vmapstep_profile_main_kernel(const vmapstep_shape* shape, const vmapstep_params* params,

@@ -199,9 +199,13 @@ class VmapStep:
 
     def train_steps(self, fc, B, pe_scale, pcs, z, gt_depth, gt_rgb, sem, depth_mask, opt: FusedAdamWState,
                     n_steps: int, ray_step: Optional[int] = None, grads_fc=None, grad_B=None,
-                    render: bool = False) -> StepResult:
+                    render: bool = False, flag_reduce=None) -> StepResult:
         """The step loop of one frame (train.py:270-326): step i trains on rays [i*ray_step, i*ray_step+R) of the
-        per-frame tensors ([n, rays_total, ...]) and applies the fused AdamW update in place."""
+        per-frame tensors ([n, rays_total, ...]) and applies the fused AdamW update in place.
+
+        ``flag_reduce``: optional callable taking the int32 [n_steps, 4] device tensor of this rank's empty-mask switches
+        and max-reducing it in place across ranks (vmap_amd.parallel); when given, the call is split into
+        vmapstep_prepare -> flag_reduce -> vmapstep_train_steps_prepared."""
         if n_steps > self.max_steps:
             raise ValueError(f"n_steps={n_steps} > max_steps={self.max_steps} this operator was sized for")
         ray_step = self.rays if ray_step is None else int(ray_step)
@@ -214,10 +218,19 @@ class VmapStep:
         bt = self._batch(pcs, z, gt_depth, gt_rgb, sem, depth_mask, rays_total=rays_total)
         res, out = self._outputs(n_steps, render)
         oc = opt.c_struct()
-        _lib.check(self.lib.vmapstep_train_steps(ctypes.byref(self.shape), ctypes.byref(pp), ctypes.byref(sc),
-                                                 ctypes.byref(bt), ray_step, n_steps, self.color_scaling,
-                                                 self.opacity_scaling, ctypes.byref(oc),
-                                                 ctypes.byref(gp) if gp is not None else None, ctypes.byref(out),
-                                                 self._ws_ptr, self._ws_bytes, self._stream()))
+        fn = self.lib.vmapstep_train_steps
+        if flag_reduce is not None:
+            off = ctypes.c_size_t(0)
+            _lib.check(self.lib.vmapstep_prepare(ctypes.byref(self.shape), ctypes.byref(pp), ctypes.byref(bt), ray_step,
+                                                 n_steps, self._ws_ptr, self._ws_bytes, ctypes.byref(off), self._stream()))
+            start = (self._ws_ptr - self.workspace.data_ptr()) + off.value
+            flags_view = self.workspace[start:start + n_steps * 16].view(torch.int32).view(n_steps, 4)
+            flag_reduce(flags_view)
+            fn = self.lib.vmapstep_train_steps_prepared
+        _lib.check(fn(ctypes.byref(self.shape), ctypes.byref(pp), ctypes.byref(sc),
+                      ctypes.byref(bt), ray_step, n_steps, self.color_scaling,
+                      self.opacity_scaling, ctypes.byref(oc),
+                      ctypes.byref(gp) if gp is not None else None, ctypes.byref(out),
+                      self._ws_ptr, self._ws_bytes, self._stream()))
         opt.step += n_steps
         return res
