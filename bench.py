@@ -143,6 +143,16 @@ def main():
         flops = layout.step_flops(n, R, S, H)
         abytes = layout.step_bytes(n, R, S, H)
         achieved = flops / (k_ms * 1e-3) / 1e12
+        # HBM-side bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE, see
+        # profiles/*_pmc_counters.json); counters cannot be sampled from inside this process
+        traffic = None
+        try:
+            pmcs = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_counters.json"))
+            if pmcs and args.config == "replica_room0_vmap":
+                with open(os.path.join(ROOT, "profiles", pmcs[-1])) as fh:
+                    traffic = json.load(fh)["_notes"]["hbm_traffic_bytes_per_launch_step_main"]
+        except Exception:
+            traffic = None
         # forward+backward only (no optimiser), same loop structure
         gfc = [torch.zeros_like(t) for t in tfc]
         gB = torch.zeros_like(tB)
@@ -162,7 +172,7 @@ def main():
                        "parallelism": f"objects sharded over {world} GPU(s); no per-step collective, one 4x{ipf}-int32 flag all-reduce per frame"},
             "roofline": {"bound": "mfma", "kernel": "step_main_h32<true>", "achieved": achieved,
                          "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
-                         "traffic": None, "kernel_ms": k_ms, "algorithmic_flops_per_launch": flops,
+                         "traffic": traffic, "kernel_ms": k_ms, "algorithmic_flops_per_launch": flops,
                          "algorithmic_bytes_per_launch": abytes,
                          "hbm_achieved_GBs": abytes / (k_ms * 1e-3) / 1e9,
                          "hbm_frac": abytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},

@@ -16,7 +16,7 @@ void fc_sizes(int H, int* sz) {
 extern "C" int vmsim_lds_bytes() { return vk::Lds32::BYTES; }
 
 // fc[t]: [n][size_t] contiguous; grads: flat slab [n][P] in natural order (14 field tensors then B).
-extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req,
+extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req, int xcd_affine,
                           const float* const* fc, const float* B, const float* scale,
                           const float* pcs, const float* z, const float* gt_depth, const float* gt_rgb,
                           const uint8_t* sem, const uint8_t* dmask, float color_w, float opac_w,
@@ -40,7 +40,7 @@ extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req,
     std::vector<float> wimg((size_t)n * vk::Lds32::IMGP, NAN);
 
     vk::StepArgs a{};
-    a.n_obj = n; a.R = R; a.S = S; a.G = G; a.NG = NG; a.NW = NW; a.PP = PP; a.prep_steps = 1; a.prep_ray_step = 0;
+    a.n_obj = n; a.R = R; a.S = S; a.G = G; a.NG = NG; a.NW = NW; a.PP = PP; a.prep_steps = 1; a.prep_ray_step = 0; a.xcd_affine = xcd_affine;
     for (int t = 0; t < 14; ++t) a.fc[t] = {const_cast<float*>(fc[t]), sz[t]};
     a.pe_B = {const_cast<float*>(B), 63};
     a.pe_scale = {const_cast<float*>(scale), 1};
@@ -57,9 +57,10 @@ extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req,
 
     sim::launch(1 + n, vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep(a); });
     const bool multi = NW < NG;
-    if (bwd && multi)  sim::launch(n * NW, vk::kWG, vk::Lds32::BYTES, [&] { vk::step_main_h32<true, true>(a); });
-    if (bwd && !multi) sim::launch(n * NW, vk::kWG, vk::Lds32::BYTES, [&] { vk::step_main_h32<true, false>(a); });
-    if (!bwd)          sim::launch(n * NW, vk::kWG, vk::Lds32::BYTES, [&] { vk::step_main_h32<false, false>(a); });
+    const int grid = xcd_affine ? 8 * ((n + 7) / 8) * NW : n * NW;
+    if (bwd && multi)  sim::launch(grid, vk::kWG, vk::Lds32::BYTES, [&] { vk::step_main_h32<true, true>(a); });
+    if (bwd && !multi) sim::launch(grid, vk::kWG, vk::Lds32::BYTES, [&] { vk::step_main_h32<true, false>(a); });
+    if (!bwd)          sim::launch(grid, vk::kWG, vk::Lds32::BYTES, [&] { vk::step_main_h32<false, false>(a); });
 
     vk::FinalizeArgs f{};
     f.n_obj = n; f.NW = NW; f.PP = PP; f.P = P;
@@ -79,7 +80,7 @@ extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req,
     f.eps = 1e-8f;
     f.step_size = (float)((double)lr / (1.0 - std::pow(0.9, step)));
     f.bias_corr2_sqrt = (float)std::sqrt(1.0 - std::pow(0.999, step));
-    const int bpo = (P + vk::kWG - 1) / vk::kWG;
+    const int bpo = (PP / 4 + vk::kWG - 1) / vk::kWG;
     sim::launch(n * bpo, vk::kWG, 2 * vk::kWG * 4, [&] { vk::step_finalize(f); });
     return 0;
 }

@@ -51,6 +51,7 @@ struct StepArgs {
     int n_obj, R, S, G, NG, NW, PP;    // G rays per pass, NG ray groups per object, NW workgroups per object
                                        // (workgroup w takes groups w, w+NW, ...), PP padded params per object
     int prep_steps; long long prep_ray_step;   // step_prep only: block b handles rays [b*ray_step, b*ray_step+R)
+    int xcd_affine;                    // 1: block b -> object 8*((b>>3)/NW) + (b&7): an object's workgroups share one XCD/L2
     TensorRef fc[kNFc];                // the 14 field tensors, nn.Module.parameters() order (model.py:28-49)
     TensorRef pe_B;                    // B_layer.weight [n,21,3] (embedding.py:75-76)
     TensorRef pe_scale;                // scale buffer [n] (embedding.py:80)
@@ -261,6 +262,37 @@ __device__ __forceinline__ void sincos_f32(float x, float& s, float& c) {
     c = ((q + 1) & 2) ? -cc : cc;
 }
 
+// The same for N independent arguments in lockstep: every step is applied to all N before the next one, so the
+// N dependency chains interleave in program order (one wave per SIMD has no other wave to hide VALU latency).
+template <int N>
+__device__ __forceinline__ void sincos_f32xN(const float (&x)[N], float (&s)[N], float (&c)[N]) {
+    float n[N], r[N], r2[N], sp[N], cp[N];
+    int q[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) n[k] = rintf(x[k] * 0.636619772367581343f);
+#pragma unroll
+    for (int k = 0; k < N; ++k) r[k] = fmaf(-n[k], 1.57079637050628662109375f, x[k]);
+#pragma unroll
+    for (int k = 0; k < N; ++k) r[k] = fmaf(-n[k], -4.37113900018624283e-8f, r[k]);
+#pragma unroll
+    for (int k = 0; k < N; ++k) r[k] = fmaf(-n[k], -1.71512449026012451e-15f, r[k]);
+#pragma unroll
+    for (int k = 0; k < N; ++k) { q[k] = (int)n[k] & 3; r2[k] = r[k] * r[k]; }
+#pragma unroll
+    for (int k = 0; k < N; ++k) { sp[k] = fmaf(r2[k], -1.9515295891e-4f, 8.3321608736e-3f); cp[k] = fmaf(r2[k], 2.443315711809948e-5f, -1.388731625493765e-3f); }
+#pragma unroll
+    for (int k = 0; k < N; ++k) { sp[k] = fmaf(r2[k], sp[k], -1.6666654611e-1f); cp[k] = fmaf(r2[k], cp[k], 4.166664568298827e-2f); }
+#pragma unroll
+    for (int k = 0; k < N; ++k) { sp[k] = fmaf(r[k] * r2[k], sp[k], r[k]); cp[k] = fmaf(r2[k] * r2[k], cp[k], fmaf(r2[k], -0.5f, 1.0f)); }
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const float ss = (q[k] & 1) ? cp[k] : sp[k];
+        const float cc = (q[k] & 1) ? sp[k] : cp[k];
+        s[k] = (q[k] & 2) ? -ss : ss;
+        c[k] = ((q[k] + 1) & 2) ? -cc : cc;
+    }
+}
+
 // One embedding slot.  c = index into the 129-wide encoding (embedding.py:85-89: 3 + f*21 + d), or -1 = padding.
 __device__ __forceinline__ void pe_slot(int c, const float (&t)[3], const float (&proj)[kDirs],
                                         float& pre, float& tv, float& fac) {
@@ -279,26 +311,40 @@ __device__ __forceinline__ void pe_slot(int c, const float (&t)[3], const float 
 template <int NSTEPS, bool BIG>
 __device__ __forceinline__ void pe_block(float (&e)[16], float (&cf)[16], int base, int limit, int kb,
                                          const float (&t)[3], const float (&proj)[kDirs], int hi) {
+    // pass 1: arguments (or xyz values / padding) of the 16 slots; pass 2: sin/cos four slots at a time
+    float arg[16], fac[16], tv[16];
+    bool is_sin[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        e[r] = 0.0f;
-        cf[r] = 0.0f;
+        arg[r] = 0.0f; fac[r] = 0.0f; tv[r] = 0.0f; is_sin[r] = false;
         if (r < NSTEPS) {
             const int l0 = 32 * kb + phi(r, 0), l1 = 32 * kb + phi(r, 1);
             const int c0 = l0 < limit ? base + l0 : -1, c1 = l1 < limit ? base + l1 : -1;
             float pre0, tv0, fac0, pre1, tv1, fac1;
             pe_slot(c0, t, proj, pre0, tv0, fac0);
             pe_slot(c1, t, proj, pre1, tv1, fac1);
-            if (c0 >= 3 || c1 >= 3) {
-                const float arg = (hi ? pre1 : pre0) * kPi;    // fl32(xb * fl32(pi)), embedding.py:88
-                float s, c;
-                if (BIG) sincosf(arg, &s, &c); else sincos_f32(arg, s, c);
-                const float v0 = c0 >= 3 ? s : tv0, v1 = c1 >= 3 ? s : tv1;
-                e[r] = hi ? v1 : v0;
-                cf[r] = c * (hi ? fac1 : fac0);
+            arg[r] = (hi ? pre1 : pre0) * kPi;                 // fl32(xb * fl32(pi)), embedding.py:88
+            fac[r] = hi ? fac1 : fac0;                          // 0 for xyz / padding slots
+            tv[r] = hi ? tv1 : tv0;
+            is_sin[r] = hi ? (c1 >= 3) : (c0 >= 3);
+        }
+    }
+#pragma unroll
+    for (int r0 = 0; r0 < 16; r0 += 4) {
+        float a4[4] = {arg[r0], arg[r0 + 1], arg[r0 + 2], arg[r0 + 3]}, s4[4], c4[4];
+        if (r0 < NSTEPS) {
+            if (BIG) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sincosf(a4[k], &s4[k], &c4[k]);
             } else {
-                e[r] = hi ? tv1 : tv0;
+                sincos_f32xN<4>(a4, s4, c4);
             }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = r0 + k;
+            e[r] = r < NSTEPS ? (is_sin[r] ? s4[k] : tv[r]) : 0.0f;
+            cf[r] = r < NSTEPS ? c4[k] * fac[r] : 0.0f;
         }
     }
 }
@@ -418,7 +464,20 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
     float* W = lds + L::WGT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p31 = lane & 31, hi = lane >> 5;
     float* Gv = lds + L::VEC + wave * L::SMALL_N - L::SMALL0;   // this wave's private small-vector gradients
-    const int obj = blockIdx.x / a.NW, wgo = blockIdx.x - obj * a.NW;
+    // Block -> (object, workgroup-of-object).  The dispatcher is observed to place block b on XCD b % 8; with the
+    // affine map all workgroups of an object sit on one XCD, so its parameter image is fetched into that L2 once
+    // instead of once per workgroup.  Pure speed/traffic choice: any placement is correct.
+    int obj, wgo;
+    if (a.xcd_affine) {
+        const int slot = blockIdx.x >> 3;
+        const int og = slot / a.NW;
+        obj = og * 8 + (blockIdx.x & 7);
+        wgo = slot - og * a.NW;
+        if (obj >= a.n_obj) return;
+    } else {
+        obj = blockIdx.x / a.NW;
+        wgo = blockIdx.x - obj * a.NW;
+    }
     unsigned* tmark = a.timing ? a.timing + ((long long)blockIdx.x * kWaves + wave) * kMarks : nullptr;
 #define VK_MARK(i) do { if (tmark && lane == 0) tmark[i] = wv::clock32(); } while (0)
     VK_MARK(0);
@@ -980,29 +1039,49 @@ struct FinalizeArgs {
 };
 
 __global__ __launch_bounds__(kWG) void step_finalize(const FinalizeArgs a) {
-    const int blocks_per_obj = (a.P + kWG - 1) / kWG;
+    // one thread per 4 consecutive flat parameters: the partial rows and the moment slabs are PP-pitched
+    // (PP % 64 == 0, 256-byte aligned) so they move as 16-byte vectors; parameter/gradient tensors are scattered
+    const int quads = a.PP / 4;
+    const int blocks_per_obj = (quads + kWG - 1) / kWG;
     const int obj = blockIdx.x / blocks_per_obj;
-    const int i = (blockIdx.x - obj * blocks_per_obj) * kWG + threadIdx.x;
-    if (a.have_grad && obj < a.n_obj && i < a.P) {
-        const float* pg = a.part_grad + (long long)obj * a.NW * a.PP + i;
-        float g = 0.0f;
-        for (int q = 0; q < a.NW; ++q) g += pg[(long long)q * a.PP];
-        int t = 0;
-#pragma unroll
-        for (int k = 1; k <= kNFc; ++k) t += i >= a.offs[k];
-        const int o = i - a.offs[t];
-        if (a.grad[t].p) a.grad[t].p[obj * a.grad[t].stride + o] = g;
+    const int q4 = (blockIdx.x - obj * blocks_per_obj) * kWG + threadIdx.x;
+    if (a.have_grad && obj < a.n_obj && q4 < quads && 4 * q4 < a.P) {
+        const int i0 = 4 * q4;
+        const wv::f32x4* pg = reinterpret_cast<const wv::f32x4*>(a.part_grad + (long long)obj * a.NW * a.PP + i0);
+        wv::f32x4 g = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int q = 0; q < a.NW; ++q) g += pg[(long long)q * (a.PP / 4)];
+        const long long s = (long long)obj * a.PP + i0;
+        wv::f32x4 m4 = {0.0f, 0.0f, 0.0f, 0.0f}, v4 = m4;
         if (a.do_adam) {
-            float* pp = a.param[t].p + obj * a.param[t].stride + o;
-            const long long s = (long long)obj * a.PP + i;
-            float p = *pp, m = a.m[s], v = a.v[s];
-            p = p * a.decay;                                              // param.mul_(1 - lr * wd)
-            m = m + (g - m) * a.one_minus_beta1;                          // exp_avg.lerp_(grad, 1 - beta1)
-            v = v * a.beta2 + (g * g) * a.one_minus_beta2;                // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
-            const float denom = sqrtf(v) / a.bias_corr2_sqrt + a.eps;
-            p = p - a.step_size * (m / denom);                            // param.addcdiv_(exp_avg, denom, -lr / bc1)
-            *pp = p; a.m[s] = m; a.v[s] = v;
-            a.wimg[(long long)obj * Lds32::IMGP + image_index(t, o)] = p;
+            m4 = *reinterpret_cast<const wv::f32x4*>(a.m + s);
+            v4 = *reinterpret_cast<const wv::f32x4*>(a.v + s);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = i0 + e;
+            if (i < a.P) {
+                int t = 0;
+#pragma unroll
+                for (int k = 1; k <= kNFc; ++k) t += i >= a.offs[k];
+                const int o = i - a.offs[t];
+                const float ge = g[e];
+                if (a.grad[t].p) a.grad[t].p[obj * a.grad[t].stride + o] = ge;
+                if (a.do_adam) {
+                    float* pp = a.param[t].p + obj * a.param[t].stride + o;
+                    float p = *pp, m = m4[e], v = v4[e];
+                    p = p * a.decay;                                          // param.mul_(1 - lr * wd)
+                    m = m + (ge - m) * a.one_minus_beta1;                     // exp_avg.lerp_(grad, 1 - beta1)
+                    v = v * a.beta2 + (ge * ge) * a.one_minus_beta2;          // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
+                    const float denom = sqrtf(v) / a.bias_corr2_sqrt + a.eps;
+                    p = p - a.step_size * (m / denom);                        // param.addcdiv_(exp_avg, denom, -lr / bc1)
+                    *pp = p; m4[e] = m; v4[e] = v;
+                    a.wimg[(long long)obj * Lds32::IMGP + image_index(t, o)] = p;
+                }
+            }
+        }
+        if (a.do_adam) {
+            *reinterpret_cast<wv::f32x4*>(a.m + s) = m4;
+            *reinterpret_cast<wv::f32x4*>(a.v + s) = v4;
         }
     }
     if (blockIdx.x == 0) {

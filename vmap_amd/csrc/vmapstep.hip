@@ -95,6 +95,8 @@ void fill_step_args(vk::StepArgs& a, const vmapstep_shape* sh, const Plan& pl, c
     std::memset(&a, 0, sizeof(a));
     a.n_obj = sh->n_obj; a.R = sh->rays; a.S = sh->samples;
     a.G = pl.G; a.NG = pl.NG; a.NW = pl.NW; a.PP = L.PP;
+    // XCD-affine block map only while every XCD's share still fits its 32 CUs in one round
+    a.xcd_affine = ((sh->n_obj + 7) / 8) * pl.NW <= 32 ? 1 : 0;
     for (int t = 0; t < VMAPSTEP_NUM_FC; ++t) a.fc[t] = {params->fc[t].ptr, params->fc[t].obj_stride};
     a.pe_B = {params->pe_B.ptr, params->pe_B.obj_stride};
     a.pe_scale = {pe_scale->ptr, pe_scale->obj_stride};
@@ -128,7 +130,8 @@ int launch_main_v(const vk::StepArgs& a, hipStream_t st) {
         if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(a.n_obj * a.NW), dim3(vk::kWG), vk::Lds32::BYTES, st, a);
+    const int grid = a.xcd_affine ? 8 * ((a.n_obj + 7) / 8) * a.NW : a.n_obj * a.NW;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(vk::kWG), vk::Lds32::BYTES, st, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "step_main launch: %s", hipGetErrorString(e));
     return VMAPSTEP_OK;
@@ -177,7 +180,7 @@ int launch_finalize(const vk::StepArgs& a, const Layout& L, const vmapstep_param
         f.step_size = (float)(lr / (1.0 - std::pow(b1, (double)step_after)));
         f.bias_corr2_sqrt = (float)std::sqrt(1.0 - std::pow(b2, (double)step_after));
     }
-    const int bpo = (L.P + vk::kWG - 1) / vk::kWG;
+    const int bpo = (L.PP / 4 + vk::kWG - 1) / vk::kWG;
     const int grid = have_grad ? a.n_obj * bpo : 1;
     hipLaunchKernelGGL(vk::step_finalize, dim3(grid), dim3(vk::kWG), 2 * vk::kWG * sizeof(float), st, f);
     hipError_t e = hipGetLastError();
@@ -385,7 +388,7 @@ int vmapstep_profile_phases(const vmapstep_shape* shape, const vmapstep_params* 
     if ((rc = check_batch(batch))) return rc;
     if (!pe_scale || !pe_scale->ptr) return fail(VMAPSTEP_ERR_ARGUMENT, "pe_scale is null");
     if (!timing || !n_workgroups) return fail(VMAPSTEP_ERR_ARGUMENT, "timing / n_workgroups is null");
-    const size_t need = (size_t)shape->n_obj * pl.NW * vk::kWaves * vk::kMarks;
+    const size_t need = (size_t)8 * ((shape->n_obj + 7) / 8) * pl.NW * vk::kWaves * vk::kMarks;
     if (timing_elems < need) return fail(VMAPSTEP_ERR_ARGUMENT, "timing buffer %zu < %zu elements", timing_elems, need);
     if ((rc = check_ws(workspace, workspace_bytes, pl))) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -393,7 +396,7 @@ int vmapstep_profile_phases(const vmapstep_shape* shape, const vmapstep_params* 
     fill_step_args(a, shape, pl, L, params, pe_scale, batch, 0, 5.0f, 10.0f, static_cast<char*>(workspace));
     a.prep_steps = 1; a.prep_ray_step = 0;
     a.timing = timing;
-    *n_workgroups = shape->n_obj * pl.NW;
+    *n_workgroups = a.xcd_affine ? 8 * ((shape->n_obj + 7) / 8) * pl.NW : shape->n_obj * pl.NW;
     if ((rc = launch_prep(a, 1, st))) return rc;
     return launch_main<true>(a, st);
 }

@@ -186,7 +186,7 @@ class VmapStep:
         pp = self._params(fc, B)
         sc = _lib.Tensor(pe_scale.data_ptr(), pe_scale.stride(0) if pe_scale.dim() else 0)
         bt = self._batch(pcs, z, gt_depth, gt_rgb, sem, depth_mask)
-        cap = self.n_obj * 64 * 4 * 16
+        cap = 8 * ((self.n_obj + 7) // 8) * 64 * 4 * 16
         buf = torch.zeros(cap, dtype=torch.int32, device=self.device)
         nwg = ctypes.c_int32(0)
         _lib.check(self.lib.vmapstep_profile_phases(ctypes.byref(self.shape), ctypes.byref(pp), ctypes.byref(sc),
@@ -195,6 +195,7 @@ class VmapStep:
         torch.cuda.synchronize()
         t = buf[: nwg.value * 64].cpu().numpy().astype("int64") & 0xFFFFFFFF
         t = t.reshape(nwg.value, 4, 16)
+        t = t[t[:, 0, 15] != 0]                  # idle blocks of the XCD-affine grid never stamp
         return t - t[:, :, 0].min()
 
     def train_steps(self, fc, B, pe_scale, pcs, z, gt_depth, gt_rgb, sem, depth_mask, opt: FusedAdamWState,
