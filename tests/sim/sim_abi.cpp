@@ -4,7 +4,7 @@
 #include <cstring>
 #include <vector>
 
-#include "step_kernels.h"
+#include "gen_kernels.h"
 
 namespace {
 void fc_sizes(int H, int* sz) {
@@ -24,7 +24,7 @@ extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req, int xcd
                           float* dbg_var, int* flags, int bwd,
                           // optional fused AdamW (params updated in copies p_out [n][P], moments m, v [n][PP])
                           int do_adam, float* p_out, float* m, float* v, int step, float lr, float wd) {
-    if (H != 32) return -1;
+    if (H % 32 != 0 || H < 32 || H > 256) return -1;
     if (G * S > vk::kMaxPts || G < 1) return -2;
     int sz[14], offs[16];
     fc_sizes(H, sz);
@@ -37,10 +37,11 @@ extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req, int xcd
 
     std::vector<float> stats(n * 4, NAN), part_grad((size_t)n * NW * PP, NAN), part_loss((size_t)n * NW * 4, NAN);
     std::vector<int> fl(4, -1);
-    std::vector<float> wimg((size_t)n * vk::Lds32::IMGP, NAN);
+    const vk::GenLayout GL = vk::gen_layout(H);
+    std::vector<float> wimg((size_t)n * GL.imgp, NAN);
 
     vk::StepArgs a{};
-    a.n_obj = n; a.R = R; a.S = S; a.G = G; a.NG = NG; a.NW = NW; a.PP = PP; a.prep_steps = 1; a.prep_ray_step = 0; a.xcd_affine = xcd_affine;
+    a.n_obj = n; a.R = R; a.S = S; a.G = G; a.NG = NG; a.NW = NW; a.PP = PP; a.prep_steps = 1; a.prep_ray_step = 0; a.xcd_affine = (xcd_affine && H == 32) ? 1 : 0; a.hidden = H;
     for (int t = 0; t < 14; ++t) a.fc[t] = {const_cast<float*>(fc[t]), sz[t]};
     a.pe_B = {const_cast<float*>(B), 63};
     a.pe_scale = {const_cast<float*>(scale), 1};
@@ -57,13 +58,23 @@ extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req, int xcd
 
     sim::launch(1 + n, vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep(a); });
     const bool multi = NW < NG;
-    const int grid = xcd_affine ? 8 * ((n + 7) / 8) * NW : n * NW;
-    if (bwd && multi)  sim::launch(grid, vk::kWG, vk::Lds32::BYTES, [&] { vk::step_main_h32<true, true>(a); });
-    if (bwd && !multi) sim::launch(grid, vk::kWG, vk::Lds32::BYTES, [&] { vk::step_main_h32<true, false>(a); });
-    if (!bwd)          sim::launch(grid, vk::kWG, vk::Lds32::BYTES, [&] { vk::step_main_h32<false, false>(a); });
+    const int grid = xcd_affine && H == 32 ? 8 * ((n + 7) / 8) * NW : n * NW;
+    if (H == 32) {
+        if (bwd && multi)  sim::launch(grid, vk::kWG, vk::Lds32::BYTES, [&] { vk::step_main_h32<true, true>(a); });
+        if (bwd && !multi) sim::launch(grid, vk::kWG, vk::Lds32::BYTES, [&] { vk::step_main_h32<true, false>(a); });
+        if (!bwd)          sim::launch(grid, vk::kWG, vk::Lds32::BYTES, [&] { vk::step_main_h32<false, false>(a); });
+    } else {
+        vk::GenArgs ga;
+        ga.s = a;
+        ga.wave_blocks = vk::gen_wave_blocks(GL.NB);
+        std::vector<float> scratch((size_t)n * NW * vk::kWaves * ga.wave_blocks * vk::kBlk, NAN);
+        ga.scratch = scratch.data();
+        if (bwd) sim::launch(n * NW, vk::kWG, vk::LdsGen::bytes(GL.small_n), [&] { vk::step_main_gen<true>(ga); });
+        else     sim::launch(n * NW, vk::kWG, vk::LdsGen::bytes(GL.small_n), [&] { vk::step_main_gen<false>(ga); });
+    }
 
     vk::FinalizeArgs f{};
-    f.n_obj = n; f.NW = NW; f.PP = PP; f.P = P;
+    f.n_obj = n; f.NW = NW; f.PP = PP; f.P = P; f.hidden = H;
     for (int t = 0; t < 16; ++t) f.offs[t] = offs[t];
     for (int t = 0; t < 15; ++t) {
         f.grad[t] = {grads ? grads + offs[t] : nullptr, P};

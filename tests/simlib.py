@@ -18,7 +18,8 @@ def build(force=False):
     srcs = [os.path.join(SIM, "sim_abi.cpp"), os.path.join(SIM, "sim_runtime.cpp")]
     deps = srcs + [os.path.join(SIM, "sim_runtime.h"), os.path.join(SIM, "wave_ops.h"),
                    os.path.join(SIM, "include", "hip", "hip_runtime.h"),
-                   os.path.join(ROOT, "vmap_amd", "csrc", "step_kernels.h")]
+                   os.path.join(ROOT, "vmap_amd", "csrc", "step_kernels.h"),
+                   os.path.join(ROOT, "vmap_amd", "csrc", "gen_kernels.h")]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)

@@ -102,3 +102,27 @@ def test_sim_kernel_matches_torch_port_on_seeded_shapes(n, R, S, seed):
         assert relerr(s[k], rend_t[k].detach().numpy()) < 2e-5, k
     for k, g in zip(GRAD_KEYS, grads_t):
         assert relerr(s[k], g.numpy()) < 2e-5, k
+
+
+@pytest.mark.parametrize("name,nw", [("h64", 0), ("h64", 2), ("bg_h128_s14", 0)])
+def test_sim_generic_width_kernel_matches_reference(name, nw):
+    """step_main_gen (hidden = 64 / 128, global-memory activations; nw=2: multi-pass accumulate) vs the fixtures."""
+    c = cases.build_case(name)
+    g = load_golden(name)
+    s = simlib.sim_step(c, NW=nw)
+    assert abs(s["loss"] - float(g["loss"])) <= 2e-5 * abs(float(g["loss"]))
+    for k in RENDER_KEYS:
+        assert relerr(s[k], g[k]) < 2e-5, k
+    for k in GRAD_KEYS:
+        assert relerr(s[k], g[k]) < 1e-4, k
+
+
+@pytest.mark.slow
+def test_sim_generic_width_kernel_imap_h256():
+    """BASELINE configs[0] (iMAP plumbing: 1 object, hidden 256, 100 rays, 14 samples): ~80 s on the simulator."""
+    c = cases.build_case("imap_h256")
+    g = load_golden("imap_h256")
+    s = simlib.sim_step(c)
+    assert abs(s["loss"] - float(g["loss"])) <= 2e-5 * abs(float(g["loss"]))
+    for k in RENDER_KEYS + GRAD_KEYS:
+        assert relerr(s[k], g[k]) < 1e-4, k

@@ -1,0 +1,469 @@
+// gen_kernels.h - the fused training step for ANY hidden width H = 32*NB (background model H=128, iMAP H=256,
+// stress config H=64): same algorithm, same matrix-instruction building blocks and the same numerics as
+// step_main_h32, but sized for widths whose parameters (up to 1.3 MB) and activations do not fit LDS/registers:
+//
+//   * weights are read straight from the object's packed parameter image in global memory (L2-resident; the
+//     image's 16-byte-aligned rows make the forward operand a global_load_dwordx4 per four MFMAs);
+//   * activations, their F-forms (lane = feature) and the cos factors of the encoding live as "register images"
+//     (16 registers x 64 lanes = 4 KiB, lane-contiguous => coalesced) in a per-wave scratch area of the workspace;
+//     every lane only ever re-reads what it wrote itself, so no cross-lane visibility protocol is involved;
+//   * loops over the NB feature blocks are runtime loops (one kernel for every width).
+//
+// Workgroup shape, compositing phase, atomic-free gradient reduction (reduce_block + partials + step_finalize) and
+// the C ABI are those of the H=32 kernel.  This is the general path (about one global round trip per 16 matrix
+// instructions); hidden = 32 keeps its LDS/register-resident specialisation.
+#pragma once
+#include "step_kernels.h"
+
+namespace vk {
+
+constexpr int kBlk = 16 * 64;            // floats in one stored register block
+
+struct GenArgs {
+    StepArgs s;
+    float* scratch;                      // [workgroups][kWaves][wave_blocks][kBlk]
+    int wave_blocks;                     // 20 + 14 * NB
+};
+
+__host__ __device__ constexpr int gen_wave_blocks(int NB) { return 20 + 14 * NB; }
+
+// LDS map of the generic kernel (floats)
+struct LdsGen {
+    static constexpr int SCR = 0;                                   // per-wave transpose scratch: kWaves x 2 x [32][33]
+    static constexpr int SCR_WAVE = 2 * 32 * 33;
+    static constexpr int STG_TILE = 32 * 33;
+    static constexpr int STG = SCR + kWaves * SCR_WAVE;             // 2 buffers x kWaves tiles
+    static constexpr int CB = STG + 2 * kWaves * STG_TILE;          // composite buffer [kMaxPts][8]
+    static constexpr int LOSS = CB + kMaxPts * 8;                   // [kWaves][4]
+    static constexpr int VEC = LOSS + kWaves * 4;                   // kWaves x small_n (runtime size)
+    __host__ __device__ static constexpr int bytes(int small_n) { return (VEC + kWaves * small_n) * 4; }
+};
+
+__device__ __forceinline__ void ldb(float (&v)[16], const float* blk, int lane) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = blk[r * 64 + lane];
+}
+__device__ __forceinline__ void stb(float* blk, const float (&v)[16], int lane) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) blk[r * 64 + lane] = v[r];
+}
+__device__ __forceinline__ void stacc(float* blk, const f32x16& a, int lane) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) blk[r * 64 + lane] = a[r];
+}
+// d-prop with a runtime row pitch
+__device__ __forceinline__ void bwd_mm_rt(f32x16& acc, const float* wcol, int ld, const float (&dy)[16]) {
+    float w[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) w[r] = wcol[((r & 3) + 8 * (r >> 2)) * ld];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc = wv::mfma32(w[r], dy[r], acc);
+}
+// quarter store with a runtime row pitch; add = accumulate onto an earlier pass of the same workgroup
+__device__ __forceinline__ void store_quarter_rt(float* out, int K, const float (&q)[4], int col0, int ncols, bool add,
+                                                 int wave, int p31, int hi) {
+    if (p31 < ncols) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float* o = out + (8 * wave + 4 * hi + i) * K + col0 + p31;
+            *o = add ? *o + q[i] : q[i];
+        }
+    }
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(kWG, 1) void step_main_gen(const GenArgs ga) {
+    const StepArgs& a = ga.s;
+    const GenLayout L = gen_layout(a.hidden);
+    const int H = L.H, NB = L.NB;
+    float* lds = wv::lds_base();
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p31 = lane & 31, hi = lane >> 5;
+    const int obj = blockIdx.x / a.NW, wgo = blockIdx.x - obj * a.NW;
+    const float* Wg = a.wimg + (long long)obj * L.imgp;                 // this object's parameter image (global)
+    float* Gv = lds + LdsGen::VEC + wave * L.small_n - L.b_in;           // private small-vector gradients, image-indexed
+    float* sb = ga.scratch + ((long long)blockIdx.x * kWaves + wave) * ga.wave_blocks * kBlk;
+    // scratch block indices
+    const int E_P = 0, E_F = 5, CFB = 10, H_P = 15, H_F = 15 + 5 * NB, D_P = 15 + 10 * NB, D_F = 15 + 12 * NB, DE = 15 + 14 * NB;
+#define BLK(i) (sb + (long long)(i) * kBlk)
+
+    if (BWD) {
+        for (int i = tid; i < kWaves * L.small_n; i += kWG) lds[LdsGen::VEC + i] = 0.0f;
+    }
+    if (tid < kWaves * 4) lds[LdsGen::LOSS + tid] = 0.0f;
+    float* out = a.part_grad + ((long long)(obj * a.NW + wgo)) * a.PP;
+    float* stg0 = lds + LdsGen::STG;
+    float* stg1 = stg0 + kWaves * LdsGen::STG_TILE;
+    float* scrX = lds + LdsGen::SCR + wave * LdsGen::SCR_WAVE;
+    float* scrD = scrX + 32 * 33;
+    float* cb = lds + LdsGen::CB;
+    const float* cbw = cb + wave * 32 * 8;
+    const float scale = a.pe_scale.p[obj * a.pe_scale.stride];
+    const float* Bg = a.pe_B.p + obj * a.pe_B.stride;
+    int stage_toggle = 0;                                               // alternates the two staging buffers
+
+    for (int grp = wgo; grp < a.NG; grp += a.NW) {
+    const bool first_pass = grp == wgo;
+    __syncthreads();
+    for (int i = tid; i < kMaxPts * 8; i += kWG) cb[i] = 0.0f;
+
+    const int ray0 = grp * a.G;
+    const int nrays = min(a.G, a.R - ray0);
+    const int npts = nrays * a.S;
+    const int pt = wave * 32 + p31;
+    const bool valid = pt < npts;
+    const int lray = valid ? pt / a.S : 0;
+    const int smp = valid ? pt - lray * a.S : 0;
+    const int ray = ray0 + lray;
+    float t[3] = {0.0f, 0.0f, 0.0f};
+    if (valid) {
+        const float* px = a.pcs + obj * a.pcs_so + ray * a.pcs_sr + smp * a.pcs_ss;
+        t[0] = px[0] / scale;
+        t[1] = px[a.pcs_sc] / scale;
+        t[2] = px[2 * a.pcs_sc] / scale;
+    }
+    float xv[16], yv[16];
+    f32x16 acc;
+    // ---- encoding: P-form, F-form and cos factors of the five encoding blocks go to scratch ----
+    {
+        float proj[kDirs];
+#pragma unroll
+        for (int d = 0; d < kDirs; ++d)
+            proj[d] = fmaf(t[2], Bg[3 * d + 2], fmaf(t[1], Bg[3 * d + 1], t[0] * Bg[3 * d]));
+        float amax = 0.0f;
+#pragma unroll
+        for (int d = 0; d < kDirs; ++d) amax = fmaxf(amax, fabsf(proj[d]));
+        const bool big = wv::wave_any(!(amax * (32.0f * kPi) < kSinCosFastLimit));
+#define ENC(i, NS, base, limit, kb)                                                                      \
+        if (!big) pe_block<NS, false>(xv, yv, base, limit, kb, t, proj, hi);                             \
+        else pe_block<NS, true>(xv, yv, base, limit, kb, t, proj, hi);                                   \
+        stb(BLK(E_P + i), xv, lane); stb(BLK(CFB + i), yv, lane);                                        \
+        to_F(yv, xv, scrX, p31, hi); stb(BLK(E_F + i), yv, lane);
+        ENC(0, 16, 0, kEmb1, 0)
+        ENC(1, 16, 0, kEmb1, 1)
+        ENC(2, 12, 0, kEmb1, 2)
+        ENC(3, 16, kEmb1, kEmb2, 0)
+        ENC(4, 6, kEmb1, kEmb2, 1)
+#undef ENC
+    }
+    __syncthreads();        // composite buffer zeroed
+
+    // ---- field MLP forward (model.py:59-83): layer l output block ob -> H_P(l, ob) ----
+    auto seg4 = [&](const float* w, int blk) { ldb(xv, BLK(blk), lane); fwd_mm<4>(acc, w, xv); };
+    auto seg3 = [&](const float* w, int blk) { ldb(xv, BLK(blk), lane); fwd_mm<3>(acc, w, xv); };
+    auto seg2 = [&](const float* w, int blk) { ldb(xv, BLK(blk), lane); fwd_mm<2>(acc, w, xv); };
+    auto finish = [&](int l, int ob) {          // ReLU, store P-form and F-form
+        relu_to(xv, acc);
+        stb(BLK(H_P + l * NB + ob), xv, lane);
+        to_F(yv, xv, scrX, p31, hi);
+        stb(BLK(H_F + l * NB + ob), yv, lane);
+    };
+    for (int ob = 0; ob < NB; ++ob) {           // :59 in_layer
+        const float* w = Wg + L.w_in + (32 * ob + p31) * L.ld_in + 4 * hi;
+        load_bias(acc, Wg + L.b_in + 32 * ob, hi);
+        seg4(w, E_P + 0); seg4(w + 32, E_P + 1); seg3(w + 64, E_P + 2);
+        finish(0, ob);
+    }
+    for (int ob = 0; ob < NB; ++ob) {           // :60 mid1
+        const float* w = Wg + L.w_m1 + (32 * ob + p31) * L.ld_m + 4 * hi;
+        load_bias(acc, Wg + L.b_m1 + 32 * ob, hi);
+        for (int kb = 0; kb < NB; ++kb) seg4(w + 32 * kb, H_P + 0 * NB + kb);
+        finish(1, ob);
+    }
+    for (int ob = 0; ob < NB; ++ob) {           // :63-64 cat_layer
+        const float* w = Wg + L.w_cat + (32 * ob + p31) * L.ld_cat + 4 * hi;
+        load_bias(acc, Wg + L.b_cat + 32 * ob, hi);
+        for (int kb = 0; kb < NB; ++kb) seg4(w + 32 * kb, H_P + 1 * NB + kb);
+        seg4(w + H, E_P + 0); seg4(w + H + 32, E_P + 1); seg3(w + H + 64, E_P + 2);
+        finish(2, ob);
+    }
+    for (int ob = 0; ob < NB; ++ob) {           // :67 mid2
+        const float* w = Wg + L.w_m2 + (32 * ob + p31) * L.ld_m + 4 * hi;
+        load_bias(acc, Wg + L.b_m2 + 32 * ob, hi);
+        for (int kb = 0; kb < NB; ++kb) seg4(w + 32 * kb, H_P + 2 * NB + kb);
+        finish(3, ob);
+    }
+    for (int ob = 0; ob < NB; ++ob) {           // :81 color_linear
+        const float* w = Wg + L.w_c + (32 * ob + p31) * L.ld_c + 4 * hi;
+        load_bias(acc, Wg + L.b_c + 32 * ob, hi);
+        for (int kb = 0; kb < NB; ++kb) seg4(w + 32 * kb, H_P + 3 * NB + kb);
+        seg4(w + H, E_P + 3); seg2(w + H + 32, E_P + 4);
+        finish(4, ob);
+    }
+    {   // heads (model.py:71,77,82-83)
+        float ra = 0.0f, r0 = 0.0f, r1 = 0.0f, r2 = 0.0f;
+        for (int kb = 0; kb < NB; ++kb) {
+            ldb(xv, BLK(H_P + 3 * NB + kb), lane);
+            ldb(yv, BLK(H_P + 4 * NB + kb), lane);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = 32 * kb + phi(r, hi);
+                ra = fmaf(Wg[L.w_a + j], xv[r], ra);
+                r0 = fmaf(Wg[L.w_oc + j], yv[r], r0);
+                r1 = fmaf(Wg[L.w_oc + H + j], yv[r], r1);
+                r2 = fmaf(Wg[L.w_oc + 2 * H + j], yv[r], r2);
+            }
+        }
+        ra += wv::swap_half(ra); r0 += wv::swap_half(r0); r1 += wv::swap_half(r1); r2 += wv::swap_half(r2);
+        ra += Wg[L.b_a]; r0 += Wg[L.b_oc]; r1 += Wg[L.b_oc + 1]; r2 += Wg[L.b_oc + 2];
+        if (valid && hi == 0) {
+            float* row = cb + pt * 8;
+            row[6] = a.z[obj * a.z_so + ray * a.z_sr + smp * a.z_ss];
+            row[0] = sigmoidf_acc(ra * 10.0f);
+            row[1] = sigmoidf_acc(r0);
+            row[2] = sigmoidf_acc(r1);
+            row[3] = sigmoidf_acc(r2);
+        }
+    }
+    __syncthreads();
+    composite_phase<BWD>(a, cb, lds + LdsGen::LOSS, obj, ray0, nrays, wave, lane, tid);
+    __syncthreads();
+
+    if (BWD) {
+    float d_raw, d_c0, d_c1, d_c2;
+    {
+        const float* row = cb + pt * 8;
+        d_raw = row[0]; d_c0 = row[1]; d_c1 = row[2]; d_c2 = row[3];
+    }
+    float dproj[kDirs];
+#pragma unroll
+    for (int d = 0; d < kDirs; ++d) dproj[d] = 0.0f;
+
+    // one reduced weight-gradient block: acc -> staged cross-wave sum -> this wave's quarter -> partial buffer
+    auto emit = [&](float* tens, int K, int row0, int col0, int ncols) {
+        float q[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        reduce_block(q, acc, (stage_toggle & 1) ? stg1 : stg0, wave, p31, hi);
+        ++stage_toggle;
+        store_quarter_rt(tens + (long long)row0 * K, K, q, col0, ncols, !first_pass, wave, p31, hi);
+    };
+    // weight gradient of one layer: delta blocks D_F(ds, ob) x input blocks; bias gradient from the same F-forms
+    auto dw_block = [&](int dfblk, int xfblk, float* tens, int K, int row0, int col0, int ncols) {
+        ldb(xv, BLK(dfblk), lane);
+        ldb(yv, BLK(xfblk), lane);
+        zero_acc(acc);
+        dw_mm(acc, xv, yv);
+        emit(tens, K, row0, col0, ncols);
+    };
+    // store a delta block (already masked) as P-form + F-form and add its bias gradient
+    auto put_delta = [&](int ds, int kb, int bias_off) {
+        stb(BLK(D_P + ds * NB + kb), xv, lane);
+        to_F(yv, xv, scrD, p31, hi);
+        stb(BLK(D_F + ds * NB + kb), yv, lane);
+        add_db(Gv + bias_off + 32 * kb, yv, p31, hi);
+    };
+
+    // ---- heads: out_alpha / out_color gradients; delta of color_linear's output -> D(0) ----
+    for (int kb = 0; kb < NB; ++kb) {
+        ldb(xv, BLK(H_F + 3 * NB + kb), lane);      // h4 F-form
+        ldb(yv, BLK(H_F + 4 * NB + kb), lane);      // hc F-form
+        float gA = 0.0f, g0 = 0.0f, g1 = 0.0f, g2 = 0.0f, sa = 0.0f, s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float* row = cbw + (r + 16 * hi) * 8;
+            const float da = row[0], q0 = row[1], q1 = row[2], q2 = row[3];
+            gA = fmaf(da, xv[r], gA);
+            g0 = fmaf(q0, yv[r], g0); g1 = fmaf(q1, yv[r], g1); g2 = fmaf(q2, yv[r], g2);
+            sa += da; s0 += q0; s1 += q1; s2 += q2;
+        }
+        gA += wv::swap_half(gA); g0 += wv::swap_half(g0); g1 += wv::swap_half(g1); g2 += wv::swap_half(g2);
+        sa += wv::swap_half(sa); s0 += wv::swap_half(s0); s1 += wv::swap_half(s1); s2 += wv::swap_half(s2);
+        if (hi == 0) {
+            const int j = 32 * kb + p31;
+            Gv[L.w_a + j] += gA;
+            Gv[L.w_oc + j] += g0;
+            Gv[L.w_oc + H + j] += g1;
+            Gv[L.w_oc + 2 * H + j] += g2;
+            if (p31 == 0 && kb == 0) {
+                Gv[L.b_a] += sa; Gv[L.b_oc + 0] += s0; Gv[L.b_oc + 1] += s1; Gv[L.b_oc + 2] += s2;
+            }
+        }
+        ldb(yv, BLK(H_P + 4 * NB + kb), lane);      // hc P-form for the ReLU mask
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = 32 * kb + phi(r, hi);
+            const float v = Wg[L.w_oc + j] * d_c0 + Wg[L.w_oc + H + j] * d_c1 + Wg[L.w_oc + 2 * H + j] * d_c2;
+            xv[r] = yv[r] > 0.0f ? v : 0.0f;
+        }
+        put_delta(0, kb, L.b_c);
+    }
+    // ---- color_linear: dW = D(0)^T [h4 | e2] ; d h4 -> D(1) ; d e2 -> dproj ----
+    {
+        float* tens = out + L.f[10];
+        const int K = H + kEmb2;
+        for (int ob = 0; ob < NB; ++ob) {
+            for (int kb = 0; kb < NB; ++kb) dw_block(D_F + 0 * NB + ob, H_F + 3 * NB + kb, tens, K, 32 * ob, 32 * kb, 32);
+            dw_block(D_F + 0 * NB + ob, E_F + 3, tens, K, 32 * ob, H, 32);
+            dw_block(D_F + 0 * NB + ob, E_F + 4, tens, K, 32 * ob, H + 32, kEmb2 - 32);
+        }
+        for (int kb = 0; kb < NB; ++kb) {           // d h4 = W_a d raw + W_c[:, :H]^T D(0), masked by h4
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = Wg[L.w_a + 32 * kb + phi(r, hi)] * d_raw;
+            for (int ob = 0; ob < NB; ++ob) {
+                ldb(yv, BLK(D_P + 0 * NB + ob), lane);
+                bwd_mm_rt(acc, Wg + L.w_c + (32 * ob + 4 * hi) * L.ld_c + 32 * kb + p31, L.ld_c, yv);
+            }
+            ldb(yv, BLK(H_P + 3 * NB + kb), lane);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xv[r] = yv[r] > 0.0f ? acc[r] : 0.0f;
+            put_delta(1, kb, L.b_m2);
+        }
+        for (int eb = 0; eb < 2; ++eb) {            // d e2
+            zero_acc(acc);
+            const int col = eb == 0 ? p31 : min(32 + p31, 46);
+            for (int ob = 0; ob < NB; ++ob) {
+                ldb(yv, BLK(D_P + 0 * NB + ob), lane);
+                bwd_mm_rt(acc, Wg + L.w_c + (32 * ob + 4 * hi) * L.ld_c + H + col, L.ld_c, yv);
+            }
+            ldb(yv, BLK(CFB + 3 + eb), lane);
+            if (eb == 0) pe_block_bwd<16>(dproj, acc, yv, kEmb1, kEmb2, 0, hi);
+            else pe_block_bwd<6>(dproj, acc, yv, kEmb1, kEmb2, 1, hi);
+        }
+    }
+    // ---- mid2: delta D(1), input h3 ; d h3 -> D(0) ----
+    {
+        float* tens = out + L.f[6];
+        for (int ob = 0; ob < NB; ++ob)
+            for (int kb = 0; kb < NB; ++kb) dw_block(D_F + 1 * NB + ob, H_F + 2 * NB + kb, tens, H, 32 * ob, 32 * kb, 32);
+        for (int kb = 0; kb < NB; ++kb) {
+            zero_acc(acc);
+            for (int ob = 0; ob < NB; ++ob) {
+                ldb(yv, BLK(D_P + 1 * NB + ob), lane);
+                bwd_mm_rt(acc, Wg + L.w_m2 + (32 * ob + 4 * hi) * L.ld_m + 32 * kb + p31, L.ld_m, yv);
+            }
+            ldb(yv, BLK(H_P + 2 * NB + kb), lane);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xv[r] = yv[r] > 0.0f ? acc[r] : 0.0f;
+            put_delta(0, kb, L.b_cat);
+        }
+    }
+    // ---- cat_layer: delta D(0), input [h2 | e1] ; d h2 -> D(1) ; d e1 -> DE (accumulators) ----
+    {
+        float* tens = out + L.f[4];
+        const int K = H + kEmb1;
+        for (int ob = 0; ob < NB; ++ob) {
+            for (int kb = 0; kb < NB; ++kb) dw_block(D_F + 0 * NB + ob, H_F + 1 * NB + kb, tens, K, 32 * ob, 32 * kb, 32);
+            dw_block(D_F + 0 * NB + ob, E_F + 0, tens, K, 32 * ob, H, 32);
+            dw_block(D_F + 0 * NB + ob, E_F + 1, tens, K, 32 * ob, H + 32, 32);
+            dw_block(D_F + 0 * NB + ob, E_F + 2, tens, K, 32 * ob, H + 64, kEmb1 - 64);
+        }
+        for (int kb = 0; kb < NB; ++kb) {
+            zero_acc(acc);
+            for (int ob = 0; ob < NB; ++ob) {
+                ldb(yv, BLK(D_P + 0 * NB + ob), lane);
+                bwd_mm_rt(acc, Wg + L.w_cat + (32 * ob + 4 * hi) * L.ld_cat + 32 * kb + p31, L.ld_cat, yv);
+            }
+            ldb(yv, BLK(H_P + 1 * NB + kb), lane);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xv[r] = yv[r] > 0.0f ? acc[r] : 0.0f;
+            put_delta(1, kb, L.b_m1);
+        }
+        for (int eb = 0; eb < 3; ++eb) {
+            zero_acc(acc);
+            const int col = eb < 2 ? 32 * eb + p31 : min(64 + p31, 88);
+            for (int ob = 0; ob < NB; ++ob) {
+                ldb(yv, BLK(D_P + 0 * NB + ob), lane);
+                bwd_mm_rt(acc, Wg + L.w_cat + (32 * ob + 4 * hi) * L.ld_cat + H + col, L.ld_cat, yv);
+            }
+            stacc(BLK(DE + eb), acc, lane);
+        }
+    }
+    // ---- mid1: delta D(1), input h1 ; d h1 -> D(0) ----
+    {
+        float* tens = out + L.f[2];
+        for (int ob = 0; ob < NB; ++ob)
+            for (int kb = 0; kb < NB; ++kb) dw_block(D_F + 1 * NB + ob, H_F + 0 * NB + kb, tens, H, 32 * ob, 32 * kb, 32);
+        for (int kb = 0; kb < NB; ++kb) {
+            zero_acc(acc);
+            for (int ob = 0; ob < NB; ++ob) {
+                ldb(yv, BLK(D_P + 1 * NB + ob), lane);
+                bwd_mm_rt(acc, Wg + L.w_m1 + (32 * ob + 4 * hi) * L.ld_m + 32 * kb + p31, L.ld_m, yv);
+            }
+            ldb(yv, BLK(H_P + 0 * NB + kb), lane);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xv[r] = yv[r] > 0.0f ? acc[r] : 0.0f;
+            put_delta(0, kb, L.b_in);
+        }
+    }
+    // ---- in_layer: delta D(0), input e1 ; d e1 += ... ; encoding backward ----
+    {
+        float* tens = out + L.f[0];
+        for (int ob = 0; ob < NB; ++ob) {
+            dw_block(D_F + 0 * NB + ob, E_F + 0, tens, kEmb1, 32 * ob, 0, 32);
+            dw_block(D_F + 0 * NB + ob, E_F + 1, tens, kEmb1, 32 * ob, 32, 32);
+            dw_block(D_F + 0 * NB + ob, E_F + 2, tens, kEmb1, 32 * ob, 64, kEmb1 - 64);
+        }
+        for (int eb = 0; eb < 3; ++eb) {
+            ldb(xv, BLK(DE + eb), lane);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = xv[r];
+            const int col = eb < 2 ? 32 * eb + p31 : min(64 + p31, 88);
+            for (int ob = 0; ob < NB; ++ob) {
+                ldb(yv, BLK(D_P + 0 * NB + ob), lane);
+                bwd_mm_rt(acc, Wg + L.w_in + (32 * ob + 4 * hi) * L.ld_in + col, L.ld_in, yv);
+            }
+            ldb(yv, BLK(CFB + eb), lane);
+            if (eb == 0) pe_block_bwd<16>(dproj, acc, yv, 0, kEmb1, 0, hi);
+            else if (eb == 1) pe_block_bwd<16>(dproj, acc, yv, 0, kEmb1, 1, hi);
+            else pe_block_bwd<12>(dproj, acc, yv, 0, kEmb1, 2, hi);
+        }
+    }
+    // ---- B_layer.weight gradient ----
+    {
+#pragma unroll
+        for (int d = 0; d < kDirs; ++d) dproj[d] += wv::swap_half(dproj[d]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int f0 = phi(r, 0), f1 = phi(r, 1);
+            const float v0 = f0 < kDirs ? dproj[f0 < kDirs ? f0 : 0] : 0.0f;
+            const float v1 = f1 < kDirs ? dproj[f1 < kDirs ? f1 : 0] : 0.0f;
+            xv[r] = hi ? v1 : v0;
+        }
+        to_F(yv, xv, scrD, p31, hi);
+        ldb(xv, BLK(E_F + 0), lane);
+        zero_acc(acc);
+        dw_mm(acc, yv, xv);
+        float q[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        reduce_block(q, acc, (stage_toggle & 1) ? stg1 : stg0, wave, p31, hi);
+        ++stage_toggle;
+        if (p31 < 3) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int d = 8 * wave + 4 * hi + i;
+                if (d < kDirs) {
+                    float* o = out + L.f[14] + 3 * d + p31;
+                    *o = first_pass ? q[i] : *o + q[i];
+                }
+            }
+        }
+    }
+    }   // BWD
+    }   // pass loop
+    __syncthreads();
+    if (tid == 0) {
+        float* pl = a.part_loss + (obj * a.NW + wgo) * 4;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            pl[k] = (lds[LdsGen::LOSS + k] + lds[LdsGen::LOSS + 4 + k]) + (lds[LdsGen::LOSS + 8 + k] + lds[LdsGen::LOSS + 12 + k]);
+        pl[3] = 0.0f;
+    }
+    if (!BWD) return;
+    // small vectors: sum of the four waves' private accumulators, image order -> flat order
+    for (int sv = tid; sv < L.small_n; sv += kWG) {
+        const float* v = lds + LdsGen::VEC + sv;
+        const float g = (v[0] + v[L.small_n]) + (v[2 * L.small_n] + v[3 * L.small_n]);
+        const int i = L.b_in + sv;
+        int o = -1;
+        if (i < L.b_m1) o = L.f[1] + (i - L.b_in);
+        else if (i < L.b_cat) o = L.f[3] + (i - L.b_m1);
+        else if (i < L.b_m2) o = L.f[5] + (i - L.b_cat);
+        else if (i < L.b_c) o = L.f[7] + (i - L.b_m2);
+        else if (i < L.w_a) o = L.f[11] + (i - L.b_c);
+        else if (i < L.w_oc) o = L.f[8] + (i - L.w_a);
+        else if (i < L.b_a) o = L.f[12] + (i - L.w_oc);
+        else if (i == L.b_a) o = L.f[9];
+        else if (i >= L.b_oc && i < L.b_oc + 3) o = L.f[13] + (i - L.b_oc);
+        if (o >= 0) out[o] = g;
+    }
+#undef BLK
+}
+
+}  // namespace vk

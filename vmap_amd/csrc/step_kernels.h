@@ -69,6 +69,7 @@ struct StepArgs {
     float* part_loss;                  // [n][NW][4]
     float* dbg_depth; float* dbg_rgb; float* dbg_opacity; float* dbg_var;   // [n][R](,3) or null
     unsigned* timing;                  // optional [workgroups][kWaves][kMarks] shader-clock stamps (diagnostics)
+    int hidden;                        // H (step_prep packs with gen_layout(hidden); step_main_h32 requires 32)
 };
 
 __device__ __forceinline__ constexpr int phi(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
@@ -147,6 +148,70 @@ __device__ __forceinline__ int image_index(int t, int o) {
         case 12: return L::W_OC + o;
         case 13: return L::B_OC + o;
         default: return L::PE_B + o;
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// Runtime layout for any hidden width H (multiple of 32): the same image map as Lds32 with H-dependent pitches
+// (all pitches and offsets multiples of 4 floats = 16 bytes) and the natural flat parameter order.  For H = 32 it
+// reproduces Lds32 / Flat32 exactly (checked by static_asserts below).
+// ---------------------------------------------------------------------------------------------------------
+struct GenLayout {
+    int H, NB;
+    int ld_in, ld_m, ld_cat, ld_c;
+    int w_in, w_m1, w_cat, w_m2, w_c, b_in, b_m1, b_cat, b_m2, b_c, w_a, w_oc, b_a, b_oc, pe_b, img, imgp;
+    int small_n;                         // floats from b_in to the end of the image
+    int f[16];                           // flat start offsets of the 15 tensors, f[15] = P
+    int P, PP;
+};
+__host__ __device__ constexpr GenLayout gen_layout(int H) {
+    GenLayout L{};
+    L.H = H; L.NB = H / 32;
+    L.ld_in = 92; L.ld_m = H + 4; L.ld_cat = H + 92; L.ld_c = H + 52;
+    L.w_in = 0;
+    L.w_m1 = L.w_in + H * L.ld_in;
+    L.w_cat = L.w_m1 + H * L.ld_m;
+    L.w_m2 = L.w_cat + H * L.ld_cat;
+    L.w_c = L.w_m2 + H * L.ld_m;
+    L.b_in = L.w_c + H * L.ld_c;
+    L.b_m1 = L.b_in + H; L.b_cat = L.b_m1 + H; L.b_m2 = L.b_cat + H; L.b_c = L.b_m2 + H;
+    L.w_a = L.b_c + H; L.w_oc = L.w_a + H; L.b_a = L.w_oc + 3 * H; L.b_oc = L.b_a + 4; L.pe_b = L.b_oc + 4;
+    L.img = L.pe_b + 64;
+    L.imgp = (L.img + 1023) / 1024 * 1024;
+    L.small_n = L.img - L.b_in;
+    const int sz[15] = {H * kEmb1, H, H * H, H, H * (H + kEmb1), H, H * H, H, H, 1, H * (H + kEmb2), H, 3 * H, 3, 63};
+    int o = 0;
+    for (int t = 0; t < 15; ++t) { L.f[t] = o; o += sz[t]; }
+    L.f[15] = o;
+    L.P = o;
+    L.PP = (o + 63) / 64 * 64;
+    return L;
+}
+static_assert(gen_layout(32).imgp == Lds32::IMGP && gen_layout(32).w_c == Lds32::W_C && gen_layout(32).pe_b == Lds32::PE_B &&
+              gen_layout(32).ld_cat == Lds32::LD_CAT && gen_layout(32).ld_c == Lds32::LD_C && gen_layout(32).ld_m == Lds32::LD_M,
+              "generic layout must reproduce the H = 32 LDS map");
+static_assert(gen_layout(32).f[10] == Flat32::W_C && gen_layout(32).f[14] == Flat32::PE_B && gen_layout(32).P == Flat32::P, "flat order");
+
+// position in the parameter image of element o of tensor t, any width
+__device__ __forceinline__ int gen_image_index(const GenLayout& L, int t, int o) {
+    const int H = L.H;
+    switch (t) {
+        case 0: { const int r = o / kEmb1; return L.w_in + r * L.ld_in + (o - r * kEmb1); }
+        case 1: return L.b_in + o;
+        case 2: { const int r = o / H; return L.w_m1 + r * L.ld_m + (o - r * H); }
+        case 3: return L.b_m1 + o;
+        case 4: { const int r = o / (H + kEmb1); return L.w_cat + r * L.ld_cat + (o - r * (H + kEmb1)); }
+        case 5: return L.b_cat + o;
+        case 6: { const int r = o / H; return L.w_m2 + r * L.ld_m + (o - r * H); }
+        case 7: return L.b_m2 + o;
+        case 8: return L.w_a + o;
+        case 9: return L.b_a + o;
+        case 10: { const int r = o / (H + kEmb2); return L.w_c + r * L.ld_c + (o - r * (H + kEmb2)); }
+        case 11: return L.b_c + o;
+        case 12: return L.w_oc + o;
+        case 13: return L.b_oc + o;
+        default: return L.pe_b + o;
     }
 }
 
@@ -380,6 +445,165 @@ __device__ __forceinline__ float up16(float x, int d, float fill, int lane) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Workgroup phase between forward and backward: per-ray compositing, loss and d loss / d raw
+// (loss.py:24-60, render_rays.py:26-96).  cb = composite buffer [kMaxPts][8]: in  row[0..3] = occupancy, colour,
+// row[6] = z ; out row[0..3] = d/d(raw alpha), d/d(raw colour).  loss_cells = per-wave loss partials [kWaves][4].
+// ---------------------------------------------------------------------------------------------------------
+template <bool BWD>
+__device__ __forceinline__ void composite_phase(const StepArgs& a, float* cb, float* loss_cells, int obj, int ray0, int nrays,
+                                                int wave, int lane, int tid) {
+    // ---- per-ray compositing, loss and d loss / d raw  (loss.py:24-60, render_rays.py:26-96) ----
+    if (a.S <= 16) {
+        // 16 lanes per ray: lane i of a group holds sample i; products/sums are scans and butterflies
+        for (int g0 = 4 * wave; g0 < nrays; g0 += 4 * kWaves) {      // wave-uniform trip count
+            const int g = g0 + (lane >> 4), i = lane & 15;
+            const bool on = g < nrays && i < a.S;
+            const int rr = ray0 + min(g, nrays - 1);
+            float* row = cb + (min(g, nrays - 1) * a.S + min(i, a.S - 1)) * 8;
+            const float o = on ? row[0] : 0.0f, c0 = on ? row[1] : 0.0f, c1 = on ? row[2] : 0.0f, c2 = on ? row[3] : 0.0f;
+            const float zi = on ? row[6] : 0.0f;
+            const float f = on ? (1.0f - o) + 1e-10f : 1.0f;         // render_rays.py:29
+            // Transmittance, depth and variance in SEQUENTIAL sample order (lane broadcasts): on saturated rays the
+            // variance is rounding noise and 1/(sqrt(V)+1e-4) amplifies it, so the reference's order is mirrored
+            // (cumprod, then product tensor, then sum; render_rays.py:31-32,47-51) instead of a tree.
+            const int gb = lane & ~15;
+            float T = 1.0f;
+            for (int j = 0; j + 1 < a.S; ++j) {
+                const float fj = wv::shfl(f, gb + j);
+                T = j < i ? T * fj : T;
+            }
+            const float w = o * T;                                     // render_rays.py:32
+            const float wz = w * zi;
+            float D = 0.0f;
+            for (int j = 0; j < a.S; ++j) D += wv::shfl(wz, gb + j);    // loss.py:27
+            const float dz = zi - D;
+            const float wd = w * (dz * dz);
+            float V = 0.0f;
+            for (int j = 0; j < a.S; ++j) V += wv::shfl(wd, gb + j);    // loss.py:28-29 (detached)
+            const float O = sum16(w, lane);                             // loss.py:31
+            const float C0 = sum16(w * c0, lane), C1 = sum16(w * c1, lane), C2 = sum16(w * c2, lane);   // loss.py:30
+            const unsigned char s = a.sem[obj * a.sem_so + rr * a.sem_sr];
+            const unsigned char dm = a.dmask[obj * a.dm_so + rr * a.dm_sr];
+            const float m_o = s != 0 ? 1.0f : 0.0f, m_s = s != 2 ? 1.0f : 0.0f;      // loss.py:16-19
+            const float m_dd = (dm != 0 && s != 0) ? 1.0f : 0.0f;                     // loss.py:37
+            const float gtd = a.gt_depth[obj * a.gd_so + rr * a.gd_sr];
+            const float* rgb = a.gt_rgb + obj * a.rgb_so + rr * a.rgb_sr;
+            const float q0 = rgb[0], q1 = rgb[a.rgb_sc], q2 = rgb[2 * a.rgb_sc];
+            const float inv_dd = a.flags[0] ? 0.0f : a.stats[obj * 4 + 0];            // render_rays.py:68-73
+            const float inv_o = a.flags[1] ? 0.0f : a.stats[obj * 4 + 1];
+            const float inv_s = a.flags[2] ? 0.0f : a.stats[obj * 4 + 2];
+            const float info = 1.0f / (sqrtf(V) + 1e-4f);                             // render_rays.py:75-79
+            const float rd = D - gtd, rc0 = C0 - q0, rc1 = C1 - q1, rc2 = C2 - q2, ro = O - m_o;
+            const bool lead = g < nrays && i == 0;
+            float ld = lead ? fabsf(rd) * m_dd * info * inv_dd : 0.0f;
+            float lc = lead ? (fabsf(rc0) + fabsf(rc1) + fabsf(rc2)) * m_o * inv_o : 0.0f;
+            float lo = lead ? fabsf(ro) * m_s * inv_s : 0.0f;
+            ld += wv::shfl(ld, lane ^ 16); lc += wv::shfl(lc, lane ^ 16); lo += wv::shfl(lo, lane ^ 16);
+            ld += wv::swap_half(ld); lc += wv::swap_half(lc); lo += wv::swap_half(lo);
+            if (lane == 0) {                                           // this wave's private loss partials
+                loss_cells[wave * 4 + 0] += ld;
+                loss_cells[wave * 4 + 1] += lc;
+                loss_cells[wave * 4 + 2] += lo;
+            }
+            if (lead) {
+                if (a.dbg_depth) a.dbg_depth[obj * a.R + rr] = D;
+                if (a.dbg_opacity) a.dbg_opacity[obj * a.R + rr] = O;
+                if (a.dbg_var) a.dbg_var[obj * a.R + rr] = V;
+                if (a.dbg_rgb) {
+                    float* q = a.dbg_rgb + (obj * a.R + rr) * 3;
+                    q[0] = C0; q[1] = C1; q[2] = C2;
+                }
+            }
+            if (BWD) {
+                const float gD = sgnf(rd) * m_dd * info * inv_dd;
+                const float gO = a.opac_w * sgnf(ro) * m_s * inv_s;
+                const float k_c = a.color_w * m_o * inv_o;
+                const float gC0 = k_c * sgnf(rc0), gC1 = k_c * sgnf(rc1), gC2 = k_c * sgnf(rc2);
+                const float gw = gD * zi + gC0 * c0 + gC1 * c1 + gC2 * c2 + gO;
+                const float gww = on ? gw * w : 0.0f;
+                // sum_{k>i} g_w_k * w_k, accumulated directly from the last sample down (no total-minus-prefix:
+                // that difference cancels catastrophically and is then divided by f, which can be 1e-10)
+                float suffix = 0.0f;
+                for (int j = a.S - 1; j > 0; --j) {
+                    const float gj = wv::shfl(gww, gb + j);
+                    suffix = j > i ? suffix + gj : suffix;
+                }
+                const float d_occ = gw * T - suffix / f;               // cumprod backward: reverse-cumsum / input
+                if (on) {
+                    row[0] = 10.0f * (d_occ * o * (1.0f - o));         // through sigmoid and the *10 (model.py:77)
+                    row[1] = w * gC0 * c0 * (1.0f - c0);               // through the colour sigmoid (model.py:83)
+                    row[2] = w * gC1 * c1 * (1.0f - c1);
+                    row[3] = w * gC2 * c2 * (1.0f - c2);
+                }
+            }
+        }
+    } else if (tid < nrays) {
+        // long rays (S > 16): one lane per ray, sequential over the samples
+        const int g = tid, rr = ray0 + g;
+        float* rows = cb + g * a.S * 8;
+        float T = 1.0f, D = 0.0f, O = 0.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
+        for (int i = 0; i < a.S; ++i) {
+            float* row = rows + i * 8;
+            const float o = row[0];
+            const float w = o * T;
+            const float zi = row[6];
+            row[4] = T; row[5] = w;
+            D += w * zi; O += w;
+            C0 += w * row[1]; C1 += w * row[2]; C2 += w * row[3];
+            T *= (1.0f - o) + 1e-10f;
+        }
+        float V = 0.0f;
+        for (int i = 0; i < a.S; ++i) {
+            const float* row = rows + i * 8;
+            const float d = row[6] - D;
+            V += row[5] * (d * d);
+        }
+        const unsigned char s = a.sem[obj * a.sem_so + rr * a.sem_sr];
+        const unsigned char dm = a.dmask[obj * a.dm_so + rr * a.dm_sr];
+        const float m_o = s != 0 ? 1.0f : 0.0f, m_s = s != 2 ? 1.0f : 0.0f;
+        const float m_dd = (dm != 0 && s != 0) ? 1.0f : 0.0f;
+        const float gtd = a.gt_depth[obj * a.gd_so + rr * a.gd_sr];
+        const float* rgb = a.gt_rgb + obj * a.rgb_so + rr * a.rgb_sr;
+        const float q0 = rgb[0], q1 = rgb[a.rgb_sc], q2 = rgb[2 * a.rgb_sc];
+        const float inv_dd = a.flags[0] ? 0.0f : a.stats[obj * 4 + 0];
+        const float inv_o = a.flags[1] ? 0.0f : a.stats[obj * 4 + 1];
+        const float inv_s = a.flags[2] ? 0.0f : a.stats[obj * 4 + 2];
+        const float info = 1.0f / (sqrtf(V) + 1e-4f);
+        const float rd = D - gtd, rc0 = C0 - q0, rc1 = C1 - q1, rc2 = C2 - q2, ro = O - m_o;
+        wv::lds_add(loss_cells + 0, fabsf(rd) * m_dd * info * inv_dd);
+        wv::lds_add(loss_cells + 1, (fabsf(rc0) + fabsf(rc1) + fabsf(rc2)) * m_o * inv_o);
+        wv::lds_add(loss_cells + 2, fabsf(ro) * m_s * inv_s);
+        if (a.dbg_depth) a.dbg_depth[obj * a.R + rr] = D;
+        if (a.dbg_opacity) a.dbg_opacity[obj * a.R + rr] = O;
+        if (a.dbg_var) a.dbg_var[obj * a.R + rr] = V;
+        if (a.dbg_rgb) {
+            float* q = a.dbg_rgb + (obj * a.R + rr) * 3;
+            q[0] = C0; q[1] = C1; q[2] = C2;
+        }
+        if (BWD) {
+            const float gD = sgnf(rd) * m_dd * info * inv_dd;
+            const float gO = a.opac_w * sgnf(ro) * m_s * inv_s;
+            const float k_c = a.color_w * m_o * inv_o;
+            const float gC0 = k_c * sgnf(rc0), gC1 = k_c * sgnf(rc1), gC2 = k_c * sgnf(rc2);
+            float suffix = 0.0f;
+            for (int i = a.S - 1; i >= 0; --i) {
+                float* row = rows + i * 8;
+                const float o = row[0], c0 = row[1], c1 = row[2], c2 = row[3];
+                const float Ti = row[4], w = row[5], zi = row[6];
+                const float gw = gD * zi + gC0 * c0 + gC1 * c1 + gC2 * c2 + gO;
+                const float f = (1.0f - o) + 1e-10f;
+                const float d_occ = gw * Ti - suffix / f;
+                suffix += gw * w;
+                row[0] = 10.0f * (d_occ * o * (1.0f - o));
+                row[1] = w * gC0 * c0 * (1.0f - c0);
+                row[2] = w * gC1 * c1 * (1.0f - c1);
+                row[3] = w * gC2 * c2 * (1.0f - c2);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // step_prep, one launch per API call:
 //   blocks [0, prep_steps)            per-object mask counts of step b and the batch-wide "any object has an
 //                                     empty mask" switches (loss.py:16-19,38,46,56; render_rays.py:68-73)
@@ -388,21 +612,18 @@ __device__ __forceinline__ float up16(float x, int d, float fill, int lane) {
 __global__ __launch_bounds__(kWG) void step_prep(const StepArgs a) {
     const int tid = threadIdx.x;
     if ((int)blockIdx.x >= a.prep_steps) {
-        using L = Lds32;
-        using F = Flat32;
+        const GenLayout L = gen_layout(a.hidden);
         const int k = blockIdx.x - a.prep_steps;
-        float* img = a.wimg + (long long)k * L::IMGP;
-        for (int i = tid; i < L::IMGP; i += kWG) img[i] = 0.0f;
+        float* img = a.wimg + (long long)k * L.imgp;
+        for (int i = tid; i < L.imgp; i += kWG) img[i] = 0.0f;
         __syncthreads();
-        for (int i = tid; i < F::P; i += kWG) {
+        for (int i = tid; i < L.P; i += kWG) {
             int t = 0;
-            const int offs[15] = {F::W_IN, F::B_IN, F::W_M1, F::B_M1, F::W_CAT, F::B_CAT, F::W_M2, F::B_M2,
-                                  F::W_A, F::B_A, F::W_C, F::B_C, F::W_OC, F::B_OC, F::PE_B};
 #pragma unroll
-            for (int q = 1; q < 15; ++q) t += i >= offs[q];
-            const int o = i - offs[t];
+            for (int q = 1; q < 15; ++q) t += i >= L.f[q];
+            const int o = i - L.f[t];
             const float v = t < kNFc ? a.fc[t].p[k * a.fc[t].stride + o] : a.pe_B.p[k * a.pe_B.stride + o];
-            img[image_index(t, o)] = v;
+            img[gen_image_index(L, t, o)] = v;
         }
         return;
     }
@@ -623,155 +844,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
     __syncthreads();
     VK_MARK(5);
 
-    // ---- per-ray compositing, loss and d loss / d raw  (loss.py:24-60, render_rays.py:26-96) ----
-    if (a.S <= 16) {
-        // 16 lanes per ray: lane i of a group holds sample i; products/sums are scans and butterflies
-        for (int g0 = 4 * wave; g0 < nrays; g0 += 4 * kWaves) {      // wave-uniform trip count
-            const int g = g0 + (lane >> 4), i = lane & 15;
-            const bool on = g < nrays && i < a.S;
-            const int rr = ray0 + min(g, nrays - 1);
-            float* row = cb + (min(g, nrays - 1) * a.S + min(i, a.S - 1)) * 8;
-            const float o = on ? row[0] : 0.0f, c0 = on ? row[1] : 0.0f, c1 = on ? row[2] : 0.0f, c2 = on ? row[3] : 0.0f;
-            const float zi = on ? row[6] : 0.0f;
-            const float f = on ? (1.0f - o) + 1e-10f : 1.0f;         // render_rays.py:29
-            // Transmittance, depth and variance in SEQUENTIAL sample order (lane broadcasts): on saturated rays the
-            // variance is rounding noise and 1/(sqrt(V)+1e-4) amplifies it, so the reference's order is mirrored
-            // (cumprod, then product tensor, then sum; render_rays.py:31-32,47-51) instead of a tree.
-            const int gb = lane & ~15;
-            float T = 1.0f;
-            for (int j = 0; j + 1 < a.S; ++j) {
-                const float fj = wv::shfl(f, gb + j);
-                T = j < i ? T * fj : T;
-            }
-            const float w = o * T;                                     // render_rays.py:32
-            const float wz = w * zi;
-            float D = 0.0f;
-            for (int j = 0; j < a.S; ++j) D += wv::shfl(wz, gb + j);    // loss.py:27
-            const float dz = zi - D;
-            const float wd = w * (dz * dz);
-            float V = 0.0f;
-            for (int j = 0; j < a.S; ++j) V += wv::shfl(wd, gb + j);    // loss.py:28-29 (detached)
-            const float O = sum16(w, lane);                             // loss.py:31
-            const float C0 = sum16(w * c0, lane), C1 = sum16(w * c1, lane), C2 = sum16(w * c2, lane);   // loss.py:30
-            const unsigned char s = a.sem[obj * a.sem_so + rr * a.sem_sr];
-            const unsigned char dm = a.dmask[obj * a.dm_so + rr * a.dm_sr];
-            const float m_o = s != 0 ? 1.0f : 0.0f, m_s = s != 2 ? 1.0f : 0.0f;      // loss.py:16-19
-            const float m_dd = (dm != 0 && s != 0) ? 1.0f : 0.0f;                     // loss.py:37
-            const float gtd = a.gt_depth[obj * a.gd_so + rr * a.gd_sr];
-            const float* rgb = a.gt_rgb + obj * a.rgb_so + rr * a.rgb_sr;
-            const float q0 = rgb[0], q1 = rgb[a.rgb_sc], q2 = rgb[2 * a.rgb_sc];
-            const float inv_dd = a.flags[0] ? 0.0f : a.stats[obj * 4 + 0];            // render_rays.py:68-73
-            const float inv_o = a.flags[1] ? 0.0f : a.stats[obj * 4 + 1];
-            const float inv_s = a.flags[2] ? 0.0f : a.stats[obj * 4 + 2];
-            const float info = 1.0f / (sqrtf(V) + 1e-4f);                             // render_rays.py:75-79
-            const float rd = D - gtd, rc0 = C0 - q0, rc1 = C1 - q1, rc2 = C2 - q2, ro = O - m_o;
-            const bool lead = g < nrays && i == 0;
-            float ld = lead ? fabsf(rd) * m_dd * info * inv_dd : 0.0f;
-            float lc = lead ? (fabsf(rc0) + fabsf(rc1) + fabsf(rc2)) * m_o * inv_o : 0.0f;
-            float lo = lead ? fabsf(ro) * m_s * inv_s : 0.0f;
-            ld += wv::shfl(ld, lane ^ 16); lc += wv::shfl(lc, lane ^ 16); lo += wv::shfl(lo, lane ^ 16);
-            ld += wv::swap_half(ld); lc += wv::swap_half(lc); lo += wv::swap_half(lo);
-            if (lane == 0) {                                           // this wave's private loss partials
-                lds[L::LOSS + wave * 4 + 0] += ld;
-                lds[L::LOSS + wave * 4 + 1] += lc;
-                lds[L::LOSS + wave * 4 + 2] += lo;
-            }
-            if (lead) {
-                if (a.dbg_depth) a.dbg_depth[obj * a.R + rr] = D;
-                if (a.dbg_opacity) a.dbg_opacity[obj * a.R + rr] = O;
-                if (a.dbg_var) a.dbg_var[obj * a.R + rr] = V;
-                if (a.dbg_rgb) {
-                    float* q = a.dbg_rgb + (obj * a.R + rr) * 3;
-                    q[0] = C0; q[1] = C1; q[2] = C2;
-                }
-            }
-            if (BWD) {
-                const float gD = sgnf(rd) * m_dd * info * inv_dd;
-                const float gO = a.opac_w * sgnf(ro) * m_s * inv_s;
-                const float k_c = a.color_w * m_o * inv_o;
-                const float gC0 = k_c * sgnf(rc0), gC1 = k_c * sgnf(rc1), gC2 = k_c * sgnf(rc2);
-                const float gw = gD * zi + gC0 * c0 + gC1 * c1 + gC2 * c2 + gO;
-                const float gww = on ? gw * w : 0.0f;
-                // sum_{k>i} g_w_k * w_k, accumulated directly from the last sample down (no total-minus-prefix:
-                // that difference cancels catastrophically and is then divided by f, which can be 1e-10)
-                float suffix = 0.0f;
-                for (int j = a.S - 1; j > 0; --j) {
-                    const float gj = wv::shfl(gww, gb + j);
-                    suffix = j > i ? suffix + gj : suffix;
-                }
-                const float d_occ = gw * T - suffix / f;               // cumprod backward: reverse-cumsum / input
-                if (on) {
-                    row[0] = 10.0f * (d_occ * o * (1.0f - o));         // through sigmoid and the *10 (model.py:77)
-                    row[1] = w * gC0 * c0 * (1.0f - c0);               // through the colour sigmoid (model.py:83)
-                    row[2] = w * gC1 * c1 * (1.0f - c1);
-                    row[3] = w * gC2 * c2 * (1.0f - c2);
-                }
-            }
-        }
-    } else if (tid < nrays) {
-        // long rays (S > 16): one lane per ray, sequential over the samples
-        const int g = tid, rr = ray0 + g;
-        float* rows = cb + g * a.S * 8;
-        float T = 1.0f, D = 0.0f, O = 0.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
-        for (int i = 0; i < a.S; ++i) {
-            float* row = rows + i * 8;
-            const float o = row[0];
-            const float w = o * T;
-            const float zi = row[6];
-            row[4] = T; row[5] = w;
-            D += w * zi; O += w;
-            C0 += w * row[1]; C1 += w * row[2]; C2 += w * row[3];
-            T *= (1.0f - o) + 1e-10f;
-        }
-        float V = 0.0f;
-        for (int i = 0; i < a.S; ++i) {
-            const float* row = rows + i * 8;
-            const float d = row[6] - D;
-            V += row[5] * (d * d);
-        }
-        const unsigned char s = a.sem[obj * a.sem_so + rr * a.sem_sr];
-        const unsigned char dm = a.dmask[obj * a.dm_so + rr * a.dm_sr];
-        const float m_o = s != 0 ? 1.0f : 0.0f, m_s = s != 2 ? 1.0f : 0.0f;
-        const float m_dd = (dm != 0 && s != 0) ? 1.0f : 0.0f;
-        const float gtd = a.gt_depth[obj * a.gd_so + rr * a.gd_sr];
-        const float* rgb = a.gt_rgb + obj * a.rgb_so + rr * a.rgb_sr;
-        const float q0 = rgb[0], q1 = rgb[a.rgb_sc], q2 = rgb[2 * a.rgb_sc];
-        const float inv_dd = a.flags[0] ? 0.0f : a.stats[obj * 4 + 0];
-        const float inv_o = a.flags[1] ? 0.0f : a.stats[obj * 4 + 1];
-        const float inv_s = a.flags[2] ? 0.0f : a.stats[obj * 4 + 2];
-        const float info = 1.0f / (sqrtf(V) + 1e-4f);
-        const float rd = D - gtd, rc0 = C0 - q0, rc1 = C1 - q1, rc2 = C2 - q2, ro = O - m_o;
-        wv::lds_add(lds + L::LOSS + 0, fabsf(rd) * m_dd * info * inv_dd);
-        wv::lds_add(lds + L::LOSS + 1, (fabsf(rc0) + fabsf(rc1) + fabsf(rc2)) * m_o * inv_o);
-        wv::lds_add(lds + L::LOSS + 2, fabsf(ro) * m_s * inv_s);
-        if (a.dbg_depth) a.dbg_depth[obj * a.R + rr] = D;
-        if (a.dbg_opacity) a.dbg_opacity[obj * a.R + rr] = O;
-        if (a.dbg_var) a.dbg_var[obj * a.R + rr] = V;
-        if (a.dbg_rgb) {
-            float* q = a.dbg_rgb + (obj * a.R + rr) * 3;
-            q[0] = C0; q[1] = C1; q[2] = C2;
-        }
-        if (BWD) {
-            const float gD = sgnf(rd) * m_dd * info * inv_dd;
-            const float gO = a.opac_w * sgnf(ro) * m_s * inv_s;
-            const float k_c = a.color_w * m_o * inv_o;
-            const float gC0 = k_c * sgnf(rc0), gC1 = k_c * sgnf(rc1), gC2 = k_c * sgnf(rc2);
-            float suffix = 0.0f;
-            for (int i = a.S - 1; i >= 0; --i) {
-                float* row = rows + i * 8;
-                const float o = row[0], c0 = row[1], c1 = row[2], c2 = row[3];
-                const float Ti = row[4], w = row[5], zi = row[6];
-                const float gw = gD * zi + gC0 * c0 + gC1 * c1 + gC2 * c2 + gO;
-                const float f = (1.0f - o) + 1e-10f;
-                const float d_occ = gw * Ti - suffix / f;
-                suffix += gw * w;
-                row[0] = 10.0f * (d_occ * o * (1.0f - o));
-                row[1] = w * gC0 * c0 * (1.0f - c0);
-                row[2] = w * gC1 * c1 * (1.0f - c1);
-                row[3] = w * gC2 * c2 * (1.0f - c2);
-            }
-        }
-    }
+    composite_phase<BWD>(a, cb, lds + L::LOSS, obj, ray0, nrays, wave, lane, tid);
     __syncthreads();
     VK_MARK(6);
     if (BWD) {
@@ -1027,7 +1100,8 @@ struct FinalizeArgs {
     TensorRef param[kNFc + 1];         // parameters (updated in place when do_adam)
     TensorRef grad[kNFc + 1];          // gradient outputs (p may be null: skip)
     float* m; float* v;                // Adam moments, [n][PP] slabs (when do_adam)
-    float* wimg;                       // [n][Lds32::IMGP] packed parameter image (updated when do_adam)
+    float* wimg;                       // [n][imgp] packed parameter image (updated when do_adam)
+    int hidden;                        // H: image layout = gen_layout(hidden)
     const float* part_grad; const float* part_loss;
     const int* flags_in; int* flags_out;
     float* loss_out;                   // [1]
@@ -1039,6 +1113,7 @@ struct FinalizeArgs {
 };
 
 __global__ __launch_bounds__(kWG) void step_finalize(const FinalizeArgs a) {
+    const GenLayout GL = gen_layout(a.hidden);
     // one thread per 4 consecutive flat parameters: the partial rows and the moment slabs are PP-pitched
     // (PP % 64 == 0, 256-byte aligned) so they move as 16-byte vectors; parameter/gradient tensors are scattered
     const int quads = a.PP / 4;
@@ -1075,7 +1150,7 @@ __global__ __launch_bounds__(kWG) void step_finalize(const FinalizeArgs a) {
                     const float denom = sqrtf(v) / a.bias_corr2_sqrt + a.eps;
                     p = p - a.step_size * (m / denom);                        // param.addcdiv_(exp_avg, denom, -lr / bc1)
                     *pp = p; m4[e] = m; v4[e] = v;
-                    a.wimg[(long long)obj * Lds32::IMGP + image_index(t, o)] = p;
+                    a.wimg[(long long)obj * GL.imgp + gen_image_index(GL, t, o)] = p;
                 }
             }
         }

@@ -11,11 +11,12 @@
 #include <cstring>
 
 #include "../../include/vmapstep.h"
-#include "step_kernels.h"
+#include "gen_kernels.h"
 
 namespace {
 
 thread_local char g_err[512] = "";
+thread_local float* g_scratch_for_launch = nullptr;   // set by fill_step_args (generic-width path)
 int g_nw_override = 0;
 
 int fail(int code, const char* fmt, ...) {
@@ -35,26 +36,26 @@ struct Layout {
     int P, PP;
 };
 void make_layout(int H, Layout& L) {
-    const int64_t s[15] = {(int64_t)H * 87, H, (int64_t)H * H, H, (int64_t)H * (H + 87), H, (int64_t)H * H, H,
-                           H, 1, (int64_t)H * (H + 42), H, 3 * H, 3, 63};
-    int o = 0;
-    for (int t = 0; t < 15; ++t) { L.sizes[t] = s[t]; L.offs[t] = o; o += (int)s[t]; }
-    L.offs[15] = o;
-    L.P = o;
-    L.PP = (o + 63) / 64 * 64;
+    const vk::GenLayout G = vk::gen_layout(H);
+    for (int t = 0; t < 15; ++t) { L.sizes[t] = G.f[t + 1] - G.f[t]; L.offs[t] = G.f[t]; }
+    L.offs[15] = G.P;
+    L.P = G.P;
+    L.PP = G.PP;
 }
 
 struct Plan {
     int G, NG, NW;
-    size_t off_stats, off_flags, off_ploss, off_pgrad, off_wimg, total;
+    size_t off_stats, off_flags, off_ploss, off_pgrad, off_wimg, off_scratch, total;
+    bool generic;      // hidden != 32: step_main_gen (global-memory activations) instead of step_main_h32
 };
 
 int make_plan(const vmapstep_shape* sh, int max_steps, Plan& pl, const Layout& L) {
     if (!sh) return fail(VMAPSTEP_ERR_ARGUMENT, "shape is null");
     if (sh->n_obj < 1 || sh->rays < 1 || sh->samples < 1 || max_steps < 1)
         return fail(VMAPSTEP_ERR_ARGUMENT, "bad shape n=%d R=%d S=%d steps=%d", sh->n_obj, sh->rays, sh->samples, max_steps);
-    if (sh->hidden != 32)
-        return fail(VMAPSTEP_ERR_UNSUPPORTED, "hidden=%d: the fused kernel implements hidden=32", sh->hidden);
+    if (sh->hidden < 32 || sh->hidden > 256 || sh->hidden % 32 != 0)
+        return fail(VMAPSTEP_ERR_UNSUPPORTED, "hidden=%d: supported widths are multiples of 32 up to 256", sh->hidden);
+    pl.generic = sh->hidden != 32;
     if (sh->samples > vk::kMaxPts)
         return fail(VMAPSTEP_ERR_UNSUPPORTED, "samples=%d > %d", sh->samples, vk::kMaxPts);
     pl.G = vk::kMaxPts / sh->samples;
@@ -69,7 +70,11 @@ int make_plan(const vmapstep_shape* sh, int max_steps, Plan& pl, const Layout& L
     pl.off_flags = o; o += align_up((size_t)max_steps * 4 * sizeof(int));
     pl.off_ploss = o; o += align_up((size_t)sh->n_obj * pl.NG * 4 * sizeof(float));     // sized for NW = NG
     pl.off_pgrad = o; o += align_up((size_t)sh->n_obj * pl.NG * L.PP * sizeof(float));
-    pl.off_wimg = o; o += align_up((size_t)sh->n_obj * vk::Lds32::IMGP * sizeof(float));
+    const vk::GenLayout GL = vk::gen_layout(sh->hidden);
+    pl.off_wimg = o; o += align_up((size_t)sh->n_obj * GL.imgp * sizeof(float));
+    pl.off_scratch = o;
+    if (pl.generic)   // per-wave register-image scratch of step_main_gen (sized for NW = NG)
+        o += align_up((size_t)sh->n_obj * pl.NG * vk::kWaves * vk::gen_wave_blocks(GL.NB) * vk::kBlk * sizeof(float));
     pl.total = o;
     return VMAPSTEP_OK;
 }
@@ -96,7 +101,7 @@ void fill_step_args(vk::StepArgs& a, const vmapstep_shape* sh, const Plan& pl, c
     a.n_obj = sh->n_obj; a.R = sh->rays; a.S = sh->samples;
     a.G = pl.G; a.NG = pl.NG; a.NW = pl.NW; a.PP = L.PP;
     // XCD-affine block map only while every XCD's share still fits its 32 CUs in one round
-    a.xcd_affine = ((sh->n_obj + 7) / 8) * pl.NW <= 32 ? 1 : 0;
+    a.xcd_affine = (!pl.generic && ((sh->n_obj + 7) / 8) * pl.NW <= 32) ? 1 : 0;
     for (int t = 0; t < VMAPSTEP_NUM_FC; ++t) a.fc[t] = {params->fc[t].ptr, params->fc[t].obj_stride};
     a.pe_B = {params->pe_B.ptr, params->pe_B.obj_stride};
     a.pe_scale = {pe_scale->ptr, pe_scale->obj_stride};
@@ -113,11 +118,13 @@ void fill_step_args(vk::StepArgs& a, const vmapstep_shape* sh, const Plan& pl, c
     a.dmask = b->depth_mask + ray0 * b->depth_mask_stride[1];
     a.dm_so = b->depth_mask_stride[0]; a.dm_sr = b->depth_mask_stride[1];
     a.color_w = cw; a.opac_w = ow;
+    a.hidden = sh->hidden;
     a.stats = reinterpret_cast<float*>(ws + pl.off_stats);
     a.flags = reinterpret_cast<int*>(ws + pl.off_flags);
     a.part_loss = reinterpret_cast<float*>(ws + pl.off_ploss);
     a.part_grad = reinterpret_cast<float*>(ws + pl.off_pgrad);
     a.wimg = reinterpret_cast<float*>(ws + pl.off_wimg);
+    g_scratch_for_launch = reinterpret_cast<float*>(ws + pl.off_scratch);
 }
 
 template <bool BWD, bool MULTI>
@@ -138,7 +145,29 @@ int launch_main_v(const vk::StepArgs& a, hipStream_t st) {
 }
 
 template <bool BWD>
+int launch_gen(const vk::StepArgs& a, hipStream_t st) {
+    static bool attr_set = false;
+    auto kern = vk::step_main_gen<BWD>;
+    const vk::GenLayout GL = vk::gen_layout(a.hidden);
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           vk::LdsGen::bytes(vk::gen_layout(256).small_n));
+        if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    vk::GenArgs ga;
+    ga.s = a;
+    ga.scratch = g_scratch_for_launch;
+    ga.wave_blocks = vk::gen_wave_blocks(GL.NB);
+    hipLaunchKernelGGL(kern, dim3(a.n_obj * a.NW), dim3(vk::kWG), vk::LdsGen::bytes(GL.small_n), st, ga);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "step_main_gen launch: %s", hipGetErrorString(e));
+    return VMAPSTEP_OK;
+}
+
+template <bool BWD>
 int launch_main(const vk::StepArgs& a, hipStream_t st) {
+    if (a.hidden != 32) return launch_gen<BWD>(a, st);
     return a.NW < a.NG ? launch_main_v<BWD, true>(a, st) : launch_main_v<BWD, false>(a, st);
 }
 
@@ -154,7 +183,7 @@ int launch_finalize(const vk::StepArgs& a, const Layout& L, const vmapstep_param
                     hipStream_t st) {
     vk::FinalizeArgs f;
     std::memset(&f, 0, sizeof(f));
-    f.n_obj = a.n_obj; f.NW = a.NW; f.PP = L.PP; f.P = L.P;
+    f.n_obj = a.n_obj; f.NW = a.NW; f.PP = L.PP; f.P = L.P; f.hidden = a.hidden;
     for (int t = 0; t < 16; ++t) f.offs[t] = L.offs[t];
     for (int t = 0; t < 15; ++t) {
         const vmapstep_tensor* pt = t < 14 ? &params->fc[t] : &params->pe_B;
@@ -388,6 +417,7 @@ int vmapstep_profile_phases(const vmapstep_shape* shape, const vmapstep_params* 
     if ((rc = check_batch(batch))) return rc;
     if (!pe_scale || !pe_scale->ptr) return fail(VMAPSTEP_ERR_ARGUMENT, "pe_scale is null");
     if (!timing || !n_workgroups) return fail(VMAPSTEP_ERR_ARGUMENT, "timing / n_workgroups is null");
+    if (pl.generic) return fail(VMAPSTEP_ERR_UNSUPPORTED, "phase stamps exist in the hidden=32 kernel only");
     const size_t need = (size_t)8 * ((shape->n_obj + 7) / 8) * pl.NW * vk::kWaves * vk::kMarks;
     if (timing_elems < need) return fail(VMAPSTEP_ERR_ARGUMENT, "timing buffer %zu < %zu elements", timing_elems, need);
     if ((rc = check_ws(workspace, workspace_bytes, pl))) return rc;

@@ -36,7 +36,7 @@ class FusedAdamWState:
     """
 
     def __init__(self, n_obj: int, hidden: int, device, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.013):
-        self.padded = (layout.param_count(hidden) + 63) // 64 * 64
+        self.padded = (layout.param_count(hidden) + 63) // 64 * 64      # == vmapstep_param_layout(...).padded_params
         self.exp_avg = torch.zeros(n_obj, self.padded, dtype=torch.float32, device=device)
         self.exp_avg_sq = torch.zeros_like(self.exp_avg)
         self.step = 0
