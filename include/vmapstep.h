@@ -135,6 +135,15 @@ int vmapstep_train_steps(const vmapstep_shape* shape, const vmapstep_params* par
 int vmapstep_prepare(const vmapstep_shape* shape, const vmapstep_params* params, const vmapstep_batch* frame,
                      int64_t ray_step, int32_t n_steps, void* workspace, size_t workspace_bytes,
                      size_t* flags_offset, void* stream);
+/* Byte offset in the workspace of the float[n_steps][n_obj][4] mask counts vmapstep_prepare wrote
+ * (N_depth&obj, N_obj, N_sem, 0).  A RAY-sharded caller (the shared background model, train.py:308-316, trained
+ * data-parallel) sum-reduces them over ranks and rewrites the switches (count == 0) before the prepared calls. */
+int vmapstep_workspace_counts_offset(const vmapstep_shape* shape, int32_t max_steps, size_t* counts_offset);
+/* vmapstep_fwd_bwd on a prepared workspace (step 0 of the prepared frame). */
+int vmapstep_fwd_bwd_prepared(const vmapstep_shape* shape, const vmapstep_params* params, const vmapstep_tensor* pe_scale,
+                              const vmapstep_batch* batch, float color_scaling, float opacity_scaling,
+                              const vmapstep_params* grads, const vmapstep_outputs* out,
+                              void* workspace, size_t workspace_bytes, void* stream);
 int vmapstep_train_steps_prepared(const vmapstep_shape* shape, const vmapstep_params* params,
                                   const vmapstep_tensor* pe_scale, const vmapstep_batch* frame, int64_t ray_step,
                                   int32_t n_steps, float color_scaling, float opacity_scaling,

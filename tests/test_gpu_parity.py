@@ -333,3 +333,81 @@ def test_prepared_split_applies_externally_reduced_flags():
     for t in range(14):
         assert relerr(gfc[t].cpu().numpy(), o[f"g_fc{t}"]) < 1e-4
     assert relerr(gB.cpu().numpy(), o["g_B"]) < 1e-4
+
+
+def test_shared_background_hip_equals_pytorch_background():
+    """The background model (hidden 128, 14 samples; train.py:308-316) on the HIP path vs the PyTorch ops path of
+    vmap_amd.parallel (world size 1: the collectives are identities, the count/flag plumbing is exercised)."""
+    from vmap_amd import fields, parallel
+    torch.manual_seed(4)
+    H, R, S = 128, 60, 14
+
+    def make():
+        torch.manual_seed(4)
+        fc = fields.OccupancyMap(hidden_size=H)
+        fc.apply(fields.init_weights)
+        pe = fields.UniDirsEmbed(max_deg=5, scale=5.0)
+        return fc, pe
+
+    b = synth.make_batch(1, R, S, seed=9)
+    bt = {k: torch.from_numpy(v[0]) for k, v in b.items()}
+    fc_ref, pe_ref = make()
+    ref = parallel.SharedBackground(fc_ref, pe_ref)
+    fc_hip, pe_hip = make()
+    hip = parallel.SharedBackgroundHip(fc_hip, pe_hip, R, S, DEV)
+    bd = {k: v.to(DEV) for k, v in bt.items()}
+    for it in range(2):
+        l_ref = float(ref.step(bt["pcs"], bt["z"], bt["gt_depth"], bt["gt_rgb"], bt["sem"], bt["depth_mask"]))
+        l_hip = float(hip.step(bd["pcs"], bd["z"], bd["gt_depth"], bd["gt_rgb"], bd["sem"], bd["depth_mask"]))
+        assert l_hip == pytest.approx(l_ref, rel=5e-5)
+    hip.write_back()
+    for p, q in zip(list(fc_hip.parameters()) + list(pe_hip.parameters()), ref.params):
+        d = (p.detach().cpu() - q.detach()).abs()
+        assert float(d.max()) <= 2 * 1.1e-3 and float(d.median()) < 1e-6
+
+
+def test_headless_driver_object_list_semantics():
+    """HipMapper: add objects, train a frame (20 steps), add another object -> re-stack with optimiser restart,
+    modules stay live views of the trained weights; first frame tracks the PyTorch port's AdamW trajectory."""
+    from oracle import vmap_oracle_torch as vt
+    from vmap_amd import driver, trainer
+    cfg = trainer.SimpleConfig(training_device=DEV, n_iter_per_frame=4)
+    cfg.obj_id = 1
+    torch.manual_seed(0)
+    n, R, S = 3, 24, 10
+    trs = [trainer.Trainer(cfg) for _ in range(n + 1)]
+    snap = [[p.detach().cpu().numpy().copy() for p in list(t.fc_occ_map.parameters()) + [t.pe.B_layer.weight]] for t in trs]
+    m = driver.HipMapper(cfg)
+    for t in trs[:n]:
+        m.add_object(t)
+    frame = synth.make_batch(n, R * cfg.n_iter_per_frame, S, seed=77)
+    fr = {k: torch.from_numpy(v).to(DEV) for k, v in frame.items()}
+    res = m.train_frame(fr["pcs"], fr["z"], fr["gt_depth"], fr["gt_rgb"], fr["sem"], fr["depth_mask"].bool())
+    m.check_flags(res)
+    # reference trajectory: the PyTorch port stepping over the same slices with torch.optim.AdamW
+    fc0 = [np.stack([snap[k][t] for k in range(n)]) for t in range(14)]
+    B0 = np.stack([snap[k][14] for k in range(n)])
+    ref = vt.CpuTrainer(fc0, B0, np.full(n, 2.0, np.float32))
+    for i in range(cfg.n_iter_per_frame):
+        sub = {k: np.ascontiguousarray(v[:, i * R:(i + 1) * R]) for k, v in frame.items()}
+        loss_i, _, _ = ref.step(sub)
+        assert float(res.loss[i]) == pytest.approx(float(loss_i), rel=3e-4)
+    # modules are live views: their parameters changed without any write-back call
+    p_now = trs[0].fc_occ_map.in_layer[0].weight
+    assert p_now.data_ptr() == m.views[0][0].data_ptr()
+    assert float((p_now.detach().cpu() - torch.from_numpy(snap[0][0])).abs().max()) > 1e-4
+    for k in range(n):
+        for t, q in enumerate(ref.fc + [ref.B]):
+            d = (m.views[t][k].cpu() - q.detach()[k]).abs()
+            assert float(d.max()) <= cfg.n_iter_per_frame * 1.2e-3 and float(d.median()) < 2e-6
+    # a new object arrives: re-stack, moments restart (utils.py:33), old objects keep their trained weights
+    trained0 = m.views[2][1].clone()
+    m.add_object(trs[n])
+    frame2 = synth.make_batch(n + 1, R * cfg.n_iter_per_frame, S, seed=78)
+    fr2 = {k: torch.from_numpy(v).to(DEV) for k, v in frame2.items()}
+    assert m._dirty
+    res2 = m.train_frame(fr2["pcs"], fr2["z"], fr2["gt_depth"], fr2["gt_rgb"], fr2["sem"], fr2["depth_mask"].bool())
+    torch.cuda.synchronize()
+    assert m.op.n_obj == n + 1 and m.opt.step == cfg.n_iter_per_frame          # fresh optimiser state
+    assert float((m.views[2][1] - trained0).abs().max()) < cfg.n_iter_per_frame * 1.2e-3   # continued from trained weights
+    assert torch.isfinite(res2.loss).all()

@@ -54,6 +54,7 @@ EXPORTS = (
     "vmapstep_last_error", "vmapstep_abi_version", "vmapstep_param_layout", "vmapstep_workspace_bytes",
     "vmapstep_fwd_bwd", "vmapstep_render", "vmapstep_train_steps", "vmapstep_set_workgroups_per_object",
     "vmapstep_profile_main_kernel", "vmapstep_profile_phases", "vmapstep_prepare", "vmapstep_train_steps_prepared",
+    "vmapstep_workspace_counts_offset", "vmapstep_fwd_bwd_prepared",
 )
 
 _lib = None
@@ -93,6 +94,8 @@ def load():
                                      ctypes.c_int32, ctypes.c_void_p, ctypes.c_size_t,
                                      ctypes.POINTER(ctypes.c_size_t), ctypes.c_void_p]
     lib.vmapstep_train_steps_prepared.argtypes = lib.vmapstep_train_steps.argtypes
+    lib.vmapstep_fwd_bwd_prepared.argtypes = lib.vmapstep_fwd_bwd.argtypes
+    lib.vmapstep_workspace_counts_offset.argtypes = [ctypes.POINTER(Shape), ctypes.c_int32, ctypes.POINTER(ctypes.c_size_t)]
     lib.vmapstep_profile_main_kernel.argtypes = [ctypes.POINTER(Shape), ctypes.POINTER(Params), ctypes.POINTER(Tensor),
                                                  ctypes.POINTER(Batch), ctypes.c_int32, ctypes.c_void_p,
                                                  ctypes.c_size_t, ctypes.c_void_p]
@@ -103,7 +106,8 @@ def load():
     lib.vmapstep_set_workgroups_per_object.argtypes = [ctypes.c_int32]
     for fn in ("vmapstep_param_layout", "vmapstep_workspace_bytes", "vmapstep_fwd_bwd", "vmapstep_render",
                "vmapstep_train_steps", "vmapstep_set_workgroups_per_object", "vmapstep_profile_main_kernel",
-               "vmapstep_profile_phases", "vmapstep_prepare", "vmapstep_train_steps_prepared"):
+               "vmapstep_profile_phases", "vmapstep_prepare", "vmapstep_train_steps_prepared",
+               "vmapstep_workspace_counts_offset", "vmapstep_fwd_bwd_prepared"):
         getattr(lib, fn).restype = ctypes.c_int
     if lib.vmapstep_abi_version() != ABI_VERSION:
         raise VmapStepError(f"ABI mismatch: library {lib.vmapstep_abi_version()} != binding {ABI_VERSION}")

@@ -63,7 +63,7 @@ struct StepArgs {
     const unsigned char* sem; long long sem_so, sem_sr;
     const unsigned char* dmask; long long dm_so, dm_sr;
     float color_w, opac_w;             // loss.py:6 defaults 5.0 / 10.0
-    float* stats;                      // [n][4]   1/(N_depth+1e-10), 1/(N_obj+1e-10), 1/(N_sem+1e-10), unused
+    float* stats;                      // [n][4]   mask counts N_depth&obj, N_obj, N_sem (exact in fp32), unused
     int* flags;                        // [4]      drop_depth, drop_colour, drop_opacity, explode
     float* part_grad;                  // [n][NW][PP]
     float* part_loss;                  // [n][NW][4]
@@ -489,9 +489,9 @@ __device__ __forceinline__ void composite_phase(const StepArgs& a, float* cb, fl
             const float gtd = a.gt_depth[obj * a.gd_so + rr * a.gd_sr];
             const float* rgb = a.gt_rgb + obj * a.rgb_so + rr * a.rgb_sr;
             const float q0 = rgb[0], q1 = rgb[a.rgb_sc], q2 = rgb[2 * a.rgb_sc];
-            const float inv_dd = a.flags[0] ? 0.0f : a.stats[obj * 4 + 0];            // render_rays.py:68-73
-            const float inv_o = a.flags[1] ? 0.0f : a.stats[obj * 4 + 1];
-            const float inv_s = a.flags[2] ? 0.0f : a.stats[obj * 4 + 2];
+            const float inv_dd = a.flags[0] ? 0.0f : 1.0f / (a.stats[obj * 4 + 0] + 1e-10f);            // render_rays.py:68-73
+            const float inv_o = a.flags[1] ? 0.0f : 1.0f / (a.stats[obj * 4 + 1] + 1e-10f);
+            const float inv_s = a.flags[2] ? 0.0f : 1.0f / (a.stats[obj * 4 + 2] + 1e-10f);
             const float info = 1.0f / (sqrtf(V) + 1e-4f);                             // render_rays.py:75-79
             const float rd = D - gtd, rc0 = C0 - q0, rc1 = C1 - q1, rc2 = C2 - q2, ro = O - m_o;
             const bool lead = g < nrays && i == 0;
@@ -565,9 +565,9 @@ __device__ __forceinline__ void composite_phase(const StepArgs& a, float* cb, fl
         const float gtd = a.gt_depth[obj * a.gd_so + rr * a.gd_sr];
         const float* rgb = a.gt_rgb + obj * a.rgb_so + rr * a.rgb_sr;
         const float q0 = rgb[0], q1 = rgb[a.rgb_sc], q2 = rgb[2 * a.rgb_sc];
-        const float inv_dd = a.flags[0] ? 0.0f : a.stats[obj * 4 + 0];
-        const float inv_o = a.flags[1] ? 0.0f : a.stats[obj * 4 + 1];
-        const float inv_s = a.flags[2] ? 0.0f : a.stats[obj * 4 + 2];
+        const float inv_dd = a.flags[0] ? 0.0f : 1.0f / (a.stats[obj * 4 + 0] + 1e-10f);
+        const float inv_o = a.flags[1] ? 0.0f : 1.0f / (a.stats[obj * 4 + 1] + 1e-10f);
+        const float inv_s = a.flags[2] ? 0.0f : 1.0f / (a.stats[obj * 4 + 2] + 1e-10f);
         const float info = 1.0f / (sqrtf(V) + 1e-4f);
         const float rd = D - gtd, rc0 = C0 - q0, rc1 = C1 - q1, rc2 = C2 - q2, ro = O - m_o;
         wv::lds_add(loss_cells + 0, fabsf(rd) * m_dd * info * inv_dd);
@@ -658,9 +658,9 @@ __global__ __launch_bounds__(kWG) void step_prep(const StepArgs a) {
         nd = cnt[0]; no = cnt[kWG]; ns = cnt[2 * kWG];
         __syncthreads();
         if (tid == 0) {
-            stats[k * 4 + 0] = 1.0f / ((float)nd + 1e-10f);   // render_rays.py:87
-            stats[k * 4 + 1] = 1.0f / ((float)no + 1e-10f);
-            stats[k * 4 + 2] = 1.0f / ((float)ns + 1e-10f);
+            stats[k * 4 + 0] = (float)nd;   // raw counts: a ray-sharded caller (shared background model) sums them over
+            stats[k * 4 + 1] = (float)no;   // ranks before the step loop; the normaliser 1/(N+1e-10) is formed in step_main
+            stats[k * 4 + 2] = (float)ns;
             stats[k * 4 + 3] = 0.0f;
         }
         drop_d |= nd == 0; drop_c |= no == 0; drop_o |= ns == 0;
@@ -861,6 +861,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
 
     // heads: out_alpha / out_color weight + bias gradients (lane = hidden feature)
     float dcp[16];   // d hc (pre-activation), P-form
+    float d4[16];    // d h4 (pre-activation), P-form
     {
         float h4F[16];
         to_F(h4F, h4, scrX, p31, hi);
@@ -895,34 +896,32 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
             const float v = W[L::W_OC + j] * d_c0 + W[L::W_OC + H + j] * d_c1 + W[L::W_OC + 2 * H + j] * d_c2;
             dcp[r] = hc[r] > 0.0f ? v : 0.0f;
         }
-        // color_linear weight gradient: [d hc]^T [h4 | e2]
+        // color_linear: delta = d hc.  Source order = issue a transpose, run the independent d-prop chain, then the
+        // dW block that consumes the transposed operand (the LDS round trip hides under 16 matrix instructions).
         to_F(dF, dcp, scrD, p31, hi);
         add_db(Gv + L::B_C, dF, p31, hi);
+        f32x16 acc2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[r] = W[L::W_A + phi(r, hi)] * d_raw;       // d h4 = W_a d raw + W_c[:, :H]^T d hc
+        bwd_mm<L::LD_C>(acc2, W + L::W_C + 4 * hi * L::LD_C + p31, dcp);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d4[r] = h4[r] > 0.0f ? acc2[r] : 0.0f;
         zero_acc(acc); dw_mm(acc, dF, h4F);
         emit_block<MULTI, H + kEmb2>(qacc[0], acc, stg0, out + F::W_C, 0, 32, wave, p31, hi);
         to_F(xF, e2a, scrX, p31, hi);
+        zero_acc(acc2);
+        bwd_mm<L::LD_C>(acc2, W + L::W_C + 4 * hi * L::LD_C + H + p31, dcp);          // d e2 (block 0)
+        pe_block_bwd<16>(dproj, acc2, c2a, kEmb1, kEmb2, 0, hi);
         zero_acc(acc); dw_mm(acc, dF, xF);
         emit_block<MULTI, H + kEmb2>(qacc[1], acc, stg1, out + F::W_C, H, 32, wave, p31, hi);
         to_F(xF, e2b, scrX, p31, hi);
+        zero_acc(acc2);
+        bwd_mm<L::LD_C>(acc2, W + L::W_C + 4 * hi * L::LD_C + H + min(32 + p31, 46), dcp);
+        pe_block_bwd<6>(dproj, acc2, c2b, kEmb1, kEmb2, 1, hi);
         zero_acc(acc); dw_mm(acc, dF, xF);
         emit_block<MULTI, H + kEmb2>(qacc[2], acc, stg0, out + F::W_C, H + 32, kEmb2 - 32, wave, p31, hi);
     }
     VK_MARK(7);
-    // d h4 = W_a d raw + W_c[:, :H]^T d hc ; d e2 = W_c[:, H:]^T d hc
-    float d4[16];
-    {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = W[L::W_A + phi(r, hi)] * d_raw;
-        bwd_mm<L::LD_C>(acc, W + L::W_C + 4 * hi * L::LD_C + p31, dcp);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) d4[r] = h4[r] > 0.0f ? acc[r] : 0.0f;
-        zero_acc(acc);
-        bwd_mm<L::LD_C>(acc, W + L::W_C + 4 * hi * L::LD_C + H + p31, dcp);
-        pe_block_bwd<16>(dproj, acc, c2a, kEmb1, kEmb2, 0, hi);
-        zero_acc(acc);
-        bwd_mm<L::LD_C>(acc, W + L::W_C + 4 * hi * L::LD_C + H + min(32 + p31, 46), dcp);
-        pe_block_bwd<6>(dproj, acc, c2b, kEmb1, kEmb2, 1, hi);
-    }
     VK_MARK(8);
     // mid2
     float d3[16];
@@ -930,40 +929,42 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
         to_F(dF, d4, scrD, p31, hi);
         to_F(xF, h3, scrX, p31, hi);
         add_db(Gv + L::B_M2, dF, p31, hi);
+        f32x16 acc2;
+        zero_acc(acc2);
+        bwd_mm<L::LD_M>(acc2, W + L::W_M2 + 4 * hi * L::LD_M + p31, d4);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d3[r] = h3[r] > 0.0f ? acc2[r] : 0.0f;
         zero_acc(acc); dw_mm(acc, dF, xF);
         emit_block<MULTI, H>(qacc[3], acc, stg1, out + F::W_M2, 0, 32, wave, p31, hi);
-        zero_acc(acc);
-        bwd_mm<L::LD_M>(acc, W + L::W_M2 + 4 * hi * L::LD_M + p31, d4);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) d3[r] = h3[r] > 0.0f ? acc[r] : 0.0f;
     }
     VK_MARK(9);
     // cat_layer
     float d2[16];
     f32x16 de1a, de1b, de1c;
     {
+        const float* wc = W + L::W_CAT + 4 * hi * L::LD_CAT;
         to_F(dF, d3, scrD, p31, hi);
         add_db(Gv + L::B_CAT, dF, p31, hi);
         to_F(xF, h2, scrX, p31, hi);
+        f32x16 acc2;
+        zero_acc(acc2);
+        bwd_mm<L::LD_CAT>(acc2, wc + p31, d3);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d2[r] = h2[r] > 0.0f ? acc2[r] : 0.0f;
         zero_acc(acc); dw_mm(acc, dF, xF);
         emit_block<MULTI, H + kEmb1>(qacc[4], acc, stg0, out + F::W_CAT, 0, 32, wave, p31, hi);
         to_F(xF, e1a, scrX, p31, hi);
+        zero_acc(de1a); bwd_mm<L::LD_CAT>(de1a, wc + H + p31, d3);
         zero_acc(acc); dw_mm(acc, dF, xF);
         emit_block<MULTI, H + kEmb1>(qacc[5], acc, stg1, out + F::W_CAT, H, 32, wave, p31, hi);
         to_F(xF, e1b, scrX, p31, hi);
+        zero_acc(de1b); bwd_mm<L::LD_CAT>(de1b, wc + H + 32 + p31, d3);
         zero_acc(acc); dw_mm(acc, dF, xF);
         emit_block<MULTI, H + kEmb1>(qacc[6], acc, stg0, out + F::W_CAT, H + 32, 32, wave, p31, hi);
         to_F(xF, e1c, scrX, p31, hi);
+        zero_acc(de1c); bwd_mm<L::LD_CAT>(de1c, wc + H + min(64 + p31, 88), d3);
         zero_acc(acc); dw_mm(acc, dF, xF);
         emit_block<MULTI, H + kEmb1>(qacc[7], acc, stg1, out + F::W_CAT, H + 64, kEmb1 - 64, wave, p31, hi);
-        const float* wc = W + L::W_CAT + 4 * hi * L::LD_CAT;
-        zero_acc(acc);
-        bwd_mm<L::LD_CAT>(acc, wc + p31, d3);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) d2[r] = h2[r] > 0.0f ? acc[r] : 0.0f;
-        zero_acc(de1a); bwd_mm<L::LD_CAT>(de1a, wc + H + p31, d3);
-        zero_acc(de1b); bwd_mm<L::LD_CAT>(de1b, wc + H + 32 + p31, d3);
-        zero_acc(de1c); bwd_mm<L::LD_CAT>(de1c, wc + H + min(64 + p31, 88), d3);
     }
     VK_MARK(10);
     // mid1
@@ -972,32 +973,33 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
         to_F(dF, d2, scrD, p31, hi);
         to_F(xF, h1, scrX, p31, hi);
         add_db(Gv + L::B_M1, dF, p31, hi);
+        f32x16 acc2;
+        zero_acc(acc2);
+        bwd_mm<L::LD_M>(acc2, W + L::W_M1 + 4 * hi * L::LD_M + p31, d2);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d1[r] = h1[r] > 0.0f ? acc2[r] : 0.0f;
         zero_acc(acc); dw_mm(acc, dF, xF);
         emit_block<MULTI, H>(qacc[8], acc, stg0, out + F::W_M1, 0, 32, wave, p31, hi);
-        zero_acc(acc);
-        bwd_mm<L::LD_M>(acc, W + L::W_M1 + 4 * hi * L::LD_M + p31, d2);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) d1[r] = h1[r] > 0.0f ? acc[r] : 0.0f;
     }
     VK_MARK(11);
     // in_layer + encoding backward
     float e1aF[16];
     {
+        const float* wi = W + L::W_IN + 4 * hi * L::LD_IN;
         to_F(dF, d1, scrD, p31, hi);
         add_db(Gv + L::B_IN, dF, p31, hi);
         to_F(e1aF, e1a, scrX, p31, hi);
+        bwd_mm<L::LD_IN>(de1a, wi + p31, d1);
         zero_acc(acc); dw_mm(acc, dF, e1aF);
         emit_block<MULTI, kEmb1>(qacc[9], acc, stg1, out + F::W_IN, 0, 32, wave, p31, hi);
         to_F(xF, e1b, scrX, p31, hi);
+        bwd_mm<L::LD_IN>(de1b, wi + 32 + p31, d1);
         zero_acc(acc); dw_mm(acc, dF, xF);
         emit_block<MULTI, kEmb1>(qacc[10], acc, stg0, out + F::W_IN, 32, 32, wave, p31, hi);
         to_F(xF, e1c, scrX, p31, hi);
+        bwd_mm<L::LD_IN>(de1c, wi + min(64 + p31, 88), d1);
         zero_acc(acc); dw_mm(acc, dF, xF);
         emit_block<MULTI, kEmb1>(qacc[11], acc, stg1, out + F::W_IN, 64, kEmb1 - 64, wave, p31, hi);
-        const float* wi = W + L::W_IN + 4 * hi * L::LD_IN;
-        bwd_mm<L::LD_IN>(de1a, wi + p31, d1);
-        bwd_mm<L::LD_IN>(de1b, wi + 32 + p31, d1);
-        bwd_mm<L::LD_IN>(de1c, wi + min(64 + p31, 88), d1);
         pe_block_bwd<16>(dproj, de1a, c1a, 0, kEmb1, 0, hi);
         pe_block_bwd<16>(dproj, de1b, c1b, 0, kEmb1, 1, hi);
         pe_block_bwd<12>(dproj, de1c, c1c, 0, kEmb1, 2, hi);

@@ -259,10 +259,10 @@ int vmapstep_workspace_bytes(const vmapstep_shape* shape, int32_t max_steps, siz
     return VMAPSTEP_OK;
 }
 
-int vmapstep_fwd_bwd(const vmapstep_shape* shape, const vmapstep_params* params, const vmapstep_tensor* pe_scale,
-                     const vmapstep_batch* batch, float color_scaling, float opacity_scaling,
-                     const vmapstep_params* grads, const vmapstep_outputs* out,
-                     void* workspace, size_t workspace_bytes, void* stream) {
+static int fwd_bwd_impl(const vmapstep_shape* shape, const vmapstep_params* params, const vmapstep_tensor* pe_scale,
+                        const vmapstep_batch* batch, float color_scaling, float opacity_scaling,
+                        const vmapstep_params* grads, const vmapstep_outputs* out,
+                        void* workspace, size_t workspace_bytes, void* stream, bool do_prep) {
     int rc;
     if (!shape) return fail(VMAPSTEP_ERR_ARGUMENT, "shape is null");
     Layout L;
@@ -280,9 +280,36 @@ int vmapstep_fwd_bwd(const vmapstep_shape* shape, const vmapstep_params* params,
     fill_step_args(a, shape, pl, L, params, pe_scale, batch, 0, color_scaling, opacity_scaling, static_cast<char*>(workspace));
     a.prep_steps = 1; a.prep_ray_step = 0;
     a.dbg_depth = out->render_depth; a.dbg_rgb = out->render_color; a.dbg_opacity = out->opacity; a.dbg_var = out->var;
-    if ((rc = launch_prep(a, 1, st))) return rc;
+    if (do_prep && (rc = launch_prep(a, 1, st))) return rc;
     if ((rc = launch_main<true>(a, st))) return rc;
     return launch_finalize(a, L, params, grads, nullptr, 0, true, out->loss, out->flags, st);
+}
+
+int vmapstep_fwd_bwd(const vmapstep_shape* shape, const vmapstep_params* params, const vmapstep_tensor* pe_scale,
+                     const vmapstep_batch* batch, float color_scaling, float opacity_scaling,
+                     const vmapstep_params* grads, const vmapstep_outputs* out,
+                     void* workspace, size_t workspace_bytes, void* stream) {
+    return fwd_bwd_impl(shape, params, pe_scale, batch, color_scaling, opacity_scaling, grads, out, workspace,
+                        workspace_bytes, stream, true);
+}
+
+int vmapstep_fwd_bwd_prepared(const vmapstep_shape* shape, const vmapstep_params* params, const vmapstep_tensor* pe_scale,
+                              const vmapstep_batch* batch, float color_scaling, float opacity_scaling,
+                              const vmapstep_params* grads, const vmapstep_outputs* out,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+    return fwd_bwd_impl(shape, params, pe_scale, batch, color_scaling, opacity_scaling, grads, out, workspace,
+                        workspace_bytes, stream, false);
+}
+
+int vmapstep_workspace_counts_offset(const vmapstep_shape* shape, int32_t max_steps, size_t* counts_offset) {
+    if (!shape || !counts_offset) return fail(VMAPSTEP_ERR_ARGUMENT, "null argument");
+    Layout L;
+    make_layout(shape->hidden, L);
+    Plan pl;
+    int rc = make_plan(shape, max_steps, pl, L);
+    if (rc) return rc;
+    *counts_offset = pl.off_stats;
+    return VMAPSTEP_OK;
 }
 
 int vmapstep_render(const vmapstep_shape* shape, const vmapstep_params* params, const vmapstep_tensor* pe_scale,

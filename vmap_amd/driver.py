@@ -1,0 +1,92 @@
+"""Headless, train.py-shaped driver of the object fields on the HIP path.
+
+Keeps the reference's object-list semantics:
+
+* objects arrive one by one, each with its own ``Trainer`` (``fc_occ_map`` + ``pe``)          train.py:123-164
+* when the list changed, everything is re-stacked (``utils.update_vmap``) and the optimiser state of the new
+  stack starts from zero - Adam moments restart, exactly like the new param group of utils.py:33     train.py:179-183
+* per frame, ``n_iter_per_frame`` optimisation steps run over slices of the per-frame sample tensors   train.py:270-326
+* the per-object modules always hold the trained weights (the write-back of train.py:331-338)
+
+but replaces the ATen op stream by ``VmapStep.train_steps`` (one C call per frame).  The stacked parameters are views
+of ONE ``[n, P]`` slab and every module parameter is re-pointed at its row of that slab, so the write-back is free:
+``trainer.fc_occ_map`` / ``trainer.pe`` read the live weights (mesh queries, checkpoints) without any copy.
+Keyframe management, sampling and visualisation stay with the caller (out of scope).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+
+from . import layout, step
+
+
+class HipMapper:
+    def __init__(self, cfg, device=None, group_reduce=None):
+        self.cfg = cfg
+        self.device = torch.device(device or cfg.training_device)
+        self.trainers: List = []
+        self._dirty = False
+        self.slab: Optional[torch.Tensor] = None
+        self.views: List[torch.Tensor] = []
+        self.scale: Optional[torch.Tensor] = None
+        self.opt: Optional[step.FusedAdamWState] = None
+        self.op: Optional[step.VmapStep] = None
+        self.flag_reduce = group_reduce          # e.g. parallel.ObjectShard(...).reduce_flags for multi-GPU
+        self.frames_trained = 0
+
+    # ---- object list ---------------------------------------------------------------------------------------
+    def add_object(self, trainer) -> int:
+        """Append one object (its ``Trainer``); the stack is rebuilt lazily before the next frame (train.py:163-164)."""
+        if self.trainers and trainer.hidden_feature_size != self.trainers[0].hidden_feature_size:
+            raise ValueError("all stacked objects share one hidden width (the background model is a separate stack)")
+        self.trainers.append(trainer)
+        self._dirty = True
+        return len(self.trainers) - 1
+
+    def restack(self, rays: int, samples: int):
+        """utils.update_vmap for the whole list: new slab, module parameters re-pointed at it, fresh optimiser state."""
+        n = len(self.trainers)
+        if n == 0:
+            raise ValueError("no objects")
+        H = self.trainers[0].hidden_feature_size
+        P = layout.param_count(H)
+        slab = torch.empty(n, P, dtype=torch.float32, device=self.device)
+        offs = layout.flat_offsets(H)
+        shapes = list(layout.fc_shapes(H)) + [layout.PE_B_SHAPE]
+        views = []
+        with torch.no_grad():
+            for t, shp in enumerate(shapes):
+                views.append(slab[:, offs[t]:offs[t] + layout.numel(shp)].view((n,) + tuple(shp)))
+            for k, tr in enumerate(self.trainers):
+                src = list(tr.fc_occ_map.parameters()) + [tr.pe.B_layer.weight]
+                for t, p in enumerate(src):
+                    views[t][k].copy_(p.detach())
+                    p.data = views[t][k]                      # the module now IS a view of the slab (free write-back)
+            self.scale = torch.stack([tr.pe.scale.detach().to(self.device).reshape(()) for tr in self.trainers]).contiguous()
+        self.slab, self.views = slab, views
+        self.opt = step.FusedAdamWState(n, H, self.device, lr=self.cfg.learning_rate, weight_decay=self.cfg.weight_decay)
+        self.op = step.VmapStep(n, rays, samples, H, device=self.device, max_steps=self.cfg.n_iter_per_frame)
+        self._dirty = False
+
+    # ---- one frame -----------------------------------------------------------------------------------------
+    def train_frame(self, pcs, z, gt_depth, gt_rgb, sem, depth_mask, render: bool = False) -> step.StepResult:
+        """The step loop of one frame: inputs are the stacked per-frame tensors of train.py:255-260
+        ([n, iters*R, S, 3], [n, iters*R, S], [n, iters*R], [n, iters*R, 3], u8 [n, iters*R], bool/u8 [n, iters*R])."""
+        iters = self.cfg.n_iter_per_frame
+        rays = pcs.shape[1] // iters
+        samples = pcs.shape[2]
+        if self._dirty or self.op is None or (self.op.rays, self.op.samples) != (rays, samples):
+            self.restack(rays, samples)
+        res = self.op.train_steps(self.views[:14], self.views[14], self.scale, pcs, z, gt_depth, gt_rgb, sem, depth_mask,
+                                  opt=self.opt, n_steps=iters, ray_step=rays, render=render, flag_reduce=self.flag_reduce)
+        self.frames_trained += 1
+        return res
+
+    def check_flags(self, res: step.StepResult):
+        """Host-side look at the device flags of a frame (the reference exits on 'loss explode', render_rays.py:88-90)."""
+        f = res.flags.cpu()
+        if bool(f[:, 3].any()):
+            raise RuntimeError("loss explode (a per-object loss term exceeded 1e5)")
+        return f

@@ -119,3 +119,72 @@ class SharedBackground:
     def _forward(self, pcs):
         alpha, color = self.fc(self.pe(pcs))
         return alpha.squeeze(-1), color
+
+
+class SharedBackgroundHip:
+    """The shared background model (train.py:308-316) trained data-parallel over RAY shards with the HIP step.
+
+    Every rank holds a replica whose 15 tensors are views of ONE ``[1, P]`` slab (so gradients are one contiguous
+    buffer); per step:  vmapstep_prepare (local mask counts) -> all_reduce(SUM) of the 3 counts -> local forward /
+    loss / backward on this rank's rays with the GLOBAL normalisers (step_main_gen for hidden 128) -> ONE
+    all_reduce(SUM) of [gradient slab | loss] (378 KB at hidden 128) -> identical AdamW on every rank.
+    """
+
+    def __init__(self, fc_occ_map: torch.nn.Module, pe: torch.nn.Module, rays_local: int, samples: int, device,
+                 lr=1e-3, weight_decay=0.013, group=None):
+        from . import layout, step
+        self.group = group
+        self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.modules = (fc_occ_map, pe)
+        H = fc_occ_map.hidden_size
+        P = layout.param_count(H)
+        dev = torch.device(device)
+        self.slab = torch.zeros(1, P, dtype=torch.float32, device=dev)
+        self.buf = torch.zeros(P + 1, dtype=torch.float32, device=dev)             # [gradient slab | loss]
+        self.gslab = self.buf[:P].view(1, P)
+        offs = layout.flat_offsets(H)
+        shapes = list(layout.fc_shapes(H)) + [layout.PE_B_SHAPE]
+        src = list(fc_occ_map.parameters()) + [pe.B_layer.weight]
+        self.views, self.gviews = [], []
+        with torch.no_grad():
+            for t, shp in enumerate(shapes):
+                n = layout.numel(shp)
+                v = self.slab[:, offs[t]:offs[t] + n].view((1,) + tuple(shp))
+                v.copy_(src[t].detach().to(dev).unsqueeze(0))
+                self.views.append(v)
+                self.gviews.append(self.gslab[:, offs[t]:offs[t] + n].view((1,) + tuple(shp)))
+        self.scale = pe.scale.detach().to(dev).reshape(1).clone()
+        self.slab.requires_grad_()
+        self.opt = torch.optim.AdamW([self.slab], lr=lr, weight_decay=weight_decay)   # elementwise: == per-tensor AdamW
+        self.op = step.VmapStep(1, rays_local, samples, H, device=dev)
+
+    def ray_slice(self, n_rays: int) -> slice:
+        return slice(self.rank, n_rays, self.world_size)
+
+    def _reduce_counts(self, counts: torch.Tensor, flags: torch.Tensor):
+        if self.world_size > 1:
+            dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=self.group)
+        flags[:3] = (counts[:, :3] == 0).any(dim=0).to(torch.int32)
+
+    def step(self, pcs, z, gt_depth, gt_rgb, sem, depth_mask) -> torch.Tensor:
+        """One optimisation step; inputs are THIS rank's ray shard ([R_local, ...]); returns the global loss."""
+        u = lambda x: x.unsqueeze(0)
+        with torch.no_grad():
+            views = [v.detach() for v in self.views]
+            res = self.op.fwd_bwd(views[:14], views[14], self.scale, u(pcs), u(z), u(gt_depth), u(gt_rgb), u(sem),
+                                  u(depth_mask), grads_fc=self.gviews[:14], grad_B=self.gviews[14],
+                                  count_reduce=self._reduce_counts)
+            self.buf[-1] = res.loss[0]
+            if self.world_size > 1:
+                dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=self.group)   # ONE message: gradients + loss
+        self.slab.grad = self.gslab
+        self.opt.step()
+        return self.buf[-1].clone()
+
+    @torch.no_grad()
+    def write_back(self):
+        """Copy the trained slab into the modules (what train.py:331-338 does for the object fields)."""
+        fc, pe = self.modules
+        for p, v in zip(list(fc.parameters()) + [pe.B_layer.weight], self.views):
+            p.copy_(v[0].to(p.device))

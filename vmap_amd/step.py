@@ -132,10 +132,18 @@ class VmapStep:
         return torch.cuda.current_stream().cuda_stream
 
     # ---- operators ------------------------------------------------------------------------------------
+    def _ws_view(self, byte_offset: int, nbytes: int) -> torch.Tensor:
+        start = (self._ws_ptr - self.workspace.data_ptr()) + byte_offset
+        return self.workspace[start:start + nbytes]
+
     def fwd_bwd(self, fc, B, pe_scale, pcs, z, gt_depth, gt_rgb, sem, depth_mask, grads_fc=None, grad_B=None,
-                render: bool = False) -> StepResult:
+                render: bool = False, count_reduce=None) -> StepResult:
         """Loss + gradients of all 15 stacked tensors (train.py:293-306 + :324). Gradients are written to
-        ``grads_fc``/``grad_B`` if given, else into freshly allocated ``p.grad`` of the parameters."""
+        ``grads_fc``/``grad_B`` if given, else into freshly allocated ``p.grad`` of the parameters.
+
+        ``count_reduce``: optional callable(counts float32 [n, 4], flags int32 [4]) for RAY-sharded data parallelism
+        (shared background model): it sums the mask counts over ranks in place and rewrites the empty-mask switches;
+        the call is then vmapstep_prepare -> count_reduce -> vmapstep_fwd_bwd_prepared."""
         if grads_fc is None:
             grads_fc = []
             for p in list(fc) + [B]:
@@ -148,10 +156,20 @@ class VmapStep:
         sc = _lib.Tensor(pe_scale.data_ptr(), pe_scale.stride(0) if pe_scale.dim() else 0)
         bt = self._batch(pcs, z, gt_depth, gt_rgb, sem, depth_mask)
         res, out = self._outputs(1, render)
-        _lib.check(self.lib.vmapstep_fwd_bwd(ctypes.byref(self.shape), ctypes.byref(pp), ctypes.byref(sc),
-                                             ctypes.byref(bt), self.color_scaling, self.opacity_scaling,
-                                             ctypes.byref(gp), ctypes.byref(out), self._ws_ptr, self._ws_bytes,
-                                             self._stream()))
+        fn = self.lib.vmapstep_fwd_bwd
+        if count_reduce is not None:
+            foff, coff = ctypes.c_size_t(0), ctypes.c_size_t(0)
+            _lib.check(self.lib.vmapstep_prepare(ctypes.byref(self.shape), ctypes.byref(pp), ctypes.byref(bt), 0, 1,
+                                                 self._ws_ptr, self._ws_bytes, ctypes.byref(foff), self._stream()))
+            _lib.check(self.lib.vmapstep_workspace_counts_offset(ctypes.byref(self.shape), 1, ctypes.byref(coff)))
+            counts = self._ws_view(coff.value, self.n_obj * 16).view(torch.float32).view(self.n_obj, 4)
+            flags = self._ws_view(foff.value, 16).view(torch.int32)
+            count_reduce(counts, flags)
+            fn = self.lib.vmapstep_fwd_bwd_prepared
+        _lib.check(fn(ctypes.byref(self.shape), ctypes.byref(pp), ctypes.byref(sc),
+                      ctypes.byref(bt), self.color_scaling, self.opacity_scaling,
+                      ctypes.byref(gp), ctypes.byref(out), self._ws_ptr, self._ws_bytes,
+                      self._stream()))
         return res
 
     def render(self, fc, B, pe_scale, pcs, z, gt_depth, gt_rgb, sem, depth_mask) -> StepResult:
@@ -224,8 +242,7 @@ class VmapStep:
             off = ctypes.c_size_t(0)
             _lib.check(self.lib.vmapstep_prepare(ctypes.byref(self.shape), ctypes.byref(pp), ctypes.byref(bt), ray_step,
                                                  n_steps, self._ws_ptr, self._ws_bytes, ctypes.byref(off), self._stream()))
-            start = (self._ws_ptr - self.workspace.data_ptr()) + off.value
-            flags_view = self.workspace[start:start + n_steps * 16].view(torch.int32).view(n_steps, 4)
+            flags_view = self._ws_view(off.value, n_steps * 16).view(torch.int32).view(n_steps, 4)
             flag_reduce(flags_view)
             fn = self.lib.vmapstep_train_steps_prepared
         _lib.check(fn(ctypes.byref(self.shape), ctypes.byref(pp), ctypes.byref(sc),
