@@ -52,6 +52,18 @@ inline void glds16(const float* g, float* lds_wave_base) {
     for (int i = 0; i < 4; ++i) d[i] = g[i];
 }
 
+template <int J>
+inline float row_bcast(float x) { return shfl(x, (sim::lane_id() & ~15) + J); }
+
+inline float row_sum16(float x) {       // same butterfly order as the device DPP sequence
+    const int l = sim::lane_id();
+    x += shfl(x, l ^ 1);
+    x += shfl(x, l ^ 2);
+    x += shfl(x, (l & ~7) + (7 - (l & 7)));
+    x += shfl(x, (l & ~15) + (15 - (l & 15)));
+    return x;
+}
+
 inline bool wave_any(bool pred) {
     const int w = sim::wave_id(), l = sim::lane_id();
     sim::g_block->xa[w][l] = pred ? 1.0f : 0.0f;

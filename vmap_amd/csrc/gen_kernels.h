@@ -215,7 +215,8 @@ __global__ __launch_bounds__(kWG, 1) void step_main_gen(const GenArgs ga) {
         }
     }
     __syncthreads();
-    composite_phase<BWD>(a, cb, lds + LdsGen::LOSS, obj, ray0, nrays, wave, lane, tid);
+    composite_phase<BWD>(a, cb, lds + LdsGen::LOSS, obj, ray0, nrays, wave, lane, tid,
+                         load_ray_meta(a, obj, ray0 + min(4 * wave + (lane >> 4), nrays - 1)));
     __syncthreads();
 
     if (BWD) {

@@ -430,28 +430,33 @@ __device__ __forceinline__ void pe_block_bwd(float (&dproj)[kDirs], const f32x16
 __device__ __forceinline__ float sigmoidf_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ __forceinline__ float sgnf(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
 
-// sum / scans over aligned groups of 16 lanes (one ray per group in the compositing phase)
-__device__ __forceinline__ float sum16(float x, int lane) {
-    x += wv::shfl(x, lane ^ 1);
-    x += wv::shfl(x, lane ^ 2);
-    x += wv::shfl(x, lane ^ 4);
-    x += wv::shfl(x, lane ^ 8);
-    return x;
-}
-// value of the lane d positions lower in the same 16-lane group, or `fill` for the first d lanes
-__device__ __forceinline__ float up16(float x, int d, float fill, int lane) {
-    const float y = wv::shfl(x, lane - d);
-    return (lane & 15) >= d ? y : fill;
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // Workgroup phase between forward and backward: per-ray compositing, loss and d loss / d raw
 // (loss.py:24-60, render_rays.py:26-96).  cb = composite buffer [kMaxPts][8]: in  row[0..3] = occupancy, colour,
 // row[6] = z ; out row[0..3] = d/d(raw alpha), d/d(raw colour).  loss_cells = per-wave loss partials [kWaves][4].
 // ---------------------------------------------------------------------------------------------------------
+// per-ray ground truth / masks / normalisers of the ray a lane composites (loaded early so the latency is hidden)
+struct RayMeta {
+    unsigned char sem, dm;
+    float gtd, q0, q1, q2;
+    float inv_dd, inv_o, inv_s;
+};
+__device__ __forceinline__ RayMeta load_ray_meta(const StepArgs& a, int obj, int rr) {
+    RayMeta m;
+    m.sem = a.sem[obj * a.sem_so + rr * a.sem_sr];
+    m.dm = a.dmask[obj * a.dm_so + rr * a.dm_sr];
+    m.gtd = a.gt_depth[obj * a.gd_so + rr * a.gd_sr];
+    const float* rgb = a.gt_rgb + obj * a.rgb_so + rr * a.rgb_sr;
+    m.q0 = rgb[0]; m.q1 = rgb[a.rgb_sc]; m.q2 = rgb[2 * a.rgb_sc];
+    m.inv_dd = a.flags[0] ? 0.0f : 1.0f / (a.stats[obj * 4 + 0] + 1e-10f);            // render_rays.py:68-73,87
+    m.inv_o = a.flags[1] ? 0.0f : 1.0f / (a.stats[obj * 4 + 1] + 1e-10f);
+    m.inv_s = a.flags[2] ? 0.0f : 1.0f / (a.stats[obj * 4 + 2] + 1e-10f);
+    return m;
+}
+
 template <bool BWD>
 __device__ __forceinline__ void composite_phase(const StepArgs& a, float* cb, float* loss_cells, int obj, int ray0, int nrays,
-                                                int wave, int lane, int tid) {
+                                                int wave, int lane, int tid, const RayMeta& pre) {
     // ---- per-ray compositing, loss and d loss / d raw  (loss.py:24-60, render_rays.py:26-96) ----
     if (a.S <= 16) {
         // 16 lanes per ray: lane i of a group holds sample i; products/sums are scans and butterflies
@@ -466,32 +471,35 @@ __device__ __forceinline__ void composite_phase(const StepArgs& a, float* cb, fl
             // Transmittance, depth and variance in SEQUENTIAL sample order (lane broadcasts): on saturated rays the
             // variance is rounding noise and 1/(sqrt(V)+1e-4) amplifies it, so the reference's order is mirrored
             // (cumprod, then product tensor, then sum; render_rays.py:31-32,47-51) instead of a tree.
-            const int gb = lane & ~15;
+            // Lanes past the ray's last sample hold f = 1 and w = 0, so running every loop over all 16 row lanes adds
+            // exact ones / zeros and leaves the sequential result over the S samples unchanged.
             float T = 1.0f;
-            for (int j = 0; j + 1 < a.S; ++j) {
-                const float fj = wv::shfl(f, gb + j);
-                T = j < i ? T * fj : T;
-            }
+#define VK_T(J) { const float fj = wv::row_bcast<J>(f); T = J < i ? T * fj : T; }
+            VK_T(0) VK_T(1) VK_T(2) VK_T(3) VK_T(4) VK_T(5) VK_T(6) VK_T(7)
+            VK_T(8) VK_T(9) VK_T(10) VK_T(11) VK_T(12) VK_T(13) VK_T(14)
+#undef VK_T
             const float w = o * T;                                     // render_rays.py:32
             const float wz = w * zi;
             float D = 0.0f;
-            for (int j = 0; j < a.S; ++j) D += wv::shfl(wz, gb + j);    // loss.py:27
+#define VK_D(J) D += wv::row_bcast<J>(wz);
+            VK_D(0) VK_D(1) VK_D(2) VK_D(3) VK_D(4) VK_D(5) VK_D(6) VK_D(7)
+            VK_D(8) VK_D(9) VK_D(10) VK_D(11) VK_D(12) VK_D(13) VK_D(14) VK_D(15)           // loss.py:27
+#undef VK_D
             const float dz = zi - D;
             const float wd = w * (dz * dz);
             float V = 0.0f;
-            for (int j = 0; j < a.S; ++j) V += wv::shfl(wd, gb + j);    // loss.py:28-29 (detached)
-            const float O = sum16(w, lane);                             // loss.py:31
-            const float C0 = sum16(w * c0, lane), C1 = sum16(w * c1, lane), C2 = sum16(w * c2, lane);   // loss.py:30
-            const unsigned char s = a.sem[obj * a.sem_so + rr * a.sem_sr];
-            const unsigned char dm = a.dmask[obj * a.dm_so + rr * a.dm_sr];
+#define VK_V(J) V += wv::row_bcast<J>(wd);
+            VK_V(0) VK_V(1) VK_V(2) VK_V(3) VK_V(4) VK_V(5) VK_V(6) VK_V(7)
+            VK_V(8) VK_V(9) VK_V(10) VK_V(11) VK_V(12) VK_V(13) VK_V(14) VK_V(15)           // loss.py:28-29 (detached)
+#undef VK_V
+            const float O = wv::row_sum16(w);                           // loss.py:31
+            const float C0 = wv::row_sum16(w * c0), C1 = wv::row_sum16(w * c1), C2 = wv::row_sum16(w * c2);   // loss.py:30
+            const RayMeta mt = g0 == 4 * wave ? pre : load_ray_meta(a, obj, rr);    // first round: prefetched by the caller
+            const unsigned char s = mt.sem, dm = mt.dm;
             const float m_o = s != 0 ? 1.0f : 0.0f, m_s = s != 2 ? 1.0f : 0.0f;      // loss.py:16-19
             const float m_dd = (dm != 0 && s != 0) ? 1.0f : 0.0f;                     // loss.py:37
-            const float gtd = a.gt_depth[obj * a.gd_so + rr * a.gd_sr];
-            const float* rgb = a.gt_rgb + obj * a.rgb_so + rr * a.rgb_sr;
-            const float q0 = rgb[0], q1 = rgb[a.rgb_sc], q2 = rgb[2 * a.rgb_sc];
-            const float inv_dd = a.flags[0] ? 0.0f : 1.0f / (a.stats[obj * 4 + 0] + 1e-10f);            // render_rays.py:68-73
-            const float inv_o = a.flags[1] ? 0.0f : 1.0f / (a.stats[obj * 4 + 1] + 1e-10f);
-            const float inv_s = a.flags[2] ? 0.0f : 1.0f / (a.stats[obj * 4 + 2] + 1e-10f);
+            const float gtd = mt.gtd, q0 = mt.q0, q1 = mt.q1, q2 = mt.q2;
+            const float inv_dd = mt.inv_dd, inv_o = mt.inv_o, inv_s = mt.inv_s;
             const float info = 1.0f / (sqrtf(V) + 1e-4f);                             // render_rays.py:75-79
             const float rd = D - gtd, rc0 = C0 - q0, rc1 = C1 - q1, rc2 = C2 - q2, ro = O - m_o;
             const bool lead = g < nrays && i == 0;
@@ -524,10 +532,10 @@ __device__ __forceinline__ void composite_phase(const StepArgs& a, float* cb, fl
                 // sum_{k>i} g_w_k * w_k, accumulated directly from the last sample down (no total-minus-prefix:
                 // that difference cancels catastrophically and is then divided by f, which can be 1e-10)
                 float suffix = 0.0f;
-                for (int j = a.S - 1; j > 0; --j) {
-                    const float gj = wv::shfl(gww, gb + j);
-                    suffix = j > i ? suffix + gj : suffix;
-                }
+#define VK_S(J) { const float gj = wv::row_bcast<J>(gww); suffix = J > i ? suffix + gj : suffix; }
+                VK_S(15) VK_S(14) VK_S(13) VK_S(12) VK_S(11) VK_S(10) VK_S(9) VK_S(8)
+                VK_S(7) VK_S(6) VK_S(5) VK_S(4) VK_S(3) VK_S(2) VK_S(1)
+#undef VK_S
                 const float d_occ = gw * T - suffix / f;               // cumprod backward: reverse-cumsum / input
                 if (on) {
                     row[0] = 10.0f * (d_occ * o * (1.0f - o));         // through sigmoid and the *10 (model.py:77)
@@ -844,7 +852,8 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
     __syncthreads();
     VK_MARK(5);
 
-    composite_phase<BWD>(a, cb, lds + L::LOSS, obj, ray0, nrays, wave, lane, tid);
+    composite_phase<BWD>(a, cb, lds + L::LOSS, obj, ray0, nrays, wave, lane, tid,
+                         load_ray_meta(a, obj, ray0 + min(4 * wave + (lane >> 4), nrays - 1)));
     __syncthreads();
     VK_MARK(6);
     if (BWD) {

@@ -21,8 +21,31 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
-// value held by the partner lane in the other 32-lane half of the wave (lane ^ 32)
-__device__ __forceinline__ float swap_half(float x) { return __shfl_xor(x, 32); }
+// value held by the partner lane in the other 32-lane half of the wave (lane ^ 32): v_permlane32_swap + select
+// (VALU only; the ds_bpermute form costs an LDS round trip of ~100 cycles that one wave per SIMD cannot hide)
+__device__ __forceinline__ float swap_half(float x) {
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float((threadIdx.x & 32) ? r[0] : r[1]);
+}
+
+// value held by lane J of this lane's 16-lane row (DPP row_newbcast: one VALU op, often fused into its consumer)
+template <int J>
+__device__ __forceinline__ float row_bcast(float x) {
+    return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), 0x150 + J, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+    return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), CTRL, 0xf, 0xf, false));
+}
+// sum over this lane's 16-lane row, result on every lane: quad butterflies, then half-row and row mirrors
+__device__ __forceinline__ float row_sum16(float x) {
+    x += dpp_mov<0xB1>(x);     // quad_perm [1,0,3,2]
+    x += dpp_mov<0x4E>(x);     // quad_perm [2,3,0,1]
+    x += dpp_mov<0x141>(x);    // row_half_mirror
+    x += dpp_mov<0x140>(x);    // row_mirror
+    return x;
+}
 
 // value of x held by lane `src` (0..63) of this wave
 __device__ __forceinline__ float shfl(float x, int src) { return __shfl(x, src & 63); }
