@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--config", default="replica_room0_vmap", choices=list(synth.CONFIGS))
     ap.add_argument("--iters-per-frame", type=int, default=20)       # config: render.iters_per_frame
+    ap.add_argument("--weights", default="f32", choices=["f32", "bf16"])   # bf16: BASELINE configs[3]/[4] (fp32 masters + accumulate)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-reps", type=int, default=200)
     args = ap.parse_args()
@@ -99,7 +100,7 @@ def main():
     tfc = [torch.from_numpy(a).to(dev) for a in fc]
     tB, tsc = torch.from_numpy(B).to(dev), torch.from_numpy(sc).to(dev)
     fr = {k: torch.from_numpy(v).to(dev) for k, v in frame.items()}
-    op = step.VmapStep(n, R, S, H, device=dev, max_steps=ipf)
+    op = step.VmapStep(n, R, S, H, device=dev, max_steps=ipf, weights=args.weights)
     opt = step.FusedAdamWState(n, H, dev, lr=1e-3, weight_decay=0.013)
     fargs = (fr["pcs"], fr["z"], fr["gt_depth"], fr["gt_rgb"], fr["sem"], fr["depth_mask"])
 
@@ -165,7 +166,8 @@ def main():
         out = {
             "metric": "training rays/sec (all objects) per step", "value": value, "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.weights == "f32" else "f32 compute on bf16-rounded weights", "data": "synthetic",
             "config": {"workload": f"{args.config}: {n} objects/GPU x 4-layer/{H}-hidden MLP, {R} rays/object, "
                                    f"{S} samples/ray, fwd+loss+bwd+fused AdamW, {ipf} steps per frame call",
                        "objects_per_gpu": n, "rays_per_object": R, "samples_per_ray": S, "hidden": H,

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VMAPSTEP_ABI_VERSION 1
+#define VMAPSTEP_ABI_VERSION 2
 #define VMAPSTEP_NUM_FC 14 /* field-MLP tensors per object, nn.Module.parameters() order (model.py:28-49) */
 
 #define VMAPSTEP_OK 0
@@ -50,7 +50,15 @@ typedef struct vmapstep_shape {
     int32_t rays;    /* rays per object per step, R                  (cfg.n_per_optim)      */
     int32_t samples; /* samples per ray, S = n_bins_cam2surface+n_bins                      */
     int32_t hidden;  /* hidden width H                               (hidden_feature_size)  */
+    int32_t weight_dtype; /* VMAPSTEP_WEIGHTS_F32 or VMAPSTEP_WEIGHTS_BF16 (see below)              */
 } vmapstep_shape;
+
+/* weight_dtype: the reference is fp32 only (AMP = False, train.py:64).  BF16 = BASELINE configs[3]/[4] "bf16 weights +
+ * fp32 accumulate": master parameters and optimiser state stay fp32, the values the kernels compute from (the packed
+ * parameter image) are the masters rounded to bfloat16 (round-to-nearest-even); products and sums are fp32.  Parity is
+ * defined against the fp32 oracle evaluated on the rounded weights. */
+#define VMAPSTEP_WEIGHTS_F32 0
+#define VMAPSTEP_WEIGHTS_BF16 1
 
 /* One stacked tensor: object k starts at ptr + k * obj_stride (elements); each object's block is dense. */
 typedef struct vmapstep_tensor {

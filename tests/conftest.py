@@ -31,3 +31,11 @@ def load_golden(name):
 
 GRAD_KEYS = [f"g_fc{t}" for t in range(14)] + ["g_B"]
 RENDER_KEYS = ["render_depth", "render_color", "opacity"]
+
+
+def round_bf16(a):
+    """float32 array -> nearest bfloat16 (ties to even), returned as float32 (the rounding vmapstep applies to the
+    parameter image when weight_dtype = bf16)."""
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32).reshape(np.shape(a))

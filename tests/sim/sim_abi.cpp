@@ -16,7 +16,7 @@ void fc_sizes(int H, int* sz) {
 extern "C" int vmsim_lds_bytes() { return vk::Lds32::BYTES; }
 
 // fc[t]: [n][size_t] contiguous; grads: flat slab [n][P] in natural order (14 field tensors then B).
-extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req, int xcd_affine,
+extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req, int xcd_affine, int weights_bf16,
                           const float* const* fc, const float* B, const float* scale,
                           const float* pcs, const float* z, const float* gt_depth, const float* gt_rgb,
                           const uint8_t* sem, const uint8_t* dmask, float color_w, float opac_w,
@@ -41,7 +41,7 @@ extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req, int xcd
     std::vector<float> wimg((size_t)n * GL.imgp, NAN);
 
     vk::StepArgs a{};
-    a.n_obj = n; a.R = R; a.S = S; a.G = G; a.NG = NG; a.NW = NW; a.PP = PP; a.prep_steps = 1; a.prep_ray_step = 0; a.xcd_affine = (xcd_affine && H == 32) ? 1 : 0; a.hidden = H;
+    a.n_obj = n; a.R = R; a.S = S; a.G = G; a.NG = NG; a.NW = NW; a.PP = PP; a.prep_steps = 1; a.prep_ray_step = 0; a.xcd_affine = (xcd_affine && H == 32) ? 1 : 0; a.hidden = H; a.weights_bf16 = weights_bf16;
     for (int t = 0; t < 14; ++t) a.fc[t] = {const_cast<float*>(fc[t]), sz[t]};
     a.pe_B = {const_cast<float*>(B), 63};
     a.pe_scale = {const_cast<float*>(scale), 1};
@@ -74,7 +74,7 @@ extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req, int xcd
     }
 
     vk::FinalizeArgs f{};
-    f.n_obj = n; f.NW = NW; f.PP = PP; f.P = P; f.hidden = H;
+    f.n_obj = n; f.NW = NW; f.PP = PP; f.P = P; f.hidden = H; f.weights_bf16 = weights_bf16;
     for (int t = 0; t < 16; ++t) f.offs[t] = offs[t];
     for (int t = 0; t < 15; ++t) {
         f.grad[t] = {grads ? grads + offs[t] : nullptr, P};

@@ -46,7 +46,7 @@ def _p(a, ty=ctypes.c_float):
     return a.ctypes.data_as(ctypes.POINTER(ty)) if a is not None else None
 
 
-def sim_step(case_or_fc, B=None, scale=None, batch=None, G=None, bwd=True, adam=None, NW=0, xcd_affine=1):
+def sim_step(case_or_fc, B=None, scale=None, batch=None, G=None, bwd=True, adam=None, NW=0, xcd_affine=1, weights_bf16=0):
     """Run prep + main + finalize on the simulator. Returns dict like oracle.training_step."""
     if isinstance(case_or_fc, dict):
         c = case_or_fc
@@ -82,7 +82,7 @@ def sim_step(case_or_fc, B=None, scale=None, batch=None, G=None, bwd=True, adam=
         do_adam = 1
         p_out, m, v, step = adam["p"], adam["m"], adam["v"], adam["step"]
     rc = lib().vmsim_step(
-        n, R, S, H, G, int(NW), int(xcd_affine), arr, _p(Bc), _p(sc), _p(pcs), _p(z), _p(gd), _p(rgb),
+        n, R, S, H, G, int(NW), int(xcd_affine), int(weights_bf16), arr, _p(Bc), _p(sc), _p(pcs), _p(z), _p(gd), _p(rgb),
         _p(sem, ctypes.c_uint8), _p(dm, ctypes.c_uint8), ctypes.c_float(5.0), ctypes.c_float(10.0),
         _p(grads), _p(loss), _p(dD), _p(dC), _p(dO), _p(dV), _p(flags, ctypes.c_int), int(bool(bwd)),
         do_adam, _p(p_out), _p(m), _p(v), int(step), ctypes.c_float(lr), ctypes.c_float(wd))

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in _declared_functions():
         assert hasattr(lib, name), name
-    assert lib.vmapstep_abi_version() == 1
+    assert lib.vmapstep_abi_version() == 2
 
 
 @pytest.mark.parametrize("H", [32, 64, 128, 256])
@@ -41,13 +41,13 @@ def test_param_layout_matches_reference_shapes(H):
 def test_workspace_and_error_reporting():
     lib = _lib.load()
     nbytes = ctypes.c_size_t()
-    sh = _lib.Shape(20, 120, 10, 32)
+    sh = _lib.Shape(20, 120, 10, 32, 0)
     assert lib.vmapstep_workspace_bytes(ctypes.byref(sh), 20, ctypes.byref(nbytes)) == 0
     assert nbytes.value > 20 * 10 * layout.param_count(32) * 4
-    bad = _lib.Shape(20, 120, 10, 48)
+    bad = _lib.Shape(20, 120, 10, 48, 0)
     assert lib.vmapstep_workspace_bytes(ctypes.byref(bad), 1, ctypes.byref(nbytes)) == -2
     assert b"hidden=48" in lib.vmapstep_last_error()
-    assert lib.vmapstep_workspace_bytes(ctypes.byref(_lib.Shape(0, 1, 1, 32)), 1, ctypes.byref(nbytes)) == -1
+    assert lib.vmapstep_workspace_bytes(ctypes.byref(_lib.Shape(0, 1, 1, 32, 0)), 1, ctypes.byref(nbytes)) == -1
     # null arguments are rejected before anything touches the device
     assert lib.vmapstep_fwd_bwd(ctypes.byref(sh), None, None, None, 5.0, 10.0, None, None, None, 0, None) == -1
     with pytest.raises(_lib.VmapStepError):

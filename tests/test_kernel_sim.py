@@ -126,3 +126,23 @@ def test_sim_generic_width_kernel_imap_h256():
     assert abs(s["loss"] - float(g["loss"])) <= 2e-5 * abs(float(g["loss"]))
     for k in RENDER_KEYS + GRAD_KEYS:
         assert relerr(s[k], g[k]) < 1e-4, k
+
+
+def test_sim_bf16_weights_equal_oracle_on_rounded_weights():
+    """weight_dtype = bf16 (BASELINE configs[3]/[4]): the kernels compute from the bfloat16-rounded parameter image with
+    fp32 products/sums == the fp32 oracle evaluated on the rounded weights (last bullet)."""
+    from conftest import round_bf16
+    c = cases.build_case("tiny")
+    fc_r = [round_bf16(a) for a in c["fc"]]
+    B_r = round_bf16(c["B"])
+    assert any(not np.array_equal(a, b) for a, b in zip(fc_r, c["fc"]))
+    s = simlib.sim_step(c, weights_bf16=1)
+    from oracle import vmap_oracle_torch as vt
+    loss_t, rend_t, grads_t = vt.CpuTrainer(fc_r, B_r, c["scale"]).step(c["batch"], update=False)
+    assert abs(s["loss"] - float(loss_t)) <= 2e-5 * abs(float(loss_t))
+    for k in RENDER_KEYS:
+        assert relerr(s[k], rend_t[k].detach().numpy()) < 2e-5, k
+    for k, g in zip(GRAD_KEYS, grads_t):
+        assert relerr(s[k], g.numpy()) < 1e-4, k
+    # and it is NOT the fp32-weight result
+    assert relerr(s["render_depth"], load_golden("tiny")["render_depth"]) > 1e-4

@@ -12,12 +12,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvmapstep.so")
 
 NUM_FC = 14
-ABI_VERSION = 1
+ABI_VERSION = 2
+WEIGHTS_F32, WEIGHTS_BF16 = 0, 1
 
 
 class Shape(ctypes.Structure):
     _fields_ = [("n_obj", ctypes.c_int32), ("rays", ctypes.c_int32), ("samples", ctypes.c_int32),
-                ("hidden", ctypes.c_int32)]
+                ("hidden", ctypes.c_int32), ("weight_dtype", ctypes.c_int32)]
 
 
 class Tensor(ctypes.Structure):

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_gen(const GenArgs ga) {
     float* cb = lds + LdsGen::CB;
     const float* cbw = cb + wave * 32 * 8;
     const float scale = a.pe_scale.p[obj * a.pe_scale.stride];
-    const float* Bg = a.pe_B.p + obj * a.pe_B.stride;
+    const float* Bg = Wg + L.pe_b;
     int stage_toggle = 0;                                               // alternates the two staging buffers
 
     for (int grp = wgo; grp < a.NG; grp += a.NW) {

@@ -70,6 +70,7 @@ struct StepArgs {
     float* dbg_depth; float* dbg_rgb; float* dbg_opacity; float* dbg_var;   // [n][R](,3) or null
     unsigned* timing;                  // optional [workgroups][kWaves][kMarks] shader-clock stamps (diagnostics)
     int hidden;                        // H (step_prep packs with gen_layout(hidden); step_main_h32 requires 32)
+    int weights_bf16;                  // 1: the parameter image holds the masters rounded to bfloat16 (RNE)
 };
 
 __device__ __forceinline__ constexpr int phi(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
@@ -213,6 +214,13 @@ __device__ __forceinline__ int gen_image_index(const GenLayout& L, int t, int o)
         case 13: return L.b_oc + o;
         default: return L.pe_b + o;
     }
+}
+
+// float32 -> nearest bfloat16 (ties to even), returned as float32
+__device__ __forceinline__ float round_bf16(float x) {
+    unsigned u = __float_as_uint(x);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return __uint_as_float(u & 0xFFFF0000u);
 }
 
 __device__ __forceinline__ void load_bias(f32x16& acc, const float* b, int hi) {
@@ -631,7 +639,7 @@ __global__ __launch_bounds__(kWG) void step_prep(const StepArgs a) {
             for (int q = 1; q < 15; ++q) t += i >= L.f[q];
             const int o = i - L.f[t];
             const float v = t < kNFc ? a.fc[t].p[k * a.fc[t].stride + o] : a.pe_B.p[k * a.pe_B.stride + o];
-            img[gen_image_index(L, t, o)] = v;
+            img[gen_image_index(L, t, o)] = a.weights_bf16 ? round_bf16(v) : v;
         }
         return;
     }
@@ -729,7 +737,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
     float* cb = lds + L::CB;
     const float* cbw = cb + wave * 32 * 8;       // this wave's 32 rows of the composite buffer
     const float scale = a.pe_scale.p[obj * a.pe_scale.stride];
-    const float* Bg = a.pe_B.p + obj * a.pe_B.stride;
+    const float* Bg = a.wimg + (long long)obj * L::IMGP + L::PE_B;   // B_layer.weight, read from the (global) image
 
     for (int grp = wgo; grp < a.NG; grp += a.NW) {   // ---- one pass = up to kMaxPts points (whole rays) ----
     __syncthreads();                                 // previous pass finished reading the composite buffer
@@ -753,7 +761,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
     }
     float proj[kDirs];
 #pragma unroll
-    for (int d = 0; d < kDirs; ++d)        // embedding.py:84 B_layer(tensor); B straight from global (wave-uniform)
+    for (int d = 0; d < kDirs; ++d)        // embedding.py:84 B_layer(tensor); B straight from the global image (wave-uniform)
         proj[d] = fmaf(t[2], Bg[3 * d + 2], fmaf(t[1], Bg[3 * d + 1], t[0] * Bg[3 * d]));
 
     // ---- first pass: start the asynchronous copy of the parameter image into LDS (lands during the encoding) ----
@@ -1113,6 +1121,7 @@ struct FinalizeArgs {
     float* m; float* v;                // Adam moments, [n][PP] slabs (when do_adam)
     float* wimg;                       // [n][imgp] packed parameter image (updated when do_adam)
     int hidden;                        // H: image layout = gen_layout(hidden)
+    int weights_bf16;                  // 1: image values are rounded to bfloat16
     const float* part_grad; const float* part_loss;
     const int* flags_in; int* flags_out;
     float* loss_out;                   // [1]
@@ -1161,7 +1170,7 @@ __global__ __launch_bounds__(kWG) void step_finalize(const FinalizeArgs a) {
                     const float denom = sqrtf(v) / a.bias_corr2_sqrt + a.eps;
                     p = p - a.step_size * (m / denom);                        // param.addcdiv_(exp_avg, denom, -lr / bc1)
                     *pp = p; m4[e] = m; v4[e] = v;
-                    a.wimg[(long long)obj * GL.imgp + gen_image_index(GL, t, o)] = p;
+                    a.wimg[(long long)obj * GL.imgp + gen_image_index(GL, t, o)] = a.weights_bf16 ? round_bf16(p) : p;
                 }
             }
         }

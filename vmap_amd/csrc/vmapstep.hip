@@ -55,6 +55,8 @@ int make_plan(const vmapstep_shape* sh, int max_steps, Plan& pl, const Layout& L
         return fail(VMAPSTEP_ERR_ARGUMENT, "bad shape n=%d R=%d S=%d steps=%d", sh->n_obj, sh->rays, sh->samples, max_steps);
     if (sh->hidden < 32 || sh->hidden > 256 || sh->hidden % 32 != 0)
         return fail(VMAPSTEP_ERR_UNSUPPORTED, "hidden=%d: supported widths are multiples of 32 up to 256", sh->hidden);
+    if (sh->weight_dtype != VMAPSTEP_WEIGHTS_F32 && sh->weight_dtype != VMAPSTEP_WEIGHTS_BF16)
+        return fail(VMAPSTEP_ERR_UNSUPPORTED, "weight_dtype=%d", sh->weight_dtype);
     pl.generic = sh->hidden != 32;
     if (sh->samples > vk::kMaxPts)
         return fail(VMAPSTEP_ERR_UNSUPPORTED, "samples=%d > %d", sh->samples, vk::kMaxPts);
@@ -119,6 +121,7 @@ void fill_step_args(vk::StepArgs& a, const vmapstep_shape* sh, const Plan& pl, c
     a.dm_so = b->depth_mask_stride[0]; a.dm_sr = b->depth_mask_stride[1];
     a.color_w = cw; a.opac_w = ow;
     a.hidden = sh->hidden;
+    a.weights_bf16 = sh->weight_dtype == VMAPSTEP_WEIGHTS_BF16 ? 1 : 0;
     a.stats = reinterpret_cast<float*>(ws + pl.off_stats);
     a.flags = reinterpret_cast<int*>(ws + pl.off_flags);
     a.part_loss = reinterpret_cast<float*>(ws + pl.off_ploss);
@@ -183,7 +186,7 @@ int launch_finalize(const vk::StepArgs& a, const Layout& L, const vmapstep_param
                     hipStream_t st) {
     vk::FinalizeArgs f;
     std::memset(&f, 0, sizeof(f));
-    f.n_obj = a.n_obj; f.NW = a.NW; f.PP = L.PP; f.P = L.P; f.hidden = a.hidden;
+    f.n_obj = a.n_obj; f.NW = a.NW; f.PP = L.PP; f.P = L.P; f.hidden = a.hidden; f.weights_bf16 = a.weights_bf16;
     for (int t = 0; t < 16; ++t) f.offs[t] = L.offs[t];
     for (int t = 0; t < 15; ++t) {
         const vmapstep_tensor* pt = t < 14 ? &params->fc[t] : &params->pe_B;

@@ -51,12 +51,14 @@ class VmapStep:
     """The fused step operator for a fixed (n_obj, rays, samples, hidden) problem shape."""
 
     def __init__(self, n_obj: int, rays: int, samples: int, hidden: int, device="cuda:0", max_steps: int = 32,
-                 color_scaling: float = 5.0, opacity_scaling: float = 10.0):
+                 color_scaling: float = 5.0, opacity_scaling: float = 10.0, weights: str = "f32"):
         self.lib = _lib.load()
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.VmapStepError("VmapStep runs on the GPU only (no CPU fallback)")
-        self.shape = _lib.Shape(n_obj, rays, samples, hidden)
+        if weights not in ("f32", "bf16"):
+            raise ValueError("weights must be 'f32' or 'bf16'")
+        self.shape = _lib.Shape(n_obj, rays, samples, hidden, _lib.WEIGHTS_BF16 if weights == "bf16" else _lib.WEIGHTS_F32)
         self.n_obj, self.rays, self.samples, self.hidden = n_obj, rays, samples, hidden
         self.max_steps = max_steps
         self.color_scaling, self.opacity_scaling = float(color_scaling), float(opacity_scaling)
