@@ -158,6 +158,45 @@ int vmapstep_train_steps_prepared(const vmapstep_shape* shape, const vmapstep_pa
                                   const vmapstep_adamw* opt, const vmapstep_params* grads,
                                   const vmapstep_outputs* out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- batched depth-guided sampler --------------------------------------------------------
+ * Replaces the per-object loop train.py:208-218 -> vmap.py:319-459 (get_training_samples / sample_3d_points) and the
+ * torch.stack of train.py:255-260: ONE launch writes the six per-frame tensors of ALL objects, contiguous
+ * [n, F*P, ...], ready for vmapstep_train_steps.  Random numbers come from a counter-based Philox4x32-10 keyed by
+ * (seed, frame_counter, object, ray): parity with the reference's torch generator is statistical; with
+ * `test_randoms` the per-ray numbers are supplied by the caller and the result is deterministic (used by the tests
+ * against the reference's own sampler). */
+typedef struct vmapstep_sample_object {      /* one entry per object, array lives in DEVICE memory */
+    const uint8_t* rgbs;       /* [K][W][H][4] RGB + pixel state (vmap.py:143-156)  */
+    const float* depth;        /* [K][W][H]                                          */
+    const float* t_wc;         /* [K][4][4]                                          */
+    const float* bbox;         /* [K][4] u lo, u hi, v lo, v hi                      */
+    int32_t n_keyframes;
+    int32_t last2[2];          /* the two latest keyframe slots (vmap.py:329-331)    */
+    float center[3];           /* obj_center                                         */
+    int32_t pad;
+} vmapstep_sample_object;
+
+typedef struct vmapstep_sample_cfg {
+    int32_t width, height;             /* W, H of the keyframe images                                  */
+    int32_t frames, samples_per_frame; /* F = n_iter_per_frame * win_size, P = n_samples_per_frame     */
+    int32_t n_bins_cam2surface, n_bins;
+    float fx, fy, cx, cy;
+    float min_depth, surface_eps, stop_eps;
+} vmapstep_sample_cfg;
+
+typedef struct vmapstep_sample_randoms {     /* test mode, device pointers, any may be NULL */
+    const int32_t* kf_ids;     /* [n][F]            */
+    const float* u_w;          /* [n][F*P]          */
+    const float* u_h;          /* [n][F*P]          */
+    const float* u_z;          /* [n][F*P][S]       */
+    const float* g_z;          /* [n][F*P][n_bins]  */
+} vmapstep_sample_randoms;
+
+int vmapstep_sample_frame(const vmapstep_sample_cfg* cfg, const vmapstep_sample_object* objects_device, int32_t n_obj,
+                          float* pcs, float* z, float* gt_depth, float* gt_rgb, uint8_t* sem, uint8_t* depth_mask,
+                          uint64_t seed, uint32_t frame_counter, const vmapstep_sample_randoms* test_randoms,
+                          void* stream);
+
 /* Measurement hook: step_prep once, then the dominant kernel (step_main, forward+backward) `reps` times back to
  * back on `stream` with nothing in between, so that events recorded around the call give its average launch
  * duration (bench.py's roofline figure).  Writes only to the workspace. */

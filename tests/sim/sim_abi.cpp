@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "gen_kernels.h"
+#include "sample_kernels.h"
 
 namespace {
 void fc_sizes(int H, int* sz) {
@@ -95,3 +96,20 @@ extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req, int xcd
     sim::launch(n * bpo, vk::kWG, 2 * vk::kWG * 4, [&] { vk::step_finalize(f); });
     return 0;
 }
+
+// sampler: host pointers everywhere (objs is a host array of vs::SampleObject with host pointers inside)
+extern "C" int vmsim_sample(const vs::SampleObject* objs, int n_obj, int W, int H, int F, int P, int n1, int n2,
+                            float fx, float fy, float cx, float cy, float min_bound, float eps, float stop_eps,
+                            unsigned long long seed, unsigned frame_counter,
+                            const int* kf_ids, const float* u_w, const float* u_h, const float* u_z, const float* g_z,
+                            float* pcs, float* z, float* gt_depth, float* gt_rgb, unsigned char* sem, unsigned char* dmask) {
+    vs::SampleArgs a{};
+    a.objs = objs; a.n_obj = n_obj; a.W = W; a.H = H; a.F = F; a.P = P; a.n1 = n1; a.n2 = n2;
+    a.fx = fx; a.fy = fy; a.cx = cx; a.cy = cy; a.min_bound = min_bound; a.eps = eps; a.stop_eps = stop_eps;
+    a.seed_lo = (unsigned)seed; a.seed_hi = (unsigned)(seed >> 32); a.frame_counter = frame_counter;
+    a.rnd.kf_ids = kf_ids; a.rnd.u_w = u_w; a.rnd.u_h = u_h; a.rnd.u_z = u_z; a.rnd.g_z = g_z;
+    a.pcs = pcs; a.z = z; a.gt_depth = gt_depth; a.gt_rgb = gt_rgb; a.sem = sem; a.depth_mask = dmask;
+    sim::launch(n_obj, vs::kWG, (3 * (size_t)F * P + vs::kWG) * 4, [&] { vs::frame_sample(a); });
+    return 0;
+}
+extern "C" int vmsim_sample_object_size() { return (int)sizeof(vs::SampleObject); }

@@ -19,7 +19,8 @@ def build(force=False):
     deps = srcs + [os.path.join(SIM, "sim_runtime.h"), os.path.join(SIM, "wave_ops.h"),
                    os.path.join(SIM, "include", "hip", "hip_runtime.h"),
                    os.path.join(ROOT, "vmap_amd", "csrc", "step_kernels.h"),
-                   os.path.join(ROOT, "vmap_amd", "csrc", "gen_kernels.h")]
+                   os.path.join(ROOT, "vmap_amd", "csrc", "gen_kernels.h"),
+                   os.path.join(ROOT, "vmap_amd", "csrc", "sample_kernels.h")]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
@@ -94,4 +95,45 @@ def sim_step(case_or_fc, B=None, scale=None, batch=None, G=None, bwd=True, adam=
         out[f"g_fc{t}"] = grads[:, o:o + sizes[t]].reshape(a.shape)
         o += sizes[t]
     out["g_B"] = grads[:, o:o + 63].reshape(n, 21, 3)
+    return out
+
+
+class _SimSampleObject(ctypes.Structure):
+    _fields_ = [("rgbs", ctypes.c_void_p), ("depth", ctypes.c_void_p), ("t_wc", ctypes.c_void_p), ("bbox", ctypes.c_void_p),
+                ("n_keyframes", ctypes.c_int32), ("last2", ctypes.c_int32 * 2), ("center", ctypes.c_float * 3),
+                ("pad", ctypes.c_int32)]
+
+
+def sim_sample(scenes, rnds, seed=0, frame_counter=0, eps=0.1, stop_eps=0.05):
+    """Run frame_sample on the simulator for a list of scenes (same W,H,F,P,n1,n2); rnds = list of per-ray random dicts
+    (test mode) or None (Philox mode).  Returns dict of arrays with a leading object dimension."""
+    L = lib()
+    assert L.vmsim_sample_object_size() == ctypes.sizeof(_SimSampleObject)
+    n = len(scenes)
+    s0 = scenes[0]
+    W, H, F, P, n1, n2 = (s0[k] for k in ("W", "H", "F", "P", "n1", "n2"))
+    S, FP = n1 + n2, F * P
+    keep = []
+    table = (_SimSampleObject * n)()
+    for i, sc in enumerate(scenes):
+        arrs = [np.ascontiguousarray(sc[k]) for k in ("rgbs", "depth", "t_wc", "bbox")]
+        keep.append(arrs)
+        table[i] = _SimSampleObject(arrs[0].ctypes.data, arrs[1].ctypes.data, arrs[2].ctypes.data, arrs[3].ctypes.data,
+                                    sc["K"], (ctypes.c_int32 * 2)(*sc["last2"]), (ctypes.c_float * 3)(*[float(v) for v in sc["center"]]), 0)
+    def cat(key, dt):
+        if rnds is None:
+            return None
+        return np.ascontiguousarray(np.stack([r[key] for r in rnds]).astype(dt))
+    kf, uw, uh, uz, gz = cat("kf_ids", np.int32), cat("u_w", np.float32), cat("u_h", np.float32), cat("u_z", np.float32), cat("g_z", np.float32)
+    out = dict(pcs=np.full((n, FP, S, 3), np.nan, np.float32), z=np.full((n, FP, S), np.nan, np.float32),
+               gt_depth=np.full((n, FP), np.nan, np.float32), gt_rgb=np.full((n, FP, 3), np.nan, np.float32),
+               sem=np.full((n, FP), 255, np.uint8), depth_mask=np.full((n, FP), 255, np.uint8))
+    fx, fy, cx, cy = s0["intr"]
+    rc = L.vmsim_sample(table, n, W, H, F, P, n1, n2, ctypes.c_float(fx), ctypes.c_float(fy), ctypes.c_float(cx), ctypes.c_float(cy),
+                        ctypes.c_float(s0["min_bound"]), ctypes.c_float(eps), ctypes.c_float(stop_eps),
+                        ctypes.c_ulonglong(seed), ctypes.c_uint(frame_counter),
+                        _p(kf, ctypes.c_int32), _p(uw), _p(uh), _p(uz), _p(gz),
+                        _p(out["pcs"]), _p(out["z"]), _p(out["gt_depth"]), _p(out["gt_rgb"]),
+                        _p(out["sem"], ctypes.c_uint8), _p(out["depth_mask"], ctypes.c_uint8))
+    assert rc == 0
     return out

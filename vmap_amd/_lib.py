@@ -51,11 +51,29 @@ class AdamW(ctypes.Structure):
                 ("exp_avg", ctypes.c_void_p), ("exp_avg_sq", ctypes.c_void_p)]
 
 
+class SampleObject(ctypes.Structure):
+    _fields_ = [("rgbs", ctypes.c_void_p), ("depth", ctypes.c_void_p), ("t_wc", ctypes.c_void_p), ("bbox", ctypes.c_void_p),
+                ("n_keyframes", ctypes.c_int32), ("last2", ctypes.c_int32 * 2), ("center", ctypes.c_float * 3),
+                ("pad", ctypes.c_int32)]
+
+
+class SampleCfg(ctypes.Structure):
+    _fields_ = [("width", ctypes.c_int32), ("height", ctypes.c_int32), ("frames", ctypes.c_int32),
+                ("samples_per_frame", ctypes.c_int32), ("n_bins_cam2surface", ctypes.c_int32), ("n_bins", ctypes.c_int32),
+                ("fx", ctypes.c_float), ("fy", ctypes.c_float), ("cx", ctypes.c_float), ("cy", ctypes.c_float),
+                ("min_depth", ctypes.c_float), ("surface_eps", ctypes.c_float), ("stop_eps", ctypes.c_float)]
+
+
+class SampleRandoms(ctypes.Structure):
+    _fields_ = [("kf_ids", ctypes.c_void_p), ("u_w", ctypes.c_void_p), ("u_h", ctypes.c_void_p), ("u_z", ctypes.c_void_p),
+                ("g_z", ctypes.c_void_p)]
+
+
 EXPORTS = (
     "vmapstep_last_error", "vmapstep_abi_version", "vmapstep_param_layout", "vmapstep_workspace_bytes",
     "vmapstep_fwd_bwd", "vmapstep_render", "vmapstep_train_steps", "vmapstep_set_workgroups_per_object",
     "vmapstep_profile_main_kernel", "vmapstep_profile_phases", "vmapstep_prepare", "vmapstep_train_steps_prepared",
-    "vmapstep_workspace_counts_offset", "vmapstep_fwd_bwd_prepared",
+    "vmapstep_workspace_counts_offset", "vmapstep_fwd_bwd_prepared", "vmapstep_sample_frame",
 )
 
 _lib = None
@@ -97,6 +115,9 @@ def load():
     lib.vmapstep_train_steps_prepared.argtypes = lib.vmapstep_train_steps.argtypes
     lib.vmapstep_fwd_bwd_prepared.argtypes = lib.vmapstep_fwd_bwd.argtypes
     lib.vmapstep_workspace_counts_offset.argtypes = [ctypes.POINTER(Shape), ctypes.c_int32, ctypes.POINTER(ctypes.c_size_t)]
+    lib.vmapstep_sample_frame.argtypes = [ctypes.POINTER(SampleCfg), ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
+                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                          ctypes.c_uint64, ctypes.c_uint32, ctypes.POINTER(SampleRandoms), ctypes.c_void_p]
     lib.vmapstep_profile_main_kernel.argtypes = [ctypes.POINTER(Shape), ctypes.POINTER(Params), ctypes.POINTER(Tensor),
                                                  ctypes.POINTER(Batch), ctypes.c_int32, ctypes.c_void_p,
                                                  ctypes.c_size_t, ctypes.c_void_p]
@@ -108,7 +129,7 @@ def load():
     for fn in ("vmapstep_param_layout", "vmapstep_workspace_bytes", "vmapstep_fwd_bwd", "vmapstep_render",
                "vmapstep_train_steps", "vmapstep_set_workgroups_per_object", "vmapstep_profile_main_kernel",
                "vmapstep_profile_phases", "vmapstep_prepare", "vmapstep_train_steps_prepared",
-               "vmapstep_workspace_counts_offset", "vmapstep_fwd_bwd_prepared"):
+               "vmapstep_workspace_counts_offset", "vmapstep_fwd_bwd_prepared", "vmapstep_sample_frame"):
         getattr(lib, fn).restype = ctypes.c_int
     if lib.vmapstep_abi_version() != ABI_VERSION:
         raise VmapStepError(f"ABI mismatch: library {lib.vmapstep_abi_version()} != binding {ABI_VERSION}")

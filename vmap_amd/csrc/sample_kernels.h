@@ -1,0 +1,225 @@
+// sample_kernels.h - batched depth-guided ray / sample-point sampler for ALL objects of a frame (gfx950).
+//
+// Replaces the per-object Python loop of the reference (train.py:208-218 calling vmap.py:319-364
+// sceneObject.get_training_samples -> vmap.py:366-459 sample_3d_points, ~30 small ATen launches per object and
+// frame, followed by torch.stack at train.py:255-260) with ONE launch that writes the six per-frame tensors directly
+// in the layout vmapstep_train_steps consumes ([n, F*P, ...]).  One workgroup per object:
+//   A  per ray: keyframe slot of its frame, pixel inside that keyframe's 2-D box, gather RGB+state / depth,
+//      pixel ray ((w-cx)/fx, (h-cy)/fy, 1) rotated by the keyframe pose                      (vmap.py:343-362, :31-41)
+//   B  max sampled depth of the object (upper bound of the bins of invalid-depth rays)        (vmap.py:391)
+//   C  per ray: n1 stratified bins camera->surface, then n2 sorted clipped-normal samples around the surface (this
+//      object) or n2 stratified bins in [d-eps, d+stop_eps] (other/unknown), or n1+n2 stratified bins over
+//      [min_bound, max depth] for invalid depth; points = origin + dir*z - centre              (vmap.py:395-457)
+// HBM-bound byte work (random gathers + ~210 B written per ray): no matrix instructions.
+//
+// Random numbers: Philox4x32-10, counter = (ray or frame, object, frame counter, stream), key = seed - every value
+// is a pure function of its coordinates (reproducible, order-independent).  The reference uses torch's global
+// generator, so parity of the random part is statistical; the deterministic part is tested bit-for-bit through the
+// test mode in which the per-ray numbers are supplied by the caller (SampleRandoms).
+#pragma once
+#include <wave_ops.h>
+
+namespace vs {
+
+constexpr int kWG = 256;
+constexpr int kMaxS = 32;
+
+struct SampleObject {                 // device-resident table, one entry per object
+    const unsigned char* rgbs;        // [K][W][H][4]  RGB + pixel state (0 other, 1 this, 2 unknown), vmap.py:143-156
+    const float* depth;               // [K][W][H]
+    const float* t_wc;                // [K][4][4]     camera-to-world pose of every keyframe
+    const float* bbox;                // [K][4]        u lo, u hi, v lo, v hi
+    int n_keyframes;
+    int last2[2];                     // the two latest keyframe slots (vmap.py:329-331)
+    float center[3];                  // obj_center
+    int pad;
+};
+
+struct SampleRandoms {                // test mode: per-ray numbers supplied by the caller (all may be null)
+    const int* kf_ids;                // [n][F]
+    const float* u_w; const float* u_h;   // [n][F*P]
+    const float* u_z;                 // [n][F*P][S]
+    const float* g_z;                 // [n][F*P][n2]
+};
+
+struct SampleArgs {
+    const SampleObject* objs;
+    int n_obj, W, H, F, P, n1, n2;
+    float fx, fy, cx, cy, min_bound, eps, stop_eps;
+    unsigned seed_lo, seed_hi, frame_counter;
+    SampleRandoms rnd;
+    float* pcs; float* z; float* gt_depth; float* gt_rgb; unsigned char* sem; unsigned char* depth_mask;   // [n][F*P]...
+};
+
+struct U4 { unsigned x, y, z, w; };
+
+__device__ __forceinline__ U4 philox4x32_10(U4 c, unsigned k0, unsigned k1) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const unsigned long long p0 = 0xD2511F53ull * c.x, p1 = 0xCD9E8D57ull * c.z;
+        const U4 n = {(unsigned)(p1 >> 32) ^ c.y ^ k0, (unsigned)p1, (unsigned)(p0 >> 32) ^ c.w ^ k1, (unsigned)p0};
+        c = n;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c;
+}
+// uniform in [0, 1) with 24 random bits (the granularity of torch.rand for float32)
+__device__ __forceinline__ float u01(unsigned r) { return (float)(r >> 8) * (1.0f / 16777216.0f); }
+
+// torch.linspace(0, 1, nb + 1)[i] for float32: step evaluated from the nearer end
+__device__ __forceinline__ float lin01(int i, int nb) {
+    const float step = 1.0f / (float)nb;
+    return i < (nb + 1) / 2 ? step * (float)i : 1.0f - step * (float)(nb - i);
+}
+
+__global__ __launch_bounds__(kWG) void frame_sample(const SampleArgs a) {
+    float* lds = wv::lds_base();
+    const int tid = threadIdx.x, k = blockIdx.x;
+    const SampleObject ob = a.objs[k];
+    const int FP = a.F * a.P, S = a.n1 + a.n2;
+    float* s_dep = lds;                                      // [FP]
+    unsigned* s_pix = reinterpret_cast<unsigned*>(lds + FP); // [FP]  iw | ih << 12 | kf << 24
+    unsigned* s_rgba = s_pix + FP;                           // [FP]
+    float* s_red = reinterpret_cast<float*>(s_rgba + FP);    // [kWG]
+
+    // ---- A: pixel choice + gathers ----
+    float dmax = -3.0e38f;
+    for (int ray = tid; ray < FP; ray += kWG) {
+        const int f = ray / a.P;
+        int kf;
+        float uw, uh;
+        if (a.rnd.kf_ids) {
+            kf = a.rnd.kf_ids[k * a.F + f];
+        } else if (ob.n_keyframes > 2 && f >= a.F - 2) {
+            kf = ob.last2[f - (a.F - 2)];                                           // vmap.py:329-331
+        } else {
+            const U4 r = philox4x32_10({(unsigned)f, (unsigned)k, a.frame_counter, 0u}, a.seed_lo, a.seed_hi);
+            kf = (int)(u01(r.x) * (float)ob.n_keyframes);
+            kf = kf < ob.n_keyframes ? kf : ob.n_keyframes - 1;
+        }
+        if (a.rnd.u_w) {
+            uw = a.rnd.u_w[k * FP + ray];
+            uh = a.rnd.u_h[k * FP + ray];
+        } else {
+            const U4 r = philox4x32_10({(unsigned)ray, (unsigned)k, a.frame_counter, 1u}, a.seed_lo, a.seed_hi);
+            uw = u01(r.x);
+            uh = u01(r.y);
+        }
+        const float* bb = ob.bbox + 4 * kf;
+        const int iw = (int)(uw * (bb[1] - bb[0]) + bb[0]);                          // vmap.py:347,350 (.long() truncates)
+        const int ih = (int)(uh * (bb[3] - bb[2]) + bb[2]);
+        const long long pix = ((long long)kf * a.W + iw) * a.H + ih;
+        const unsigned rgba = reinterpret_cast<const unsigned*>(ob.rgbs)[pix];       // vmap.py:353
+        const float d = ob.depth[pix];                                               // vmap.py:354
+        s_dep[ray] = d;
+        s_pix[ray] = (unsigned)iw | ((unsigned)ih << 12) | ((unsigned)kf << 24);
+        s_rgba[ray] = rgba;
+        dmax = fmaxf(dmax, d);
+    }
+    // ---- B: max sampled depth of this object (vmap.py:391) ----
+    s_red[tid] = dmax;
+    __syncthreads();
+    for (int w = kWG / 2; w > 0; w >>= 1) {
+        if (tid < w) s_red[tid] = fmaxf(s_red[tid], s_red[tid + w]);
+        __syncthreads();
+    }
+    const float max_bound = s_red[0];
+
+    // ---- C: depth samples and points ----
+    for (int ray = tid; ray < FP; ray += kWG) {
+        const unsigned px = s_pix[ray], rgba = s_rgba[ray];
+        const int iw = px & 0xFFF, ih = (px >> 12) & 0xFFF, kf = px >> 24;
+        const float d = s_dep[ray];
+        const unsigned state = rgba >> 24;
+        const bool invalid = d <= a.min_bound;                                        // vmap.py:389
+        const bool is_obj = state == 1u;
+        float uz[kMaxS];
+#pragma unroll
+        for (int j0 = 0; j0 < kMaxS; j0 += 4) {
+            if (j0 < S) {
+                if (a.rnd.u_z) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) uz[j0 + j] = j0 + j < S ? a.rnd.u_z[((long long)k * FP + ray) * S + j0 + j] : 0.0f;
+                } else {
+                    const U4 r = philox4x32_10({(unsigned)ray, (unsigned)k, a.frame_counter, 2u + (unsigned)(j0 >> 2)}, a.seed_lo, a.seed_hi);
+                    uz[j0] = u01(r.x); uz[j0 + 1] = u01(r.y); uz[j0 + 2] = u01(r.z); uz[j0 + 3] = u01(r.w);
+                }
+            }
+        }
+        float zs[kMaxS];
+#pragma unroll
+        for (int j = 0; j < kMaxS; ++j) zs[j] = 0.0f;
+        if (invalid) {                                                                // vmap.py:395-399
+            const float rng = max_bound - a.min_bound, len = rng / (float)S;
+#pragma unroll
+            for (int j = 0; j < kMaxS; ++j)
+                if (j < S) zs[j] = (rng * lin01(j, S) + a.min_bound) + uz[j] * len;
+        } else {
+            {                                                                         // vmap.py:408-410
+                const float rng = (d - a.eps) - a.min_bound, len = rng / (float)a.n1;
+#pragma unroll
+                for (int j = 0; j < kMaxS; ++j)
+                    if (j < a.n1) zs[j] = (rng * lin01(j, a.n1) + a.min_bound) + uz[j] * len;
+            }
+            if (is_obj) {                                                             // vmap.py:425-430, :75-87
+                float g[16];
+#pragma unroll
+                for (int j0 = 0; j0 < 16; j0 += 4) {
+                    if (a.rnd.g_z) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) g[j0 + j] = j0 + j < a.n2 ? a.rnd.g_z[((long long)k * FP + ray) * a.n2 + j0 + j] : 3.0e38f;
+                    } else {
+                        const U4 r = philox4x32_10({(unsigned)ray, (unsigned)k, a.frame_counter, 16u + (unsigned)(j0 >> 2)}, a.seed_lo, a.seed_hi);
+                        const float r0 = sqrtf(-2.0f * logf(1.0f - u01(r.x))), r1 = sqrtf(-2.0f * logf(1.0f - u01(r.z)));
+                        const float t0 = 6.28318530718f * u01(r.y), t1 = 6.28318530718f * u01(r.w);
+                        g[j0] = r0 * cosf(t0); g[j0 + 1] = r0 * sinf(t0); g[j0 + 2] = r1 * cosf(t1); g[j0 + 3] = r1 * sinf(t1);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 16; ++j) g[j] = j < a.n2 ? g[j] * (a.eps / 3.0f) : 3.0e38f;   // normal_(0, delta/3); pad sorts last
+#pragma unroll
+                for (int pass = 0; pass < 16; ++pass) {                                // odd-even transposition sort
+#pragma unroll
+                    for (int j = pass & 1; j + 1 < 16; j += 2) {
+                        const float lo = fminf(g[j], g[j + 1]), hi = fmaxf(g[j], g[j + 1]);
+                        g[j] = lo; g[j + 1] = hi;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    if (j < a.n2) zs[a.n1 + j] = d + fminf(fmaxf(g[j], -a.eps), a.eps);   // clip, vmap.py:82-83
+            } else {                                                                  // vmap.py:441-445
+                const float lo = d - a.eps, rng = (d + a.stop_eps) - lo, len = rng / (float)a.n2;
+#pragma unroll
+                for (int j = 0; j < kMaxS; ++j)
+                    if (j >= a.n1 && j < S) zs[j] = (rng * lin01(j - a.n1, a.n2) + lo) + uz[j] * len;
+            }
+        }
+        // ray in the world frame (vmap.py:31-41, :507-516) and the sample points (vmap.py:452-454)
+        const float* T = ob.t_wc + 16 * kf;
+        const float dx = ((float)iw - a.cx) / a.fx, dy = ((float)ih - a.cy) / a.fy;
+        const float wx = T[0] * dx + T[1] * dy + T[2], wy = T[4] * dx + T[5] * dy + T[6], wz = T[8] * dx + T[9] * dy + T[10];
+        const float ox = T[3], oy = T[7], oz = T[11];
+        const long long row = (long long)k * FP + ray;
+        float* pz = a.z + row * S;
+        float* pp = a.pcs + row * S * 3;
+#pragma unroll
+        for (int j = 0; j < kMaxS; ++j) {
+            if (j < S) {
+                pz[j] = zs[j];
+                pp[3 * j + 0] = (ox + wx * zs[j]) - ob.center[0];
+                pp[3 * j + 1] = (oy + wy * zs[j]) - ob.center[1];
+                pp[3 * j + 2] = (oz + wz * zs[j]) - ob.center[2];
+            }
+        }
+        a.gt_depth[row] = d;
+        a.gt_rgb[row * 3 + 0] = (float)(rgba & 0xFF) / 255.0f;                         // train.py:257 gt_rgb / 255.
+        a.gt_rgb[row * 3 + 1] = (float)((rgba >> 8) & 0xFF) / 255.0f;
+        a.gt_rgb[row * 3 + 2] = (float)((rgba >> 16) & 0xFF) / 255.0f;
+        a.sem[row] = (unsigned char)state;                                            // obj_labels
+        a.depth_mask[row] = invalid ? 0 : 1;                                          // valid_depth_mask
+    }
+}
+
+}  // namespace vs

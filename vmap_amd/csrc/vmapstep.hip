@@ -12,6 +12,7 @@
 
 #include "../../include/vmapstep.h"
 #include "gen_kernels.h"
+#include "sample_kernels.h"
 
 namespace {
 
@@ -459,6 +460,45 @@ int vmapstep_profile_phases(const vmapstep_shape* shape, const vmapstep_params* 
     *n_workgroups = a.xcd_affine ? 8 * ((shape->n_obj + 7) / 8) * pl.NW : shape->n_obj * pl.NW;
     if ((rc = launch_prep(a, 1, st))) return rc;
     return launch_main<true>(a, st);
+}
+
+static_assert(sizeof(vmapstep_sample_object) == sizeof(vs::SampleObject), "sample object table layout");
+
+int vmapstep_sample_frame(const vmapstep_sample_cfg* cfg, const vmapstep_sample_object* objects_device, int32_t n_obj,
+                          float* pcs, float* z, float* gt_depth, float* gt_rgb, uint8_t* sem, uint8_t* depth_mask,
+                          uint64_t seed, uint32_t frame_counter, const vmapstep_sample_randoms* test_randoms,
+                          void* stream) {
+    if (!cfg || !objects_device || !pcs || !z || !gt_depth || !gt_rgb || !sem || !depth_mask)
+        return fail(VMAPSTEP_ERR_ARGUMENT, "null argument");
+    const int S = cfg->n_bins_cam2surface + cfg->n_bins;
+    const long long FP = (long long)cfg->frames * cfg->samples_per_frame;
+    if (n_obj < 1 || cfg->frames < 1 || cfg->samples_per_frame < 1 || cfg->n_bins_cam2surface < 1 || cfg->n_bins < 1)
+        return fail(VMAPSTEP_ERR_ARGUMENT, "bad sampler shape");
+    if (S > vs::kMaxS || cfg->n_bins > 16 || cfg->width > 4095 || cfg->height > 4095 || FP > 12000)
+        return fail(VMAPSTEP_ERR_UNSUPPORTED, "sampler limits: S<=32, n_bins<=16, W,H<=4095, F*P<=12000");
+    vs::SampleArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.objs = reinterpret_cast<const vs::SampleObject*>(objects_device);
+    a.n_obj = n_obj; a.W = cfg->width; a.H = cfg->height; a.F = cfg->frames; a.P = cfg->samples_per_frame;
+    a.n1 = cfg->n_bins_cam2surface; a.n2 = cfg->n_bins;
+    a.fx = cfg->fx; a.fy = cfg->fy; a.cx = cfg->cx; a.cy = cfg->cy;
+    a.min_bound = cfg->min_depth; a.eps = cfg->surface_eps; a.stop_eps = cfg->stop_eps;
+    a.seed_lo = (unsigned)seed; a.seed_hi = (unsigned)(seed >> 32); a.frame_counter = frame_counter;
+    if (test_randoms) {
+        a.rnd.kf_ids = test_randoms->kf_ids; a.rnd.u_w = test_randoms->u_w; a.rnd.u_h = test_randoms->u_h;
+        a.rnd.u_z = test_randoms->u_z; a.rnd.g_z = test_randoms->g_z;
+    }
+    a.pcs = pcs; a.z = z; a.gt_depth = gt_depth; a.gt_rgb = gt_rgb; a.sem = sem; a.depth_mask = depth_mask;
+    const size_t lds = (3 * (size_t)FP + vs::kWG) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(vs::frame_sample), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(vs::frame_sample, dim3(n_obj), dim3(vs::kWG), lds, static_cast<hipStream_t>(stream), a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "frame_sample launch: %s", hipGetErrorString(e));
+    return VMAPSTEP_OK;
 }
 
 }  // extern "C"

@@ -1,0 +1,78 @@
+"""Host side of the batched HIP sampler: keyframe buffers of all objects in, the six per-frame tensors out.
+
+Mirrors the call the reference makes per object and frame - ``obj_k.get_training_samples(n_iter_per_frame * win_size,
+n_samples_per_frame, rays_dir_cache)`` (train.py:208-218, vmap.py:319-364) followed by the reshapes and ``torch.stack``
+of train.py:213-218,255-260 - but for every object in ONE launch (``vmapstep_sample_frame``).  Keyframe management
+(which frames are kept, pruning) stays with the caller; this class only needs, per object, the tensors the reference's
+``sceneObject`` already owns: ``rgbs_batch``, ``depth_batch``, ``t_wc_batch``, ``bbox``, ``n_keyframes``,
+``lastest_kf_queue[-2:]`` and ``obj_center``.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+class FrameSampler:
+    def __init__(self, width, height, frames, samples_per_frame, n_bins_cam2surface, n_bins, fx, fy, cx, cy,
+                 min_depth=0.0, surface_eps=0.1, stop_eps=0.05, device="cuda:0", seed=0):
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        self.cfg = _lib.SampleCfg(width, height, frames, samples_per_frame, n_bins_cam2surface, n_bins,
+                                  fx, fy, cx, cy, min_depth, surface_eps, stop_eps)
+        self.F, self.P, self.S = frames, samples_per_frame, n_bins_cam2surface + n_bins
+        self.seed = int(seed)
+        self.frame_counter = 0
+        self._table = None
+        self._keep = None
+        self.n_obj = 0
+
+    def set_objects(self, objects: Sequence[dict]):
+        """objects: per object dict(rgbs u8 [K,W,H,4], depth f32 [K,W,H], t_wc f32 [K,4,4], bbox f32 [K,4],
+        n_keyframes int, last2 (int, int), center (3 floats)); tensors on this sampler's device, contiguous."""
+        n = len(objects)
+        host = (_lib.SampleObject * n)()
+        keep = []
+        for i, o in enumerate(objects):
+            for k, dt in (("rgbs", torch.uint8), ("depth", torch.float32), ("t_wc", torch.float32), ("bbox", torch.float32)):
+                t = o[k]
+                if t.dtype != dt or t.device != self.device or not t.is_contiguous():
+                    raise ValueError(f"object {i}: {k} must be a contiguous {dt} tensor on {self.device}")
+            keep.append((o["rgbs"], o["depth"], o["t_wc"], o["bbox"]))
+            c = [float(v) for v in (o["center"].reshape(-1).tolist() if torch.is_tensor(o["center"]) else o["center"])]
+            if len(c) == 1:
+                c = c * 3                                   # the reference's default obj_center is the scalar 0.0
+            host[i] = _lib.SampleObject(o["rgbs"].data_ptr(), o["depth"].data_ptr(), o["t_wc"].data_ptr(), o["bbox"].data_ptr(),
+                                        int(o["n_keyframes"]), (ctypes.c_int32 * 2)(*[int(v) for v in o["last2"]]),
+                                        (ctypes.c_float * 3)(*c), 0)
+        raw = np.frombuffer(bytes(host), dtype=np.uint8).copy()
+        self._table = torch.from_numpy(raw).to(self.device)
+        self._keep = keep
+        self.n_obj = n
+
+    def sample(self, test_randoms: Optional[dict] = None):
+        """One frame of samples for all objects -> dict(pcs [n,F*P,S,3], z [n,F*P,S], gt_depth [n,F*P], gt_rgb [n,F*P,3],
+        sem u8 [n,F*P], depth_mask u8 [n,F*P]) on the device.  ``test_randoms``: dict of device tensors kf_ids int32
+        [n,F], u_w/u_h f32 [n,F*P], u_z [n,F*P,S], g_z [n,F*P,n_bins] (deterministic test mode)."""
+        if self._table is None:
+            raise RuntimeError("set_objects() first")
+        n, FP, S, dev = self.n_obj, self.F * self.P, self.S, self.device
+        out = dict(pcs=torch.empty(n, FP, S, 3, device=dev), z=torch.empty(n, FP, S, device=dev),
+                   gt_depth=torch.empty(n, FP, device=dev), gt_rgb=torch.empty(n, FP, 3, device=dev),
+                   sem=torch.empty(n, FP, dtype=torch.uint8, device=dev), depth_mask=torch.empty(n, FP, dtype=torch.uint8, device=dev))
+        rnd = None
+        if test_randoms is not None:
+            rnd = _lib.SampleRandoms(*[test_randoms[k].data_ptr() if test_randoms.get(k) is not None else None
+                                       for k in ("kf_ids", "u_w", "u_h", "u_z", "g_z")])
+        _lib.check(self.lib.vmapstep_sample_frame(ctypes.byref(self.cfg), self._table.data_ptr(), n,
+                                                  out["pcs"].data_ptr(), out["z"].data_ptr(), out["gt_depth"].data_ptr(),
+                                                  out["gt_rgb"].data_ptr(), out["sem"].data_ptr(), out["depth_mask"].data_ptr(),
+                                                  self.seed, self.frame_counter, ctypes.byref(rnd) if rnd is not None else None,
+                                                  torch.cuda.current_stream().cuda_stream))
+        self.frame_counter += 1
+        return out
