@@ -197,6 +197,15 @@ int vmapstep_sample_frame(const vmapstep_sample_cfg* cfg, const vmapstep_sample_
                           uint64_t seed, uint32_t frame_counter, const vmapstep_sample_randoms* test_randoms,
                           void* stream);
 
+/* ---- inference query -------------------------------------------------------------------
+ * Occupancy sigmoid(alpha) and colour of ONE object's field (object `obj_index` of the stacked tensors) at `n_points`
+ * arbitrary points of the object frame: what Trainer.eval_points (trainer.py:77-95) computes chunk by chunk for mesh
+ * extraction.  hidden = 32 only in this version.  workspace >= vmapstep_query_workspace_bytes(). */
+int vmapstep_query_workspace_bytes(int32_t hidden, size_t* bytes);
+int vmapstep_query_points(int32_t hidden, const vmapstep_params* params, const vmapstep_tensor* pe_scale, int32_t obj_index,
+                          const float* points, int64_t n_points, const int64_t points_stride[2],
+                          float* occupancy, float* color, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Measurement hook: step_prep once, then the dominant kernel (step_main, forward+backward) `reps` times back to
  * back on `stream` with nothing in between, so that events recorded around the call give its average launch
  * duration (bench.py's roofline figure).  Writes only to the workspace. */

@@ -6,6 +6,7 @@
 
 #include "gen_kernels.h"
 #include "sample_kernels.h"
+#include "query_kernels.h"
 
 namespace {
 void fc_sizes(int H, int* sz) {
@@ -113,3 +114,19 @@ extern "C" int vmsim_sample(const vs::SampleObject* objs, int n_obj, int W, int 
     return 0;
 }
 extern "C" int vmsim_sample_object_size() { return (int)sizeof(vs::SampleObject); }
+
+// query: pack the image of one object then run field_query_h32 (host pointers)
+extern "C" int vmsim_query(const float* const* fc, const float* B, const float* scale, const float* pts, long long n_pts,
+                           float* occ, float* rgb, int grid) {
+    std::vector<float> img(vk::Lds32::IMGP, NAN);
+    vk::StepArgs a{};
+    a.n_obj = 1; a.hidden = 32; a.prep_steps = 0;
+    for (int t = 0; t < 14; ++t) a.fc[t] = {const_cast<float*>(fc[t]), 0};
+    a.pe_B = {const_cast<float*>(B), 0};
+    a.wimg = img.data();
+    sim::launch(1, vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep(a); });
+    vk::QueryArgs q{};
+    q.wimg = img.data(); q.scale = scale; q.pts = pts; q.pts_sn = 3; q.pts_sc = 1; q.n_pts = n_pts; q.occ = occ; q.rgb = rgb;
+    sim::launch(grid, vk::kWG, vk::Lds32::IMGP * 4, [&] { vk::field_query_h32(q); });
+    return 0;
+}

@@ -20,7 +20,8 @@ def build(force=False):
                    os.path.join(SIM, "include", "hip", "hip_runtime.h"),
                    os.path.join(ROOT, "vmap_amd", "csrc", "step_kernels.h"),
                    os.path.join(ROOT, "vmap_amd", "csrc", "gen_kernels.h"),
-                   os.path.join(ROOT, "vmap_amd", "csrc", "sample_kernels.h")]
+                   os.path.join(ROOT, "vmap_amd", "csrc", "sample_kernels.h"),
+                   os.path.join(ROOT, "vmap_amd", "csrc", "query_kernels.h")]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
@@ -137,3 +138,18 @@ def sim_sample(scenes, rnds, seed=0, frame_counter=0, eps=0.1, stop_eps=0.05):
                         _p(out["sem"], ctypes.c_uint8), _p(out["depth_mask"], ctypes.c_uint8))
     assert rc == 0
     return out
+
+
+def sim_query(fc_k, B_k, scale_k, pts, grid=3):
+    """field_query_h32 on the simulator for one object: fc_k = 14 arrays (no object dim), pts [N,3]."""
+    fc_c = [np.ascontiguousarray(a, dtype=np.float32) for a in fc_k]
+    arr = (ctypes.POINTER(ctypes.c_float) * 14)(*[_p(a) for a in fc_c])
+    Bc = np.ascontiguousarray(B_k, dtype=np.float32)
+    sc = np.ascontiguousarray([scale_k], dtype=np.float32)
+    p = np.ascontiguousarray(pts, dtype=np.float32)
+    n = p.shape[0]
+    occ = np.full(n, np.nan, np.float32)
+    rgb = np.full((n, 3), np.nan, np.float32)
+    rc = lib().vmsim_query(arr, _p(Bc), _p(sc), _p(p), ctypes.c_longlong(n), _p(occ), _p(rgb), int(grid))
+    assert rc == 0
+    return occ, rgb

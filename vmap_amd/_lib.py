@@ -74,6 +74,7 @@ EXPORTS = (
     "vmapstep_fwd_bwd", "vmapstep_render", "vmapstep_train_steps", "vmapstep_set_workgroups_per_object",
     "vmapstep_profile_main_kernel", "vmapstep_profile_phases", "vmapstep_prepare", "vmapstep_train_steps_prepared",
     "vmapstep_workspace_counts_offset", "vmapstep_fwd_bwd_prepared", "vmapstep_sample_frame",
+    "vmapstep_query_workspace_bytes", "vmapstep_query_points",
 )
 
 _lib = None
@@ -118,6 +119,10 @@ def load():
     lib.vmapstep_sample_frame.argtypes = [ctypes.POINTER(SampleCfg), ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                           ctypes.c_uint64, ctypes.c_uint32, ctypes.POINTER(SampleRandoms), ctypes.c_void_p]
+    lib.vmapstep_query_workspace_bytes.argtypes = [ctypes.c_int32, ctypes.POINTER(ctypes.c_size_t)]
+    lib.vmapstep_query_points.argtypes = [ctypes.c_int32, ctypes.POINTER(Params), ctypes.POINTER(Tensor), ctypes.c_int32,
+                                          ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64), ctypes.c_void_p,
+                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
     lib.vmapstep_profile_main_kernel.argtypes = [ctypes.POINTER(Shape), ctypes.POINTER(Params), ctypes.POINTER(Tensor),
                                                  ctypes.POINTER(Batch), ctypes.c_int32, ctypes.c_void_p,
                                                  ctypes.c_size_t, ctypes.c_void_p]
@@ -129,7 +134,8 @@ def load():
     for fn in ("vmapstep_param_layout", "vmapstep_workspace_bytes", "vmapstep_fwd_bwd", "vmapstep_render",
                "vmapstep_train_steps", "vmapstep_set_workgroups_per_object", "vmapstep_profile_main_kernel",
                "vmapstep_profile_phases", "vmapstep_prepare", "vmapstep_train_steps_prepared",
-               "vmapstep_workspace_counts_offset", "vmapstep_fwd_bwd_prepared", "vmapstep_sample_frame"):
+               "vmapstep_workspace_counts_offset", "vmapstep_fwd_bwd_prepared", "vmapstep_sample_frame",
+               "vmapstep_query_workspace_bytes", "vmapstep_query_points"):
         getattr(lib, fn).restype = ctypes.c_int
     if lib.vmapstep_abi_version() != ABI_VERSION:
         raise VmapStepError(f"ABI mismatch: library {lib.vmapstep_abi_version()} != binding {ABI_VERSION}")

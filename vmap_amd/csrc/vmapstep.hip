@@ -13,6 +13,7 @@
 #include "../../include/vmapstep.h"
 #include "gen_kernels.h"
 #include "sample_kernels.h"
+#include "query_kernels.h"
 
 namespace {
 
@@ -460,6 +461,54 @@ int vmapstep_profile_phases(const vmapstep_shape* shape, const vmapstep_params* 
     *n_workgroups = a.xcd_affine ? 8 * ((shape->n_obj + 7) / 8) * pl.NW : shape->n_obj * pl.NW;
     if ((rc = launch_prep(a, 1, st))) return rc;
     return launch_main<true>(a, st);
+}
+
+int vmapstep_query_workspace_bytes(int32_t hidden, size_t* bytes) {
+    if (!bytes) return fail(VMAPSTEP_ERR_ARGUMENT, "bytes is null");
+    if (hidden != 32) return fail(VMAPSTEP_ERR_UNSUPPORTED, "hidden=%d: the query kernel implements hidden=32", hidden);
+    *bytes = align_up((size_t)vk::Lds32::IMGP * sizeof(float));
+    return VMAPSTEP_OK;
+}
+
+int vmapstep_query_points(int32_t hidden, const vmapstep_params* params, const vmapstep_tensor* pe_scale, int32_t obj_index,
+                          const float* points, int64_t n_points, const int64_t points_stride[2],
+                          float* occupancy, float* color, void* workspace, size_t workspace_bytes, void* stream) {
+    int rc;
+    size_t need = 0;
+    if ((rc = vmapstep_query_workspace_bytes(hidden, &need))) return rc;
+    if ((rc = check_params(params, "params", false))) return rc;
+    if (!pe_scale || !pe_scale->ptr || !points || !points_stride || !occupancy || !color || obj_index < 0 || n_points < 0)
+        return fail(VMAPSTEP_ERR_ARGUMENT, "null / negative argument");
+    if (!workspace || reinterpret_cast<uintptr_t>(workspace) % kAlign || workspace_bytes < need)
+        return fail(VMAPSTEP_ERR_WORKSPACE, "workspace must be 256-byte aligned and >= %zu bytes", need);
+    if (n_points == 0) return VMAPSTEP_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // pack this object's image (step_prep's pack role, zero mask-statistics blocks)
+    vk::StepArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.n_obj = 1; a.hidden = hidden; a.prep_steps = 0;
+    for (int t = 0; t < VMAPSTEP_NUM_FC; ++t) a.fc[t] = {params->fc[t].ptr + (long long)obj_index * params->fc[t].obj_stride, 0};
+    a.pe_B = {params->pe_B.ptr + (long long)obj_index * params->pe_B.obj_stride, 0};
+    a.wimg = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(vk::step_prep, dim3(1), dim3(vk::kWG), 3 * vk::kWG * sizeof(int), st, a);
+    vk::QueryArgs q;
+    q.wimg = a.wimg;
+    q.scale = pe_scale->ptr + (long long)obj_index * pe_scale->obj_stride;
+    q.pts = points; q.pts_sn = points_stride[0]; q.pts_sc = points_stride[1];
+    q.n_pts = n_points; q.occ = occupancy; q.rgb = color;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(vk::field_query_h32),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, vk::Lds32::IMGP * sizeof(float));
+        if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    const long long chunks = (n_points + vk::kMaxPts - 1) / vk::kMaxPts;
+    const int grid = (int)(chunks < 768 ? chunks : 768);          // 3 resident workgroups per CU share the matrix pipes
+    hipLaunchKernelGGL(vk::field_query_h32, dim3(grid), dim3(vk::kWG), vk::Lds32::IMGP * sizeof(float), st, q);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "field_query launch: %s", hipGetErrorString(e));
+    return VMAPSTEP_OK;
 }
 
 static_assert(sizeof(vmapstep_sample_object) == sizeof(vs::SampleObject), "sample object table layout");

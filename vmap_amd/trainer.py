@@ -31,16 +31,48 @@ class Trainer:
 
     @torch.no_grad()
     def eval_points(self, points: torch.Tensor, chunk_size: int = 100000):
-        """Occupancy and colour at arbitrary points of this object's frame (trainer.py:77-95)."""
-        alphas, colors = [], []
-        for k in range(0, points.shape[0], chunk_size):
-            a, c = self.fc_occ_map(self.pe(points[k:k + chunk_size]))
-            alphas.append(a.squeeze(-1))
-            colors.append(c)
-        occ = torch.sigmoid(torch.cat(alphas))
+        """Occupancy and colour at arbitrary points of this object's frame (trainer.py:77-95).  On the GPU with hidden
+        32 this is ONE launch of the HIP query kernel (vmapstep_query_points); otherwise the modules' PyTorch forward
+        in chunks like the reference."""
+        if points.is_cuda and self.hidden_feature_size == 32:
+            occ, color = self._eval_points_hip(points)
+        else:
+            alphas, colors = [], []
+            for k in range(0, points.shape[0], chunk_size):
+                a, c = self.fc_occ_map(self.pe(points[k:k + chunk_size]))
+                alphas.append(a.squeeze(-1))
+                colors.append(c)
+            occ, color = torch.sigmoid(torch.cat(alphas)), torch.cat(colors)
         if occ.max() == 0:
             return None
-        return occ, torch.cat(colors)
+        return occ, color
+
+    def _eval_points_hip(self, points: torch.Tensor):
+        import ctypes
+        from . import _lib
+        lib = _lib.load()
+        pts = points if points.dtype == torch.float32 else points.float()
+        n = pts.shape[0]
+        dev = pts.device
+        nb = ctypes.c_size_t(0)
+        _lib.check(lib.vmapstep_query_workspace_bytes(self.hidden_feature_size, ctypes.byref(nb)))
+        ws = torch.empty(nb.value + 256, dtype=torch.uint8, device=dev)
+        ws_ptr = ws.data_ptr() + (-ws.data_ptr()) % 256
+        pp = _lib.Params()
+        for t, p in enumerate(self.fc_occ_map.parameters()):
+            if not p.is_contiguous() or p.device != dev:
+                raise ValueError("field parameters must be contiguous and on the points' device")
+            pp.fc[t] = _lib.Tensor(p.data_ptr(), 0)
+        pp.pe_B = _lib.Tensor(self.pe.B_layer.weight.data_ptr(), 0)
+        scale = self.pe.scale.reshape(1).to(dev, torch.float32).contiguous()
+        sc = _lib.Tensor(scale.data_ptr(), 0)
+        occ = torch.empty(n, dtype=torch.float32, device=dev)
+        col = torch.empty(n, 3, dtype=torch.float32, device=dev)
+        strides = (ctypes.c_int64 * 2)(pts.stride(0), pts.stride(1))
+        _lib.check(lib.vmapstep_query_points(self.hidden_feature_size, ctypes.byref(pp), ctypes.byref(sc), 0, pts.data_ptr(), n,
+                                             strides, occ.data_ptr(), col.data_ptr(), ws_ptr, nb.value,
+                                             torch.cuda.current_stream().cuda_stream))
+        return occ, col
 
 
 class SimpleConfig:
