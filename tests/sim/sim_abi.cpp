@@ -127,6 +127,6 @@ extern "C" int vmsim_query(const float* const* fc, const float* B, const float* 
     sim::launch(1, vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep(a); });
     vk::QueryArgs q{};
     q.wimg = img.data(); q.scale = scale; q.pts = pts; q.pts_sn = 3; q.pts_sc = 1; q.n_pts = n_pts; q.occ = occ; q.rgb = rgb;
-    sim::launch(grid, vk::kWG, vk::Lds32::IMGP * 4, [&] { vk::field_query_h32(q); });
+    sim::launch(grid, vk::kWG, vk::Lds32::IMGP * 4, [&] { vk::field_query_h32<2>(q); });
     return 0;
 }

@@ -3,6 +3,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#define WV_WAVES_PER_SIMD(n)
+
 namespace wv {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -77,6 +79,13 @@ inline bool wave_any(bool pred) {
 inline void wave_lds_fence() { sim::wave_barrier(); }
 
 inline float* lds_base() { return reinterpret_cast<float*>(sim::g_block->lds.data()); }
+
+template <class T>
+inline const T& kernarg_late(const T& a) { return a; }
+
+inline float opaque(float x) { return x; }
+
+inline void sched_fence() {}
 
 inline unsigned clock32() { return (unsigned)sim::g_yields; }
 

@@ -30,8 +30,8 @@ __host__ __device__ constexpr int gen_wave_blocks(int NB) { return 20 + 14 * NB;
 // LDS map of the generic kernel (floats)
 struct LdsGen {
     static constexpr int SCR = 0;                                   // per-wave transpose scratch: kWaves x 2 x [32][33]
-    static constexpr int SCR_WAVE = 2 * 32 * 33;
-    static constexpr int STG_TILE = 32 * 33;
+    static constexpr int SCR_WAVE = Lds32::SCR_WAVE;                // same tile strides as the hidden-32 kernel (shared helpers)
+    static constexpr int STG_TILE = Lds32::STG_TILE;
     static constexpr int STG = SCR + kWaves * SCR_WAVE;             // 2 buffers x kWaves tiles
     static constexpr int CB = STG + 2 * kWaves * STG_TILE;          // composite buffer [kMaxPts][8]
     static constexpr int LOSS = CB + kMaxPts * 8;                   // [kWaves][4]
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_gen(const GenArgs ga) {
     float* stg0 = lds + LdsGen::STG;
     float* stg1 = stg0 + kWaves * LdsGen::STG_TILE;
     float* scrX = lds + LdsGen::SCR + wave * LdsGen::SCR_WAVE;
-    float* scrD = scrX + 32 * 33;
+    float* scrD = scrX + Lds32::SCR_TILE;
     float* cb = lds + LdsGen::CB;
     const float* cbw = cb + wave * 32 * 8;
     const float scale = a.pe_scale.p[obj * a.pe_scale.stride];

@@ -19,7 +19,8 @@ struct QueryArgs {
     float* rgb;                        // [N,3]  sigmoid(raw colour)
 };
 
-__global__ __launch_bounds__(kWG, 1) void field_query_h32(const QueryArgs a) {
+template <int WPE>
+__global__ __launch_bounds__(kWG) WV_WAVES_PER_SIMD(WPE) void field_query_h32(const QueryArgs a) {
     using L = Lds32;
     constexpr int H = 32;
     float* lds = wv::lds_base();
@@ -47,30 +48,26 @@ __global__ __launch_bounds__(kWG, 1) void field_query_h32(const QueryArgs a) {
 #pragma unroll
         for (int d = 0; d < kDirs; ++d)
             proj[d] = fmaf(t[2], Bg[3 * d + 2], fmaf(t[1], Bg[3 * d + 1], t[0] * Bg[3 * d]));
-        float e1a[16], e1b[16], e1c[16], e2a[16], e2b[16], cf[16];
-        {
-            float amax = 0.0f;
+        // the far-point decision (accurate range reduction) is made once per wave and tile, like step_main_h32
+        float amax = 0.0f;
 #pragma unroll
-            for (int d = 0; d < kDirs; ++d) amax = fmaxf(amax, fabsf(proj[d]));
-            if (!wv::wave_any(!(amax * (32.0f * kPi) < kSinCosFastLimit))) {
-                pe_block<16, false>(e1a, cf, 0, kEmb1, 0, t, proj, hi);
-                pe_block<16, false>(e1b, cf, 0, kEmb1, 1, t, proj, hi);
-                pe_block<12, false>(e1c, cf, 0, kEmb1, 2, t, proj, hi);
-                pe_block<16, false>(e2a, cf, kEmb1, kEmb2, 0, t, proj, hi);
-                pe_block<6, false>(e2b, cf, kEmb1, kEmb2, 1, t, proj, hi);
-            } else {
-                pe_block<16, true>(e1a, cf, 0, kEmb1, 0, t, proj, hi);
-                pe_block<16, true>(e1b, cf, 0, kEmb1, 1, t, proj, hi);
-                pe_block<12, true>(e1c, cf, 0, kEmb1, 2, t, proj, hi);
-                pe_block<16, true>(e2a, cf, kEmb1, kEmb2, 0, t, proj, hi);
-                pe_block<6, true>(e2b, cf, kEmb1, kEmb2, 1, t, proj, hi);
-            }
+        for (int d = 0; d < kDirs; ++d) amax = fmaxf(amax, fabsf(proj[d]));
+        const bool big = wv::wave_any(!(amax * (32.0f * kPi) < kSinCosFastLimit));
+        float e1a[16], e1b[16], e1c[16], cf[16];
+        if (!big) {
+            pe_block<16, false>(e1a, cf, 0, kEmb1, 0, t, proj, hi);
+            pe_block<16, false>(e1b, cf, 0, kEmb1, 1, t, proj, hi);
+            pe_block<12, false>(e1c, cf, 0, kEmb1, 2, t, proj, hi);
+        } else {
+            pe_block<16, true>(e1a, cf, 0, kEmb1, 0, t, proj, hi);
+            pe_block<16, true>(e1b, cf, 0, kEmb1, 1, t, proj, hi);
+            pe_block<12, true>(e1c, cf, 0, kEmb1, 2, t, proj, hi);
         }
         if (first) {
             __syncthreads();            // parameter image landed (uniform: every workgroup has at least one chunk)
             first = false;
         }
-        float h1[16], h2[16], h3[16], h4[16], hc[16];
+        float h1[16], h2[16], h4[16], hc[16];
         f32x16 acc;
         {
             const float* w = W + L::W_IN + p31 * L::LD_IN + 4 * hi;
@@ -87,14 +84,24 @@ __global__ __launch_bounds__(kWG, 1) void field_query_h32(const QueryArgs a) {
             const float* w = W + L::W_CAT + p31 * L::LD_CAT + 4 * hi;
             load_bias(acc, W + L::B_CAT, hi);
             fwd_mm<4>(acc, w, h2); fwd_mm<4>(acc, w + H, e1a); fwd_mm<4>(acc, w + H + 32, e1b); fwd_mm<3>(acc, w + H + 64, e1c);
-            relu_to(h3, acc);
+            relu_to(h1, acc);           // h3 (h1 is dead)
         }
         {
             load_bias(acc, W + L::B_M2, hi);
-            fwd_mm<4>(acc, W + L::W_M2 + p31 * L::LD_M + 4 * hi, h3);
+            fwd_mm<4>(acc, W + L::W_M2 + p31 * L::LD_M + 4 * hi, h1);
             relu_to(h4, acc);
         }
         {
+            // the colour head's share of the encoding is produced here, after the first 87 features are dead, so the
+            // kernel fits 168 registers (3 waves per SIMD: one wave's sincos overlaps another's matrix instructions)
+            float e2a[16], e2b[16];
+            if (!big) {
+                pe_block<16, false>(e2a, cf, kEmb1, kEmb2, 0, t, proj, hi);
+                pe_block<6, false>(e2b, cf, kEmb1, kEmb2, 1, t, proj, hi);
+            } else {
+                pe_block<16, true>(e2a, cf, kEmb1, kEmb2, 0, t, proj, hi);
+                pe_block<6, true>(e2b, cf, kEmb1, kEmb2, 1, t, proj, hi);
+            }
             const float* w = W + L::W_C + p31 * L::LD_C + 4 * hi;
             load_bias(acc, W + L::B_C, hi);
             fwd_mm<4>(acc, w, h4); fwd_mm<4>(acc, w + H, e2a); fwd_mm<2>(acc, w + H + 32, e2b);

@@ -108,9 +108,12 @@ struct Lds32 {
     static constexpr int WGT = 0;                 // weight image
     static constexpr int SMALL0 = B_IN;           // small vectors of the image: biases, heads, B
     static constexpr int SMALL_N = IMG - B_IN;
-    static constexpr int SCR = IMGP;              // per-wave transpose scratch: kWaves x 2 x [32][33]
-    static constexpr int SCR_WAVE = 2 * 32 * 33;
-    static constexpr int STG_TILE = 32 * 33;      // one staged 32x32 weight-gradient block
+    static constexpr int TP = 36;                 // pitch of the 32x32 exchange tiles: 4 * odd, so the 16-byte reads of
+                                                  // a row by 16 lanes tile the 64 banks exactly (MI355X_MICROARCH.md, LDS)
+    static constexpr int SCR = IMGP;              // per-wave transpose scratch: kWaves x 2 x [32][TP]
+    static constexpr int SCR_TILE = 32 * TP;
+    static constexpr int SCR_WAVE = 2 * SCR_TILE;
+    static constexpr int STG_TILE = 32 * TP;      // one staged 32x32 weight-gradient block
     static constexpr int STG = SCR + kWaves * SCR_WAVE;       // 2 buffers x kWaves tiles
     static constexpr int VEC = STG + 2 * kWaves * STG_TILE;   // per-wave private small-vector gradient accumulators
     static constexpr int CB = VEC + kWaves * SMALL_N;         // composite buffer [kMaxPts][8]
@@ -293,12 +296,194 @@ __device__ __forceinline__ void add_db(float* gb, const float (&dyF)[16], int p3
     s += wv::swap_half(s);
     if (hi == 0) gb[p31] += s;
 }
+// the same sum kept in a register (written to the small-vector area once, after the last unit: an LDS
+// read-modify-write between two chains is a fully exposed round trip)
+__device__ __forceinline__ float db_sum(const float (&dyF)[16]) {
+    float s = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += dyF[r];
+    return s + wv::swap_half(s);
+}
 // this wave's quarter of a reduced block -> natural row-major tensor (row length K), columns col0 .. col0+ncols-1
 template <int K>
 __device__ __forceinline__ void store_quarter(float* out, const float (&q)[4], int col0, int ncols, int wave, int p31, int hi) {
     if (p31 < ncols) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) out[(8 * wave + 4 * hi + i) * K + col0 + p31] = q[i];
+    }
+}
+// ---- split-phase forms (the backward is software-pipelined by hand: one wave per SIMD has nobody else to hide an
+// LDS round trip or a barrier, so every round trip is started BEFORE a 16-deep matrix-instruction chain and consumed
+// after it) ----
+template <int LD>
+__device__ __forceinline__ void bwd_w(float (&w)[16], const float* wcol) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) w[r] = wcol[((r & 3) + 8 * (r >> 2)) * LD];
+}
+__device__ __forceinline__ void bwd_fma(f32x16& acc, const float (&w)[16], const float (&dy)[16]) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc = wv::mfma32(w[r], dy[r], acc);
+}
+// Exchange tiles.  One wave with nobody to share its SIMD gets a fifth of the LDS rate on 4-byte reads but the full
+// rate on 16-byte reads and on stores, so every tile is laid out for 16-byte reads:
+//   transpose tile [feature][point]: P-form lanes store single dwords (lane = point: consecutive addresses), F-form
+//     lanes (lane = feature) read their 16 points as four 16-byte loads;
+//   staging tile [column][row]: a lane's registers 4j..4j+3 are rows 8j+4hi..+3 of its column: four 16-byte stores;
+//     the reducing wave reads its rows 8w+4hi..+3 of the four waves' tiles as four 16-byte loads.
+__device__ __forceinline__ void toF_put(float* scr, const float (&P)[16], int p31, int hi) {
+    wv::wave_lds_fence();   // earlier reads of this tile are ordered before the overwrite
+#pragma unroll
+    for (int r = 0; r < 16; ++r) scr[phi(r, hi) * Lds32::TP + p31] = P[r];
+    wv::wave_lds_fence();
+}
+__device__ __forceinline__ void toF_get(float (&F)[16], const float* scr, int p31, int hi) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const wv::f32x4 v = *reinterpret_cast<const wv::f32x4*>(scr + p31 * Lds32::TP + 16 * hi + 4 * j);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) F[4 * j + i] = v[i];
+    }
+}
+__device__ __forceinline__ void stage_put(float* stage, const f32x16& acc, int wave, int p31, int hi) {
+    float* mine = stage + wave * Lds32::STG_TILE + p31 * Lds32::TP + 4 * hi;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        wv::f32x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = acc[4 * j + i];
+        *reinterpret_cast<wv::f32x4*>(mine + 8 * j) = v;
+    }
+}
+// after the workgroup barrier that follows stage_put: this wave's quarter (rows 8w..8w+7) of the four staged tiles
+__device__ __forceinline__ void stage_get(float (&q)[4], const float* stage, int wave, int p31, int hi) {
+    const float* rd = stage + p31 * Lds32::TP + 8 * wave + 4 * hi;
+    const wv::f32x4 t0 = *reinterpret_cast<const wv::f32x4*>(rd);
+    const wv::f32x4 t1 = *reinterpret_cast<const wv::f32x4*>(rd + Lds32::STG_TILE);
+    const wv::f32x4 t2 = *reinterpret_cast<const wv::f32x4*>(rd + 2 * Lds32::STG_TILE);
+    const wv::f32x4 t3 = *reinterpret_cast<const wv::f32x4*>(rd + 3 * Lds32::STG_TILE);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] += (t0[i] + t1[i]) + (t2[i] + t3[i]);
+}
+// d-prop chain of one unit (16 matrix instructions, acc += W^T dy) with the unit's LDS traffic threaded through it, a
+// few DS instructions after every matrix instruction: staging of the previous weight-gradient tile, the P->F
+// transposes of this unit's delta (HAS_D) and input block (HAS_X).  Issued as one burst the DS queue back-pressures
+// instruction issue and the matrix pipe idles; spread over the chain most of it is hidden.
+template <bool HAS_D, bool HAS_X, bool HAS_STAGE>
+__device__ __forceinline__ void p_chain(f32x16& accP, const float (&w)[16], const float (&dy)[16],
+                                        float* scrD, const float (&dP)[16], float (&dF)[16],
+                                        float* scrX, const float (&xP)[16], float (&xF)[16],
+                                        float* stage, const f32x16& accPrev, int wave, int p31, int hi) {
+    constexpr int N_ST = HAS_STAGE ? 4 : 0, N_D = HAS_D ? 16 : 0, N_X = HAS_X ? 16 : 0;
+    constexpr int N_GD = HAS_D ? 4 : 0, N_GX = HAS_X ? 4 : 0;
+    constexpr int PUT0 = N_ST, GET0 = PUT0 + N_D + N_X, TOTAL = GET0 + N_GD + N_GX;
+    constexpr int PER = (TOTAL + 2) / 3;             // DS work after the 4th, 8th and 12th matrix instruction; the
+                                                     // last four cover its latency before the barrier that follows.
+                                                     // Matrix instructions stay in back-to-back groups of four: a
+                                                     // dependent one issued right behind its producer forwards the
+                                                     // accumulator, any instruction in between costs ~40 cycles.
+    float* mine = stage + wave * Lds32::STG_TILE + p31 * Lds32::TP + 4 * hi;
+    wv::wave_lds_fence();
+    wv::sched_fence();          // the VALU work before the chain stays before it
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int r = 4 * g; r < 4 * g + 4; ++r) accP = wv::mfma32(w[r], dy[r], accP);
+        wv::sched_fence();
+#pragma unroll
+        for (int i = g * PER; i < (g + 1) * PER; ++i) {
+            if (g == 3 || i >= TOTAL) continue;
+            if (i == GET0) wv::wave_lds_fence();
+            if (i < PUT0) {
+                wv::f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = accPrev[4 * i + e];
+                *reinterpret_cast<wv::f32x4*>(mine + 8 * i) = v;
+            } else if (i < PUT0 + N_D) {
+                const int k = i - PUT0;
+                scrD[phi(k, hi) * Lds32::TP + p31] = dP[k];
+            } else if (i < GET0) {
+                const int k = i - PUT0 - N_D;
+                scrX[phi(k, hi) * Lds32::TP + p31] = xP[k];
+            } else if (i < GET0 + N_GD) {
+                const int j = i - GET0;
+                const wv::f32x4 v = *reinterpret_cast<const wv::f32x4*>(scrD + p31 * Lds32::TP + 16 * hi + 4 * j);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dF[4 * j + e] = v[e];
+            } else {
+                const int j = i - GET0 - N_GD;
+                const wv::f32x4 v = *reinterpret_cast<const wv::f32x4*>(scrX + p31 * Lds32::TP + 16 * hi + 4 * j);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xF[4 * j + e] = v[e];
+            }
+        }
+        wv::sched_fence();
+    }
+}
+// weight-gradient chain of one unit (acc += dyF^T xF) that also fetches the weight column operands of the NEXT unit's
+// d-prop chain (LDN = row pitch of that matrix, 0 = nothing to fetch)
+template <int LDN>
+__device__ __forceinline__ void dw_chain(f32x16& acc, const float (&dyF)[16], const float (&xF)[16],
+                                         float (&wn)[16], const float* wcol_next) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int r = 4 * g; r < 4 * g + 4; ++r) acc = wv::mfma32(dyF[r], xF[r], acc);
+        wv::sched_fence();
+        if (LDN > 0 && g < 2) {
+#pragma unroll
+            for (int k = 8 * g; k < 8 * g + 8; ++k) wn[k] = wcol_next[((k & 3) + 8 * (k >> 2)) * LDN];
+        }
+        wv::sched_fence();
+    }
+}
+// the same chain that also finishes the PREVIOUS block (after the workgroup barrier that follows its staging): the
+// four staged tiles are read after the first group of matrix instructions and summed / stored after the third, so
+// neither the LDS latency nor the store address arithmetic sits between two chains
+template <int LDN, bool MULTI, int K>
+__device__ __forceinline__ void dw_chain_fin(f32x16& acc, const float (&dyF)[16], const float (&xF)[16],
+                                             float (&wn)[16], const float* wcol_next,
+                                             float (&qp)[4], const float* stage, float* out, int col0, int ncols,
+                                             int wave, int p31, int hi) {
+    wv::f32x4 t0, t1, t2, t3;
+    const float* rd = stage + p31 * Lds32::TP + 8 * wave + 4 * hi;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int r = 4 * g; r < 4 * g + 4; ++r) acc = wv::mfma32(dyF[r], xF[r], acc);
+        wv::sched_fence();
+        if (g == 0) {
+            t0 = *reinterpret_cast<const wv::f32x4*>(rd);
+            t1 = *reinterpret_cast<const wv::f32x4*>(rd + Lds32::STG_TILE);
+            t2 = *reinterpret_cast<const wv::f32x4*>(rd + 2 * Lds32::STG_TILE);
+            t3 = *reinterpret_cast<const wv::f32x4*>(rd + 3 * Lds32::STG_TILE);
+        }
+        if (LDN > 0 && g < 2) {
+#pragma unroll
+            for (int k = 8 * g; k < 8 * g + 8; ++k) wn[k] = wcol_next[((k & 3) + 8 * (k >> 2)) * LDN];
+        }
+        if (g == 2) {
+            if (MULTI) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) qp[i] += (t0[i] + t1[i]) + (t2[i] + t3[i]);
+            } else {
+                float q[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) q[i] = 0.0f + ((t0[i] + t1[i]) + (t2[i] + t3[i]));
+                store_quarter<K>(out, q, col0, ncols, wave, p31, hi);
+            }
+        }
+        wv::sched_fence();
+    }
+}
+template <bool MULTI, int K>
+__device__ __forceinline__ void finish_block(float (&qp)[4], const float* stage, float* out, int col0, int ncols,
+                                             int wave, int p31, int hi) {
+    if (MULTI) {
+        stage_get(qp, stage, wave, p31, hi);
+    } else {
+        float q[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        stage_get(q, stage, wave, p31, hi);
+        store_quarter<K>(out, q, col0, ncols, wave, p31, hi);
     }
 }
 template <bool MULTI, int K>
@@ -733,7 +918,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
     float* stg0 = lds + L::STG;
     float* stg1 = stg0 + kWaves * L::STG_TILE;
     float* scrX = lds + L::SCR + wave * L::SCR_WAVE;
-    float* scrD = scrX + 32 * 33;
+    float* scrD = scrX + L::SCR_TILE;
     float* cb = lds + L::CB;
     const float* cbw = cb + wave * 32 * 8;       // this wave's 32 rows of the composite buffer
     const float scale = a.pe_scale.p[obj * a.pe_scale.stride];
@@ -860,8 +1045,11 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
     __syncthreads();
     VK_MARK(5);
 
-    composite_phase<BWD>(a, cb, lds + L::LOSS, obj, ray0, nrays, wave, lane, tid,
-                         load_ray_meta(a, obj, ray0 + min(4 * wave + (lane >> 4), nrays - 1)));
+    {
+        const StepArgs& al = wv::kernarg_late(a);      // batch pointers, strides and loss weights: fetched here
+        composite_phase<BWD>(al, cb, lds + L::LOSS, obj, ray0, nrays, wave, lane, tid,
+                             load_ray_meta(al, obj, ray0 + min(4 * wave + (lane >> 4), nrays - 1)));
+    }
     __syncthreads();
     VK_MARK(6);
     if (BWD) {
@@ -877,12 +1065,16 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
     for (int d = 0; d < kDirs; ++d) dproj[d] = 0.0f;
 
     // heads: out_alpha / out_color weight + bias gradients (lane = hidden feature)
+    float gb_c = 0.0f;   // bias gradients of the five hidden layers (lane = feature), stored after the last unit
+    float w[16];     // weight-column operands of the next d-prop chain (fetched during the previous dW chain)
     float dcp[16];   // d hc (pre-activation), P-form
     float d4[16];    // d h4 (pre-activation), P-form
     {
         float h4F[16];
-        to_F(h4F, h4, scrX, p31, hi);
-        to_F(xF, hc, scrD, p31, hi);             // hcF
+        toF_put(scrX, h4, p31, hi);
+        toF_put(scrD, hc, p31, hi);
+        toF_get(h4F, scrX, p31, hi);
+        toF_get(xF, scrD, p31, hi);              // hcF
         float ga = 0.0f, g0 = 0.0f, g1 = 0.0f, g2 = 0.0f, sa = 0.0f, s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -911,118 +1103,136 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
         for (int r = 0; r < 16; ++r) {
             const int j = phi(r, hi);
             const float v = W[L::W_OC + j] * d_c0 + W[L::W_OC + H + j] * d_c1 + W[L::W_OC + 2 * H + j] * d_c2;
-            dcp[r] = hc[r] > 0.0f ? v : 0.0f;
+            dcp[r] = wv::opaque(hc[r]) > 0.0f ? v : 0.0f;
         }
-        // color_linear: delta = d hc.  Source order = issue a transpose, run the independent d-prop chain, then the
-        // dW block that consumes the transposed operand (the LDS round trip hides under 16 matrix instructions).
-        to_F(dF, dcp, scrD, p31, hi);
-        add_db(Gv + L::B_C, dF, p31, hi);
+        // ---- 13 units, one 32x32 weight-gradient block each.  A unit = d-prop chain (16 matrix instructions carrying
+        // the unit's transposes and the staging of the previous block), workgroup barrier, reduction + store of the
+        // previous block, the VALU work that needs the chain's result, then the dW chain (16 matrix instructions
+        // carrying the weight-column loads of the next unit). ----
         f32x16 acc2;
+        // unit 0: color_linear, x = h4 (already transposed for the heads)
+        bwd_w<L::LD_C>(w, W + L::W_C + 4 * hi * L::LD_C + p31);
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc2[r] = W[L::W_A + phi(r, hi)] * d_raw;       // d h4 = W_a d raw + W_c[:, :H]^T d hc
-        bwd_mm<L::LD_C>(acc2, W + L::W_C + 4 * hi * L::LD_C + p31, dcp);
+        p_chain<true, false, false>(acc2, w, dcp, scrD, dcp, dF, scrX, dcp, xF, stg0, acc, wave, p31, hi);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) d4[r] = h4[r] > 0.0f ? acc2[r] : 0.0f;
-        zero_acc(acc); dw_mm(acc, dF, h4F);
-        emit_block<MULTI, H + kEmb2>(qacc[0], acc, stg0, out + F::W_C, 0, 32, wave, p31, hi);
-        to_F(xF, e2a, scrX, p31, hi);
+        for (int r = 0; r < 16; ++r) d4[r] = wv::opaque(h4[r]) > 0.0f ? acc2[r] : 0.0f;
+        gb_c = db_sum(dF);
+        zero_acc(acc);
+        dw_chain<L::LD_C>(acc, dF, h4F, w, W + L::W_C + 4 * hi * L::LD_C + H + p31);
+        // unit 1: x = e2 block 0
         zero_acc(acc2);
-        bwd_mm<L::LD_C>(acc2, W + L::W_C + 4 * hi * L::LD_C + H + p31, dcp);          // d e2 (block 0)
+        p_chain<false, true, true>(acc2, w, dcp, scrD, dcp, dF, scrX, e2a, xF, stg0, acc, wave, p31, hi);   // d e2 (block 0)
+        __syncthreads();
         pe_block_bwd<16>(dproj, acc2, c2a, kEmb1, kEmb2, 0, hi);
-        zero_acc(acc); dw_mm(acc, dF, xF);
-        emit_block<MULTI, H + kEmb2>(qacc[1], acc, stg1, out + F::W_C, H, 32, wave, p31, hi);
-        to_F(xF, e2b, scrX, p31, hi);
+        zero_acc(acc);
+        dw_chain_fin<L::LD_C, MULTI, H + kEmb2>(acc, dF, xF, w, W + L::W_C + 4 * hi * L::LD_C + H + min(32 + p31, 46),
+                     qacc[0], stg0, out + F::W_C, 0, 32, wave, p31, hi);
+        // unit 2: x = e2 block 1
         zero_acc(acc2);
-        bwd_mm<L::LD_C>(acc2, W + L::W_C + 4 * hi * L::LD_C + H + min(32 + p31, 46), dcp);
+        p_chain<false, true, true>(acc2, w, dcp, scrD, dcp, dF, scrX, e2b, xF, stg1, acc, wave, p31, hi);
+        __syncthreads();
         pe_block_bwd<6>(dproj, acc2, c2b, kEmb1, kEmb2, 1, hi);
-        zero_acc(acc); dw_mm(acc, dF, xF);
-        emit_block<MULTI, H + kEmb2>(qacc[2], acc, stg0, out + F::W_C, H + 32, kEmb2 - 32, wave, p31, hi);
+        zero_acc(acc);
+        dw_chain_fin<L::LD_M, MULTI, H + kEmb2>(acc, dF, xF, w, W + L::W_M2 + 4 * hi * L::LD_M + p31,
+                     qacc[1], stg1, out + F::W_C, H, 32, wave, p31, hi);
     }
     VK_MARK(7);
     VK_MARK(8);
-    // mid2
-    float d3[16];
-    {
-        to_F(dF, d4, scrD, p31, hi);
-        to_F(xF, h3, scrX, p31, hi);
-        add_db(Gv + L::B_M2, dF, p31, hi);
-        f32x16 acc2;
-        zero_acc(acc2);
-        bwd_mm<L::LD_M>(acc2, W + L::W_M2 + 4 * hi * L::LD_M + p31, d4);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) d3[r] = h3[r] > 0.0f ? acc2[r] : 0.0f;
-        zero_acc(acc); dw_mm(acc, dF, xF);
-        emit_block<MULTI, H>(qacc[3], acc, stg1, out + F::W_M2, 0, 32, wave, p31, hi);
-    }
-    VK_MARK(9);
-    // cat_layer
-    float d2[16];
-    f32x16 de1a, de1b, de1c;
-    {
-        const float* wc = W + L::W_CAT + 4 * hi * L::LD_CAT;
-        to_F(dF, d3, scrD, p31, hi);
-        add_db(Gv + L::B_CAT, dF, p31, hi);
-        to_F(xF, h2, scrX, p31, hi);
-        f32x16 acc2;
-        zero_acc(acc2);
-        bwd_mm<L::LD_CAT>(acc2, wc + p31, d3);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) d2[r] = h2[r] > 0.0f ? acc2[r] : 0.0f;
-        zero_acc(acc); dw_mm(acc, dF, xF);
-        emit_block<MULTI, H + kEmb1>(qacc[4], acc, stg0, out + F::W_CAT, 0, 32, wave, p31, hi);
-        to_F(xF, e1a, scrX, p31, hi);
-        zero_acc(de1a); bwd_mm<L::LD_CAT>(de1a, wc + H + p31, d3);
-        zero_acc(acc); dw_mm(acc, dF, xF);
-        emit_block<MULTI, H + kEmb1>(qacc[5], acc, stg1, out + F::W_CAT, H, 32, wave, p31, hi);
-        to_F(xF, e1b, scrX, p31, hi);
-        zero_acc(de1b); bwd_mm<L::LD_CAT>(de1b, wc + H + 32 + p31, d3);
-        zero_acc(acc); dw_mm(acc, dF, xF);
-        emit_block<MULTI, H + kEmb1>(qacc[6], acc, stg0, out + F::W_CAT, H + 32, 32, wave, p31, hi);
-        to_F(xF, e1c, scrX, p31, hi);
-        zero_acc(de1c); bwd_mm<L::LD_CAT>(de1c, wc + H + min(64 + p31, 88), d3);
-        zero_acc(acc); dw_mm(acc, dF, xF);
-        emit_block<MULTI, H + kEmb1>(qacc[7], acc, stg1, out + F::W_CAT, H + 64, kEmb1 - 64, wave, p31, hi);
-    }
-    VK_MARK(10);
-    // mid1
-    float d1[16];
-    {
-        to_F(dF, d2, scrD, p31, hi);
-        to_F(xF, h1, scrX, p31, hi);
-        add_db(Gv + L::B_M1, dF, p31, hi);
-        f32x16 acc2;
-        zero_acc(acc2);
-        bwd_mm<L::LD_M>(acc2, W + L::W_M1 + 4 * hi * L::LD_M + p31, d2);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) d1[r] = h1[r] > 0.0f ? acc2[r] : 0.0f;
-        zero_acc(acc); dw_mm(acc, dF, xF);
-        emit_block<MULTI, H>(qacc[8], acc, stg0, out + F::W_M1, 0, 32, wave, p31, hi);
-    }
-    VK_MARK(11);
-    // in_layer + encoding backward
     float e1aF[16];
     {
+        float d3[16], dn[16], dF3[16];
+        f32x16 acc2, de;
+        const float* wc = W + L::W_CAT + 4 * hi * L::LD_CAT;
         const float* wi = W + L::W_IN + 4 * hi * L::LD_IN;
-        to_F(dF, d1, scrD, p31, hi);
-        add_db(Gv + L::B_IN, dF, p31, hi);
-        to_F(e1aF, e1a, scrX, p31, hi);
-        bwd_mm<L::LD_IN>(de1a, wi + p31, d1);
-        zero_acc(acc); dw_mm(acc, dF, e1aF);
-        emit_block<MULTI, kEmb1>(qacc[9], acc, stg1, out + F::W_IN, 0, 32, wave, p31, hi);
-        to_F(xF, e1b, scrX, p31, hi);
-        bwd_mm<L::LD_IN>(de1b, wi + 32 + p31, d1);
-        zero_acc(acc); dw_mm(acc, dF, xF);
-        emit_block<MULTI, kEmb1>(qacc[10], acc, stg0, out + F::W_IN, 32, 32, wave, p31, hi);
-        to_F(xF, e1c, scrX, p31, hi);
-        bwd_mm<L::LD_IN>(de1c, wi + min(64 + p31, 88), d1);
-        zero_acc(acc); dw_mm(acc, dF, xF);
-        emit_block<MULTI, kEmb1>(qacc[11], acc, stg1, out + F::W_IN, 64, kEmb1 - 64, wave, p31, hi);
-        pe_block_bwd<16>(dproj, de1a, c1a, 0, kEmb1, 0, hi);
-        pe_block_bwd<16>(dproj, de1b, c1b, 0, kEmb1, 1, hi);
-        pe_block_bwd<12>(dproj, de1c, c1c, 0, kEmb1, 2, hi);
+        // unit 3: mid2, delta = d4, x = h3
+        zero_acc(acc2);
+        p_chain<true, true, true>(acc2, w, d4, scrD, d4, dF, scrX, h3, xF, stg0, acc, wave, p31, hi);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d3[r] = wv::opaque(h3[r]) > 0.0f ? acc2[r] : 0.0f;
+        const float gb_m2 = db_sum(dF);
+        zero_acc(acc);
+        dw_chain_fin<L::LD_CAT, MULTI, H + kEmb2>(acc, dF, xF, w, wc + p31,
+                     qacc[2], stg0, out + F::W_C, H + 32, kEmb2 - 32, wave, p31, hi);
+        VK_MARK(9);
+        // unit 4: cat_layer, delta = d3 (its transpose dF3 is kept for the three e1 blocks), x = h2
+        zero_acc(acc2);
+        p_chain<true, true, true>(acc2, w, d3, scrD, d3, dF3, scrX, h2, xF, stg1, acc, wave, p31, hi);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dn[r] = wv::opaque(h2[r]) > 0.0f ? acc2[r] : 0.0f;          // d2
+        const float gb_cat = db_sum(dF3);
+        zero_acc(acc);
+        dw_chain_fin<L::LD_M, MULTI, H>(acc, dF3, xF, w, W + L::W_M1 + 4 * hi * L::LD_M + p31,
+                     qacc[3], stg1, out + F::W_M2, 0, 32, wave, p31, hi);
+        VK_MARK(10);
+        // unit 5: mid1, delta = d2, x = h1
+        zero_acc(acc2);
+        p_chain<true, true, true>(acc2, w, dn, scrD, dn, dF, scrX, h1, xF, stg0, acc, wave, p31, hi);
+        __syncthreads();
+        const float gb_m1 = db_sum(dF);
+        zero_acc(acc);
+        dw_chain_fin<L::LD_CAT, MULTI, H + kEmb1>(acc, dF, xF, w, wc + H + p31,
+                     qacc[4], stg0, out + F::W_CAT, 0, 32, wave, p31, hi);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dn[r] = wv::opaque(h1[r]) > 0.0f ? acc2[r] : 0.0f;          // d1 (d2 is dead: its chain is done)
+        VK_MARK(11);
+        // units 6..11: the three blocks of e1 feed both cat_layer (delta d3) and in_layer (delta d1): one transpose of
+        // the block, two d-prop chains into the same accumulator, two weight-gradient blocks
+        // unit 6: cat_layer x e1 block 0
+        zero_acc(de);
+        p_chain<false, true, true>(de, w, d3, scrD, d3, dF, scrX, e1a, e1aF, stg1, acc, wave, p31, hi);
+        __syncthreads();
+        zero_acc(acc);
+        dw_chain_fin<L::LD_IN, MULTI, H>(acc, dF3, e1aF, w, wi + p31,
+                     qacc[8], stg1, out + F::W_M1, 0, 32, wave, p31, hi);
+        // unit 7: in_layer x e1 block 0 (transposes delta d1 once)
+        p_chain<true, false, true>(de, w, dn, scrD, dn, dF, scrX, dn, xF, stg0, acc, wave, p31, hi);
+        __syncthreads();
+        const float gb_in = db_sum(dF);
+        pe_block_bwd<16>(dproj, de, c1a, 0, kEmb1, 0, hi);
+        zero_acc(acc);
+        dw_chain_fin<L::LD_CAT, MULTI, H + kEmb1>(acc, dF, e1aF, w, wc + H + 32 + p31,
+                     qacc[5], stg0, out + F::W_CAT, H, 32, wave, p31, hi);
+        // unit 8: cat_layer x e1 block 1
+        zero_acc(de);
+        p_chain<false, true, true>(de, w, d3, scrD, d3, dF, scrX, e1b, xF, stg1, acc, wave, p31, hi);
+        __syncthreads();
+        zero_acc(acc);
+        dw_chain_fin<L::LD_IN, MULTI, kEmb1>(acc, dF3, xF, w, wi + 32 + p31,
+                     qacc[9], stg1, out + F::W_IN, 0, 32, wave, p31, hi);
+        // unit 9: in_layer x e1 block 1
+        p_chain<false, false, true>(de, w, dn, scrD, dn, dF, scrX, dn, xF, stg0, acc, wave, p31, hi);
+        __syncthreads();
+        pe_block_bwd<16>(dproj, de, c1b, 0, kEmb1, 1, hi);
+        zero_acc(acc);
+        dw_chain_fin<L::LD_CAT, MULTI, H + kEmb1>(acc, dF, xF, w, wc + H + min(64 + p31, 88),
+                     qacc[6], stg0, out + F::W_CAT, H + 32, 32, wave, p31, hi);
+        // unit 10: cat_layer x e1 block 2
+        zero_acc(de);
+        p_chain<false, true, true>(de, w, d3, scrD, d3, dF, scrX, e1c, xF, stg1, acc, wave, p31, hi);
+        __syncthreads();
+        zero_acc(acc);
+        dw_chain_fin<L::LD_IN, MULTI, kEmb1>(acc, dF3, xF, w, wi + min(64 + p31, 88),
+                     qacc[10], stg1, out + F::W_IN, 32, 32, wave, p31, hi);
+        // unit 11: in_layer x e1 block 2
+        p_chain<false, false, true>(de, w, dn, scrD, dn, dF, scrX, dn, xF, stg0, acc, wave, p31, hi);
+        __syncthreads();
+        pe_block_bwd<12>(dproj, de, c1c, 0, kEmb1, 2, hi);
+        zero_acc(acc);
+        dw_chain_fin<0, MULTI, H + kEmb1>(acc, dF, xF, w, wi,
+                     qacc[7], stg0, out + F::W_CAT, H + 64, kEmb1 - 64, wave, p31, hi);
+        if (hi == 0) {
+            Gv[L::B_C + p31] += gb_c;
+            Gv[L::B_M2 + p31] += gb_m2;
+            Gv[L::B_CAT + p31] += gb_cat;
+            Gv[L::B_M1 + p31] += gb_m1;
+            Gv[L::B_IN + p31] += gb_in;
+        }
     }
     VK_MARK(12);
-    // B_layer.weight gradient: dB[d][j] = sum_points dproj[d] * t[j]  (t = encoding columns 0..2)
+    // unit 12: B_layer.weight gradient: dB[d][j] = sum_points dproj[d] * t[j]  (t = encoding columns 0..2)
     {
         float dpP[16];
 #pragma unroll
@@ -1034,13 +1244,19 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
             const float v1 = f1 < kDirs ? dproj[f1 < kDirs ? f1 : 0] : 0.0f;
             dpP[r] = hi ? v1 : v0;
         }
-        to_F(dF, dpP, scrD, p31, hi);
+        toF_put(scrD, dpP, p31, hi);
+        toF_get(dF, scrD, p31, hi);
+        stage_put(stg1, acc, wave, p31, hi);
+        __syncthreads();
+        finish_block<MULTI, kEmb1>(qacc[11], stg1, out + F::W_IN, 64, kEmb1 - 64, wave, p31, hi);
         zero_acc(acc); dw_mm(acc, dF, e1aF);
+        stage_put(stg0, acc, wave, p31, hi);
+        __syncthreads();
         if (MULTI) {
-            reduce_block(qacc[12], acc, stg0, wave, p31, hi);   // rows = direction d (21 valid), cols 0..2 = xyz
+            stage_get(qacc[12], stg0, wave, p31, hi);           // rows = direction d (21 valid), cols 0..2 = xyz
         } else {
             float q[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            reduce_block(q, acc, stg0, wave, p31, hi);
+            stage_get(q, stg0, wave, p31, hi);
             if (p31 < 3) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -1052,6 +1268,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
     }
     VK_MARK(13);
     }   // BWD
+    if (!MULTI) break;      // one pass per workgroup: no back edge, so nothing of the body is hoisted to the entry
     }   // pass loop
     __syncthreads();
     VK_MARK(14);

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "../../include/vmapstep.h"
@@ -496,16 +497,25 @@ int vmapstep_query_points(int32_t hidden, const vmapstep_params* params, const v
     q.scale = pe_scale->ptr + (long long)obj_index * pe_scale->obj_stride;
     q.pts = points; q.pts_sn = points_stride[0]; q.pts_sc = points_stride[1];
     q.n_pts = n_points; q.occ = occupancy; q.rgb = color;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(vk::field_query_h32),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, vk::Lds32::IMGP * sizeof(float));
+    static int wpe = 0;
+    if (!wpe) {
+        const char* ev = std::getenv("VMAPSTEP_QUERY_WPE");          // measurement knob: waves per SIMD of the query kernel
+        int v = ev ? std::atoi(ev) : 2;
+        if (v < 1 || v > 3) v = 2;
+        const void* fn = v == 1 ? reinterpret_cast<const void*>(vk::field_query_h32<1>)
+                       : v == 2 ? reinterpret_cast<const void*>(vk::field_query_h32<2>)
+                                : reinterpret_cast<const void*>(vk::field_query_h32<3>);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, vk::Lds32::IMGP * sizeof(float));
         if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_set = true;
+        wpe = v;
     }
     const long long chunks = (n_points + vk::kMaxPts - 1) / vk::kMaxPts;
-    const int grid = (int)(chunks < 768 ? chunks : 768);          // 3 resident workgroups per CU share the matrix pipes
-    hipLaunchKernelGGL(vk::field_query_h32, dim3(grid), dim3(vk::kWG), vk::Lds32::IMGP * sizeof(float), st, q);
+    const long long cap = 256LL * wpe;                             // resident workgroups: wpe per CU
+    const int grid = (int)(chunks < cap ? chunks : cap);
+    const size_t lds = vk::Lds32::IMGP * sizeof(float);
+    if (wpe == 1) hipLaunchKernelGGL(vk::field_query_h32<1>, dim3(grid), dim3(vk::kWG), lds, st, q);
+    else if (wpe == 2) hipLaunchKernelGGL(vk::field_query_h32<2>, dim3(grid), dim3(vk::kWG), lds, st, q);
+    else hipLaunchKernelGGL(vk::field_query_h32<3>, dim3(grid), dim3(vk::kWG), lds, st, q);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "field_query launch: %s", hipGetErrorString(e));
     return VMAPSTEP_OK;

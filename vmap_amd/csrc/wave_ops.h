@@ -8,6 +8,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// occupancy request of a kernel: exactly n waves per SIMD (the register allocator's budget is 512 / n)
+#define WV_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n, n)))
+
 namespace wv {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -73,6 +76,28 @@ extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds_bytes[];
 __device__ __forceinline__ float* lds_base() { return reinterpret_cast<float*>(dyn_lds_bytes); }
 
 // shader-clock timestamp (low 32 bits of s_memtime)
+// The kernel's by-value argument struct, re-read from the kernarg segment at the point of use.  Fields accessed
+// through the function parameter are all fetched in the prologue; a kernel that keeps 500 vector registers live has
+// no scalar registers to park them in, and every later use becomes a v_readlane of a spilled SGPR.  A phase that
+// needs a dozen pointers and strides reads them here instead (scalar loads, one latency per phase).
+template <class T>
+__device__ __forceinline__ const T& kernarg_late(const T&) {
+    auto p = (const __attribute__((address_space(4))) T*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return *(const T*)p;
+}
+
+// The value, with its origin hidden from the optimiser (no instruction).  The backward's ReLU masks test opaque(h) > 0:
+// given the plain h = max(acc, 0) the compiler proves (h > 0) == (acc > 0), evaluates all 80 masks during the forward
+// and parks them in 160 spilled SGPRs.
+__device__ __forceinline__ float opaque(float x) {
+    asm("" : "+v"(x));
+    return x;
+}
+
+// nothing may be moved across this point by the instruction scheduler (hand-placed software pipelining)
+__device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+
 __device__ __forceinline__ unsigned clock32() { return (unsigned)__builtin_amdgcn_s_memtime(); }
 
 __device__ __forceinline__ void lds_add(float* p, float v) { atomicAdd(p, v); }   // ds_add_f32
