@@ -58,7 +58,7 @@ extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req, int xcd
     a.part_grad = part_grad.data(); a.part_loss = part_loss.data(); a.wimg = wimg.data();
     a.dbg_depth = dbg_depth; a.dbg_rgb = dbg_rgb; a.dbg_opacity = dbg_opacity; a.dbg_var = dbg_var;
 
-    sim::launch(1 + n, vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep(a); });
+    sim::launch(1 + n * (vk::gen_layout(H).imgp / 1024), vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep(a); });
     const bool multi = NW < NG;
     const int grid = xcd_affine && H == 32 ? 8 * ((n + 7) / 8) * NW : n * NW;
     if (H == 32) {
@@ -124,7 +124,7 @@ extern "C" int vmsim_query(const float* const* fc, const float* B, const float* 
     for (int t = 0; t < 14; ++t) a.fc[t] = {const_cast<float*>(fc[t]), 0};
     a.pe_B = {const_cast<float*>(B), 0};
     a.wimg = img.data();
-    sim::launch(1, vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep(a); });
+    sim::launch(vk::Lds32::IMGP / 1024, vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep(a); });
     vk::QueryArgs q{};
     q.wimg = img.data(); q.scale = scale; q.pts = pts; q.pts_sn = 3; q.pts_sc = 1; q.n_pts = n_pts; q.occ = occ; q.rgb = rgb;
     sim::launch(grid, vk::kWG, vk::Lds32::IMGP * 4, [&] { vk::field_query_h32<2>(q); });

@@ -219,6 +219,33 @@ __device__ __forceinline__ int gen_image_index(const GenLayout& L, int t, int o)
     }
 }
 
+// inverse: which tensor element sits at image position x (false = zero padding)
+__device__ __forceinline__ bool gen_image_source(const GenLayout& L, int x, int& t, int& o) {
+    const int H = L.H;
+    if (x < L.b_in) {
+        int base, ld, nc;
+        if (x < L.w_m1) { t = 0; base = L.w_in; ld = L.ld_in; nc = kEmb1; }
+        else if (x < L.w_cat) { t = 2; base = L.w_m1; ld = L.ld_m; nc = H; }
+        else if (x < L.w_m2) { t = 4; base = L.w_cat; ld = L.ld_cat; nc = H + kEmb1; }
+        else if (x < L.w_c) { t = 6; base = L.w_m2; ld = L.ld_m; nc = H; }
+        else { t = 10; base = L.w_c; ld = L.ld_c; nc = H + kEmb2; }
+        const int r = (x - base) / ld, c = (x - base) - r * ld;
+        o = r * nc + c;
+        return c < nc;
+    }
+    if (x < L.b_m1) { t = 1; o = x - L.b_in; return true; }
+    if (x < L.b_cat) { t = 3; o = x - L.b_m1; return true; }
+    if (x < L.b_m2) { t = 5; o = x - L.b_cat; return true; }
+    if (x < L.b_c) { t = 7; o = x - L.b_m2; return true; }
+    if (x < L.w_a) { t = 11; o = x - L.b_c; return true; }
+    if (x < L.w_oc) { t = 8; o = x - L.w_a; return true; }
+    if (x < L.b_a) { t = 12; o = x - L.w_oc; return true; }
+    if (x < L.b_oc) { t = 9; o = x - L.b_a; return o < 1; }
+    if (x < L.pe_b) { t = 13; o = x - L.b_oc; return o < 3; }
+    t = 14; o = x - L.pe_b;
+    return o < 63;
+}
+
 // float32 -> nearest bfloat16 (ties to even), returned as float32
 __device__ __forceinline__ float round_bf16(float x) {
     unsigned u = __float_as_uint(x);
@@ -808,66 +835,70 @@ __device__ __forceinline__ void composite_phase(const StepArgs& a, float* cb, fl
 // step_prep, one launch per API call:
 //   blocks [0, prep_steps)            per-object mask counts of step b and the batch-wide "any object has an
 //                                     empty mask" switches (loss.py:16-19,38,46,56; render_rays.py:68-73)
-//   blocks [prep_steps, +n_obj)       pack object k's 15 tensors into its LDS-layout parameter image
+//   blocks [prep_steps, +n_obj*imgp/1024)  pack the objects' 15 tensors into their LDS-layout parameter images
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kWG) void step_prep(const StepArgs a) {
     const int tid = threadIdx.x;
     if ((int)blockIdx.x >= a.prep_steps) {
+        // pack: imgp / 1024 workgroups per object, one 16-byte image slot per thread (destination-major: the zero
+        // padding is written by the same pass, no barrier, coalesced stores)
         const GenLayout L = gen_layout(a.hidden);
-        const int k = blockIdx.x - a.prep_steps;
-        float* img = a.wimg + (long long)k * L.imgp;
-        for (int i = tid; i < L.imgp; i += kWG) img[i] = 0.0f;
-        __syncthreads();
-        for (int i = tid; i < L.P; i += kWG) {
-            int t = 0;
+        const int per_obj = L.imgp / 1024;
+        const int b = blockIdx.x - a.prep_steps;
+        const int k = b / per_obj;
+        const int x0 = (b - k * per_obj) * 1024 + 4 * tid;
+        wv::f32x4 v;
 #pragma unroll
-            for (int q = 1; q < 15; ++q) t += i >= L.f[q];
-            const int o = i - L.f[t];
-            const float v = t < kNFc ? a.fc[t].p[k * a.fc[t].stride + o] : a.pe_B.p[k * a.pe_B.stride + o];
-            img[gen_image_index(L, t, o)] = a.weights_bf16 ? round_bf16(v) : v;
+        for (int e = 0; e < 4; ++e) {
+            int t, o;
+            float f = 0.0f;
+            if (gen_image_source(L, x0 + e, t, o))
+                f = t < kNFc ? a.fc[t].p[k * a.fc[t].stride + o] : a.pe_B.p[k * a.pe_B.stride + o];
+            v[e] = a.weights_bf16 ? round_bf16(f) : f;
         }
+        *reinterpret_cast<wv::f32x4*>(a.wimg + (long long)k * L.imgp + x0) = v;
         return;
     }
-    float* lds = wv::lds_base();   // 3 * kWG ints worth
-    int* cnt = reinterpret_cast<int*>(lds);
+    // one wave per object (objects w, w+4, ...): per-lane counts over the rays, a shuffle tree, no workgroup barrier
+    // per object (the old form - one block reduction per object, 20 in sequence - took 25 us per frame)
+    float* lds = wv::lds_base();
+    int* dropw = reinterpret_cast<int*>(lds);          // [kWaves]
+    const int lane = tid & 63, wave = tid >> 6;
     const int step = blockIdx.x;                       // one workgroup per optimisation step of the frame
     const unsigned char* sem = a.sem + step * a.prep_ray_step * a.sem_sr;
     const unsigned char* dmask = a.dmask + step * a.prep_ray_step * a.dm_sr;
     float* stats = a.stats + (long long)step * a.n_obj * 4;
     int* flags = a.flags + step * 4;
-    int drop_d = 0, drop_c = 0, drop_o = 0;
-    for (int k = 0; k < a.n_obj; ++k) {
-        int nd = 0, no = 0, ns = 0;
-        for (int r = tid; r < a.R; r += kWG) {
+    int drop = 0;                                      // bit 0 depth, bit 1 colour, bit 2 opacity
+    for (int k = wave; k < a.n_obj; k += kWaves) {
+        float nd = 0.0f, no = 0.0f, ns = 0.0f;         // counts < 2^24: exact in float32
+        for (int r = lane; r < a.R; r += 64) {
             const unsigned char s = sem[k * a.sem_so + r * a.sem_sr];
             const unsigned char dm = dmask[k * a.dm_so + r * a.dm_sr];
-            const int mo = s != 0, ms = s != 2;
-            nd += (dm != 0) && mo;
-            no += mo;
-            ns += ms;
+            const bool mo = s != 0, ms = s != 2;
+            nd += ((dm != 0) && mo) ? 1.0f : 0.0f;
+            no += mo ? 1.0f : 0.0f;
+            ns += ms ? 1.0f : 0.0f;
         }
-        cnt[tid] = nd; cnt[kWG + tid] = no; cnt[2 * kWG + tid] = ns;
-        __syncthreads();
-        for (int w = kWG / 2; w > 0; w >>= 1) {
-            if (tid < w) {
-                cnt[tid] += cnt[tid + w];
-                cnt[kWG + tid] += cnt[kWG + tid + w];
-                cnt[2 * kWG + tid] += cnt[2 * kWG + tid + w];
-            }
-            __syncthreads();
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) {
+            nd += wv::shfl(nd, lane ^ m); no += wv::shfl(no, lane ^ m); ns += wv::shfl(ns, lane ^ m);
         }
-        nd = cnt[0]; no = cnt[kWG]; ns = cnt[2 * kWG];
-        __syncthreads();
-        if (tid == 0) {
-            stats[k * 4 + 0] = (float)nd;   // raw counts: a ray-sharded caller (shared background model) sums them over
-            stats[k * 4 + 1] = (float)no;   // ranks before the step loop; the normaliser 1/(N+1e-10) is formed in step_main
-            stats[k * 4 + 2] = (float)ns;
+        if (lane == 0) {
+            stats[k * 4 + 0] = nd;          // raw counts: a ray-sharded caller (shared background model) sums them over
+            stats[k * 4 + 1] = no;          // ranks before the step loop; the normaliser 1/(N+1e-10) is formed in step_main
+            stats[k * 4 + 2] = ns;
             stats[k * 4 + 3] = 0.0f;
         }
-        drop_d |= nd == 0; drop_c |= no == 0; drop_o |= ns == 0;
+        drop |= (nd == 0.0f ? 1 : 0) | (no == 0.0f ? 2 : 0) | (ns == 0.0f ? 4 : 0);
     }
+    if (lane == 0) dropw[wave] = drop;
+    __syncthreads();
     if (tid == 0) {
-        flags[0] = drop_d; flags[1] = drop_c; flags[2] = drop_o; flags[3] = 0;
+        int d = 0;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) d |= dropw[w];
+        flags[0] = d & 1; flags[1] = (d >> 1) & 1; flags[2] = (d >> 2) & 1; flags[3] = 0;
     }
 }
 
@@ -1361,7 +1392,25 @@ __global__ __launch_bounds__(kWG) void step_finalize(const FinalizeArgs a) {
         const int i0 = 4 * q4;
         const wv::f32x4* pg = reinterpret_cast<const wv::f32x4*>(a.part_grad + (long long)obj * a.NW * a.PP + i0);
         wv::f32x4 g = {0.0f, 0.0f, 0.0f, 0.0f};
-        for (int q = 0; q < a.NW; ++q) g += pg[(long long)q * (a.PP / 4)];
+        {
+            // ordered sum over the NW partials; eight independent 16-byte loads in flight per lane (the kernel is
+            // latency-bound: 240 workgroups of one wave per SIMD, 10 MB to read)
+            const long long qs = a.PP / 4;
+            int q = 0;
+            for (; q + 8 <= a.NW; q += 8) {
+                wv::f32x4 t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = pg[(q + u) * qs];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) g += t[u];
+            }
+            wv::f32x4 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = q + u < a.NW ? pg[(q + u) * qs] : wv::f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (q + u < a.NW) g += t[u];
+        }
         const long long s = (long long)obj * a.PP + i0;
         wv::f32x4 m4 = {0.0f, 0.0f, 0.0f, 0.0f}, v4 = m4;
         if (a.do_adam) {

@@ -178,7 +178,8 @@ int launch_main(const vk::StepArgs& a, hipStream_t st) {
 }
 
 int launch_prep(const vk::StepArgs& a, int n_steps, hipStream_t st) {
-    hipLaunchKernelGGL(vk::step_prep, dim3(n_steps + a.n_obj), dim3(vk::kWG), 3 * vk::kWG * sizeof(int), st, a);
+    const int pack_blocks = a.n_obj * (vk::gen_layout(a.hidden).imgp / 1024);
+    hipLaunchKernelGGL(vk::step_prep, dim3(n_steps + pack_blocks), dim3(vk::kWG), 3 * vk::kWG * sizeof(int), st, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "step_prep launch: %s", hipGetErrorString(e));
     return VMAPSTEP_OK;
@@ -491,7 +492,7 @@ int vmapstep_query_points(int32_t hidden, const vmapstep_params* params, const v
     for (int t = 0; t < VMAPSTEP_NUM_FC; ++t) a.fc[t] = {params->fc[t].ptr + (long long)obj_index * params->fc[t].obj_stride, 0};
     a.pe_B = {params->pe_B.ptr + (long long)obj_index * params->pe_B.obj_stride, 0};
     a.wimg = static_cast<float*>(workspace);
-    hipLaunchKernelGGL(vk::step_prep, dim3(1), dim3(vk::kWG), 3 * vk::kWG * sizeof(int), st, a);
+    hipLaunchKernelGGL(vk::step_prep, dim3(vk::Lds32::IMGP / 1024), dim3(vk::kWG), 3 * vk::kWG * sizeof(int), st, a);
     vk::QueryArgs q;
     q.wimg = a.wimg;
     q.scale = pe_scale->ptr + (long long)obj_index * pe_scale->obj_stride;
