@@ -84,6 +84,7 @@ template <class T>
 inline const T& kernarg_late(const T& a) { return a; }
 
 inline float opaque(float x) { return x; }
+inline int opaque_iter(int x) { return x; }
 
 inline void sched_fence() {}
 

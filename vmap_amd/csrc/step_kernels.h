@@ -955,7 +955,11 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
     const float scale = a.pe_scale.p[obj * a.pe_scale.stride];
     const float* Bg = a.wimg + (long long)obj * L::IMGP + L::PE_B;   // B_layer.weight, read from the (global) image
 
+    const int tid_k = tid;
     for (int grp = wgo; grp < a.NG; grp += a.NW) {   // ---- one pass = up to kMaxPts points (whole rays) ----
+    // lane coordinates of this pass (shadowing the kernel-scope ones): opaque per iteration in multi-pass mode
+    const int tid = MULTI ? wv::opaque_iter(tid_k) : tid_k;
+    const int lane = tid & 63, wave = tid >> 6, p31 = lane & 31, hi = lane >> 5;
     __syncthreads();                                 // previous pass finished reading the composite buffer
     for (int i = tid; i < kMaxPts * 8; i += kWG) cb[i] = 0.0f;   // padding rows must read as zero
 

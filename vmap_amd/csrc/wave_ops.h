@@ -95,6 +95,14 @@ __device__ __forceinline__ float opaque(float x) {
     return x;
 }
 
+// An integer the optimiser must assume changes at every execution (no instruction).  step_main_h32's multi-pass loop
+// re-derives its lane coordinates from opaque_iter(threadIdx.x): otherwise every lane mask and LDS address of the
+// 6000-instruction body is loop-invariant, gets hoisted in front of the loop and is kept in (spilled) registers.
+__device__ __forceinline__ int opaque_iter(int x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
 // nothing may be moved across this point by the instruction scheduler (hand-placed software pipelining)
 __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 
