@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VMAPSTEP_ABI_VERSION 2
+#define VMAPSTEP_ABI_VERSION 3
 #define VMAPSTEP_NUM_FC 14 /* field-MLP tensors per object, nn.Module.parameters() order (model.py:28-49) */
 
 #define VMAPSTEP_OK 0
@@ -173,7 +173,13 @@ typedef struct vmapstep_sample_object {      /* one entry per object, array live
     int32_t n_keyframes;
     int32_t last2[2];          /* the two latest keyframe slots (vmap.py:329-331)    */
     float center[3];           /* obj_center                                         */
-    int32_t pad;
+    int32_t obj_id;            /* shared-store mode: instance id of this object      */
+    /* Shared frame store (one copy of every frame for all objects instead of vmap.py:143-176's per-object buffers):
+     * slots == NULL: rgbs/depth/t_wc are this object's own [K] buffers.  slots != NULL: they are the store's arrays,
+     * keyframe k of the object is store slot slots[k] (< 256), byte 3 of a pixel is unused and the pixel state comes
+     * from the store's instance image `inst` (train.py:128-130). */
+    const int32_t* slots;      /* [K] or NULL                                        */
+    const int32_t* inst;       /* [C][W][H] or NULL                                  */
 } vmapstep_sample_object;
 
 typedef struct vmapstep_sample_cfg {

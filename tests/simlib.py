@@ -102,7 +102,7 @@ def sim_step(case_or_fc, B=None, scale=None, batch=None, G=None, bwd=True, adam=
 class _SimSampleObject(ctypes.Structure):
     _fields_ = [("rgbs", ctypes.c_void_p), ("depth", ctypes.c_void_p), ("t_wc", ctypes.c_void_p), ("bbox", ctypes.c_void_p),
                 ("n_keyframes", ctypes.c_int32), ("last2", ctypes.c_int32 * 2), ("center", ctypes.c_float * 3),
-                ("pad", ctypes.c_int32)]
+                ("obj_id", ctypes.c_int32), ("slots", ctypes.c_void_p), ("inst", ctypes.c_void_p)]
 
 
 def sim_sample(scenes, rnds, seed=0, frame_counter=0, eps=0.1, stop_eps=0.05):
@@ -117,10 +117,21 @@ def sim_sample(scenes, rnds, seed=0, frame_counter=0, eps=0.1, stop_eps=0.05):
     keep = []
     table = (_SimSampleObject * n)()
     for i, sc in enumerate(scenes):
+        if "store" in sc:      # shared frame store: dict(rgbx u8 [C,W,H,4], depth, inst i32, t_wc) + slots i32 [K] + obj_id
+            st = sc["store"]
+            arrs = [np.ascontiguousarray(st["rgbx"], dtype=np.uint8), np.ascontiguousarray(st["depth"], dtype=np.float32),
+                    np.ascontiguousarray(st["t_wc"], dtype=np.float32), np.ascontiguousarray(sc["bbox"], dtype=np.float32),
+                    np.ascontiguousarray(sc["slots"], dtype=np.int32), np.ascontiguousarray(st["inst"], dtype=np.int32)]
+            keep.append(arrs)
+            table[i] = _SimSampleObject(arrs[0].ctypes.data, arrs[1].ctypes.data, arrs[2].ctypes.data, arrs[3].ctypes.data,
+                                        sc["K"], (ctypes.c_int32 * 2)(*sc["last2"]), (ctypes.c_float * 3)(*[float(v) for v in sc["center"]]),
+                                        int(sc["obj_id"]), arrs[4].ctypes.data, arrs[5].ctypes.data)
+            continue
         arrs = [np.ascontiguousarray(sc[k]) for k in ("rgbs", "depth", "t_wc", "bbox")]
         keep.append(arrs)
         table[i] = _SimSampleObject(arrs[0].ctypes.data, arrs[1].ctypes.data, arrs[2].ctypes.data, arrs[3].ctypes.data,
-                                    sc["K"], (ctypes.c_int32 * 2)(*sc["last2"]), (ctypes.c_float * 3)(*[float(v) for v in sc["center"]]), 0)
+                                    sc["K"], (ctypes.c_int32 * 2)(*sc["last2"]), (ctypes.c_float * 3)(*[float(v) for v in sc["center"]]),
+                                    0, None, None)
     def cat(key, dt):
         if rnds is None:
             return None

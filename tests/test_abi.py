@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in _declared_functions():
         assert hasattr(lib, name), name
-    assert lib.vmapstep_abi_version() == 2
+    assert lib.vmapstep_abi_version() == 3
 
 
 @pytest.mark.parametrize("H", [32, 64, 128, 256])

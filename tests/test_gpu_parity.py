@@ -52,7 +52,7 @@ H32_CASES = [n for n, v in cases.CASES.items() if v[3] == 32]
 
 def test_native_library_is_loaded():
     lib = _lib.load()
-    assert lib.vmapstep_abi_version() == 2
+    assert lib.vmapstep_abi_version() == _lib.ABI_VERSION == 3
     assert torch.cuda.is_available()
     assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
 

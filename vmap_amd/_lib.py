@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvmapstep.so")
 
 NUM_FC = 14
-ABI_VERSION = 2
+ABI_VERSION = 3
 WEIGHTS_F32, WEIGHTS_BF16 = 0, 1
 
 
@@ -54,7 +54,7 @@ class AdamW(ctypes.Structure):
 class SampleObject(ctypes.Structure):
     _fields_ = [("rgbs", ctypes.c_void_p), ("depth", ctypes.c_void_p), ("t_wc", ctypes.c_void_p), ("bbox", ctypes.c_void_p),
                 ("n_keyframes", ctypes.c_int32), ("last2", ctypes.c_int32 * 2), ("center", ctypes.c_float * 3),
-                ("pad", ctypes.c_int32)]
+                ("obj_id", ctypes.c_int32), ("slots", ctypes.c_void_p), ("inst", ctypes.c_void_p)]
 
 
 class SampleCfg(ctypes.Structure):

@@ -32,7 +32,13 @@ struct SampleObject {                 // device-resident table, one entry per ob
     int n_keyframes;
     int last2[2];                     // the two latest keyframe slots (vmap.py:329-331)
     float center[3];                  // obj_center
-    int pad;
+    int obj_id;                       // shared-store mode: instance id of this object
+    // Shared frame store.  slots == nullptr: rgbs/depth/t_wc are this object's own [K] buffers
+    // as in the reference.  slots != nullptr: they are the arrays of ONE store shared by all objects, keyframe k of
+    // this object lives in store slot slots[k], the 4th byte of a pixel is unused and the pixel state is derived from
+    // the store's instance image (train.py:128-130: inst == obj_id -> 1 this, inst == -1 -> 2 unknown, else 0 other).
+    const int* slots;                 // [K] store slot (< 256) of every keyframe of this object, or nullptr
+    const int* inst;                  // [C][W][H] instance ids of the store, or nullptr
 };
 
 struct SampleRandoms {                // test mode: per-ray numbers supplied by the caller (all may be null)
@@ -109,11 +115,16 @@ __global__ __launch_bounds__(kWG) void frame_sample(const SampleArgs a) {
         const float* bb = ob.bbox + 4 * kf;
         const int iw = (int)(uw * (bb[1] - bb[0]) + bb[0]);                          // vmap.py:347,350 (.long() truncates)
         const int ih = (int)(uh * (bb[3] - bb[2]) + bb[2]);
-        const long long pix = ((long long)kf * a.W + iw) * a.H + ih;
-        const unsigned rgba = reinterpret_cast<const unsigned*>(ob.rgbs)[pix];       // vmap.py:353
+        const int slot = ob.slots ? ob.slots[kf] : kf;                               // where this keyframe's pixels and pose live
+        const long long pix = ((long long)slot * a.W + iw) * a.H + ih;
+        unsigned rgba = reinterpret_cast<const unsigned*>(ob.rgbs)[pix];             // vmap.py:353
+        if (ob.inst) {
+            const int id = ob.inst[pix];
+            rgba = (rgba & 0x00FFFFFFu) | (id == ob.obj_id ? (1u << 24) : id == -1 ? (2u << 24) : 0u);
+        }
         const float d = ob.depth[pix];                                               // vmap.py:354
         s_dep[ray] = d;
-        s_pix[ray] = (unsigned)iw | ((unsigned)ih << 12) | ((unsigned)kf << 24);
+        s_pix[ray] = (unsigned)iw | ((unsigned)ih << 12) | ((unsigned)slot << 24);
         s_rgba[ray] = rgba;
         dmax = fmaxf(dmax, d);
     }
@@ -129,7 +140,7 @@ __global__ __launch_bounds__(kWG) void frame_sample(const SampleArgs a) {
     // ---- C: depth samples and points ----
     for (int ray = tid; ray < FP; ray += kWG) {
         const unsigned px = s_pix[ray], rgba = s_rgba[ray];
-        const int iw = px & 0xFFF, ih = (px >> 12) & 0xFFF, kf = px >> 24;
+        const int iw = px & 0xFFF, ih = (px >> 12) & 0xFFF, kf = px >> 24;       // kf = slot of the pose
         const float d = s_dep[ray];
         const unsigned state = rgba >> 24;
         const bool invalid = d <= a.min_bound;                                        // vmap.py:389

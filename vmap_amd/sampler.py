@@ -33,23 +33,42 @@ class FrameSampler:
         self.n_obj = 0
 
     def set_objects(self, objects: Sequence[dict]):
-        """objects: per object dict(rgbs u8 [K,W,H,4], depth f32 [K,W,H], t_wc f32 [K,4,4], bbox f32 [K,4],
-        n_keyframes int, last2 (int, int), center (3 floats)); tensors on this sampler's device, contiguous."""
+        """objects: per object EITHER the reference's own buffers - dict(rgbs u8 [K,W,H,4], depth f32 [K,W,H], t_wc f32
+        [K,4,4], bbox f32 [K,4], n_keyframes int, last2 (int, int), center (3 floats)) - OR an entry over a shared frame
+        store (``keyframes.ObjectKeyframes.sampler_entry()``: dict(store, slots i32 [K], bbox, n_keyframes, last2,
+        center, obj_id)).  Tensors on this sampler's device, contiguous."""
         n = len(objects)
         host = (_lib.SampleObject * n)()
         keep = []
+
+        def chk(i, name, t, dt):
+            if t.dtype != dt or t.device != self.device or not t.is_contiguous():
+                raise ValueError(f"object {i}: {name} must be a contiguous {dt} tensor on {self.device}")
+
         for i, o in enumerate(objects):
-            for k, dt in (("rgbs", torch.uint8), ("depth", torch.float32), ("t_wc", torch.float32), ("bbox", torch.float32)):
-                t = o[k]
-                if t.dtype != dt or t.device != self.device or not t.is_contiguous():
-                    raise ValueError(f"object {i}: {k} must be a contiguous {dt} tensor on {self.device}")
-            keep.append((o["rgbs"], o["depth"], o["t_wc"], o["bbox"]))
             c = [float(v) for v in (o["center"].reshape(-1).tolist() if torch.is_tensor(o["center"]) else o["center"])]
             if len(c) == 1:
                 c = c * 3                                   # the reference's default obj_center is the scalar 0.0
-            host[i] = _lib.SampleObject(o["rgbs"].data_ptr(), o["depth"].data_ptr(), o["t_wc"].data_ptr(), o["bbox"].data_ptr(),
-                                        int(o["n_keyframes"]), (ctypes.c_int32 * 2)(*[int(v) for v in o["last2"]]),
-                                        (ctypes.c_float * 3)(*c), 0)
+            last2 = (ctypes.c_int32 * 2)(*[int(v) for v in o["last2"]])
+            chk(i, "bbox", o["bbox"], torch.float32)
+            if "store" in o:
+                st = o["store"]
+                if st.W != self.cfg.width or st.H != self.cfg.height:
+                    raise ValueError(f"object {i}: store is {st.W}x{st.H}, sampler is {self.cfg.width}x{self.cfg.height}")
+                chk(i, "slots", o["slots"], torch.int32)
+                for name, t, dt in (("store.rgbx", st.rgbx, torch.uint8), ("store.depth", st.depth, torch.float32),
+                                    ("store.t_wc", st.t_wc, torch.float32), ("store.inst", st.inst, torch.int32)):
+                    chk(i, name, t, dt)
+                keep.append((st.rgbx, st.depth, st.t_wc, st.inst, o["slots"], o["bbox"]))
+                host[i] = _lib.SampleObject(st.rgbx.data_ptr(), st.depth.data_ptr(), st.t_wc.data_ptr(), o["bbox"].data_ptr(),
+                                            int(o["n_keyframes"]), last2, (ctypes.c_float * 3)(*c), int(o["obj_id"]),
+                                            o["slots"].data_ptr(), st.inst.data_ptr())
+            else:
+                for k, dt in (("rgbs", torch.uint8), ("depth", torch.float32), ("t_wc", torch.float32)):
+                    chk(i, k, o[k], dt)
+                keep.append((o["rgbs"], o["depth"], o["t_wc"], o["bbox"]))
+                host[i] = _lib.SampleObject(o["rgbs"].data_ptr(), o["depth"].data_ptr(), o["t_wc"].data_ptr(), o["bbox"].data_ptr(),
+                                            int(o["n_keyframes"]), last2, (ctypes.c_float * 3)(*c), 0, None, None)
         raw = np.frombuffer(bytes(host), dtype=np.uint8).copy()
         self._table = torch.from_numpy(raw).to(self.device)
         self._keep = keep
