@@ -206,7 +206,8 @@ int vmapstep_sample_frame(const vmapstep_sample_cfg* cfg, const vmapstep_sample_
 /* ---- inference query -------------------------------------------------------------------
  * Occupancy sigmoid(alpha) and colour of ONE object's field (object `obj_index` of the stacked tensors) at `n_points`
  * arbitrary points of the object frame: what Trainer.eval_points (trainer.py:77-95) computes chunk by chunk for mesh
- * extraction.  hidden = 32 only in this version.  workspace >= vmapstep_query_workspace_bytes(). */
+ * extraction.  Any supported width (32: LDS-resident weights; 64..256: weights streamed from the L2-resident image).
+ * workspace >= vmapstep_query_workspace_bytes(hidden). */
 int vmapstep_query_workspace_bytes(int32_t hidden, size_t* bytes);
 int vmapstep_query_points(int32_t hidden, const vmapstep_params* params, const vmapstep_tensor* pe_scale, int32_t obj_index,
                           const float* points, int64_t n_points, const int64_t points_stride[2],

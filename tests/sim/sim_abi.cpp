@@ -115,18 +115,25 @@ extern "C" int vmsim_sample(const vs::SampleObject* objs, int n_obj, int W, int 
 }
 extern "C" int vmsim_sample_object_size() { return (int)sizeof(vs::SampleObject); }
 
-// query: pack the image of one object then run field_query_h32 (host pointers)
+// query: pack the image of one object then run the query kernel of that width (host pointers)
 extern "C" int vmsim_query(const float* const* fc, const float* B, const float* scale, const float* pts, long long n_pts,
-                           float* occ, float* rgb, int grid) {
-    std::vector<float> img(vk::Lds32::IMGP, NAN);
+                           float* occ, float* rgb, int grid, int H) {
+    const vk::GenLayout GL = vk::gen_layout(H);
+    std::vector<float> img(GL.imgp, NAN);
     vk::StepArgs a{};
-    a.n_obj = 1; a.hidden = 32; a.prep_steps = 0;
+    a.n_obj = 1; a.hidden = H; a.prep_steps = 0;
     for (int t = 0; t < 14; ++t) a.fc[t] = {const_cast<float*>(fc[t]), 0};
     a.pe_B = {const_cast<float*>(B), 0};
     a.wimg = img.data();
-    sim::launch(vk::Lds32::IMGP / 1024, vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep(a); });
+    sim::launch(GL.imgp / 1024, vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep(a); });
     vk::QueryArgs q{};
     q.wimg = img.data(); q.scale = scale; q.pts = pts; q.pts_sn = 3; q.pts_sc = 1; q.n_pts = n_pts; q.occ = occ; q.rgb = rgb;
-    sim::launch(grid, vk::kWG, vk::Lds32::IMGP * 4, [&] { vk::field_query_h32<2>(q); });
+    switch (H / 32) {
+        case 1: sim::launch(grid, vk::kWG, vk::Lds32::IMGP * 4, [&] { vk::field_query_h32<2>(q); }); break;
+        case 2: sim::launch(grid, vk::kWG, 64, [&] { vk::field_query_gen<2>(q); }); break;
+        case 4: sim::launch(grid, vk::kWG, 64, [&] { vk::field_query_gen<4>(q); }); break;
+        case 8: sim::launch(grid, vk::kWG, 8 * 1024 * vk::kWaves * 4, [&] { vk::field_query_gen<8>(q); }); break;
+        default: return -2;
+    }
     return 0;
 }

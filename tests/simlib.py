@@ -151,7 +151,7 @@ def sim_sample(scenes, rnds, seed=0, frame_counter=0, eps=0.1, stop_eps=0.05):
     return out
 
 
-def sim_query(fc_k, B_k, scale_k, pts, grid=3):
+def sim_query(fc_k, B_k, scale_k, pts, grid=3, H=32):
     """field_query_h32 on the simulator for one object: fc_k = 14 arrays (no object dim), pts [N,3]."""
     fc_c = [np.ascontiguousarray(a, dtype=np.float32) for a in fc_k]
     arr = (ctypes.POINTER(ctypes.c_float) * 14)(*[_p(a) for a in fc_c])
@@ -161,6 +161,6 @@ def sim_query(fc_k, B_k, scale_k, pts, grid=3):
     n = p.shape[0]
     occ = np.full(n, np.nan, np.float32)
     rgb = np.full((n, 3), np.nan, np.float32)
-    rc = lib().vmsim_query(arr, _p(Bc), _p(sc), _p(p), ctypes.c_longlong(n), _p(occ), _p(rgb), int(grid))
+    rc = lib().vmsim_query(arr, _p(Bc), _p(sc), _p(p), ctypes.c_longlong(n), _p(occ), _p(rgb), int(grid), int(H))
     assert rc == 0
     return occ, rgb

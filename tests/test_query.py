@@ -10,8 +10,8 @@ from oracle import vmap_oracle as vo
 from vmap_amd import synth
 
 
-def _one_object(seed=3, gain=1.0):
-    fc, B, scale = synth.make_params(2, 32, scale=1.7, seed=seed, gain=gain)
+def _one_object(seed=3, gain=1.0, H=32):
+    fc, B, scale = synth.make_params(2, H, scale=1.7, seed=seed, gain=gain)
     k = 1
     return [a[k] for a in fc], B[k], float(np.asarray(scale).reshape(-1)[k])
 
@@ -34,6 +34,17 @@ def test_sim_query_matches_oracle(n_pts, grid):
     assert np.isfinite(occ).all() and np.isfinite(rgb).all()
     assert np.abs(occ - o_occ).max() < 2e-5
     assert np.abs(rgb - o_rgb).max() < 2e-5
+
+
+@pytest.mark.parametrize("H,n_pts", [(64, 300), (128, 200), (256, 70)])
+def test_sim_query_generic_widths_match_oracle(H, n_pts):
+    import simlib
+    fc_k, B_k, sc = _one_object(seed=H, H=H)
+    pts = np.random.default_rng(H).uniform(-1.2, 1.2, size=(n_pts, 3)).astype(np.float32)
+    occ, rgb = simlib.sim_query(fc_k, B_k, sc, pts, grid=2, H=H)
+    o_occ, o_rgb = _oracle_query(fc_k, B_k, sc, pts)
+    assert np.isfinite(occ).all() and np.isfinite(rgb).all()
+    assert np.abs(occ - o_occ).max() < 3e-5 and np.abs(rgb - o_rgb).max() < 3e-5
 
 
 def test_sim_query_far_point_uses_accurate_path():
@@ -76,6 +87,23 @@ def test_gpu_eval_points_matches_modules_and_oracle():
     occ, col = tr.eval_points(pts)
     o_occ, o_rgb = _oracle_query(fc_k, tr.pe.B_layer.weight.detach().cpu().numpy(), float(tr.pe.scale), pts.cpu().numpy())
     assert np.abs(occ.cpu().numpy() - o_occ).max() < 2e-5 and np.abs(col.cpu().numpy() - o_rgb).max() < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H", [64, 96, 128, 256])
+def test_gpu_eval_points_generic_widths(H):
+    import torch
+    from vmap_amd.trainer import Trainer, SimpleConfig
+    torch.manual_seed(H)
+    tr = Trainer(SimpleConfig(training_device="cuda:0", hidden_feature_size=H))
+    g = torch.Generator().manual_seed(2)
+    for n in (5, 1000, 20_011):
+        pts = ((torch.rand(n, 3, generator=g) * 2 - 1) * 1.5).cuda()
+        occ, col = tr.eval_points(pts)
+        with torch.no_grad():
+            a, c = tr.fc_occ_map(tr.pe(pts))
+        assert (occ - torch.sigmoid(a.squeeze(-1))).abs().max().item() < 3e-5
+        assert (col - c).abs().max().item() < 3e-5
 
 
 @pytest.mark.gpu

@@ -12,11 +12,10 @@ from vmap_amd import layout  # noqa: E402
 from vmap_amd.trainer import SimpleConfig, Trainer  # noqa: E402
 
 torch.manual_seed(0)
-tr = Trainer(SimpleConfig(training_device="cuda:0", hidden_feature_size=32))
-res = {"tool": "query_bench", "device": torch.cuda.get_device_properties(0).gcnArchName, "hidden": 32, "grids": []}
-H = 32
-flop_pt = 2 * (layout.EMB1 * H + H * H + (H + layout.EMB1) * H + H * H + (H + layout.EMB2) * H + H + 3 * H)
-for dim in (100, 256):
+res = {"tool": "query_bench", "device": torch.cuda.get_device_properties(0).gcnArchName, "grids": []}
+for H, dim in ((32, 100), (32, 256), (128, 100), (128, 256), (256, 100)):
+    tr = Trainer(SimpleConfig(training_device="cuda:0", hidden_feature_size=H))
+    flop_pt = 2 * (layout.EMB1 * H + H * H + (H + layout.EMB1) * H + H * H + (H + layout.EMB2) * H + H + 3 * H)
     n = dim ** 3
     pts = torch.rand(n, 3, device="cuda") * 2 - 1
     tr.eval_points(pts[:4096]); torch.cuda.synchronize()
@@ -37,7 +36,7 @@ for dim in (100, 256):
         eager(); torch.cuda.synchronize()
         e0.record(); ro, rc = eager(); e1.record(); torch.cuda.synchronize()
     eager_ms = e0.elapsed_time(e1)
-    res["grids"].append({"grid_dim": dim, "points": n, "hip_ms": hip_ms, "eager_torch_ms": eager_ms,
+    res["grids"].append({"hidden": H, "grid_dim": dim, "points": n, "hip_ms": hip_ms, "eager_torch_ms": eager_ms,
                          "points_per_s": n / hip_ms * 1e3, "tflops_fp32": flop_pt * n / hip_ms * 1e-9,
                          "frac_of_fp32_mfma_peak": flop_pt * n / hip_ms * 1e-9 / 157.3,
                          "max_abs_diff_occ": (occ - ro).abs().max().item(), "max_abs_diff_rgb": (col - rc).abs().max().item()})

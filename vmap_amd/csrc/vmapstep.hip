@@ -467,8 +467,9 @@ int vmapstep_profile_phases(const vmapstep_shape* shape, const vmapstep_params* 
 
 int vmapstep_query_workspace_bytes(int32_t hidden, size_t* bytes) {
     if (!bytes) return fail(VMAPSTEP_ERR_ARGUMENT, "bytes is null");
-    if (hidden != 32) return fail(VMAPSTEP_ERR_UNSUPPORTED, "hidden=%d: the query kernel implements hidden=32", hidden);
-    *bytes = align_up((size_t)vk::Lds32::IMGP * sizeof(float));
+    if (hidden < 32 || hidden > 256 || hidden % 32 != 0)
+        return fail(VMAPSTEP_ERR_UNSUPPORTED, "hidden=%d: supported widths are multiples of 32 up to 256", hidden);
+    *bytes = align_up((size_t)vk::gen_layout(hidden).imgp * sizeof(float));
     return VMAPSTEP_OK;
 }
 
@@ -492,31 +493,47 @@ int vmapstep_query_points(int32_t hidden, const vmapstep_params* params, const v
     for (int t = 0; t < VMAPSTEP_NUM_FC; ++t) a.fc[t] = {params->fc[t].ptr + (long long)obj_index * params->fc[t].obj_stride, 0};
     a.pe_B = {params->pe_B.ptr + (long long)obj_index * params->pe_B.obj_stride, 0};
     a.wimg = static_cast<float*>(workspace);
-    hipLaunchKernelGGL(vk::step_prep, dim3(vk::Lds32::IMGP / 1024), dim3(vk::kWG), 3 * vk::kWG * sizeof(int), st, a);
+    hipLaunchKernelGGL(vk::step_prep, dim3(vk::gen_layout(hidden).imgp / 1024), dim3(vk::kWG), 3 * vk::kWG * sizeof(int), st, a);
     vk::QueryArgs q;
     q.wimg = a.wimg;
     q.scale = pe_scale->ptr + (long long)obj_index * pe_scale->obj_stride;
     q.pts = points; q.pts_sn = points_stride[0]; q.pts_sc = points_stride[1];
     q.n_pts = n_points; q.occ = occupancy; q.rgb = color;
-    static int wpe = 0;
-    if (!wpe) {
-        const char* ev = std::getenv("VMAPSTEP_QUERY_WPE");          // measurement knob: waves per SIMD of the query kernel
-        int v = ev ? std::atoi(ev) : 2;
-        if (v < 1 || v > 3) v = 2;
-        const void* fn = v == 1 ? reinterpret_cast<const void*>(vk::field_query_h32<1>)
-                       : v == 2 ? reinterpret_cast<const void*>(vk::field_query_h32<2>)
-                                : reinterpret_cast<const void*>(vk::field_query_h32<3>);
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, vk::Lds32::IMGP * sizeof(float));
-        if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-        wpe = v;
-    }
     const long long chunks = (n_points + vk::kMaxPts - 1) / vk::kMaxPts;
-    const long long cap = 256LL * wpe;                             // resident workgroups: wpe per CU
-    const int grid = (int)(chunks < cap ? chunks : cap);
-    const size_t lds = vk::Lds32::IMGP * sizeof(float);
-    if (wpe == 1) hipLaunchKernelGGL(vk::field_query_h32<1>, dim3(grid), dim3(vk::kWG), lds, st, q);
-    else if (wpe == 2) hipLaunchKernelGGL(vk::field_query_h32<2>, dim3(grid), dim3(vk::kWG), lds, st, q);
-    else hipLaunchKernelGGL(vk::field_query_h32<3>, dim3(grid), dim3(vk::kWG), lds, st, q);
+    if (hidden == 32) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(vk::field_query_h32<2>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, vk::Lds32::IMGP * sizeof(float));
+            if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+            attr_set = true;
+        }
+        const int grid = (int)(chunks < 512 ? chunks : 512);          // two resident workgroups per CU (236 registers each)
+        hipLaunchKernelGGL(vk::field_query_h32<2>, dim3(grid), dim3(vk::kWG), vk::Lds32::IMGP * sizeof(float), st, q);
+    } else {
+        const int grid = (int)(chunks < 256 ? chunks : 256);
+        const int nb = hidden / 32;
+        const size_t lds = nb > 4 ? (size_t)nb * 1024 * vk::kWaves * sizeof(float) : 0;   // second activation set (NB > 4)
+        static bool attr_set = false;
+        if (!attr_set) {
+            const void* big[4] = {reinterpret_cast<const void*>(vk::field_query_gen<5>), reinterpret_cast<const void*>(vk::field_query_gen<6>),
+                                  reinterpret_cast<const void*>(vk::field_query_gen<7>), reinterpret_cast<const void*>(vk::field_query_gen<8>)};
+            for (int i = 0; i < 4; ++i) {
+                hipError_t e = hipFuncSetAttribute(big[i], hipFuncAttributeMaxDynamicSharedMemorySize, (5 + i) * 1024 * vk::kWaves * (int)sizeof(float));
+                if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+            }
+            attr_set = true;
+        }
+        switch (nb) {
+            case 2: hipLaunchKernelGGL(vk::field_query_gen<2>, dim3(grid), dim3(vk::kWG), lds, st, q); break;
+            case 3: hipLaunchKernelGGL(vk::field_query_gen<3>, dim3(grid), dim3(vk::kWG), lds, st, q); break;
+            case 4: hipLaunchKernelGGL(vk::field_query_gen<4>, dim3(grid), dim3(vk::kWG), lds, st, q); break;
+            case 5: hipLaunchKernelGGL(vk::field_query_gen<5>, dim3(grid), dim3(vk::kWG), lds, st, q); break;
+            case 6: hipLaunchKernelGGL(vk::field_query_gen<6>, dim3(grid), dim3(vk::kWG), lds, st, q); break;
+            case 7: hipLaunchKernelGGL(vk::field_query_gen<7>, dim3(grid), dim3(vk::kWG), lds, st, q); break;
+            default: hipLaunchKernelGGL(vk::field_query_gen<8>, dim3(grid), dim3(vk::kWG), lds, st, q); break;
+        }
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "field_query launch: %s", hipGetErrorString(e));
     return VMAPSTEP_OK;

@@ -31,10 +31,10 @@ class Trainer:
 
     @torch.no_grad()
     def eval_points(self, points: torch.Tensor, chunk_size: int = 100000):
-        """Occupancy and colour at arbitrary points of this object's frame (trainer.py:77-95).  On the GPU with hidden
-        32 this is ONE launch of the HIP query kernel (vmapstep_query_points); otherwise the modules' PyTorch forward
-        in chunks like the reference."""
-        if points.is_cuda and self.hidden_feature_size == 32:
+        """Occupancy and colour at arbitrary points of this object's frame (trainer.py:77-95).  On the GPU this is ONE
+        launch of the HIP query kernel (vmapstep_query_points); on the CPU the modules' PyTorch forward in chunks like
+        the reference."""
+        if points.is_cuda and self.hidden_feature_size % 32 == 0 and 32 <= self.hidden_feature_size <= 256:
             occ, color = self._eval_points_hip(points)
         else:
             alphas, colors = [], []
