@@ -83,7 +83,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
-    dist = world > 1
+    # VMAP_BENCH_FORCE_DIST=1 exercises the N>1 code path (process group, flag all-reduce, max-over-ranks timing) with a
+    # single rank - the only way to run it on a 1-GPU box
+    dist = world > 1 or os.environ.get("VMAP_BENCH_FORCE_DIST") == "1"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if dist:
