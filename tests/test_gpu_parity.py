@@ -263,6 +263,33 @@ def test_full_size_properties_headline_config():
         assert relerr(s2[k], s[k]) < 2e-6, k
 
 
+@pytest.mark.parametrize("name", ["cfg2", "scannet_scale"])
+def test_results_are_bitwise_repeatable(name):
+    """No atomics anywhere and every cross-wave / cross-workgroup sum is ordered: 40 runs of the same step (single-pass
+    and multi-pass kernels) must be bit-identical.  A missing barrier or a reused exchange tile in the hand-pipelined
+    backward would show up here as a flipped bit long before it moves a 1e-4 tolerance."""
+    c = cases.build_case(name)
+    fc, B, sc, b = _to_dev(c)
+    lib = _lib.load()
+    old = lib.vmapstep_set_workgroups_per_object(0 if name == "cfg2" else 3)      # 3 of 10 ray groups per workgroup: multi-pass
+    try:
+        op = step.VmapStep(c["n"], c["R"], c["S"], c["H"], device=DEV)
+        ref = None
+        for it in range(40):
+            gfc = [torch.full_like(t, float("nan")) for t in fc]
+            gB = torch.full_like(B, float("nan"))
+            res = op.fwd_bwd(fc, B, sc, b["pcs"], b["z"], b["gt_depth"], b["gt_rgb"], b["sem"], b["depth_mask"],
+                             grads_fc=gfc, grad_B=gB, render=True)
+            cur = [res.loss.clone(), res.render_depth.clone(), res.render_color.clone()] + gfc + [gB]
+            if ref is None:
+                ref = cur
+            else:
+                for x, y in zip(cur, ref):
+                    assert torch.equal(x, y), it
+    finally:
+        lib.vmapstep_set_workgroups_per_object(old)
+
+
 def test_unsupported_hidden_width_fails_loudly():
     with pytest.raises(_lib.VmapStepError, match="hidden=48"):
         step.VmapStep(4, 32, 10, 48, device=DEV)
