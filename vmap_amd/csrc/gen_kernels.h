@@ -101,7 +101,10 @@ __global__ __launch_bounds__(kWG, 1) void step_main_gen(const GenArgs ga) {
     const float* Bg = Wg + L.pe_b;
     int stage_toggle = 0;                                               // alternates the two staging buffers
 
+    const int tid_k = tid;
     for (int grp = wgo; grp < a.NG; grp += a.NW) {
+    // lane coordinates of this pass, opaque per iteration (see step_main_h32: keeps the body's invariants in the body)
+    const int tid = wv::opaque_iter(tid_k), lane = tid & 63, wave = tid >> 6, p31 = lane & 31, hi = lane >> 5;
     const bool first_pass = grp == wgo;
     __syncthreads();
     for (int i = tid; i < kMaxPts * 8; i += kWG) cb[i] = 0.0f;
@@ -137,7 +140,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_gen(const GenArgs ga) {
         if (!big) pe_block<NS, false>(xv, yv, base, limit, kb, t, proj, hi);                             \
         else pe_block<NS, true>(xv, yv, base, limit, kb, t, proj, hi);                                   \
         stb(BLK(E_P + i), xv, lane); stb(BLK(CFB + i), yv, lane);                                        \
-        to_F(yv, xv, scrX, p31, hi); stb(BLK(E_F + i), yv, lane);
+        toF_put(scrX, xv, p31, hi); toF_get(yv, scrX, p31, hi); stb(BLK(E_F + i), yv, lane);
         ENC(0, 16, 0, kEmb1, 0)
         ENC(1, 16, 0, kEmb1, 1)
         ENC(2, 12, 0, kEmb1, 2)
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_gen(const GenArgs ga) {
     auto finish = [&](int l, int ob) {          // ReLU, store P-form and F-form
         relu_to(xv, acc);
         stb(BLK(H_P + l * NB + ob), xv, lane);
-        to_F(yv, xv, scrX, p31, hi);
+        toF_put(scrX, xv, p31, hi); toF_get(yv, scrX, p31, hi);
         stb(BLK(H_F + l * NB + ob), yv, lane);
     };
     for (int ob = 0; ob < NB; ++ob) {           // :59 in_layer
@@ -215,8 +218,11 @@ __global__ __launch_bounds__(kWG, 1) void step_main_gen(const GenArgs ga) {
         }
     }
     __syncthreads();
-    composite_phase<BWD>(a, cb, lds + LdsGen::LOSS, obj, ray0, nrays, wave, lane, tid,
-                         load_ray_meta(a, obj, ray0 + min(4 * wave + (lane >> 4), nrays - 1)));
+    {
+        const StepArgs& al = wv::kernarg_late(ga).s;
+        composite_phase<BWD>(al, cb, lds + LdsGen::LOSS, obj, ray0, nrays, wave, lane, tid,
+                             load_ray_meta(al, obj, ray0 + min(4 * wave + (lane >> 4), nrays - 1)));
+    }
     __syncthreads();
 
     if (BWD) {
@@ -232,7 +238,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_gen(const GenArgs ga) {
     // one reduced weight-gradient block: acc -> staged cross-wave sum -> this wave's quarter -> partial buffer
     auto emit = [&](float* tens, int K, int row0, int col0, int ncols) {
         float q[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        reduce_block(q, acc, (stage_toggle & 1) ? stg1 : stg0, wave, p31, hi);
+        { float* stg_ = (stage_toggle & 1) ? stg1 : stg0; stage_put(stg_, acc, wave, p31, hi); __syncthreads(); stage_get(q, stg_, wave, p31, hi); }
         ++stage_toggle;
         store_quarter_rt(tens + (long long)row0 * K, K, q, col0, ncols, !first_pass, wave, p31, hi);
     };
@@ -247,7 +253,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_gen(const GenArgs ga) {
     // store a delta block (already masked) as P-form + F-form and add its bias gradient
     auto put_delta = [&](int ds, int kb, int bias_off) {
         stb(BLK(D_P + ds * NB + kb), xv, lane);
-        to_F(yv, xv, scrD, p31, hi);
+        toF_put(scrD, xv, p31, hi); toF_get(yv, scrD, p31, hi);
         stb(BLK(D_F + ds * NB + kb), yv, lane);
         add_db(Gv + bias_off + 32 * kb, yv, p31, hi);
     };
@@ -418,12 +424,12 @@ __global__ __launch_bounds__(kWG, 1) void step_main_gen(const GenArgs ga) {
             const float v1 = f1 < kDirs ? dproj[f1 < kDirs ? f1 : 0] : 0.0f;
             xv[r] = hi ? v1 : v0;
         }
-        to_F(yv, xv, scrD, p31, hi);
+        toF_put(scrD, xv, p31, hi); toF_get(yv, scrD, p31, hi);
         ldb(xv, BLK(E_F + 0), lane);
         zero_acc(acc);
         dw_mm(acc, yv, xv);
         float q[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        reduce_block(q, acc, (stage_toggle & 1) ? stg1 : stg0, wave, p31, hi);
+        { float* stg_ = (stage_toggle & 1) ? stg1 : stg0; stage_put(stg_, acc, wave, p31, hi); __syncthreads(); stage_get(q, stg_, wave, p31, hi); }
         ++stage_toggle;
         if (p31 < 3) {
 #pragma unroll
