@@ -174,7 +174,7 @@ def main():
                                    f"{S} samples/ray, fwd+loss+bwd+fused AdamW, {ipf} steps per frame call",
                        "objects_per_gpu": n, "rays_per_object": R, "samples_per_ray": S, "hidden": H,
                        "parallelism": f"objects sharded over {world} GPU(s); no per-step collective, one 4x{ipf}-int32 flag all-reduce per frame"},
-            "roofline": {"bound": "mfma", "kernel": "step_main_h32<true>", "achieved": achieved,
+            "roofline": {"bound": "mfma", "kernel": "step_main_h32<true>" if H == 32 else "step_main_gen<true>", "achieved": achieved,
                          "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
                          "traffic": traffic, "kernel_ms": k_ms, "algorithmic_flops_per_launch": flops,
                          "algorithmic_bytes_per_launch": abytes,
