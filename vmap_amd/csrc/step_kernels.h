@@ -19,11 +19,12 @@
 //   forward   Y^T = W * X^T      : A = W[j][k] from LDS (lane = j, ds_read_b128), B = X in P-form -> Y in P-form
 //   d-prop    dX^T = W^T * dY^T  : A = W[j][k] from LDS (lane = k), B = dY in P-form ->  dX in P-form
 //   dW        dW = dY^T * X      : A = dY in F-form, B = X in F-form  (F-form: lane = feature, register r
-//                                  <-> point r + 16*hi; obtained from P-form through a 32x33 LDS transpose)
+//                                  <-> point r + 16*hi; obtained from P-form through a wave-private LDS tile)
+// The backward is 13 hand-pipelined units of two 16-deep matrix chains each (p_chain / dw_chain_fin below).
 //
 // Numerics: fp32 throughout, ~1 ulp sin/cos/exp, IEEE division/sqrt; the only reorderings w.r.t. the reference
 // are summation orders.  Weight gradients are reduced without atomics: across the 4 waves through staged LDS
-// tiles (reduce_block), across workgroups by plain stores of partials + an ordered sum in step_finalize.
+// tiles (stage_put / stage_get), across workgroups by plain stores of partials + an ordered sum in step_finalize.
 #pragma once
 #include <wave_ops.h>   // resolved through -I: csrc/ (device) or tests/sim/ (CPU SIMT executor)
 
@@ -277,42 +278,10 @@ __device__ __forceinline__ void fwd_mm(f32x16& acc, const float* wrow, const flo
         for (int i = 0; i < 4; ++i) acc = wv::mfma32(w[i], x[4 * q + i], acc);
     }
 }
-// d-prop: acc[p][k] += sum_j W[phi(r,hi)][k] * dy[p][phi(r,hi)];  wcol = &W[4*hi][k = column of this lane]
-template <int LD>
-__device__ __forceinline__ void bwd_mm(f32x16& acc, const float* wcol, const float (&dy)[16]) {
-    float w[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) w[r] = wcol[((r & 3) + 8 * (r >> 2)) * LD];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc = wv::mfma32(w[r], dy[r], acc);
-}
 // dW: acc[j][k] += sum_q dyF[q][j] * xF[q][k]
 __device__ __forceinline__ void dw_mm(f32x16& acc, const float (&dyF)[16], const float (&xF)[16]) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc = wv::mfma32(dyF[r], xF[r], acc);
-}
-// P-form -> F-form through a wave-private [32][33] LDS tile
-__device__ __forceinline__ void to_F(float (&F)[16], const float (&P)[16], float* scr, int p31, int hi) {
-    wv::wave_lds_fence();   // earlier reads of this tile are done
-#pragma unroll
-    for (int r = 0; r < 16; ++r) scr[p31 * 33 + phi(r, hi)] = P[r];
-    wv::wave_lds_fence();
-#pragma unroll
-    for (int r = 0; r < 16; ++r) F[r] = scr[(r + 16 * hi) * 33 + p31];
-}
-// Cross-wave sum of one 32x32 weight-gradient block without atomics: every wave stages its partial tile
-// (lane = column k, register r <-> row phi(r,hi)), one workgroup barrier, then wave w adds rows 8w..8w+7 of the
-// four tiles (its quarter: lane (k, hi), i -> row 8w + 4hi + i) into q.  Consecutive blocks alternate between
-// two staging buffers, so one barrier per block suffices.
-__device__ __forceinline__ void reduce_block(float (&q)[4], const f32x16& acc, float* stage, int wave, int p31, int hi) {
-    float* mine = stage + wave * Lds32::STG_TILE + p31;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) mine[phi(r, hi) * 33] = acc[r];
-    __syncthreads();
-    const float* rd = stage + (8 * wave + 4 * hi) * 33 + p31;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-        q[i] += (rd[i * 33] + rd[Lds32::STG_TILE + i * 33]) + (rd[2 * Lds32::STG_TILE + i * 33] + rd[3 * Lds32::STG_TILE + i * 33]);
 }
 // bias gradient: sum over the 32 points of a tile of dY (F-form), lane = feature; accumulated in the wave's
 // private small-vector area (single owner lane per address -> plain read-modify-write)
@@ -510,17 +479,6 @@ __device__ __forceinline__ void finish_block(float (&qp)[4], const float* stage,
     } else {
         float q[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         stage_get(q, stage, wave, p31, hi);
-        store_quarter<K>(out, q, col0, ncols, wave, p31, hi);
-    }
-}
-template <bool MULTI, int K>
-__device__ __forceinline__ void emit_block(float (&qp)[4], const f32x16& acc, float* stage, float* out, int col0, int ncols,
-                                           int wave, int p31, int hi) {
-    if (MULTI) {
-        reduce_block(qp, acc, stage, wave, p31, hi);
-    } else {
-        float q[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        reduce_block(q, acc, stage, wave, p31, hi);
         store_quarter<K>(out, q, col0, ncols, wave, p31, hi);
     }
 }
