@@ -228,7 +228,10 @@ int vmapstep_profile_phases(const vmapstep_shape* shape, const vmapstep_params* 
                             uint32_t* timing, size_t timing_elems, int32_t* n_workgroups,
                             void* workspace, size_t workspace_bytes, void* stream);
 
-/* Tuning knob (0 = automatic): workgroups per object of the fused kernel. Returns the previous value. */
+/* Tuning knob (0 = automatic): workgroups per object of the fused kernel. Returns the previous value.
+ * Three more values select the kernel of hidden 128 / 256 for measurements and tests: -1 the general kernel
+ * (step_main_gen), -3 the tile-per-workgroup kernel (step_main_wide), -2 the automatic choice (wide when every
+ * 32-point tile gets its own workgroup, i.e. at most 256 tiles). */
 int vmapstep_set_workgroups_per_object(int32_t nw);
 
 #ifdef __cplusplus

@@ -4,7 +4,7 @@
 #include <cstring>
 #include <vector>
 
-#include "gen_kernels.h"
+#include "wide_kernels.h"
 #include "sample_kernels.h"
 #include "query_kernels.h"
 
@@ -16,6 +16,8 @@ void fc_sizes(int H, int* sz) {
 }  // namespace
 
 extern "C" int vmsim_lds_bytes() { return vk::Lds32::BYTES; }
+static int g_wide = 0;
+extern "C" void vmsim_set_wide(int w) { g_wide = w; }   // hidden 128 / 256: run step_main_wide (caller passes G * S <= 32)
 
 // fc[t]: [n][size_t] contiguous; grads: flat slab [n][P] in natural order (14 field tensors then B).
 extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req, int xcd_affine, int weights_bf16,
@@ -71,7 +73,12 @@ extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req, int xcd
         ga.wave_blocks = vk::gen_wave_blocks(GL.NB);
         std::vector<float> scratch((size_t)n * NW * vk::kWaves * ga.wave_blocks * vk::kBlk, NAN);
         ga.scratch = scratch.data();
-        if (bwd) sim::launch(n * NW, vk::kWG, vk::LdsGen::bytes(GL.small_n), [&] { vk::step_main_gen<true>(ga); });
+        if (g_wide) {
+            if (H % 128 != 0 || G * S > vk::kWideTile) return -3;
+            ga.s.wide = 1;
+            if (bwd) sim::launch(n * NW, vk::kWG, vk::LdsGen::bytes(GL.small_n), [&] { vk::step_main_wide<true>(ga); });
+            else     sim::launch(n * NW, vk::kWG, vk::LdsGen::bytes(GL.small_n), [&] { vk::step_main_wide<false>(ga); });
+        } else if (bwd) sim::launch(n * NW, vk::kWG, vk::LdsGen::bytes(GL.small_n), [&] { vk::step_main_gen<true>(ga); });
         else     sim::launch(n * NW, vk::kWG, vk::LdsGen::bytes(GL.small_n), [&] { vk::step_main_gen<false>(ga); });
     }
 

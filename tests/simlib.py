@@ -21,7 +21,8 @@ def build(force=False):
                    os.path.join(ROOT, "vmap_amd", "csrc", "step_kernels.h"),
                    os.path.join(ROOT, "vmap_amd", "csrc", "gen_kernels.h"),
                    os.path.join(ROOT, "vmap_amd", "csrc", "sample_kernels.h"),
-                   os.path.join(ROOT, "vmap_amd", "csrc", "query_kernels.h")]
+                   os.path.join(ROOT, "vmap_amd", "csrc", "query_kernels.h"),
+                   os.path.join(ROOT, "vmap_amd", "csrc", "wide_kernels.h")]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
@@ -48,7 +49,7 @@ def _p(a, ty=ctypes.c_float):
     return a.ctypes.data_as(ctypes.POINTER(ty)) if a is not None else None
 
 
-def sim_step(case_or_fc, B=None, scale=None, batch=None, G=None, bwd=True, adam=None, NW=0, xcd_affine=1, weights_bf16=0):
+def sim_step(case_or_fc, B=None, scale=None, batch=None, G=None, bwd=True, adam=None, NW=0, xcd_affine=1, weights_bf16=0, wide=False):
     """Run prep + main + finalize on the simulator. Returns dict like oracle.training_step."""
     if isinstance(case_or_fc, dict):
         c = case_or_fc
@@ -58,7 +59,8 @@ def sim_step(case_or_fc, B=None, scale=None, batch=None, G=None, bwd=True, adam=
     n, R, S = batch["z"].shape
     H = fc[2].shape[-1]
     if G is None:
-        G = max(1, 128 // S)
+        G = max(1, (32 if wide else 128) // S)
+    lib().vmsim_set_wide(1 if wide else 0)
     fc_c = [np.ascontiguousarray(a, dtype=np.float32) for a in fc]
     sizes = [a[0].size for a in fc_c]
     P = sum(sizes) + 63

@@ -297,12 +297,26 @@ def test_unsupported_hidden_width_fails_loudly():
         step.VmapStep(4, 32, 10, 512, device=DEV)
 
 
-@pytest.mark.parametrize("name", ["h64", "bg_h128_s14", "imap_h256"])
-def test_generic_width_kernel_matches_reference_fixture(name):
-    """hidden = 64 / 128 (background model shapes) / 256 (iMAP, BASELINE configs[0]) through step_main_gen."""
+@pytest.mark.parametrize("name,kernel", [("h64", "gen"), ("bg_h128_s14", "wide"), ("imap_h256", "wide"),
+                                         ("bg_h128_s14", "gen"), ("imap_h256", "gen"), ("bg_h128_s14", "wide_multipass")])
+def test_generic_width_kernel_matches_reference_fixture(name, kernel):
+    """hidden = 64 / 128 (background model shapes) / 256 (iMAP, BASELINE configs[0]): step_main_wide (tile per
+    workgroup, the default at 128 / 256; also with 3 workgroups looping over the ray groups) and step_main_gen."""
     c = cases.build_case(name)
     g = load_golden(name)
-    s = _run(c)
+    lib = _lib.load()
+    old = 0
+    try:
+        if kernel == "gen":
+            lib.vmapstep_set_workgroups_per_object(-1)
+        if kernel.startswith("wide"):
+            lib.vmapstep_set_workgroups_per_object(-3)
+        if kernel == "wide_multipass":
+            old = lib.vmapstep_set_workgroups_per_object(3)
+        s = _run(c)
+    finally:
+        lib.vmapstep_set_workgroups_per_object(-2)
+        lib.vmapstep_set_workgroups_per_object(old)
     assert abs(s["loss"] - float(g["loss"])) <= 2e-5 * abs(float(g["loss"]))
     for k in RENDER_KEYS:
         assert relerr(s[k], g[k]) < 2e-5, k

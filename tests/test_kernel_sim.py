@@ -117,6 +117,34 @@ def test_sim_generic_width_kernel_matches_reference(name, nw):
         assert relerr(s[k], g[k]) < 1e-4, k
 
 
+@pytest.mark.parametrize("nw", [0, 5])
+def test_sim_wide_kernel_matches_reference(nw):
+    """step_main_wide (hidden 128: one 32-point tile per workgroup, output blocks split over the four waves;
+    nw=5: five passes per workgroup accumulate into its partial buffer) vs the background-shaped fixture."""
+    c = cases.build_case("bg_h128_s14")
+    g = load_golden("bg_h128_s14")
+    s = simlib.sim_step(c, NW=nw, wide=True)
+    assert abs(s["loss"] - float(g["loss"])) <= 2e-5 * abs(float(g["loss"]))
+    for k in RENDER_KEYS:
+        assert relerr(s[k], g[k]) < 2e-5, k
+    for k in GRAD_KEYS:
+        assert relerr(s[k], g[k]) < 1e-4, k
+    o = simlib.sim_step(c, NW=0)                      # the general kernel on the same case
+    for k in GRAD_KEYS:
+        assert relerr(s[k], o[k]) < 2e-5, k
+
+
+@pytest.mark.slow
+def test_sim_wide_kernel_imap_h256():
+    """hidden 256 (two output blocks per wave) on the iMAP plumbing fixture."""
+    c = cases.build_case("imap_h256")
+    g = load_golden("imap_h256")
+    s = simlib.sim_step(c, wide=True)
+    assert abs(s["loss"] - float(g["loss"])) <= 2e-5 * abs(float(g["loss"]))
+    for k in RENDER_KEYS + GRAD_KEYS:
+        assert relerr(s[k], g[k]) < 1e-4, k
+
+
 @pytest.mark.slow
 def test_sim_generic_width_kernel_imap_h256():
     """BASELINE configs[0] (iMAP plumbing: 1 object, hidden 256, 100 rays, 14 samples): ~80 s on the simulator."""

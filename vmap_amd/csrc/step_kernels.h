@@ -72,6 +72,7 @@ struct StepArgs {
     unsigned* timing;                  // optional [workgroups][kWaves][kMarks] shader-clock stamps (diagnostics)
     int hidden;                        // H (step_prep packs with gen_layout(hidden); step_main_h32 requires 32)
     int weights_bf16;                  // 1: the parameter image holds the masters rounded to bfloat16 (RNE)
+    int wide;                          // 1: step_main_wide (tile per workgroup, G*S <= 32) instead of step_main_gen
 };
 
 __device__ __forceinline__ constexpr int phi(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }

@@ -1,0 +1,438 @@
+// wide_kernels.h - fused training step for WIDE fields (hidden = 128, 256: the background model, iMAP), gfx950.
+//
+// step_main_gen gives every wave a 32-point tile of its own: at hidden 128 that is 4368 exact-fp32 matrix instructions
+// on ONE wave (>= 116 us) while the background model's 525 tiles leave half of the chip's 1024 SIMDs idle.  Here a
+// tile belongs to the WORKGROUP and the four waves split every layer by 32-wide OUTPUT block (wave w owns blocks
+// w, w+4, ...): forward block ob, the delta block ob, the weight-gradient rows of block ob.  Inputs a wave does not own
+// come from the other waves through the same lane-contiguous "register images" step_main_gen keeps in its scratch
+// area (all four waves hold the same 32 points on the same lanes, so an image written by one wave is directly another
+// wave's matrix operand), separated by workgroup barriers; the per-wave LDS transpose tiles stay private.  A weight-
+// gradient block now has ONE producer per tile, so there is no cross-wave reduction: blocks are stored (first pass)
+// or accumulated (later passes of the same workgroup) straight into the workgroup's partial buffer.
+// Same arithmetic and summation orders per block as step_main_gen except for the order in which a workgroup's tiles
+// are added (per-pass accumulation instead of a 4-tile staged sum).  model.py:54-85, loss.py:5-62 as cited there.
+#pragma once
+#include "gen_kernels.h"
+
+namespace vk {
+
+constexpr int kWideTile = 32;            // sample points per workgroup pass
+
+// full 32x32 block (lane = column, register r <-> row phi(r,hi)) -> row-major tensor; add = accumulate
+__device__ __forceinline__ void store_block_rt(float* tens, int K, const f32x16& acc, int col0, int ncols, bool add,
+                                               int p31, int hi) {
+    if (p31 < ncols) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float* o = tens + (long long)phi(r, hi) * K + col0 + p31;
+            *o = add ? *o + acc[r] : acc[r];
+        }
+    }
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(kWG, 1) void step_main_wide(const GenArgs ga) {
+    const StepArgs& a = ga.s;
+    const GenLayout L = gen_layout(a.hidden);
+    const int H = L.H, NB = L.NB;
+    float* lds = wv::lds_base();
+    const int tid_k = threadIdx.x;
+    const int obj = blockIdx.x / a.NW, wgo = blockIdx.x - obj * a.NW;
+    const float* Wg = a.wimg + (long long)obj * L.imgp;
+    float* sb = ga.scratch + (long long)blockIdx.x * ga.wave_blocks * kBlk;      // ONE set of images per workgroup
+    const int E_P = 0, E_F = 5, CFB = 10, H_P = 15, H_F = 15 + 5 * NB, D_P = 15 + 10 * NB, D_F = 15 + 12 * NB, DE = 15 + 14 * NB;
+#define BLK(i) (sb + (long long)(i) * kBlk)
+    if (BWD) {
+        for (int i = tid_k; i < kWaves * L.small_n; i += kWG) lds[LdsGen::VEC + i] = 0.0f;
+    }
+    if (tid_k < kWaves * 4) lds[LdsGen::LOSS + tid_k] = 0.0f;
+    float* out = a.part_grad + ((long long)(obj * a.NW + wgo)) * a.PP;
+    float* cb = lds + LdsGen::CB;
+    float* dpx = lds + LdsGen::STG;                                      // [kWaves][kDirs][64] d(proj) partials of the waves
+    const float scale = a.pe_scale.p[obj * a.pe_scale.stride];
+    const float* Bg = Wg + L.pe_b;
+
+    for (int grp = wgo; grp < a.NG; grp += a.NW) {
+    const int tid = wv::opaque_iter(tid_k), lane = tid & 63, wave = tid >> 6, p31 = lane & 31, hi = lane >> 5;
+    float* Gv = lds + LdsGen::VEC + wave * L.small_n - L.b_in;           // this wave's private small-vector gradients
+    float* scrX = lds + LdsGen::SCR + wave * LdsGen::SCR_WAVE;
+    float* scrD = scrX + Lds32::SCR_TILE;
+    const bool first_pass = grp == wgo;
+    __syncthreads();                                                     // previous pass done with cb and the images
+    for (int i = tid; i < kMaxPts * 8; i += kWG) cb[i] = 0.0f;
+
+    const int ray0 = grp * a.G;
+    const int nrays = min(a.G, a.R - ray0);
+    const int npts = nrays * a.S;                                        // <= 32
+    const int pt = p31;                                                  // every wave holds the same 32 points
+    const bool valid = pt < npts;
+    const int lray = valid ? pt / a.S : 0;
+    const int smp = valid ? pt - lray * a.S : 0;
+    const int ray = ray0 + lray;
+    float xv[16], yv[16];
+    f32x16 acc;
+    // ---- encoding: wave 0..2 the three blocks of e1, wave 3 the two of e2; P-form, F-form, cos factors -> images ----
+    {
+        float t[3] = {0.0f, 0.0f, 0.0f};
+        if (valid) {
+            const float* px = a.pcs + obj * a.pcs_so + ray * a.pcs_sr + smp * a.pcs_ss;
+            t[0] = px[0] / scale;
+            t[1] = px[a.pcs_sc] / scale;
+            t[2] = px[2 * a.pcs_sc] / scale;
+        }
+        float proj[kDirs];
+#pragma unroll
+        for (int d = 0; d < kDirs; ++d)
+            proj[d] = fmaf(t[2], Bg[3 * d + 2], fmaf(t[1], Bg[3 * d + 1], t[0] * Bg[3 * d]));
+        float amax = 0.0f;
+#pragma unroll
+        for (int d = 0; d < kDirs; ++d) amax = fmaxf(amax, fabsf(proj[d]));
+        const bool big = wv::wave_any(!(amax * (32.0f * kPi) < kSinCosFastLimit));
+#define ENC(i, NS, base, limit, kb)                                                                      \
+        {                                                                                                \
+            if (!big) pe_block<NS, false>(xv, yv, base, limit, kb, t, proj, hi);                         \
+            else pe_block<NS, true>(xv, yv, base, limit, kb, t, proj, hi);                               \
+            stb(BLK(E_P + i), xv, lane); stb(BLK(CFB + i), yv, lane);                                    \
+            toF_put(scrX, xv, p31, hi); toF_get(yv, scrX, p31, hi); stb(BLK(E_F + i), yv, lane);         \
+        }
+        if (wave == 0) ENC(0, 16, 0, kEmb1, 0)
+        else if (wave == 1) ENC(1, 16, 0, kEmb1, 1)
+        else if (wave == 2) ENC(2, 12, 0, kEmb1, 2)
+        else { ENC(3, 16, kEmb1, kEmb2, 0) ENC(4, 6, kEmb1, kEmb2, 1) }
+#undef ENC
+    }
+    __syncthreads();
+
+    // ---- field MLP forward: wave w produces output blocks ob = w, w+4, ... of every layer ----
+    auto seg4 = [&](const float* w, int blk) { ldb(xv, BLK(blk), lane); fwd_mm<4>(acc, w, xv); };
+    auto seg3 = [&](const float* w, int blk) { ldb(xv, BLK(blk), lane); fwd_mm<3>(acc, w, xv); };
+    auto seg2 = [&](const float* w, int blk) { ldb(xv, BLK(blk), lane); fwd_mm<2>(acc, w, xv); };
+    auto finish = [&](int l, int ob) {
+        relu_to(xv, acc);
+        stb(BLK(H_P + l * NB + ob), xv, lane);
+        toF_put(scrX, xv, p31, hi); toF_get(yv, scrX, p31, hi);
+        stb(BLK(H_F + l * NB + ob), yv, lane);
+    };
+    for (int ob = wave; ob < NB; ob += kWaves) {           // :59 in_layer
+        const float* w = Wg + L.w_in + (32 * ob + p31) * L.ld_in + 4 * hi;
+        load_bias(acc, Wg + L.b_in + 32 * ob, hi);
+        seg4(w, E_P + 0); seg4(w + 32, E_P + 1); seg3(w + 64, E_P + 2);
+        finish(0, ob);
+    }
+    __syncthreads();
+    for (int ob = wave; ob < NB; ob += kWaves) {           // :60 mid1
+        const float* w = Wg + L.w_m1 + (32 * ob + p31) * L.ld_m + 4 * hi;
+        load_bias(acc, Wg + L.b_m1 + 32 * ob, hi);
+        for (int kb = 0; kb < NB; ++kb) seg4(w + 32 * kb, H_P + 0 * NB + kb);
+        finish(1, ob);
+    }
+    __syncthreads();
+    for (int ob = wave; ob < NB; ob += kWaves) {           // :63-64 cat_layer
+        const float* w = Wg + L.w_cat + (32 * ob + p31) * L.ld_cat + 4 * hi;
+        load_bias(acc, Wg + L.b_cat + 32 * ob, hi);
+        for (int kb = 0; kb < NB; ++kb) seg4(w + 32 * kb, H_P + 1 * NB + kb);
+        seg4(w + H, E_P + 0); seg4(w + H + 32, E_P + 1); seg3(w + H + 64, E_P + 2);
+        finish(2, ob);
+    }
+    __syncthreads();
+    for (int ob = wave; ob < NB; ob += kWaves) {           // :67 mid2
+        const float* w = Wg + L.w_m2 + (32 * ob + p31) * L.ld_m + 4 * hi;
+        load_bias(acc, Wg + L.b_m2 + 32 * ob, hi);
+        for (int kb = 0; kb < NB; ++kb) seg4(w + 32 * kb, H_P + 2 * NB + kb);
+        finish(3, ob);
+    }
+    __syncthreads();
+    for (int ob = wave; ob < NB; ob += kWaves) {           // :81 color_linear
+        const float* w = Wg + L.w_c + (32 * ob + p31) * L.ld_c + 4 * hi;
+        load_bias(acc, Wg + L.b_c + 32 * ob, hi);
+        for (int kb = 0; kb < NB; ++kb) seg4(w + 32 * kb, H_P + 3 * NB + kb);
+        seg4(w + H, E_P + 3); seg2(w + H + 32, E_P + 4);
+        finish(4, ob);
+    }
+    __syncthreads();
+    if (wave == 0) {   // heads (model.py:71,77,82-83): 4 dot products over all H features, one wave
+        float ra = 0.0f, r0 = 0.0f, r1 = 0.0f, r2 = 0.0f;
+        for (int kb = 0; kb < NB; ++kb) {
+            ldb(xv, BLK(H_P + 3 * NB + kb), lane);
+            ldb(yv, BLK(H_P + 4 * NB + kb), lane);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = 32 * kb + phi(r, hi);
+                ra = fmaf(Wg[L.w_a + j], xv[r], ra);
+                r0 = fmaf(Wg[L.w_oc + j], yv[r], r0);
+                r1 = fmaf(Wg[L.w_oc + H + j], yv[r], r1);
+                r2 = fmaf(Wg[L.w_oc + 2 * H + j], yv[r], r2);
+            }
+        }
+        ra += wv::swap_half(ra); r0 += wv::swap_half(r0); r1 += wv::swap_half(r1); r2 += wv::swap_half(r2);
+        ra += Wg[L.b_a]; r0 += Wg[L.b_oc]; r1 += Wg[L.b_oc + 1]; r2 += Wg[L.b_oc + 2];
+        if (valid && hi == 0) {
+            float* row = cb + pt * 8;
+            row[6] = a.z[obj * a.z_so + ray * a.z_sr + smp * a.z_ss];
+            row[0] = sigmoidf_acc(ra * 10.0f);
+            row[1] = sigmoidf_acc(r0);
+            row[2] = sigmoidf_acc(r1);
+            row[3] = sigmoidf_acc(r2);
+        }
+    }
+    __syncthreads();
+    {
+        const StepArgs& al = wv::kernarg_late(ga).s;
+        composite_phase<BWD>(al, cb, lds + LdsGen::LOSS, obj, ray0, nrays, wave, lane, tid,
+                             load_ray_meta(al, obj, ray0 + min(4 * wave + (lane >> 4), nrays - 1)));
+    }
+    __syncthreads();
+
+    if (BWD) {
+    float d_raw, d_c0, d_c1, d_c2;
+    {
+        const float* row = cb + pt * 8;
+        d_raw = row[0]; d_c0 = row[1]; d_c1 = row[2]; d_c2 = row[3];
+    }
+    float dproj[kDirs];
+#pragma unroll
+    for (int d = 0; d < kDirs; ++d) dproj[d] = 0.0f;
+
+    // weight-gradient block (ob, x-block): one producer per tile -> straight into the workgroup's partial buffer
+    auto dw_block = [&](int dfblk, int xfblk, float* tens, int K, int row0, int col0, int ncols) {
+        ldb(xv, BLK(dfblk), lane);
+        ldb(yv, BLK(xfblk), lane);
+        zero_acc(acc);
+        dw_mm(acc, xv, yv);
+        store_block_rt(tens + (long long)row0 * K, K, acc, col0, ncols, !first_pass, p31, hi);
+    };
+    auto put_delta = [&](int ds, int kb, int bias_off) {
+        stb(BLK(D_P + ds * NB + kb), xv, lane);
+        toF_put(scrD, xv, p31, hi); toF_get(yv, scrD, p31, hi);
+        stb(BLK(D_F + ds * NB + kb), yv, lane);
+        add_db(Gv + bias_off + 32 * kb, yv, p31, hi);
+    };
+    const float* cbw = cb;                                  // rows 0..31 = this tile's points
+
+    // ---- heads: gradients of out_alpha / out_color; delta of color_linear's output -> D(0) ----
+    for (int kb = wave; kb < NB; kb += kWaves) {
+        ldb(xv, BLK(H_F + 3 * NB + kb), lane);      // h4 F-form
+        ldb(yv, BLK(H_F + 4 * NB + kb), lane);      // hc F-form
+        float gA = 0.0f, g0 = 0.0f, g1 = 0.0f, g2 = 0.0f, sa = 0.0f, s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float* row = cbw + (r + 16 * hi) * 8;
+            const float da = row[0], q0 = row[1], q1 = row[2], q2 = row[3];
+            gA = fmaf(da, xv[r], gA);
+            g0 = fmaf(q0, yv[r], g0); g1 = fmaf(q1, yv[r], g1); g2 = fmaf(q2, yv[r], g2);
+            sa += da; s0 += q0; s1 += q1; s2 += q2;
+        }
+        gA += wv::swap_half(gA); g0 += wv::swap_half(g0); g1 += wv::swap_half(g1); g2 += wv::swap_half(g2);
+        sa += wv::swap_half(sa); s0 += wv::swap_half(s0); s1 += wv::swap_half(s1); s2 += wv::swap_half(s2);
+        if (hi == 0) {
+            const int j = 32 * kb + p31;
+            Gv[L.w_a + j] += gA;
+            Gv[L.w_oc + j] += g0;
+            Gv[L.w_oc + H + j] += g1;
+            Gv[L.w_oc + 2 * H + j] += g2;
+            if (p31 == 0 && kb == 0) {
+                Gv[L.b_a] += sa; Gv[L.b_oc + 0] += s0; Gv[L.b_oc + 1] += s1; Gv[L.b_oc + 2] += s2;
+            }
+        }
+        ldb(yv, BLK(H_P + 4 * NB + kb), lane);      // hc P-form for the ReLU mask
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = 32 * kb + phi(r, hi);
+            const float v = Wg[L.w_oc + j] * d_c0 + Wg[L.w_oc + H + j] * d_c1 + Wg[L.w_oc + 2 * H + j] * d_c2;
+            xv[r] = yv[r] > 0.0f ? v : 0.0f;
+        }
+        put_delta(0, kb, L.b_c);
+    }
+    __syncthreads();
+    // ---- color_linear: dW = D(0)^T [h4 | e2] ; d h4 -> D(1) ; d e2 -> dproj (waves 0, 1) ----
+    {
+        float* tens = out + L.f[10];
+        const int K = H + kEmb2;
+        for (int ob = wave; ob < NB; ob += kWaves) {
+            for (int kb = 0; kb < NB; ++kb) dw_block(D_F + 0 * NB + ob, H_F + 3 * NB + kb, tens, K, 32 * ob, 32 * kb, 32);
+            dw_block(D_F + 0 * NB + ob, E_F + 3, tens, K, 32 * ob, H, 32);
+            dw_block(D_F + 0 * NB + ob, E_F + 4, tens, K, 32 * ob, H + 32, kEmb2 - 32);
+        }
+        for (int kb = wave; kb < NB; kb += kWaves) {           // d h4 = W_a d raw + W_c[:, :H]^T D(0), masked by h4
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = Wg[L.w_a + 32 * kb + phi(r, hi)] * d_raw;
+            for (int ob = 0; ob < NB; ++ob) {
+                ldb(yv, BLK(D_P + 0 * NB + ob), lane);
+                bwd_mm_rt(acc, Wg + L.w_c + (32 * ob + 4 * hi) * L.ld_c + 32 * kb + p31, L.ld_c, yv);
+            }
+            ldb(yv, BLK(H_P + 3 * NB + kb), lane);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xv[r] = yv[r] > 0.0f ? acc[r] : 0.0f;
+            put_delta(1, kb, L.b_m2);
+        }
+        if (wave >= 2) {                                        // d e2: block 0 on wave 2, block 1 on wave 3
+            const int eb = wave - 2;
+            zero_acc(acc);
+            const int col = eb == 0 ? p31 : min(32 + p31, 46);
+            for (int ob = 0; ob < NB; ++ob) {
+                ldb(yv, BLK(D_P + 0 * NB + ob), lane);
+                bwd_mm_rt(acc, Wg + L.w_c + (32 * ob + 4 * hi) * L.ld_c + H + col, L.ld_c, yv);
+            }
+            ldb(yv, BLK(CFB + 3 + eb), lane);
+            if (eb == 0) pe_block_bwd<16>(dproj, acc, yv, kEmb1, kEmb2, 0, hi);
+            else pe_block_bwd<6>(dproj, acc, yv, kEmb1, kEmb2, 1, hi);
+        }
+    }
+    __syncthreads();
+    // ---- mid2: delta D(1), input h3 ; d h3 -> D(0) ----
+    {
+        float* tens = out + L.f[6];
+        for (int ob = wave; ob < NB; ob += kWaves)
+            for (int kb = 0; kb < NB; ++kb) dw_block(D_F + 1 * NB + ob, H_F + 2 * NB + kb, tens, H, 32 * ob, 32 * kb, 32);
+        for (int kb = wave; kb < NB; kb += kWaves) {
+            zero_acc(acc);
+            for (int ob = 0; ob < NB; ++ob) {
+                ldb(yv, BLK(D_P + 1 * NB + ob), lane);
+                bwd_mm_rt(acc, Wg + L.w_m2 + (32 * ob + 4 * hi) * L.ld_m + 32 * kb + p31, L.ld_m, yv);
+            }
+            ldb(yv, BLK(H_P + 2 * NB + kb), lane);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xv[r] = yv[r] > 0.0f ? acc[r] : 0.0f;
+            put_delta(0, kb, L.b_cat);
+        }
+    }
+    __syncthreads();
+    // ---- cat_layer: delta D(0), input [h2 | e1] ; d h2 -> D(1) ; d e1 -> DE images (waves 0..2) ----
+    {
+        float* tens = out + L.f[4];
+        const int K = H + kEmb1;
+        for (int ob = wave; ob < NB; ob += kWaves) {
+            for (int kb = 0; kb < NB; ++kb) dw_block(D_F + 0 * NB + ob, H_F + 1 * NB + kb, tens, K, 32 * ob, 32 * kb, 32);
+            dw_block(D_F + 0 * NB + ob, E_F + 0, tens, K, 32 * ob, H, 32);
+            dw_block(D_F + 0 * NB + ob, E_F + 1, tens, K, 32 * ob, H + 32, 32);
+            dw_block(D_F + 0 * NB + ob, E_F + 2, tens, K, 32 * ob, H + 64, kEmb1 - 64);
+        }
+        for (int kb = wave; kb < NB; kb += kWaves) {
+            zero_acc(acc);
+            for (int ob = 0; ob < NB; ++ob) {
+                ldb(yv, BLK(D_P + 0 * NB + ob), lane);
+                bwd_mm_rt(acc, Wg + L.w_cat + (32 * ob + 4 * hi) * L.ld_cat + 32 * kb + p31, L.ld_cat, yv);
+            }
+            ldb(yv, BLK(H_P + 1 * NB + kb), lane);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xv[r] = yv[r] > 0.0f ? acc[r] : 0.0f;
+            put_delta(1, kb, L.b_m1);
+        }
+        if (wave < 3) {
+            const int eb = wave;
+            zero_acc(acc);
+            const int col = eb < 2 ? 32 * eb + p31 : min(64 + p31, 88);
+            for (int ob = 0; ob < NB; ++ob) {
+                ldb(yv, BLK(D_P + 0 * NB + ob), lane);
+                bwd_mm_rt(acc, Wg + L.w_cat + (32 * ob + 4 * hi) * L.ld_cat + H + col, L.ld_cat, yv);
+            }
+            stacc(BLK(DE + eb), acc, lane);                     // re-read by the same wave in the in_layer phase
+        }
+    }
+    __syncthreads();
+    // ---- mid1: delta D(1), input h1 ; d h1 -> D(0) ----
+    {
+        float* tens = out + L.f[2];
+        for (int ob = wave; ob < NB; ob += kWaves)
+            for (int kb = 0; kb < NB; ++kb) dw_block(D_F + 1 * NB + ob, H_F + 0 * NB + kb, tens, H, 32 * ob, 32 * kb, 32);
+        for (int kb = wave; kb < NB; kb += kWaves) {
+            zero_acc(acc);
+            for (int ob = 0; ob < NB; ++ob) {
+                ldb(yv, BLK(D_P + 1 * NB + ob), lane);
+                bwd_mm_rt(acc, Wg + L.w_m1 + (32 * ob + 4 * hi) * L.ld_m + 32 * kb + p31, L.ld_m, yv);
+            }
+            ldb(yv, BLK(H_P + 0 * NB + kb), lane);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xv[r] = yv[r] > 0.0f ? acc[r] : 0.0f;
+            put_delta(0, kb, L.b_in);
+        }
+    }
+    __syncthreads();
+    // ---- in_layer: delta D(0), input e1 ; d e1 += ... (waves 0..2) ; encoding backward ----
+    {
+        float* tens = out + L.f[0];
+        for (int ob = wave; ob < NB; ob += kWaves) {
+            dw_block(D_F + 0 * NB + ob, E_F + 0, tens, kEmb1, 32 * ob, 0, 32);
+            dw_block(D_F + 0 * NB + ob, E_F + 1, tens, kEmb1, 32 * ob, 32, 32);
+            dw_block(D_F + 0 * NB + ob, E_F + 2, tens, kEmb1, 32 * ob, 64, kEmb1 - 64);
+        }
+        if (wave < 3) {
+            const int eb = wave;
+            ldb(xv, BLK(DE + eb), lane);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = xv[r];
+            const int col = eb < 2 ? 32 * eb + p31 : min(64 + p31, 88);
+            for (int ob = 0; ob < NB; ++ob) {
+                ldb(yv, BLK(D_P + 0 * NB + ob), lane);
+                bwd_mm_rt(acc, Wg + L.w_in + (32 * ob + 4 * hi) * L.ld_in + col, L.ld_in, yv);
+            }
+            ldb(yv, BLK(CFB + eb), lane);
+            if (eb == 0) pe_block_bwd<16>(dproj, acc, yv, 0, kEmb1, 0, hi);
+            else if (eb == 1) pe_block_bwd<16>(dproj, acc, yv, 0, kEmb1, 1, hi);
+            else pe_block_bwd<12>(dproj, acc, yv, 0, kEmb1, 2, hi);
+        }
+    }
+    // ---- B_layer.weight gradient: sum the waves' d(proj) partials, then dB = d(proj)^T t on wave 0 ----
+#pragma unroll
+    for (int d = 0; d < kDirs; ++d) dpx[(wave * kDirs + d) * 64 + lane] = dproj[d];
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int d = 0; d < kDirs; ++d)
+            dproj[d] = (dpx[d * 64 + lane] + dpx[(kDirs + d) * 64 + lane]) + (dpx[(2 * kDirs + d) * 64 + lane] + dpx[(3 * kDirs + d) * 64 + lane]);
+#pragma unroll
+        for (int d = 0; d < kDirs; ++d) dproj[d] += wv::swap_half(dproj[d]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int f0 = phi(r, 0), f1 = phi(r, 1);
+            const float v0 = f0 < kDirs ? dproj[f0 < kDirs ? f0 : 0] : 0.0f;
+            const float v1 = f1 < kDirs ? dproj[f1 < kDirs ? f1 : 0] : 0.0f;
+            xv[r] = hi ? v1 : v0;
+        }
+        toF_put(scrD, xv, p31, hi); toF_get(yv, scrD, p31, hi);
+        ldb(xv, BLK(E_F + 0), lane);
+        zero_acc(acc);
+        dw_mm(acc, yv, xv);
+        if (p31 < 3) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int d = phi(r, hi);
+                if (d < kDirs) {
+                    float* o = out + L.f[14] + 3 * d + p31;
+                    *o = first_pass ? acc[r] : *o + acc[r];
+                }
+            }
+        }
+    }
+    }   // BWD
+    }   // pass loop
+#undef BLK
+    __syncthreads();
+    const int tid = tid_k;
+    if (tid == 0) {
+        float* pl = a.part_loss + (obj * a.NW + wgo) * 4;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            pl[k] = (lds[LdsGen::LOSS + k] + lds[LdsGen::LOSS + 4 + k]) + (lds[LdsGen::LOSS + 8 + k] + lds[LdsGen::LOSS + 12 + k]);
+        pl[3] = 0.0f;
+    }
+    if (!BWD) return;
+    for (int sv = tid; sv < L.small_n; sv += kWG) {
+        const float* v = lds + LdsGen::VEC + sv;
+        const float g = (v[0] + v[L.small_n]) + (v[2 * L.small_n] + v[3 * L.small_n]);
+        const int i = L.b_in + sv;
+        int o = -1;
+        if (i < L.b_m1) o = L.f[1] + (i - L.b_in);
+        else if (i < L.b_cat) o = L.f[3] + (i - L.b_m1);
+        else if (i < L.b_m2) o = L.f[5] + (i - L.b_cat);
+        else if (i < L.b_c) o = L.f[7] + (i - L.b_m2);
+        else if (i < L.w_a) o = L.f[11] + (i - L.b_c);
+        else if (i < L.w_oc) o = L.f[8] + (i - L.w_a);
+        else if (i < L.b_a) o = L.f[12] + (i - L.w_oc);
+        else if (i == L.b_a) o = L.f[9];
+        else if (i >= L.b_oc && i < L.b_oc + 3) o = L.f[13] + (i - L.b_oc);
+        if (o >= 0) out[o] = g;
+    }
+}
+
+}  // namespace vk
