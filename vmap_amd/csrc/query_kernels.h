@@ -184,7 +184,7 @@ __global__ __launch_bounds__(kWG, 1) void field_query_gen(const QueryArgs a) {
             if constexpr (LDSB) {
                 relu_to(tmp, v);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) hBl[ob * 1024 + r * 64 + lane] = tmp[r];
+                for (int r = 0; r < 16; ++r) hBl[ob * 1024 + (r >> 2) * 256 + lane * 4 + (r & 3)] = tmp[r];   // 16-byte chunks per lane
             } else {
                 relu_to(hB[ob], v);
             }
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(kWG, 1) void field_query_gen(const QueryArgs a) {
         auto mmB = [&](f32x16& c, const float* w, int kb) {
             if constexpr (LDSB) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) tmp[r] = hBl[kb * 1024 + r * 64 + lane];
+                for (int r = 0; r < 16; ++r) tmp[r] = hBl[kb * 1024 + (r >> 2) * 256 + lane * 4 + (r & 3)];
                 fwd_mm<4>(c, w, tmp);
             } else {
                 fwd_mm<4>(c, w, hB[kb]);
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(kWG, 1) void field_query_gen(const QueryArgs a) {
         for (int kb = 0; kb < NB; ++kb) {
             if constexpr (LDSB) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) tmp[r] = hBl[kb * 1024 + r * 64 + lane];
+                for (int r = 0; r < 16; ++r) tmp[r] = hBl[kb * 1024 + (r >> 2) * 256 + lane * 4 + (r & 3)];
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
