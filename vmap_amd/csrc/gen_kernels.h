@@ -68,6 +68,64 @@ __device__ __forceinline__ void stacc(float* blk, const f32x16& a, int lane) {
         *reinterpret_cast<wv::f32x4*>(blk + j * 256 + lane * 4) = t;
     }
 }
+// ---- software-pipelined matrix chains over register images in global memory ----
+// A wave of these kernels spends most of its time waiting for memory (background shape: 57 % of its cycles in
+// s_waitcnt): every 16-deep matrix chain needs one register image (4 x 16 B per lane) and 16 weights per lane, all
+// through global loads of L2 latency, and the feature-block loops are runtime loops the compiler does not pipeline.
+// Here the operands of segment i+1 are requested before the chain of segment i is issued (two named operand sets).
+struct FSeg { const float* w; const float* x; };      // w: this lane's weight row (32 consecutive k), x: register image
+template <class F>
+__device__ __forceinline__ void chain_fwd(f32x16& acc, int n, F seg, int lane) {
+    float xa[16], xb[16];
+    wv::f32x4 wa[4], wb[4];
+    auto ld = [&](int i, float (&x)[16], wv::f32x4 (&w)[4]) {
+        const FSeg s = seg(i);
+        ldb(x, s.x, lane);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w[q] = *reinterpret_cast<const wv::f32x4*>(s.w + 8 * q);
+    };
+    auto mm = [&](const float (&x)[16], const wv::f32x4 (&w)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc = wv::mfma32(w[q][i], x[4 * q + i], acc);
+        }
+    };
+    ld(0, xa, wa);
+    int i = 0;
+    for (; i + 1 < n; i += 2) {
+        ld(i + 1, xb, wb);
+        mm(xa, wa);
+        if (i + 2 < n) ld(i + 2, xa, wa);
+        mm(xb, wb);
+    }
+    if (i < n) mm(xa, wa);
+}
+struct BSeg { const float* wcol; const float* x; };   // wcol: &W[32*ob + 4*hi][this lane's column], x: delta image (P-form)
+template <class F>
+__device__ __forceinline__ void chain_bwd(f32x16& acc, int n, int ld_w, F seg, int lane) {
+    float xa[16], xb[16], wa[16], wb[16];
+    auto ld = [&](int i, float (&x)[16], float (&w)[16]) {
+        const BSeg s = seg(i);
+        ldb(x, s.x, lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) w[r] = s.wcol[((r & 3) + 8 * (r >> 2)) * ld_w];
+    };
+    auto mm = [&](const float (&x)[16], const float (&w)[16]) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc = wv::mfma32(w[r], x[r], acc);
+    };
+    ld(0, xa, wa);
+    int i = 0;
+    for (; i + 1 < n; i += 2) {
+        ld(i + 1, xb, wb);
+        mm(xa, wa);
+        if (i + 2 < n) ld(i + 2, xa, wa);
+        mm(xb, wb);
+    }
+    if (i < n) mm(xa, wa);
+}
+
 // d-prop with a runtime row pitch
 __device__ __forceinline__ void bwd_mm_rt(f32x16& acc, const float* wcol, int ld, const float (&dy)[16]) {
     float w[16];
@@ -168,9 +226,6 @@ __global__ __launch_bounds__(kWG, 1) void step_main_gen(const GenArgs ga) {
     __syncthreads();        // composite buffer zeroed
 
     // ---- field MLP forward (model.py:59-83): layer l output block ob -> H_P(l, ob) ----
-    auto seg4 = [&](const float* w, int blk) { ldb(xv, BLK(blk), lane); fwd_mm<4>(acc, w, xv); };
-    auto seg3 = [&](const float* w, int blk) { ldb(xv, BLK(blk), lane); fwd_mm<3>(acc, w, xv); };
-    auto seg2 = [&](const float* w, int blk) { ldb(xv, BLK(blk), lane); fwd_mm<2>(acc, w, xv); };
     auto finish = [&](int l, int ob) {          // ReLU, store P-form and F-form
         relu_to(xv, acc);
         stb(BLK(H_P + l * NB + ob), xv, lane);
@@ -180,33 +235,31 @@ __global__ __launch_bounds__(kWG, 1) void step_main_gen(const GenArgs ga) {
     for (int ob = 0; ob < NB; ++ob) {           // :59 in_layer
         const float* w = Wg + L.w_in + (32 * ob + p31) * L.ld_in + 4 * hi;
         load_bias(acc, Wg + L.b_in + 32 * ob, hi);
-        seg4(w, E_P + 0); seg4(w + 32, E_P + 1); seg3(w + 64, E_P + 2);
+        chain_fwd(acc, 3, [&](int i) { return FSeg{w + 32 * i, BLK(E_P + i)}; }, lane);   // zero weights/encodings pad block 2
         finish(0, ob);
     }
     for (int ob = 0; ob < NB; ++ob) {           // :60 mid1
         const float* w = Wg + L.w_m1 + (32 * ob + p31) * L.ld_m + 4 * hi;
         load_bias(acc, Wg + L.b_m1 + 32 * ob, hi);
-        for (int kb = 0; kb < NB; ++kb) seg4(w + 32 * kb, H_P + 0 * NB + kb);
+        chain_fwd(acc, NB, [&](int i) { return FSeg{w + 32 * i, BLK(H_P + 0 * NB + i)}; }, lane);
         finish(1, ob);
     }
     for (int ob = 0; ob < NB; ++ob) {           // :63-64 cat_layer
         const float* w = Wg + L.w_cat + (32 * ob + p31) * L.ld_cat + 4 * hi;
         load_bias(acc, Wg + L.b_cat + 32 * ob, hi);
-        for (int kb = 0; kb < NB; ++kb) seg4(w + 32 * kb, H_P + 1 * NB + kb);
-        seg4(w + H, E_P + 0); seg4(w + H + 32, E_P + 1); seg3(w + H + 64, E_P + 2);
+        chain_fwd(acc, NB + 3, [&](int i) { return i < NB ? FSeg{w + 32 * i, BLK(H_P + 1 * NB + i)} : FSeg{w + H + 32 * (i - NB), BLK(E_P + (i - NB))}; }, lane);
         finish(2, ob);
     }
     for (int ob = 0; ob < NB; ++ob) {           // :67 mid2
         const float* w = Wg + L.w_m2 + (32 * ob + p31) * L.ld_m + 4 * hi;
         load_bias(acc, Wg + L.b_m2 + 32 * ob, hi);
-        for (int kb = 0; kb < NB; ++kb) seg4(w + 32 * kb, H_P + 2 * NB + kb);
+        chain_fwd(acc, NB, [&](int i) { return FSeg{w + 32 * i, BLK(H_P + 2 * NB + i)}; }, lane);
         finish(3, ob);
     }
     for (int ob = 0; ob < NB; ++ob) {           // :81 color_linear
         const float* w = Wg + L.w_c + (32 * ob + p31) * L.ld_c + 4 * hi;
         load_bias(acc, Wg + L.b_c + 32 * ob, hi);
-        for (int kb = 0; kb < NB; ++kb) seg4(w + 32 * kb, H_P + 3 * NB + kb);
-        seg4(w + H, E_P + 3); seg2(w + H + 32, E_P + 4);
+        chain_fwd(acc, NB + 2, [&](int i) { return i < NB ? FSeg{w + 32 * i, BLK(H_P + 3 * NB + i)} : FSeg{w + H + 32 * (i - NB), BLK(E_P + 3 + (i - NB))}; }, lane);
         finish(4, ob);
     }
     {   // heads (model.py:71,77,82-83)
@@ -321,10 +374,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_gen(const GenArgs ga) {
         for (int kb = 0; kb < NB; ++kb) {           // d h4 = W_a d raw + W_c[:, :H]^T D(0), masked by h4
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = Wg[L.w_a + 32 * kb + phi(r, hi)] * d_raw;
-            for (int ob = 0; ob < NB; ++ob) {
-                ldb(yv, BLK(D_P + 0 * NB + ob), lane);
-                bwd_mm_rt(acc, Wg + L.w_c + (32 * ob + 4 * hi) * L.ld_c + 32 * kb + p31, L.ld_c, yv);
-            }
+            chain_bwd(acc, NB, L.ld_c, [&](int ob) { return BSeg{Wg + L.w_c + (32 * ob + 4 * hi) * L.ld_c + 32 * kb + p31, BLK(D_P + 0 * NB + ob)}; }, lane);
             ldb(yv, BLK(H_P + 3 * NB + kb), lane);
 #pragma unroll
             for (int r = 0; r < 16; ++r) xv[r] = yv[r] > 0.0f ? acc[r] : 0.0f;
@@ -333,10 +383,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_gen(const GenArgs ga) {
         for (int eb = 0; eb < 2; ++eb) {            // d e2
             zero_acc(acc);
             const int col = eb == 0 ? p31 : min(32 + p31, 46);
-            for (int ob = 0; ob < NB; ++ob) {
-                ldb(yv, BLK(D_P + 0 * NB + ob), lane);
-                bwd_mm_rt(acc, Wg + L.w_c + (32 * ob + 4 * hi) * L.ld_c + H + col, L.ld_c, yv);
-            }
+            chain_bwd(acc, NB, L.ld_c, [&](int ob) { return BSeg{Wg + L.w_c + (32 * ob + 4 * hi) * L.ld_c + H + col, BLK(D_P + 0 * NB + ob)}; }, lane);
             ldb(yv, BLK(CFB + 3 + eb), lane);
             if (eb == 0) pe_block_bwd<16>(dproj, acc, yv, kEmb1, kEmb2, 0, hi);
             else pe_block_bwd<6>(dproj, acc, yv, kEmb1, kEmb2, 1, hi);
@@ -349,10 +396,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_gen(const GenArgs ga) {
             for (int kb = 0; kb < NB; ++kb) dw_block(D_F + 1 * NB + ob, H_F + 2 * NB + kb, tens, H, 32 * ob, 32 * kb, 32);
         for (int kb = 0; kb < NB; ++kb) {
             zero_acc(acc);
-            for (int ob = 0; ob < NB; ++ob) {
-                ldb(yv, BLK(D_P + 1 * NB + ob), lane);
-                bwd_mm_rt(acc, Wg + L.w_m2 + (32 * ob + 4 * hi) * L.ld_m + 32 * kb + p31, L.ld_m, yv);
-            }
+            chain_bwd(acc, NB, L.ld_m, [&](int ob) { return BSeg{Wg + L.w_m2 + (32 * ob + 4 * hi) * L.ld_m + 32 * kb + p31, BLK(D_P + 1 * NB + ob)}; }, lane);
             ldb(yv, BLK(H_P + 2 * NB + kb), lane);
 #pragma unroll
             for (int r = 0; r < 16; ++r) xv[r] = yv[r] > 0.0f ? acc[r] : 0.0f;
@@ -371,10 +415,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_gen(const GenArgs ga) {
         }
         for (int kb = 0; kb < NB; ++kb) {
             zero_acc(acc);
-            for (int ob = 0; ob < NB; ++ob) {
-                ldb(yv, BLK(D_P + 0 * NB + ob), lane);
-                bwd_mm_rt(acc, Wg + L.w_cat + (32 * ob + 4 * hi) * L.ld_cat + 32 * kb + p31, L.ld_cat, yv);
-            }
+            chain_bwd(acc, NB, L.ld_cat, [&](int ob) { return BSeg{Wg + L.w_cat + (32 * ob + 4 * hi) * L.ld_cat + 32 * kb + p31, BLK(D_P + 0 * NB + ob)}; }, lane);
             ldb(yv, BLK(H_P + 1 * NB + kb), lane);
 #pragma unroll
             for (int r = 0; r < 16; ++r) xv[r] = yv[r] > 0.0f ? acc[r] : 0.0f;
@@ -383,10 +424,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_gen(const GenArgs ga) {
         for (int eb = 0; eb < 3; ++eb) {
             zero_acc(acc);
             const int col = eb < 2 ? 32 * eb + p31 : min(64 + p31, 88);
-            for (int ob = 0; ob < NB; ++ob) {
-                ldb(yv, BLK(D_P + 0 * NB + ob), lane);
-                bwd_mm_rt(acc, Wg + L.w_cat + (32 * ob + 4 * hi) * L.ld_cat + H + col, L.ld_cat, yv);
-            }
+            chain_bwd(acc, NB, L.ld_cat, [&](int ob) { return BSeg{Wg + L.w_cat + (32 * ob + 4 * hi) * L.ld_cat + H + col, BLK(D_P + 0 * NB + ob)}; }, lane);
             stacc(BLK(DE + eb), acc, lane);
         }
     }
@@ -397,10 +435,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_gen(const GenArgs ga) {
             for (int kb = 0; kb < NB; ++kb) dw_block(D_F + 1 * NB + ob, H_F + 0 * NB + kb, tens, H, 32 * ob, 32 * kb, 32);
         for (int kb = 0; kb < NB; ++kb) {
             zero_acc(acc);
-            for (int ob = 0; ob < NB; ++ob) {
-                ldb(yv, BLK(D_P + 1 * NB + ob), lane);
-                bwd_mm_rt(acc, Wg + L.w_m1 + (32 * ob + 4 * hi) * L.ld_m + 32 * kb + p31, L.ld_m, yv);
-            }
+            chain_bwd(acc, NB, L.ld_m, [&](int ob) { return BSeg{Wg + L.w_m1 + (32 * ob + 4 * hi) * L.ld_m + 32 * kb + p31, BLK(D_P + 1 * NB + ob)}; }, lane);
             ldb(yv, BLK(H_P + 0 * NB + kb), lane);
 #pragma unroll
             for (int r = 0; r < 16; ++r) xv[r] = yv[r] > 0.0f ? acc[r] : 0.0f;
@@ -420,10 +455,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_gen(const GenArgs ga) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = xv[r];
             const int col = eb < 2 ? 32 * eb + p31 : min(64 + p31, 88);
-            for (int ob = 0; ob < NB; ++ob) {
-                ldb(yv, BLK(D_P + 0 * NB + ob), lane);
-                bwd_mm_rt(acc, Wg + L.w_in + (32 * ob + 4 * hi) * L.ld_in + col, L.ld_in, yv);
-            }
+            chain_bwd(acc, NB, L.ld_in, [&](int ob) { return BSeg{Wg + L.w_in + (32 * ob + 4 * hi) * L.ld_in + col, BLK(D_P + 0 * NB + ob)}; }, lane);
             ldb(yv, BLK(CFB + eb), lane);
             if (eb == 0) pe_block_bwd<16>(dproj, acc, yv, 0, kEmb1, 0, hi);
             else if (eb == 1) pe_block_bwd<16>(dproj, acc, yv, 0, kEmb1, 1, hi);

@@ -104,9 +104,6 @@ __global__ __launch_bounds__(kWG, 1) void step_main_wide(const GenArgs ga) {
     __syncthreads();
 
     // ---- field MLP forward: wave w produces output blocks ob = w, w+4, ... of every layer ----
-    auto seg4 = [&](const float* w, int blk) { ldb(xv, BLK(blk), lane); fwd_mm<4>(acc, w, xv); };
-    auto seg3 = [&](const float* w, int blk) { ldb(xv, BLK(blk), lane); fwd_mm<3>(acc, w, xv); };
-    auto seg2 = [&](const float* w, int blk) { ldb(xv, BLK(blk), lane); fwd_mm<2>(acc, w, xv); };
     auto finish = [&](int l, int ob) {
         relu_to(xv, acc);
         stb(BLK(H_P + l * NB + ob), xv, lane);
@@ -116,37 +113,35 @@ __global__ __launch_bounds__(kWG, 1) void step_main_wide(const GenArgs ga) {
     for (int ob = wave; ob < NB; ob += kWaves) {           // :59 in_layer
         const float* w = Wg + L.w_in + (32 * ob + p31) * L.ld_in + 4 * hi;
         load_bias(acc, Wg + L.b_in + 32 * ob, hi);
-        seg4(w, E_P + 0); seg4(w + 32, E_P + 1); seg3(w + 64, E_P + 2);
+        chain_fwd(acc, 3, [&](int i) { return FSeg{w + 32 * i, BLK(E_P + i)}; }, lane);   // zero weights/encodings pad block 2
         finish(0, ob);
     }
     __syncthreads();
     for (int ob = wave; ob < NB; ob += kWaves) {           // :60 mid1
         const float* w = Wg + L.w_m1 + (32 * ob + p31) * L.ld_m + 4 * hi;
         load_bias(acc, Wg + L.b_m1 + 32 * ob, hi);
-        for (int kb = 0; kb < NB; ++kb) seg4(w + 32 * kb, H_P + 0 * NB + kb);
+        chain_fwd(acc, NB, [&](int i) { return FSeg{w + 32 * i, BLK(H_P + 0 * NB + i)}; }, lane);
         finish(1, ob);
     }
     __syncthreads();
     for (int ob = wave; ob < NB; ob += kWaves) {           // :63-64 cat_layer
         const float* w = Wg + L.w_cat + (32 * ob + p31) * L.ld_cat + 4 * hi;
         load_bias(acc, Wg + L.b_cat + 32 * ob, hi);
-        for (int kb = 0; kb < NB; ++kb) seg4(w + 32 * kb, H_P + 1 * NB + kb);
-        seg4(w + H, E_P + 0); seg4(w + H + 32, E_P + 1); seg3(w + H + 64, E_P + 2);
+        chain_fwd(acc, NB + 3, [&](int i) { return i < NB ? FSeg{w + 32 * i, BLK(H_P + 1 * NB + i)} : FSeg{w + H + 32 * (i - NB), BLK(E_P + (i - NB))}; }, lane);
         finish(2, ob);
     }
     __syncthreads();
     for (int ob = wave; ob < NB; ob += kWaves) {           // :67 mid2
         const float* w = Wg + L.w_m2 + (32 * ob + p31) * L.ld_m + 4 * hi;
         load_bias(acc, Wg + L.b_m2 + 32 * ob, hi);
-        for (int kb = 0; kb < NB; ++kb) seg4(w + 32 * kb, H_P + 2 * NB + kb);
+        chain_fwd(acc, NB, [&](int i) { return FSeg{w + 32 * i, BLK(H_P + 2 * NB + i)}; }, lane);
         finish(3, ob);
     }
     __syncthreads();
     for (int ob = wave; ob < NB; ob += kWaves) {           // :81 color_linear
         const float* w = Wg + L.w_c + (32 * ob + p31) * L.ld_c + 4 * hi;
         load_bias(acc, Wg + L.b_c + 32 * ob, hi);
-        for (int kb = 0; kb < NB; ++kb) seg4(w + 32 * kb, H_P + 3 * NB + kb);
-        seg4(w + H, E_P + 3); seg2(w + H + 32, E_P + 4);
+        chain_fwd(acc, NB + 2, [&](int i) { return i < NB ? FSeg{w + 32 * i, BLK(H_P + 3 * NB + i)} : FSeg{w + H + 32 * (i - NB), BLK(E_P + 3 + (i - NB))}; }, lane);
         finish(4, ob);
     }
     __syncthreads();
@@ -256,10 +251,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_wide(const GenArgs ga) {
         for (int kb = wave; kb < NB; kb += kWaves) {           // d h4 = W_a d raw + W_c[:, :H]^T D(0), masked by h4
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = Wg[L.w_a + 32 * kb + phi(r, hi)] * d_raw;
-            for (int ob = 0; ob < NB; ++ob) {
-                ldb(yv, BLK(D_P + 0 * NB + ob), lane);
-                bwd_mm_rt(acc, Wg + L.w_c + (32 * ob + 4 * hi) * L.ld_c + 32 * kb + p31, L.ld_c, yv);
-            }
+            chain_bwd(acc, NB, L.ld_c, [&](int ob) { return BSeg{Wg + L.w_c + (32 * ob + 4 * hi) * L.ld_c + 32 * kb + p31, BLK(D_P + 0 * NB + ob)}; }, lane);
             ldb(yv, BLK(H_P + 3 * NB + kb), lane);
 #pragma unroll
             for (int r = 0; r < 16; ++r) xv[r] = yv[r] > 0.0f ? acc[r] : 0.0f;
@@ -269,10 +261,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_wide(const GenArgs ga) {
             const int eb = wave - 2;
             zero_acc(acc);
             const int col = eb == 0 ? p31 : min(32 + p31, 46);
-            for (int ob = 0; ob < NB; ++ob) {
-                ldb(yv, BLK(D_P + 0 * NB + ob), lane);
-                bwd_mm_rt(acc, Wg + L.w_c + (32 * ob + 4 * hi) * L.ld_c + H + col, L.ld_c, yv);
-            }
+            chain_bwd(acc, NB, L.ld_c, [&](int ob) { return BSeg{Wg + L.w_c + (32 * ob + 4 * hi) * L.ld_c + H + col, BLK(D_P + 0 * NB + ob)}; }, lane);
             ldb(yv, BLK(CFB + 3 + eb), lane);
             if (eb == 0) pe_block_bwd<16>(dproj, acc, yv, kEmb1, kEmb2, 0, hi);
             else pe_block_bwd<6>(dproj, acc, yv, kEmb1, kEmb2, 1, hi);
@@ -286,10 +275,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_wide(const GenArgs ga) {
             for (int kb = 0; kb < NB; ++kb) dw_block(D_F + 1 * NB + ob, H_F + 2 * NB + kb, tens, H, 32 * ob, 32 * kb, 32);
         for (int kb = wave; kb < NB; kb += kWaves) {
             zero_acc(acc);
-            for (int ob = 0; ob < NB; ++ob) {
-                ldb(yv, BLK(D_P + 1 * NB + ob), lane);
-                bwd_mm_rt(acc, Wg + L.w_m2 + (32 * ob + 4 * hi) * L.ld_m + 32 * kb + p31, L.ld_m, yv);
-            }
+            chain_bwd(acc, NB, L.ld_m, [&](int ob) { return BSeg{Wg + L.w_m2 + (32 * ob + 4 * hi) * L.ld_m + 32 * kb + p31, BLK(D_P + 1 * NB + ob)}; }, lane);
             ldb(yv, BLK(H_P + 2 * NB + kb), lane);
 #pragma unroll
             for (int r = 0; r < 16; ++r) xv[r] = yv[r] > 0.0f ? acc[r] : 0.0f;
@@ -309,10 +295,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_wide(const GenArgs ga) {
         }
         for (int kb = wave; kb < NB; kb += kWaves) {
             zero_acc(acc);
-            for (int ob = 0; ob < NB; ++ob) {
-                ldb(yv, BLK(D_P + 0 * NB + ob), lane);
-                bwd_mm_rt(acc, Wg + L.w_cat + (32 * ob + 4 * hi) * L.ld_cat + 32 * kb + p31, L.ld_cat, yv);
-            }
+            chain_bwd(acc, NB, L.ld_cat, [&](int ob) { return BSeg{Wg + L.w_cat + (32 * ob + 4 * hi) * L.ld_cat + 32 * kb + p31, BLK(D_P + 0 * NB + ob)}; }, lane);
             ldb(yv, BLK(H_P + 1 * NB + kb), lane);
 #pragma unroll
             for (int r = 0; r < 16; ++r) xv[r] = yv[r] > 0.0f ? acc[r] : 0.0f;
@@ -322,10 +305,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_wide(const GenArgs ga) {
             const int eb = wave;
             zero_acc(acc);
             const int col = eb < 2 ? 32 * eb + p31 : min(64 + p31, 88);
-            for (int ob = 0; ob < NB; ++ob) {
-                ldb(yv, BLK(D_P + 0 * NB + ob), lane);
-                bwd_mm_rt(acc, Wg + L.w_cat + (32 * ob + 4 * hi) * L.ld_cat + H + col, L.ld_cat, yv);
-            }
+            chain_bwd(acc, NB, L.ld_cat, [&](int ob) { return BSeg{Wg + L.w_cat + (32 * ob + 4 * hi) * L.ld_cat + H + col, BLK(D_P + 0 * NB + ob)}; }, lane);
             stacc(BLK(DE + eb), acc, lane);                     // re-read by the same wave in the in_layer phase
         }
     }
@@ -337,10 +317,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_wide(const GenArgs ga) {
             for (int kb = 0; kb < NB; ++kb) dw_block(D_F + 1 * NB + ob, H_F + 0 * NB + kb, tens, H, 32 * ob, 32 * kb, 32);
         for (int kb = wave; kb < NB; kb += kWaves) {
             zero_acc(acc);
-            for (int ob = 0; ob < NB; ++ob) {
-                ldb(yv, BLK(D_P + 1 * NB + ob), lane);
-                bwd_mm_rt(acc, Wg + L.w_m1 + (32 * ob + 4 * hi) * L.ld_m + 32 * kb + p31, L.ld_m, yv);
-            }
+            chain_bwd(acc, NB, L.ld_m, [&](int ob) { return BSeg{Wg + L.w_m1 + (32 * ob + 4 * hi) * L.ld_m + 32 * kb + p31, BLK(D_P + 1 * NB + ob)}; }, lane);
             ldb(yv, BLK(H_P + 0 * NB + kb), lane);
 #pragma unroll
             for (int r = 0; r < 16; ++r) xv[r] = yv[r] > 0.0f ? acc[r] : 0.0f;
@@ -362,10 +339,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_wide(const GenArgs ga) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = xv[r];
             const int col = eb < 2 ? 32 * eb + p31 : min(64 + p31, 88);
-            for (int ob = 0; ob < NB; ++ob) {
-                ldb(yv, BLK(D_P + 0 * NB + ob), lane);
-                bwd_mm_rt(acc, Wg + L.w_in + (32 * ob + 4 * hi) * L.ld_in + col, L.ld_in, yv);
-            }
+            chain_bwd(acc, NB, L.ld_in, [&](int ob) { return BSeg{Wg + L.w_in + (32 * ob + 4 * hi) * L.ld_in + col, BLK(D_P + 0 * NB + ob)}; }, lane);
             ldb(yv, BLK(CFB + eb), lane);
             if (eb == 0) pe_block_bwd<16>(dproj, acc, yv, 0, kEmb1, 0, hi);
             else if (eb == 1) pe_block_bwd<16>(dproj, acc, yv, 0, kEmb1, 1, hi);
