@@ -189,12 +189,30 @@ __global__ __launch_bounds__(kWG, 1) void step_main_wide(const GenArgs ga) {
     for (int d = 0; d < kDirs; ++d) dproj[d] = 0.0f;
 
     // weight-gradient block (ob, x-block): one producer per tile -> straight into the workgroup's partial buffer
-    auto dw_block = [&](int dfblk, int xfblk, float* tens, int K, int row0, int col0, int ncols) {
-        ldb(xv, BLK(dfblk), lane);
-        ldb(yv, BLK(xfblk), lane);
-        zero_acc(acc);
-        dw_mm(acc, xv, yv);
-        store_block_rt(tens + (long long)row0 * K, K, acc, col0, ncols, !first_pass, p31, hi);
+    // weight-gradient blocks of one output-row block: delta image (F-form) loaded once, the input image of block i+1
+    // requested before the chain of block i
+    struct XSeg { int blk, col0, ncols; };
+    auto dw_row = [&](int dfblk, int n, auto xs, float* tens, int K, int row0) {
+        float df[16], xa[16], xb[16];
+        ldb(df, BLK(dfblk), lane);
+        XSeg s = xs(0), sn = s;
+        ldb(xa, BLK(s.blk), lane);
+        int i = 0;
+        for (; i + 1 < n; i += 2) {
+            sn = xs(i + 1);
+            ldb(xb, BLK(sn.blk), lane);
+            zero_acc(acc); dw_mm(acc, df, xa);
+            store_block_rt(tens + (long long)row0 * K, K, acc, s.col0, s.ncols, !first_pass, p31, hi);
+            s = sn;
+            if (i + 2 < n) { sn = xs(i + 2); ldb(xa, BLK(sn.blk), lane); }
+            zero_acc(acc); dw_mm(acc, df, xb);
+            store_block_rt(tens + (long long)row0 * K, K, acc, s.col0, s.ncols, !first_pass, p31, hi);
+            s = sn;
+        }
+        if (i < n) {
+            zero_acc(acc); dw_mm(acc, df, xa);
+            store_block_rt(tens + (long long)row0 * K, K, acc, s.col0, s.ncols, !first_pass, p31, hi);
+        }
     };
     auto put_delta = [&](int ds, int kb, int bias_off) {
         stb(BLK(D_P + ds * NB + kb), xv, lane);
@@ -244,9 +262,8 @@ __global__ __launch_bounds__(kWG, 1) void step_main_wide(const GenArgs ga) {
         float* tens = out + L.f[10];
         const int K = H + kEmb2;
         for (int ob = wave; ob < NB; ob += kWaves) {
-            for (int kb = 0; kb < NB; ++kb) dw_block(D_F + 0 * NB + ob, H_F + 3 * NB + kb, tens, K, 32 * ob, 32 * kb, 32);
-            dw_block(D_F + 0 * NB + ob, E_F + 3, tens, K, 32 * ob, H, 32);
-            dw_block(D_F + 0 * NB + ob, E_F + 4, tens, K, 32 * ob, H + 32, kEmb2 - 32);
+            dw_row(D_F + 0 * NB + ob, NB + 2, [&](int i) { return i < NB ? XSeg{H_F + 3 * NB + i, 32 * i, 32}
+                                                                        : XSeg{E_F + 3 + (i - NB), H + 32 * (i - NB), i == NB ? 32 : kEmb2 - 32}; }, tens, K, 32 * ob);
         }
         for (int kb = wave; kb < NB; kb += kWaves) {           // d h4 = W_a d raw + W_c[:, :H]^T D(0), masked by h4
 #pragma unroll
@@ -272,7 +289,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_wide(const GenArgs ga) {
     {
         float* tens = out + L.f[6];
         for (int ob = wave; ob < NB; ob += kWaves)
-            for (int kb = 0; kb < NB; ++kb) dw_block(D_F + 1 * NB + ob, H_F + 2 * NB + kb, tens, H, 32 * ob, 32 * kb, 32);
+            dw_row(D_F + 1 * NB + ob, NB, [&](int i) { return XSeg{H_F + 2 * NB + i, 32 * i, 32}; }, tens, H, 32 * ob);
         for (int kb = wave; kb < NB; kb += kWaves) {
             zero_acc(acc);
             chain_bwd(acc, NB, L.ld_m, [&](int ob) { return BSeg{Wg + L.w_m2 + (32 * ob + 4 * hi) * L.ld_m + 32 * kb + p31, BLK(D_P + 1 * NB + ob)}; }, lane);
@@ -288,10 +305,8 @@ __global__ __launch_bounds__(kWG, 1) void step_main_wide(const GenArgs ga) {
         float* tens = out + L.f[4];
         const int K = H + kEmb1;
         for (int ob = wave; ob < NB; ob += kWaves) {
-            for (int kb = 0; kb < NB; ++kb) dw_block(D_F + 0 * NB + ob, H_F + 1 * NB + kb, tens, K, 32 * ob, 32 * kb, 32);
-            dw_block(D_F + 0 * NB + ob, E_F + 0, tens, K, 32 * ob, H, 32);
-            dw_block(D_F + 0 * NB + ob, E_F + 1, tens, K, 32 * ob, H + 32, 32);
-            dw_block(D_F + 0 * NB + ob, E_F + 2, tens, K, 32 * ob, H + 64, kEmb1 - 64);
+            dw_row(D_F + 0 * NB + ob, NB + 3, [&](int i) { return i < NB ? XSeg{H_F + 1 * NB + i, 32 * i, 32}
+                                                                        : XSeg{E_F + (i - NB), H + 32 * (i - NB), i - NB < 2 ? 32 : kEmb1 - 64}; }, tens, K, 32 * ob);
         }
         for (int kb = wave; kb < NB; kb += kWaves) {
             zero_acc(acc);
@@ -314,7 +329,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_wide(const GenArgs ga) {
     {
         float* tens = out + L.f[2];
         for (int ob = wave; ob < NB; ob += kWaves)
-            for (int kb = 0; kb < NB; ++kb) dw_block(D_F + 1 * NB + ob, H_F + 0 * NB + kb, tens, H, 32 * ob, 32 * kb, 32);
+            dw_row(D_F + 1 * NB + ob, NB, [&](int i) { return XSeg{H_F + 0 * NB + i, 32 * i, 32}; }, tens, H, 32 * ob);
         for (int kb = wave; kb < NB; kb += kWaves) {
             zero_acc(acc);
             chain_bwd(acc, NB, L.ld_m, [&](int ob) { return BSeg{Wg + L.w_m1 + (32 * ob + 4 * hi) * L.ld_m + 32 * kb + p31, BLK(D_P + 1 * NB + ob)}; }, lane);
@@ -329,9 +344,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_wide(const GenArgs ga) {
     {
         float* tens = out + L.f[0];
         for (int ob = wave; ob < NB; ob += kWaves) {
-            dw_block(D_F + 0 * NB + ob, E_F + 0, tens, kEmb1, 32 * ob, 0, 32);
-            dw_block(D_F + 0 * NB + ob, E_F + 1, tens, kEmb1, 32 * ob, 32, 32);
-            dw_block(D_F + 0 * NB + ob, E_F + 2, tens, kEmb1, 32 * ob, 64, kEmb1 - 64);
+            dw_row(D_F + 0 * NB + ob, 3, [&](int i) { return XSeg{E_F + i, 32 * i, i < 2 ? 32 : kEmb1 - 64}; }, tens, kEmb1, 32 * ob);
         }
         if (wave < 3) {
             const int eb = wave;
