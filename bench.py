@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--config", default="replica_room0_vmap", choices=list(synth.CONFIGS))
     ap.add_argument("--iters-per-frame", type=int, default=20)       # config: render.iters_per_frame
     ap.add_argument("--weights", default="f32", choices=["f32", "bf16"])   # bf16: BASELINE configs[3]/[4] (fp32 masters + accumulate)
+    ap.add_argument("--kernel", default="auto", choices=["auto", "gen", "wide", "wide2"])   # hidden 128 / 256: which fused kernel (measurement)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-reps", type=int, default=200)
     args = ap.parse_args()
@@ -102,6 +103,9 @@ def main():
     tfc = [torch.from_numpy(a).to(dev) for a in fc]
     tB, tsc = torch.from_numpy(B).to(dev), torch.from_numpy(sc).to(dev)
     fr = {k: torch.from_numpy(v).to(dev) for k, v in frame.items()}
+    if args.kernel != "auto":
+        from vmap_amd import _lib
+        _lib.load().vmapstep_set_workgroups_per_object({"gen": -1, "wide": -3, "wide2": -4}[args.kernel])
     op = step.VmapStep(n, R, S, H, device=dev, max_steps=ipf, weights=args.weights)
     opt = step.FusedAdamWState(n, H, dev, lr=1e-3, weight_decay=0.013)
     fargs = (fr["pcs"], fr["z"], fr["gt_depth"], fr["gt_rgb"], fr["sem"], fr["depth_mask"])
@@ -174,7 +178,7 @@ def main():
                                    f"{S} samples/ray, fwd+loss+bwd+fused AdamW, {ipf} steps per frame call",
                        "objects_per_gpu": n, "rays_per_object": R, "samples_per_ray": S, "hidden": H,
                        "parallelism": f"objects sharded over {world} GPU(s); no per-step collective, one 4x{ipf}-int32 flag all-reduce per frame"},
-            "roofline": {"bound": "mfma", "kernel": "step_main_h32<true>" if H == 32 else "step_main_gen<true>", "achieved": achieved,
+            "roofline": {"bound": "mfma", "kernel": "step_main_h32<true>" if H == 32 else "step_main_gen / step_main_wide (hidden 128, 256: chosen by tile count)", "achieved": achieved,
                          "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
                          "traffic": traffic, "kernel_ms": k_ms, "algorithmic_flops_per_launch": flops,
                          "algorithmic_bytes_per_launch": abytes,

@@ -229,9 +229,9 @@ int vmapstep_profile_phases(const vmapstep_shape* shape, const vmapstep_params* 
                             void* workspace, size_t workspace_bytes, void* stream);
 
 /* Tuning knob (0 = automatic): workgroups per object of the fused kernel. Returns the previous value.
- * Three more values select the kernel of hidden 128 / 256 for measurements and tests: -1 the general kernel
- * (step_main_gen), -3 the tile-per-workgroup kernel (step_main_wide), -2 the automatic choice (wide when every
- * 32-point tile gets its own workgroup, i.e. at most 256 tiles). */
+ * More values select the kernel of hidden 128 / 256 for measurements and tests: -1 step_main_gen (one wave per
+ * tile), -3 step_main_wide<4> (one tile per workgroup, four waves per tile), -4 step_main_wide<2> (four tiles per
+ * workgroup, two waves per tile), -2 the automatic choice. */
 int vmapstep_set_workgroups_per_object(int32_t nw);
 
 #ifdef __cplusplus

@@ -17,7 +17,7 @@ void fc_sizes(int H, int* sz) {
 
 extern "C" int vmsim_lds_bytes() { return vk::Lds32::BYTES; }
 static int g_wide = 0;
-extern "C" void vmsim_set_wide(int w) { g_wide = w; }   // hidden 128 / 256: run step_main_wide (caller passes G * S <= 32)
+extern "C" void vmsim_set_wide(int w) { g_wide = w; }   // hidden 128 / 256: 1 = step_main_wide<4> (G * S <= 32), 2 = step_main_wide<2>
 
 // fc[t]: [n][size_t] contiguous; grads: flat slab [n][P] in natural order (14 field tensors then B).
 extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req, int xcd_affine, int weights_bf16,
@@ -73,11 +73,18 @@ extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req, int xcd
         ga.wave_blocks = vk::gen_wave_blocks(GL.NB);
         std::vector<float> scratch((size_t)n * NW * vk::kWaves * ga.wave_blocks * vk::kBlk, NAN);
         ga.scratch = scratch.data();
-        if (g_wide) {
+        if (g_wide == 1) {
             if (H % 128 != 0 || G * S > vk::kWideTile) return -3;
             ga.s.wide = 1;
-            if (bwd) sim::launch(n * NW, vk::kWG, vk::LdsGen::bytes(GL.small_n), [&] { vk::step_main_wide<true>(ga); });
-            else     sim::launch(n * NW, vk::kWG, vk::LdsGen::bytes(GL.small_n), [&] { vk::step_main_wide<false>(ga); });
+            const int lb = vk::LdsWide<4>::bytes(GL.small_n);
+            if (bwd) sim::launch(n * NW, 256, lb, [&] { vk::step_main_wide<true, 4>(ga); });
+            else     sim::launch(n * NW, 256, lb, [&] { vk::step_main_wide<false, 4>(ga); });
+        } else if (g_wide == 2) {
+            if (H % 128 != 0) return -3;
+            ga.s.wide = 2;
+            const int lb = vk::LdsWide<2>::bytes(GL.small_n);
+            if (bwd) sim::launch(n * NW, 512, lb, [&] { vk::step_main_wide<true, 2>(ga); });
+            else     sim::launch(n * NW, 512, lb, [&] { vk::step_main_wide<false, 2>(ga); });
         } else if (bwd) sim::launch(n * NW, vk::kWG, vk::LdsGen::bytes(GL.small_n), [&] { vk::step_main_gen<true>(ga); });
         else     sim::launch(n * NW, vk::kWG, vk::LdsGen::bytes(GL.small_n), [&] { vk::step_main_gen<false>(ga); });
     }

@@ -59,8 +59,8 @@ def sim_step(case_or_fc, B=None, scale=None, batch=None, G=None, bwd=True, adam=
     n, R, S = batch["z"].shape
     H = fc[2].shape[-1]
     if G is None:
-        G = max(1, (32 if wide else 128) // S)
-    lib().vmsim_set_wide(1 if wide else 0)
+        G = max(1, (32 if wide in (True, 1) else 128) // S)
+    lib().vmsim_set_wide(int(wide))       # 0 general kernel, 1 / True step_main_wide<4>, 2 step_main_wide<2>
     fc_c = [np.ascontiguousarray(a, dtype=np.float32) for a in fc]
     sizes = [a[0].size for a in fc_c]
     P = sum(sizes) + 63

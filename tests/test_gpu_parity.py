@@ -298,10 +298,11 @@ def test_unsupported_hidden_width_fails_loudly():
 
 
 @pytest.mark.parametrize("name,kernel", [("h64", "gen"), ("bg_h128_s14", "wide"), ("imap_h256", "wide"),
-                                         ("bg_h128_s14", "gen"), ("imap_h256", "gen"), ("bg_h128_s14", "wide_multipass")])
+                                         ("bg_h128_s14", "gen"), ("imap_h256", "gen"), ("bg_h128_s14", "wide_multipass"),
+                                         ("bg_h128_s14", "wide2"), ("imap_h256", "wide2"), ("bg_h128_s14", "wide2_multipass")])
 def test_generic_width_kernel_matches_reference_fixture(name, kernel):
     """hidden = 64 / 128 (background model shapes) / 256 (iMAP, BASELINE configs[0]): step_main_wide (tile per
-    workgroup, the default at 128 / 256; also with 3 workgroups looping over the ray groups) and step_main_gen."""
+    workgroup / four tiles per workgroup, also with fewer workgroups than ray groups) and step_main_gen."""
     c = cases.build_case(name)
     g = load_golden(name)
     lib = _lib.load()
@@ -309,10 +310,14 @@ def test_generic_width_kernel_matches_reference_fixture(name, kernel):
     try:
         if kernel == "gen":
             lib.vmapstep_set_workgroups_per_object(-1)
-        if kernel.startswith("wide"):
+        if kernel in ("wide", "wide_multipass"):
             lib.vmapstep_set_workgroups_per_object(-3)
+        if kernel in ("wide2", "wide2_multipass"):
+            lib.vmapstep_set_workgroups_per_object(-4)
         if kernel == "wide_multipass":
             old = lib.vmapstep_set_workgroups_per_object(3)
+        if kernel == "wide2_multipass":
+            old = lib.vmapstep_set_workgroups_per_object(1)
         s = _run(c)
     finally:
         lib.vmapstep_set_workgroups_per_object(-2)

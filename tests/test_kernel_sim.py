@@ -117,6 +117,20 @@ def test_sim_generic_width_kernel_matches_reference(name, nw):
         assert relerr(s[k], g[k]) < 1e-4, k
 
 
+@pytest.mark.parametrize("nw", [0, 2])
+def test_sim_wide2_kernel_matches_reference(nw):
+    """step_main_wide<2> (hidden 128: four tiles per 512-thread workgroup, two waves per tile, staged 4-tile sums;
+    nw=2: two passes per workgroup) vs the background-shaped fixture."""
+    c = cases.build_case("bg_h128_s14")
+    g = load_golden("bg_h128_s14")
+    s = simlib.sim_step(c, NW=nw, wide=2)
+    assert abs(s["loss"] - float(g["loss"])) <= 2e-5 * abs(float(g["loss"]))
+    for k in RENDER_KEYS:
+        assert relerr(s[k], g[k]) < 2e-5, k
+    for k in GRAD_KEYS:
+        assert relerr(s[k], g[k]) < 1e-4, k
+
+
 @pytest.mark.parametrize("nw", [0, 5])
 def test_sim_wide_kernel_matches_reference(nw):
     """step_main_wide (hidden 128: one 32-point tile per workgroup, output blocks split over the four waves;

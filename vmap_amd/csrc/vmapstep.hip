@@ -22,8 +22,7 @@ namespace {
 thread_local char g_err[512] = "";
 thread_local float* g_scratch_for_launch = nullptr;   // set by fill_step_args (generic-width path)
 int g_nw_override = 0;
-int g_force_gen = 0;      // measurement / test hooks: kernel choice for hidden 128 / 256
-int g_force_wide = 0;
+int g_force_kernel = 0;   // measurement / test hook, hidden 128 / 256: 0 automatic, 1 step_main_gen, 2 step_main_wide<4>, 3 step_main_wide<2>
 
 int fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -53,7 +52,8 @@ struct Plan {
     int G, NG, NW;
     size_t off_stats, off_flags, off_ploss, off_pgrad, off_wimg, off_scratch, total;
     bool generic;      // hidden != 32: step_main_gen (global-memory activations) instead of step_main_h32
-    bool wide;         // hidden 128 / 256 and samples <= 32: step_main_wide (tile per workgroup, output blocks per wave)
+    int wide;          // hidden 128 / 256: 0 = step_main_gen, 1 = step_main_wide<4> (one tile per workgroup, four waves
+                       // per tile), 2 = step_main_wide<2> (four tiles per 512-thread workgroup, two waves per tile)
 };
 
 int make_plan(const vmapstep_shape* sh, int max_steps, Plan& pl, const Layout& L) {
@@ -67,17 +67,21 @@ int make_plan(const vmapstep_shape* sh, int max_steps, Plan& pl, const Layout& L
     pl.generic = sh->hidden != 32;
     if (sh->samples > vk::kMaxPts)
         return fail(VMAPSTEP_ERR_UNSUPPORTED, "samples=%d > %d", sh->samples, vk::kMaxPts);
-    // step_main_wide (one 32-point tile per workgroup, waves split the output blocks) pays the object's whole parameter
-    // set in partial-gradient traffic per TILE (4x step_main_gen's per 128 points), so it is chosen only where the
-    // problem is latency-bound: every tile gets its own workgroup in a single pass (iMAP plumbing: 1.47 -> 0.44 ms;
-    // the 600-tile background batch is faster on step_main_gen: 0.53 vs 0.65 ms).  g_force_gen / g_force_wide: hooks.
-    pl.wide = false;
-    if (pl.generic && sh->hidden % 128 == 0 && sh->samples <= vk::kWideTile && !g_force_gen) {
-        const int gw = std::min(vk::kWideTile / sh->samples, sh->rays);
-        const long long tiles = (long long)sh->n_obj * ((sh->rays + gw - 1) / gw);
-        pl.wide = g_force_wide || tiles <= 256;
+    // Wide fields (hidden 128 / 256).  step_main_wide<4>: one 32-point tile per workgroup, four waves split its output
+    // blocks - for latency-bound batches where every tile gets its own workgroup (it pays the whole parameter set in
+    // partial-gradient traffic per 32 points).  step_main_wide<2>: four tiles per 512-thread workgroup, two waves per tile
+    // (twice step_main_gen's waves for the same tiles and partial traffic).  step_main_gen: one wave per tile.
+    pl.wide = 0;
+    if (pl.generic && sh->hidden % 128 == 0 && g_force_kernel != 1) {
+        if (sh->samples <= vk::kWideTile) {
+            const int gw = std::min(vk::kWideTile / sh->samples, sh->rays);
+            const long long tiles = (long long)sh->n_obj * ((sh->rays + gw - 1) / gw);
+            if (g_force_kernel == 2 || (g_force_kernel == 0 && tiles <= 256)) pl.wide = 1;
+        }
+        if (!pl.wide && g_force_kernel == 3) pl.wide = 2;      // measured: no gain over step_main_gen at 600 tiles (both are
+                                                                 // bound by the traffic of the per-tile register images), not automatic
     }
-    pl.G = (pl.wide ? vk::kWideTile : vk::kMaxPts) / sh->samples;
+    pl.G = (pl.wide == 1 ? vk::kWideTile : vk::kMaxPts) / sh->samples;
     if (pl.G > sh->rays) pl.G = sh->rays;
     pl.NG = (sh->rays + pl.G - 1) / pl.G;
     int nw = g_nw_override > 0 ? g_nw_override : 256 / sh->n_obj;
@@ -85,7 +89,7 @@ int make_plan(const vmapstep_shape* sh, int max_steps, Plan& pl, const Layout& L
     if (nw > pl.NG) nw = pl.NG;
     pl.NW = nw;
     // buffers that exist once per workgroup are sized for the largest NW a later override may ask for
-    const size_t nw_cap = pl.wide ? (size_t)std::max(nw, std::min(pl.NG, 256)) : (size_t)pl.NG;
+    const size_t nw_cap = pl.wide == 1 ? (size_t)std::max(nw, std::min(pl.NG, 256)) : (size_t)pl.NG;
     size_t o = 0;
     pl.off_stats = o; o += align_up((size_t)max_steps * sh->n_obj * 4 * sizeof(float));
     pl.off_flags = o; o += align_up((size_t)max_steps * 4 * sizeof(int));
@@ -95,7 +99,7 @@ int make_plan(const vmapstep_shape* sh, int max_steps, Plan& pl, const Layout& L
     pl.off_wimg = o; o += align_up((size_t)sh->n_obj * GL.imgp * sizeof(float));
     pl.off_scratch = o;
     if (pl.generic)   // register-image scratch: per wave (step_main_gen) or per workgroup (step_main_wide)
-        o += align_up((size_t)sh->n_obj * nw_cap * (pl.wide ? 1 : vk::kWaves) * vk::gen_wave_blocks(GL.NB) * vk::kBlk * sizeof(float));
+        o += align_up((size_t)sh->n_obj * nw_cap * (pl.wide == 1 ? 1 : vk::kWaves) * vk::gen_wave_blocks(GL.NB) * vk::kBlk * sizeof(float));
     pl.total = o;
     return VMAPSTEP_OK;
 }
@@ -141,7 +145,7 @@ void fill_step_args(vk::StepArgs& a, const vmapstep_shape* sh, const Plan& pl, c
     a.color_w = cw; a.opac_w = ow;
     a.hidden = sh->hidden;
     a.weights_bf16 = sh->weight_dtype == VMAPSTEP_WEIGHTS_BF16 ? 1 : 0;
-    a.wide = pl.wide ? 1 : 0;
+    a.wide = pl.wide;
     a.stats = reinterpret_cast<float*>(ws + pl.off_stats);
     a.flags = reinterpret_cast<int*>(ws + pl.off_flags);
     a.part_loss = reinterpret_cast<float*>(ws + pl.off_ploss);
@@ -188,14 +192,15 @@ int launch_gen(const vk::StepArgs& a, hipStream_t st) {
     return VMAPSTEP_OK;
 }
 
-template <bool BWD>
+template <bool BWD, int SPLIT>
 int launch_wide(const vk::StepArgs& a, hipStream_t st) {
+    using LW = vk::LdsWide<SPLIT>;
     static bool attr_set = false;
-    auto kern = vk::step_main_wide<BWD>;
+    auto kern = vk::step_main_wide<BWD, SPLIT>;
     const vk::GenLayout GL = vk::gen_layout(a.hidden);
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           vk::LdsGen::bytes(vk::gen_layout(256).small_n));
+                                           LW::bytes(vk::gen_layout(256).small_n));
         if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
@@ -203,7 +208,7 @@ int launch_wide(const vk::StepArgs& a, hipStream_t st) {
     ga.s = a;
     ga.scratch = g_scratch_for_launch;
     ga.wave_blocks = vk::gen_wave_blocks(GL.NB);
-    hipLaunchKernelGGL(kern, dim3(a.n_obj * a.NW), dim3(vk::kWG), vk::LdsGen::bytes(GL.small_n), st, ga);
+    hipLaunchKernelGGL(kern, dim3(a.n_obj * a.NW), dim3(64 * LW::NWAVES), LW::bytes(GL.small_n), st, ga);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "step_main_wide launch: %s", hipGetErrorString(e));
     return VMAPSTEP_OK;
@@ -211,7 +216,7 @@ int launch_wide(const vk::StepArgs& a, hipStream_t st) {
 
 template <bool BWD>
 int launch_main(const vk::StepArgs& a, hipStream_t st) {
-    if (a.hidden != 32) return a.wide ? launch_wide<BWD>(a, st) : launch_gen<BWD>(a, st);
+    if (a.hidden != 32) return a.wide == 1 ? launch_wide<BWD, 4>(a, st) : a.wide == 2 ? launch_wide<BWD, 2>(a, st) : launch_gen<BWD>(a, st);
     return a.NW < a.NG ? launch_main_v<BWD, true>(a, st) : launch_main_v<BWD, false>(a, st);
 }
 
@@ -278,9 +283,10 @@ int vmapstep_abi_version(void) { return VMAPSTEP_ABI_VERSION; }
 
 int vmapstep_set_workgroups_per_object(int32_t nw) {
     int old = g_nw_override;
-    if (nw == -1) { g_force_gen = 1; g_force_wide = 0; return old; }    // hooks: kernel for hidden 128 / 256
-    if (nw == -2) { g_force_gen = 0; g_force_wide = 0; return old; }
-    if (nw == -3) { g_force_wide = 1; g_force_gen = 0; return old; }
+    if (nw == -1) { g_force_kernel = 1; return old; }    // hooks: kernel for hidden 128 / 256
+    if (nw == -2) { g_force_kernel = 0; return old; }
+    if (nw == -3) { g_force_kernel = 2; return old; }
+    if (nw == -4) { g_force_kernel = 3; return old; }
     g_nw_override = nw > 0 ? nw : 0;
     return old;
 }

@@ -16,7 +16,7 @@
 
 namespace vk {
 
-constexpr int kWideTile = 32;            // sample points per workgroup pass
+constexpr int kWideTile = 32;            // sample points per workgroup pass with one tile per workgroup (SPLIT = 4)
 
 // full 32x32 block (lane = column, register r <-> row phi(r,hi)) -> row-major tensor; add = accumulate
 __device__ __forceinline__ void store_block_rt(float* tens, int K, const f32x16& acc, int col0, int ncols, bool add,
@@ -30,8 +30,29 @@ __device__ __forceinline__ void store_block_rt(float* tens, int K, const f32x16&
     }
 }
 
-template <bool BWD>
-__global__ __launch_bounds__(kWG, 1) void step_main_wide(const GenArgs ga) {
+// LDS map (floats).  SPLIT = waves per tile, TPW = tiles per workgroup.
+template <int SPLIT>
+struct LdsWide {
+    static constexpr int TPW = SPLIT == 4 ? 1 : 4;
+    static constexpr int NWAVES = SPLIT * TPW;
+    static constexpr int SCR = 0;                                        // one transpose tile per wave
+    static constexpr int DPX = NWAVES * kDirs * 64;                      // d(proj) partials of all waves
+    static constexpr int STG_N = TPW > 1 ? SPLIT * 2 * TPW * Lds32::STG_TILE : 0;   // per group: 2 buffers x TPW staged tiles
+    static constexpr int STG = SCR + NWAVES * Lds32::SCR_TILE;           // staging; also holds DPX (used after the last block)
+    static constexpr int CB = STG + (STG_N > DPX ? STG_N : DPX);
+    static constexpr int LOSS = CB + kMaxPts * 8;
+    static constexpr int VEC = LOSS + kWaves * 4;                        // TPW x small_n (every entry has one owner per tile)
+    __host__ __device__ static constexpr int bytes(int small_n) { return (VEC + TPW * small_n) * 4; }
+};
+
+// SPLIT = 4: one 32-point tile per 256-thread workgroup, wave w owns output blocks w, w+4, ...; a weight-gradient block
+//            has one producer per workgroup pass and is stored / accumulated directly.
+// SPLIT = 2: four tiles per 512-thread workgroup (two waves per SIMD), the two waves of a tile own the even / odd output
+//            blocks; weight-gradient blocks are summed over the four tiles through staged LDS tiles like step_main_gen.
+template <bool BWD, int SPLIT>
+__global__ __launch_bounds__(64 * LdsWide<SPLIT>::NWAVES, 1) void step_main_wide(const GenArgs ga) {
+    using LW = LdsWide<SPLIT>;
+    constexpr int TPW = LW::TPW, NWAVES = LW::NWAVES, NT = 64 * NWAVES;
     const StepArgs& a = ga.s;
     const GenLayout L = gen_layout(a.hidden);
     const int H = L.H, NB = L.NB;
@@ -39,32 +60,35 @@ __global__ __launch_bounds__(kWG, 1) void step_main_wide(const GenArgs ga) {
     const int tid_k = threadIdx.x;
     const int obj = blockIdx.x / a.NW, wgo = blockIdx.x - obj * a.NW;
     const float* Wg = a.wimg + (long long)obj * L.imgp;
-    float* sb = ga.scratch + (long long)blockIdx.x * ga.wave_blocks * kBlk;      // ONE set of images per workgroup
     const int E_P = 0, E_F = 5, CFB = 10, H_P = 15, H_F = 15 + 5 * NB, D_P = 15 + 10 * NB, D_F = 15 + 12 * NB, DE = 15 + 14 * NB;
 #define BLK(i) (sb + (long long)(i) * kBlk)
     if (BWD) {
-        for (int i = tid_k; i < kWaves * L.small_n; i += kWG) lds[LdsGen::VEC + i] = 0.0f;
+        for (int i = tid_k; i < TPW * L.small_n; i += NT) lds[LW::VEC + i] = 0.0f;
     }
-    if (tid_k < kWaves * 4) lds[LdsGen::LOSS + tid_k] = 0.0f;
+    if (tid_k < kWaves * 4) lds[LW::LOSS + tid_k] = 0.0f;
     float* out = a.part_grad + ((long long)(obj * a.NW + wgo)) * a.PP;
-    float* cb = lds + LdsGen::CB;
-    float* dpx = lds + LdsGen::STG;                                      // [kWaves][kDirs][64] d(proj) partials of the waves
+    float* cb = lds + LW::CB;
+    float* dpx = lds + LW::STG;                                          // [NWAVES][kDirs][64]
     const float scale = a.pe_scale.p[obj * a.pe_scale.stride];
     const float* Bg = Wg + L.pe_b;
+    int stage_toggle = 0;
 
     for (int grp = wgo; grp < a.NG; grp += a.NW) {
     const int tid = wv::opaque_iter(tid_k), lane = tid & 63, wave = tid >> 6, p31 = lane & 31, hi = lane >> 5;
-    float* Gv = lds + LdsGen::VEC + wave * L.small_n - L.b_in;           // this wave's private small-vector gradients
-    float* scrX = lds + LdsGen::SCR + wave * LdsGen::SCR_WAVE;
-    float* scrD = scrX + Lds32::SCR_TILE;
+    const int tile = wave / SPLIT, sw = wave - tile * SPLIT;             // this wave: sub-wave sw of tile `tile`
+    float* sb = ga.scratch + ((long long)blockIdx.x * TPW + tile) * ga.wave_blocks * kBlk;   // one image set per tile
+    float* Gv = lds + LW::VEC + tile * L.small_n - L.b_in;               // small-vector gradients of this tile
+    float* scrX = lds + LW::SCR + wave * Lds32::SCR_TILE;
+    float* scrD = scrX;                                                  // put / get pairs are immediate: one tile suffices
+    float* stg = lds + LW::STG + sw * 2 * TPW * Lds32::STG_TILE;         // this group's two staging buffers (TPW > 1)
     const bool first_pass = grp == wgo;
     __syncthreads();                                                     // previous pass done with cb and the images
-    for (int i = tid; i < kMaxPts * 8; i += kWG) cb[i] = 0.0f;
+    for (int i = tid; i < kMaxPts * 8; i += NT) cb[i] = 0.0f;
 
     const int ray0 = grp * a.G;
     const int nrays = min(a.G, a.R - ray0);
-    const int npts = nrays * a.S;                                        // <= 32
-    const int pt = p31;                                                  // every wave holds the same 32 points
+    const int npts = nrays * a.S;                                        // <= 32 * TPW
+    const int pt = tile * 32 + p31;                                      // the SPLIT waves of a tile hold the same 32 points
     const bool valid = pt < npts;
     const int lray = valid ? pt / a.S : 0;
     const int smp = valid ? pt - lray * a.S : 0;
@@ -95,10 +119,12 @@ __global__ __launch_bounds__(kWG, 1) void step_main_wide(const GenArgs ga) {
             stb(BLK(E_P + i), xv, lane); stb(BLK(CFB + i), yv, lane);                                    \
             toF_put(scrX, xv, p31, hi); toF_get(yv, scrX, p31, hi); stb(BLK(E_F + i), yv, lane);         \
         }
-        if (wave == 0) ENC(0, 16, 0, kEmb1, 0)
-        else if (wave == 1) ENC(1, 16, 0, kEmb1, 1)
-        else if (wave == 2) ENC(2, 12, 0, kEmb1, 2)
-        else { ENC(3, 16, kEmb1, kEmb2, 0) ENC(4, 6, kEmb1, kEmb2, 1) }
+        // the five encoding blocks are dealt round-robin to the SPLIT waves of the tile
+        if (0 % SPLIT == sw) ENC(0, 16, 0, kEmb1, 0)
+        if (1 % SPLIT == sw) ENC(1, 16, 0, kEmb1, 1)
+        if (2 % SPLIT == sw) ENC(2, 12, 0, kEmb1, 2)
+        if (3 % SPLIT == sw) ENC(3, 16, kEmb1, kEmb2, 0)
+        if (4 % SPLIT == sw) ENC(4, 6, kEmb1, kEmb2, 1)
 #undef ENC
     }
     __syncthreads();
@@ -110,42 +136,42 @@ __global__ __launch_bounds__(kWG, 1) void step_main_wide(const GenArgs ga) {
         toF_put(scrX, xv, p31, hi); toF_get(yv, scrX, p31, hi);
         stb(BLK(H_F + l * NB + ob), yv, lane);
     };
-    for (int ob = wave; ob < NB; ob += kWaves) {           // :59 in_layer
+    for (int ob = sw; ob < NB; ob += SPLIT) {           // :59 in_layer
         const float* w = Wg + L.w_in + (32 * ob + p31) * L.ld_in + 4 * hi;
         load_bias(acc, Wg + L.b_in + 32 * ob, hi);
         chain_fwd(acc, 3, [&](int i) { return FSeg{w + 32 * i, BLK(E_P + i)}; }, lane);   // zero weights/encodings pad block 2
         finish(0, ob);
     }
     __syncthreads();
-    for (int ob = wave; ob < NB; ob += kWaves) {           // :60 mid1
+    for (int ob = sw; ob < NB; ob += SPLIT) {           // :60 mid1
         const float* w = Wg + L.w_m1 + (32 * ob + p31) * L.ld_m + 4 * hi;
         load_bias(acc, Wg + L.b_m1 + 32 * ob, hi);
         chain_fwd(acc, NB, [&](int i) { return FSeg{w + 32 * i, BLK(H_P + 0 * NB + i)}; }, lane);
         finish(1, ob);
     }
     __syncthreads();
-    for (int ob = wave; ob < NB; ob += kWaves) {           // :63-64 cat_layer
+    for (int ob = sw; ob < NB; ob += SPLIT) {           // :63-64 cat_layer
         const float* w = Wg + L.w_cat + (32 * ob + p31) * L.ld_cat + 4 * hi;
         load_bias(acc, Wg + L.b_cat + 32 * ob, hi);
         chain_fwd(acc, NB + 3, [&](int i) { return i < NB ? FSeg{w + 32 * i, BLK(H_P + 1 * NB + i)} : FSeg{w + H + 32 * (i - NB), BLK(E_P + (i - NB))}; }, lane);
         finish(2, ob);
     }
     __syncthreads();
-    for (int ob = wave; ob < NB; ob += kWaves) {           // :67 mid2
+    for (int ob = sw; ob < NB; ob += SPLIT) {           // :67 mid2
         const float* w = Wg + L.w_m2 + (32 * ob + p31) * L.ld_m + 4 * hi;
         load_bias(acc, Wg + L.b_m2 + 32 * ob, hi);
         chain_fwd(acc, NB, [&](int i) { return FSeg{w + 32 * i, BLK(H_P + 2 * NB + i)}; }, lane);
         finish(3, ob);
     }
     __syncthreads();
-    for (int ob = wave; ob < NB; ob += kWaves) {           // :81 color_linear
+    for (int ob = sw; ob < NB; ob += SPLIT) {           // :81 color_linear
         const float* w = Wg + L.w_c + (32 * ob + p31) * L.ld_c + 4 * hi;
         load_bias(acc, Wg + L.b_c + 32 * ob, hi);
         chain_fwd(acc, NB + 2, [&](int i) { return i < NB ? FSeg{w + 32 * i, BLK(H_P + 3 * NB + i)} : FSeg{w + H + 32 * (i - NB), BLK(E_P + 3 + (i - NB))}; }, lane);
         finish(4, ob);
     }
     __syncthreads();
-    if (wave == 0) {   // heads (model.py:71,77,82-83): 4 dot products over all H features, one wave
+    if (sw == 0) {   // heads (model.py:71,77,82-83): 4 dot products over all H features, one wave per tile
         float ra = 0.0f, r0 = 0.0f, r1 = 0.0f, r2 = 0.0f;
         for (int kb = 0; kb < NB; ++kb) {
             ldb(xv, BLK(H_P + 3 * NB + kb), lane);
@@ -173,8 +199,9 @@ __global__ __launch_bounds__(kWG, 1) void step_main_wide(const GenArgs ga) {
     __syncthreads();
     {
         const StepArgs& al = wv::kernarg_late(ga).s;
-        composite_phase<BWD>(al, cb, lds + LdsGen::LOSS, obj, ray0, nrays, wave, lane, tid,
-                             load_ray_meta(al, obj, ray0 + min(4 * wave + (lane >> 4), nrays - 1)));
+        if (wave < kWaves)                 // the compositing helper is written for four waves (16 rays per round)
+            composite_phase<BWD>(al, cb, lds + LW::LOSS, obj, ray0, nrays, wave, lane, tid,
+                                 load_ray_meta(al, obj, ray0 + min(4 * wave + (lane >> 4), nrays - 1)));
     }
     __syncthreads();
 
@@ -189,6 +216,22 @@ __global__ __launch_bounds__(kWG, 1) void step_main_wide(const GenArgs ga) {
     for (int d = 0; d < kDirs; ++d) dproj[d] = 0.0f;
 
     // weight-gradient block (ob, x-block): one producer per tile -> straight into the workgroup's partial buffer
+    // one weight-gradient block of this wave: with one tile per workgroup it has a single producer and goes straight to
+    // the partial buffer; with four tiles it is summed over the tiles through this group's staged LDS tiles (the other
+    // group emits its own block in the same barrier)
+    auto emit = [&](float* tens, int K, int row0, int col0, int ncols) {
+        if constexpr (TPW == 1) {
+            store_block_rt(tens + (long long)row0 * K, K, acc, col0, ncols, !first_pass, p31, hi);
+        } else {
+            float q[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            float* st = stg + (stage_toggle & 1) * TPW * Lds32::STG_TILE;
+            stage_put(st, acc, tile, p31, hi);
+            __syncthreads();
+            stage_get(q, st, tile, p31, hi);
+            ++stage_toggle;
+            store_quarter_rt(tens + (long long)row0 * K, K, q, col0, ncols, !first_pass, tile, p31, hi);
+        }
+    };
     // weight-gradient blocks of one output-row block: delta image (F-form) loaded once, the input image of block i+1
     // requested before the chain of block i
     struct XSeg { int blk, col0, ncols; };
@@ -202,16 +245,16 @@ __global__ __launch_bounds__(kWG, 1) void step_main_wide(const GenArgs ga) {
             sn = xs(i + 1);
             ldb(xb, BLK(sn.blk), lane);
             zero_acc(acc); dw_mm(acc, df, xa);
-            store_block_rt(tens + (long long)row0 * K, K, acc, s.col0, s.ncols, !first_pass, p31, hi);
+            emit(tens, K, row0, s.col0, s.ncols);
             s = sn;
             if (i + 2 < n) { sn = xs(i + 2); ldb(xa, BLK(sn.blk), lane); }
             zero_acc(acc); dw_mm(acc, df, xb);
-            store_block_rt(tens + (long long)row0 * K, K, acc, s.col0, s.ncols, !first_pass, p31, hi);
+            emit(tens, K, row0, s.col0, s.ncols);
             s = sn;
         }
         if (i < n) {
             zero_acc(acc); dw_mm(acc, df, xa);
-            store_block_rt(tens + (long long)row0 * K, K, acc, s.col0, s.ncols, !first_pass, p31, hi);
+            emit(tens, K, row0, s.col0, s.ncols);
         }
     };
     auto put_delta = [&](int ds, int kb, int bias_off) {
@@ -220,10 +263,10 @@ __global__ __launch_bounds__(kWG, 1) void step_main_wide(const GenArgs ga) {
         stb(BLK(D_F + ds * NB + kb), yv, lane);
         add_db(Gv + bias_off + 32 * kb, yv, p31, hi);
     };
-    const float* cbw = cb;                                  // rows 0..31 = this tile's points
+    const float* cbw = cb + tile * 32 * 8;                  // this tile's 32 rows of the composite buffer
 
     // ---- heads: gradients of out_alpha / out_color; delta of color_linear's output -> D(0) ----
-    for (int kb = wave; kb < NB; kb += kWaves) {
+    for (int kb = sw; kb < NB; kb += SPLIT) {
         ldb(xv, BLK(H_F + 3 * NB + kb), lane);      // h4 F-form
         ldb(yv, BLK(H_F + 4 * NB + kb), lane);      // hc F-form
         float gA = 0.0f, g0 = 0.0f, g1 = 0.0f, g2 = 0.0f, sa = 0.0f, s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
@@ -261,11 +304,11 @@ __global__ __launch_bounds__(kWG, 1) void step_main_wide(const GenArgs ga) {
     {
         float* tens = out + L.f[10];
         const int K = H + kEmb2;
-        for (int ob = wave; ob < NB; ob += kWaves) {
+        for (int ob = sw; ob < NB; ob += SPLIT) {
             dw_row(D_F + 0 * NB + ob, NB + 2, [&](int i) { return i < NB ? XSeg{H_F + 3 * NB + i, 32 * i, 32}
                                                                         : XSeg{E_F + 3 + (i - NB), H + 32 * (i - NB), i == NB ? 32 : kEmb2 - 32}; }, tens, K, 32 * ob);
         }
-        for (int kb = wave; kb < NB; kb += kWaves) {           // d h4 = W_a d raw + W_c[:, :H]^T D(0), masked by h4
+        for (int kb = sw; kb < NB; kb += SPLIT) {           // d h4 = W_a d raw + W_c[:, :H]^T D(0), masked by h4
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = Wg[L.w_a + 32 * kb + phi(r, hi)] * d_raw;
             chain_bwd(acc, NB, L.ld_c, [&](int ob) { return BSeg{Wg + L.w_c + (32 * ob + 4 * hi) * L.ld_c + 32 * kb + p31, BLK(D_P + 0 * NB + ob)}; }, lane);
@@ -274,8 +317,8 @@ __global__ __launch_bounds__(kWG, 1) void step_main_wide(const GenArgs ga) {
             for (int r = 0; r < 16; ++r) xv[r] = yv[r] > 0.0f ? acc[r] : 0.0f;
             put_delta(1, kb, L.b_m2);
         }
-        if (wave >= 2) {                                        // d e2: block 0 on wave 2, block 1 on wave 3
-            const int eb = wave - 2;
+        for (int eb = 0; eb < 2; ++eb) {                        // d e2: the two blocks dealt to the tile's waves
+            if ((eb + 1) % SPLIT != sw) continue;
             zero_acc(acc);
             const int col = eb == 0 ? p31 : min(32 + p31, 46);
             chain_bwd(acc, NB, L.ld_c, [&](int ob) { return BSeg{Wg + L.w_c + (32 * ob + 4 * hi) * L.ld_c + H + col, BLK(D_P + 0 * NB + ob)}; }, lane);
@@ -288,9 +331,9 @@ __global__ __launch_bounds__(kWG, 1) void step_main_wide(const GenArgs ga) {
     // ---- mid2: delta D(1), input h3 ; d h3 -> D(0) ----
     {
         float* tens = out + L.f[6];
-        for (int ob = wave; ob < NB; ob += kWaves)
+        for (int ob = sw; ob < NB; ob += SPLIT)
             dw_row(D_F + 1 * NB + ob, NB, [&](int i) { return XSeg{H_F + 2 * NB + i, 32 * i, 32}; }, tens, H, 32 * ob);
-        for (int kb = wave; kb < NB; kb += kWaves) {
+        for (int kb = sw; kb < NB; kb += SPLIT) {
             zero_acc(acc);
             chain_bwd(acc, NB, L.ld_m, [&](int ob) { return BSeg{Wg + L.w_m2 + (32 * ob + 4 * hi) * L.ld_m + 32 * kb + p31, BLK(D_P + 1 * NB + ob)}; }, lane);
             ldb(yv, BLK(H_P + 2 * NB + kb), lane);
@@ -304,11 +347,11 @@ __global__ __launch_bounds__(kWG, 1) void step_main_wide(const GenArgs ga) {
     {
         float* tens = out + L.f[4];
         const int K = H + kEmb1;
-        for (int ob = wave; ob < NB; ob += kWaves) {
+        for (int ob = sw; ob < NB; ob += SPLIT) {
             dw_row(D_F + 0 * NB + ob, NB + 3, [&](int i) { return i < NB ? XSeg{H_F + 1 * NB + i, 32 * i, 32}
                                                                         : XSeg{E_F + (i - NB), H + 32 * (i - NB), i - NB < 2 ? 32 : kEmb1 - 64}; }, tens, K, 32 * ob);
         }
-        for (int kb = wave; kb < NB; kb += kWaves) {
+        for (int kb = sw; kb < NB; kb += SPLIT) {
             zero_acc(acc);
             chain_bwd(acc, NB, L.ld_cat, [&](int ob) { return BSeg{Wg + L.w_cat + (32 * ob + 4 * hi) * L.ld_cat + 32 * kb + p31, BLK(D_P + 0 * NB + ob)}; }, lane);
             ldb(yv, BLK(H_P + 1 * NB + kb), lane);
@@ -316,8 +359,8 @@ __global__ __launch_bounds__(kWG, 1) void step_main_wide(const GenArgs ga) {
             for (int r = 0; r < 16; ++r) xv[r] = yv[r] > 0.0f ? acc[r] : 0.0f;
             put_delta(1, kb, L.b_m1);
         }
-        if (wave < 3) {
-            const int eb = wave;
+        for (int eb = 0; eb < 3; ++eb) {
+            if (eb % SPLIT != sw) continue;
             zero_acc(acc);
             const int col = eb < 2 ? 32 * eb + p31 : min(64 + p31, 88);
             chain_bwd(acc, NB, L.ld_cat, [&](int ob) { return BSeg{Wg + L.w_cat + (32 * ob + 4 * hi) * L.ld_cat + H + col, BLK(D_P + 0 * NB + ob)}; }, lane);
@@ -328,9 +371,9 @@ __global__ __launch_bounds__(kWG, 1) void step_main_wide(const GenArgs ga) {
     // ---- mid1: delta D(1), input h1 ; d h1 -> D(0) ----
     {
         float* tens = out + L.f[2];
-        for (int ob = wave; ob < NB; ob += kWaves)
+        for (int ob = sw; ob < NB; ob += SPLIT)
             dw_row(D_F + 1 * NB + ob, NB, [&](int i) { return XSeg{H_F + 0 * NB + i, 32 * i, 32}; }, tens, H, 32 * ob);
-        for (int kb = wave; kb < NB; kb += kWaves) {
+        for (int kb = sw; kb < NB; kb += SPLIT) {
             zero_acc(acc);
             chain_bwd(acc, NB, L.ld_m, [&](int ob) { return BSeg{Wg + L.w_m1 + (32 * ob + 4 * hi) * L.ld_m + 32 * kb + p31, BLK(D_P + 1 * NB + ob)}; }, lane);
             ldb(yv, BLK(H_P + 0 * NB + kb), lane);
@@ -343,11 +386,11 @@ __global__ __launch_bounds__(kWG, 1) void step_main_wide(const GenArgs ga) {
     // ---- in_layer: delta D(0), input e1 ; d e1 += ... (waves 0..2) ; encoding backward ----
     {
         float* tens = out + L.f[0];
-        for (int ob = wave; ob < NB; ob += kWaves) {
+        for (int ob = sw; ob < NB; ob += SPLIT) {
             dw_row(D_F + 0 * NB + ob, 3, [&](int i) { return XSeg{E_F + i, 32 * i, i < 2 ? 32 : kEmb1 - 64}; }, tens, kEmb1, 32 * ob);
         }
-        if (wave < 3) {
-            const int eb = wave;
+        for (int eb = 0; eb < 3; ++eb) {
+            if (eb % SPLIT != sw) continue;
             ldb(xv, BLK(DE + eb), lane);
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = xv[r];
@@ -359,14 +402,20 @@ __global__ __launch_bounds__(kWG, 1) void step_main_wide(const GenArgs ga) {
             else pe_block_bwd<12>(dproj, acc, yv, 0, kEmb1, 2, hi);
         }
     }
-    // ---- B_layer.weight gradient: sum the waves' d(proj) partials, then dB = d(proj)^T t on wave 0 ----
+    // ---- B_layer.weight gradient: sum the d(proj) partials of the tile's waves, dB = d(proj)^T t on its first wave ----
+    __syncthreads();                                    // (TPW > 1) the last staged block is consumed: the area is reused
 #pragma unroll
     for (int d = 0; d < kDirs; ++d) dpx[(wave * kDirs + d) * 64 + lane] = dproj[d];
     __syncthreads();
-    if (wave == 0) {
+    if (sw == 0) {
+        const float* px = dpx + (long long)tile * SPLIT * kDirs * 64 + lane;
 #pragma unroll
-        for (int d = 0; d < kDirs; ++d)
-            dproj[d] = (dpx[d * 64 + lane] + dpx[(kDirs + d) * 64 + lane]) + (dpx[(2 * kDirs + d) * 64 + lane] + dpx[(3 * kDirs + d) * 64 + lane]);
+        for (int d = 0; d < kDirs; ++d) {
+            if constexpr (SPLIT == 4)
+                dproj[d] = (px[d * 64] + px[(kDirs + d) * 64]) + (px[(2 * kDirs + d) * 64] + px[(3 * kDirs + d) * 64]);
+            else
+                dproj[d] = px[d * 64] + px[(kDirs + d) * 64];
+        }
 #pragma unroll
         for (int d = 0; d < kDirs; ++d) dproj[d] += wv::swap_half(dproj[d]);
 #pragma unroll
@@ -379,14 +428,33 @@ __global__ __launch_bounds__(kWG, 1) void step_main_wide(const GenArgs ga) {
         toF_put(scrD, xv, p31, hi); toF_get(yv, scrD, p31, hi);
         ldb(xv, BLK(E_F + 0), lane);
         zero_acc(acc);
-        dw_mm(acc, yv, xv);
-        if (p31 < 3) {
+        dw_mm(acc, yv, xv);                             // rows = direction d (21 valid), cols 0..2 = xyz
+    }
+    if constexpr (TPW == 1) {
+        if (sw == 0 && p31 < 3) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int d = phi(r, hi);
                 if (d < kDirs) {
                     float* o = out + L.f[14] + 3 * d + p31;
                     *o = first_pass ? acc[r] : *o + acc[r];
+                }
+            }
+        }
+    } else {
+        __syncthreads();                                // every tile has read its d(proj) partials
+        float* st = lds + LW::STG;                      // group 0, buffer 0
+        if (sw == 0) stage_put(st, acc, tile, p31, hi);
+        __syncthreads();
+        if (sw == 0 && p31 < 3) {
+            float q[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            stage_get(q, st, tile, p31, hi);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int d = 8 * tile + 4 * hi + i;
+                if (d < kDirs) {
+                    float* o = out + L.f[14] + 3 * d + p31;
+                    *o = first_pass ? q[i] : *o + q[i];
                 }
             }
         }
@@ -400,13 +468,15 @@ __global__ __launch_bounds__(kWG, 1) void step_main_wide(const GenArgs ga) {
         float* pl = a.part_loss + (obj * a.NW + wgo) * 4;
 #pragma unroll
         for (int k = 0; k < 3; ++k)
-            pl[k] = (lds[LdsGen::LOSS + k] + lds[LdsGen::LOSS + 4 + k]) + (lds[LdsGen::LOSS + 8 + k] + lds[LdsGen::LOSS + 12 + k]);
+            pl[k] = (lds[LW::LOSS + k] + lds[LW::LOSS + 4 + k]) + (lds[LW::LOSS + 8 + k] + lds[LW::LOSS + 12 + k]);
         pl[3] = 0.0f;
     }
     if (!BWD) return;
-    for (int sv = tid; sv < L.small_n; sv += kWG) {
-        const float* v = lds + LdsGen::VEC + sv;
-        const float g = (v[0] + v[L.small_n]) + (v[2 * L.small_n] + v[3 * L.small_n]);
+    // small vectors: sum over the tiles of the workgroup, image order -> flat order
+    for (int sv = tid; sv < L.small_n; sv += NT) {
+        const float* v = lds + LW::VEC + sv;
+        float g = v[0];
+        if constexpr (TPW == 4) g = (v[0] + v[L.small_n]) + (v[2 * L.small_n] + v[3 * L.small_n]);
         const int i = L.b_in + sv;
         int o = -1;
         if (i < L.b_m1) o = L.f[1] + (i - L.b_in);
