@@ -126,6 +126,73 @@ __device__ __forceinline__ void chain_bwd(f32x16& acc, int n, int ld_w, F seg, i
     if (i < n) mm(xa, wa);
 }
 
+// Paired forms: TWO output blocks per loaded operand image (the kernels are bound by the traffic of the register images:
+// ~1.3 MB read per 32-point tile at hidden 128 when every output block re-reads its inputs).  The two accumulators are
+// independent, so their matrix instructions alternate.
+template <class F>
+__device__ __forceinline__ void chain_fwd2(f32x16& a0, f32x16& a1, int n, long long wskip, F seg, int lane) {
+    float xa[16], xb[16];
+    wv::f32x4 wa0[4], wa1[4], wb0[4], wb1[4];
+    auto ld = [&](int i, float (&x)[16], wv::f32x4 (&w0)[4], wv::f32x4 (&w1)[4]) {
+        const FSeg s = seg(i);
+        ldb(x, s.x, lane);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            w0[q] = *reinterpret_cast<const wv::f32x4*>(s.w + 8 * q);
+            w1[q] = *reinterpret_cast<const wv::f32x4*>(s.w + wskip + 8 * q);
+        }
+    };
+    auto mm = [&](const float (&x)[16], const wv::f32x4 (&w0)[4], const wv::f32x4 (&w1)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a0 = wv::mfma32(w0[q][i], x[4 * q + i], a0);
+                a1 = wv::mfma32(w1[q][i], x[4 * q + i], a1);
+            }
+        }
+    };
+    ld(0, xa, wa0, wa1);
+    int i = 0;
+    for (; i + 1 < n; i += 2) {
+        ld(i + 1, xb, wb0, wb1);
+        mm(xa, wa0, wa1);
+        if (i + 2 < n) ld(i + 2, xa, wa0, wa1);
+        mm(xb, wb0, wb1);
+    }
+    if (i < n) mm(xa, wa0, wa1);
+}
+struct BSeg2 { const float* wcol0; const float* wcol1; const float* x; };
+template <class F>
+__device__ __forceinline__ void chain_bwd2(f32x16& a0, f32x16& a1, int n, int ld_w, F seg, int lane) {
+    float xa[16], xb[16], wa0[16], wa1[16], wb0[16], wb1[16];
+    auto ld = [&](int i, float (&x)[16], float (&w0)[16], float (&w1)[16]) {
+        const BSeg2 s = seg(i);
+        ldb(x, s.x, lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            w0[r] = s.wcol0[((r & 3) + 8 * (r >> 2)) * ld_w];
+            w1[r] = s.wcol1[((r & 3) + 8 * (r >> 2)) * ld_w];
+        }
+    };
+    auto mm = [&](const float (&x)[16], const float (&w0)[16], const float (&w1)[16]) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            a0 = wv::mfma32(w0[r], x[r], a0);
+            a1 = wv::mfma32(w1[r], x[r], a1);
+        }
+    };
+    ld(0, xa, wa0, wa1);
+    int i = 0;
+    for (; i + 1 < n; i += 2) {
+        ld(i + 1, xb, wb0, wb1);
+        mm(xa, wa0, wa1);
+        if (i + 2 < n) ld(i + 2, xa, wa0, wa1);
+        mm(xb, wb0, wb1);
+    }
+    if (i < n) mm(xa, wa0, wa1);
+}
+
 // d-prop with a runtime row pitch
 __device__ __forceinline__ void bwd_mm_rt(f32x16& acc, const float* wcol, int ld, const float (&dy)[16]) {
     float w[16];
@@ -226,41 +293,77 @@ __global__ __launch_bounds__(kWG, 1) void step_main_gen(const GenArgs ga) {
     __syncthreads();        // composite buffer zeroed
 
     // ---- field MLP forward (model.py:59-83): layer l output block ob -> H_P(l, ob) ----
-    auto finish = [&](int l, int ob) {          // ReLU, store P-form and F-form
-        relu_to(xv, acc);
+    f32x16 acc1;
+    auto finish = [&](int l, int ob, const f32x16& av) {          // ReLU, store P-form and F-form
+        relu_to(xv, av);
         stb(BLK(H_P + l * NB + ob), xv, lane);
         toF_put(scrX, xv, p31, hi); toF_get(yv, scrX, p31, hi);
         stb(BLK(H_F + l * NB + ob), yv, lane);
     };
-    for (int ob = 0; ob < NB; ++ob) {           // :59 in_layer
+    for (int ob = 0; ob < NB; ob += 2) {           // :59 in_layer (zero weights / encodings pad block 2)
         const float* w = Wg + L.w_in + (32 * ob + p31) * L.ld_in + 4 * hi;
         load_bias(acc, Wg + L.b_in + 32 * ob, hi);
-        chain_fwd(acc, 3, [&](int i) { return FSeg{w + 32 * i, BLK(E_P + i)}; }, lane);   // zero weights/encodings pad block 2
-        finish(0, ob);
+        if (ob + 1 < NB) {
+            load_bias(acc1, Wg + L.b_in + 32 * ob + 32, hi);
+            chain_fwd2(acc, acc1, 3, 32LL * L.ld_in, [&](int i) { return FSeg{w + 32 * i, BLK(E_P + i)}; }, lane);
+            finish(0, ob, acc);
+            finish(0, ob + 1, acc1);
+        } else {
+            chain_fwd(acc, 3, [&](int i) { return FSeg{w + 32 * i, BLK(E_P + i)}; }, lane);
+            finish(0, ob, acc);
+        }
     }
-    for (int ob = 0; ob < NB; ++ob) {           // :60 mid1
+    for (int ob = 0; ob < NB; ob += 2) {           // :60 mid1
         const float* w = Wg + L.w_m1 + (32 * ob + p31) * L.ld_m + 4 * hi;
         load_bias(acc, Wg + L.b_m1 + 32 * ob, hi);
-        chain_fwd(acc, NB, [&](int i) { return FSeg{w + 32 * i, BLK(H_P + 0 * NB + i)}; }, lane);
-        finish(1, ob);
+        if (ob + 1 < NB) {
+            load_bias(acc1, Wg + L.b_m1 + 32 * ob + 32, hi);
+            chain_fwd2(acc, acc1, NB, 32LL * L.ld_m, [&](int i) { return FSeg{w + 32 * i, BLK(H_P + 0 * NB + i)}; }, lane);
+            finish(1, ob, acc);
+            finish(1, ob + 1, acc1);
+        } else {
+            chain_fwd(acc, NB, [&](int i) { return FSeg{w + 32 * i, BLK(H_P + 0 * NB + i)}; }, lane);
+            finish(1, ob, acc);
+        }
     }
-    for (int ob = 0; ob < NB; ++ob) {           // :63-64 cat_layer
+    for (int ob = 0; ob < NB; ob += 2) {           // :63-64 cat_layer
         const float* w = Wg + L.w_cat + (32 * ob + p31) * L.ld_cat + 4 * hi;
         load_bias(acc, Wg + L.b_cat + 32 * ob, hi);
-        chain_fwd(acc, NB + 3, [&](int i) { return i < NB ? FSeg{w + 32 * i, BLK(H_P + 1 * NB + i)} : FSeg{w + H + 32 * (i - NB), BLK(E_P + (i - NB))}; }, lane);
-        finish(2, ob);
+        if (ob + 1 < NB) {
+            load_bias(acc1, Wg + L.b_cat + 32 * ob + 32, hi);
+            chain_fwd2(acc, acc1, NB + 3, 32LL * L.ld_cat, [&](int i) { return i < NB ? FSeg{w + 32 * i, BLK(H_P + 1 * NB + i)} : FSeg{w + H + 32 * (i - NB), BLK(E_P + (i - NB))}; }, lane);
+            finish(2, ob, acc);
+            finish(2, ob + 1, acc1);
+        } else {
+            chain_fwd(acc, NB + 3, [&](int i) { return i < NB ? FSeg{w + 32 * i, BLK(H_P + 1 * NB + i)} : FSeg{w + H + 32 * (i - NB), BLK(E_P + (i - NB))}; }, lane);
+            finish(2, ob, acc);
+        }
     }
-    for (int ob = 0; ob < NB; ++ob) {           // :67 mid2
+    for (int ob = 0; ob < NB; ob += 2) {           // :67 mid2
         const float* w = Wg + L.w_m2 + (32 * ob + p31) * L.ld_m + 4 * hi;
         load_bias(acc, Wg + L.b_m2 + 32 * ob, hi);
-        chain_fwd(acc, NB, [&](int i) { return FSeg{w + 32 * i, BLK(H_P + 2 * NB + i)}; }, lane);
-        finish(3, ob);
+        if (ob + 1 < NB) {
+            load_bias(acc1, Wg + L.b_m2 + 32 * ob + 32, hi);
+            chain_fwd2(acc, acc1, NB, 32LL * L.ld_m, [&](int i) { return FSeg{w + 32 * i, BLK(H_P + 2 * NB + i)}; }, lane);
+            finish(3, ob, acc);
+            finish(3, ob + 1, acc1);
+        } else {
+            chain_fwd(acc, NB, [&](int i) { return FSeg{w + 32 * i, BLK(H_P + 2 * NB + i)}; }, lane);
+            finish(3, ob, acc);
+        }
     }
-    for (int ob = 0; ob < NB; ++ob) {           // :81 color_linear
+    for (int ob = 0; ob < NB; ob += 2) {           // :81 color_linear
         const float* w = Wg + L.w_c + (32 * ob + p31) * L.ld_c + 4 * hi;
         load_bias(acc, Wg + L.b_c + 32 * ob, hi);
-        chain_fwd(acc, NB + 2, [&](int i) { return i < NB ? FSeg{w + 32 * i, BLK(H_P + 3 * NB + i)} : FSeg{w + H + 32 * (i - NB), BLK(E_P + 3 + (i - NB))}; }, lane);
-        finish(4, ob);
+        if (ob + 1 < NB) {
+            load_bias(acc1, Wg + L.b_c + 32 * ob + 32, hi);
+            chain_fwd2(acc, acc1, NB + 2, 32LL * L.ld_c, [&](int i) { return i < NB ? FSeg{w + 32 * i, BLK(H_P + 3 * NB + i)} : FSeg{w + H + 32 * (i - NB), BLK(E_P + 3 + (i - NB))}; }, lane);
+            finish(4, ob, acc);
+            finish(4, ob + 1, acc1);
+        } else {
+            chain_fwd(acc, NB + 2, [&](int i) { return i < NB ? FSeg{w + 32 * i, BLK(H_P + 3 * NB + i)} : FSeg{w + H + 32 * (i - NB), BLK(E_P + 3 + (i - NB))}; }, lane);
+            finish(4, ob, acc);
+        }
     }
     {   // heads (model.py:71,77,82-83)
         float ra = 0.0f, r0 = 0.0f, r1 = 0.0f, r2 = 0.0f;
@@ -345,6 +448,57 @@ __global__ __launch_bounds__(kWG, 1) void step_main_gen(const GenArgs ga) {
         stb(BLK(D_F + ds * NB + kb), yv, lane);
         add_db(Gv + bias_off + 32 * kb, yv, p31, hi);
     };
+    // two delta rows share every input image (paired form of dw_row)
+    auto dw_row2 = [&](int dfblk0, int dfblk1, int n, auto xs, float* tens, int K, int row0) {
+        float df0[16], df1[16], xa[16], xb[16];
+        ldb(df0, BLK(dfblk0), lane);
+        ldb(df1, BLK(dfblk1), lane);
+        XSeg s = xs(0), sn = s;
+        ldb(xa, BLK(s.blk), lane);
+        for (int i = 0; i < n; i += 2) {
+            if (i + 1 < n) { sn = xs(i + 1); ldb(xb, BLK(sn.blk), lane); }
+            zero_acc(acc); dw_mm(acc, df0, xa);
+            emit(tens, K, row0, s.col0, s.ncols);
+            zero_acc(acc); dw_mm(acc, df1, xa);
+            emit(tens, K, row0 + 32, s.col0, s.ncols);
+            if (i + 1 >= n) break;
+            s = sn;
+            if (i + 2 < n) { sn = xs(i + 2); ldb(xa, BLK(sn.blk), lane); }
+            zero_acc(acc); dw_mm(acc, df0, xb);
+            emit(tens, K, row0, s.col0, s.ncols);
+            zero_acc(acc); dw_mm(acc, df1, xb);
+            emit(tens, K, row0 + 32, s.col0, s.ncols);
+            s = sn;
+        }
+    };
+    auto dw_rows = [&](int dfbase, int n, auto xs, float* tens, int K) {          // all NB delta rows of a layer, in pairs
+        for (int ob = 0; ob < NB; ob += 2) {
+            if (ob + 1 < NB) dw_row2(dfbase + ob, dfbase + ob + 1, n, xs, tens, K, 32 * ob);
+            else dw_row(dfbase + ob, n, xs, tens, K, 32 * ob);
+        }
+    };
+    // delta of a hidden layer: d h(l) block kb = init + sum_ob W[ob rows][kb cols]^T D(dsrc, ob), masked by h(l, kb); two
+    // output blocks per pass over the delta images
+    auto d_hidden = [&](auto init, const float* wb, int ldw, int dsrc, int hl, int ddst, int bias_off) {
+        for (int kb = 0; kb < NB; kb += 2) {
+            init(acc, kb);
+            if (kb + 1 < NB) {
+                init(acc1, kb + 1);
+                chain_bwd2(acc, acc1, NB, ldw, [&](int ob) {
+                    const float* c = wb + (32 * ob + 4 * hi) * ldw + 32 * kb + p31;
+                    return BSeg2{c, c + 32, BLK(D_P + dsrc * NB + ob)}; }, lane);
+            } else {
+                chain_bwd(acc, NB, ldw, [&](int ob) { return BSeg{wb + (32 * ob + 4 * hi) * ldw + 32 * kb + p31, BLK(D_P + dsrc * NB + ob)}; }, lane);
+            }
+            for (int u = 0; u < 2 && kb + u < NB; ++u) {
+                ldb(yv, BLK(H_P + hl * NB + kb + u), lane);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xv[r] = yv[r] > 0.0f ? (u ? acc1[r] : acc[r]) : 0.0f;
+                put_delta(ddst, kb + u, bias_off);
+            }
+        }
+    };
+    auto zero_init = [&](f32x16& v, int) { zero_acc(v); };
 
     // ---- heads: out_alpha / out_color gradients; delta of color_linear's output -> D(0) ----
     for (int kb = 0; kb < NB; ++kb) {
@@ -384,96 +538,75 @@ __global__ __launch_bounds__(kWG, 1) void step_main_gen(const GenArgs ga) {
     {
         float* tens = out + L.f[10];
         const int K = H + kEmb2;
-        for (int ob = 0; ob < NB; ++ob) {
-            dw_row(D_F + 0 * NB + ob, NB + 2, [&](int i) { return i < NB ? XSeg{H_F + 3 * NB + i, 32 * i, 32}
-                                                                        : XSeg{E_F + 3 + (i - NB), H + 32 * (i - NB), i == NB ? 32 : kEmb2 - 32}; }, tens, K, 32 * ob);
-        }
-        for (int kb = 0; kb < NB; ++kb) {           // d h4 = W_a d raw + W_c[:, :H]^T D(0), masked by h4
+        dw_rows(D_F + 0 * NB, NB + 2, [&](int i) { return i < NB ? XSeg{H_F + 3 * NB + i, 32 * i, 32}
+                                                                 : XSeg{E_F + 3 + (i - NB), H + 32 * (i - NB), i == NB ? 32 : kEmb2 - 32}; }, tens, K);
+        // d h4 = W_a d raw + W_c[:, :H]^T D(0), masked by h4
+        d_hidden([&](f32x16& v, int kb) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = Wg[L.w_a + 32 * kb + phi(r, hi)] * d_raw;
-            chain_bwd(acc, NB, L.ld_c, [&](int ob) { return BSeg{Wg + L.w_c + (32 * ob + 4 * hi) * L.ld_c + 32 * kb + p31, BLK(D_P + 0 * NB + ob)}; }, lane);
-            ldb(yv, BLK(H_P + 3 * NB + kb), lane);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) xv[r] = yv[r] > 0.0f ? acc[r] : 0.0f;
-            put_delta(1, kb, L.b_m2);
-        }
-        for (int eb = 0; eb < 2; ++eb) {            // d e2
-            zero_acc(acc);
-            const int col = eb == 0 ? p31 : min(32 + p31, 46);
-            chain_bwd(acc, NB, L.ld_c, [&](int ob) { return BSeg{Wg + L.w_c + (32 * ob + 4 * hi) * L.ld_c + H + col, BLK(D_P + 0 * NB + ob)}; }, lane);
-            ldb(yv, BLK(CFB + 3 + eb), lane);
-            if (eb == 0) pe_block_bwd<16>(dproj, acc, yv, kEmb1, kEmb2, 0, hi);
-            else pe_block_bwd<6>(dproj, acc, yv, kEmb1, kEmb2, 1, hi);
+            for (int r = 0; r < 16; ++r) v[r] = Wg[L.w_a + 32 * kb + phi(r, hi)] * d_raw; }, Wg + L.w_c, L.ld_c, 0, 3, 1, L.b_m2);
+        {   // d e2: both blocks in one pass over D(0)
+            zero_acc(acc); zero_acc(acc1);
+            chain_bwd2(acc, acc1, NB, L.ld_c, [&](int ob) {
+                const float* c = Wg + L.w_c + (32 * ob + 4 * hi) * L.ld_c + H;
+                return BSeg2{c + p31, c + min(32 + p31, 46), BLK(D_P + 0 * NB + ob)}; }, lane);
+            ldb(yv, BLK(CFB + 3), lane);
+            pe_block_bwd<16>(dproj, acc, yv, kEmb1, kEmb2, 0, hi);
+            ldb(yv, BLK(CFB + 4), lane);
+            pe_block_bwd<6>(dproj, acc1, yv, kEmb1, kEmb2, 1, hi);
         }
     }
     // ---- mid2: delta D(1), input h3 ; d h3 -> D(0) ----
     {
         float* tens = out + L.f[6];
-        for (int ob = 0; ob < NB; ++ob)
-            dw_row(D_F + 1 * NB + ob, NB, [&](int i) { return XSeg{H_F + 2 * NB + i, 32 * i, 32}; }, tens, H, 32 * ob);
-        for (int kb = 0; kb < NB; ++kb) {
-            zero_acc(acc);
-            chain_bwd(acc, NB, L.ld_m, [&](int ob) { return BSeg{Wg + L.w_m2 + (32 * ob + 4 * hi) * L.ld_m + 32 * kb + p31, BLK(D_P + 1 * NB + ob)}; }, lane);
-            ldb(yv, BLK(H_P + 2 * NB + kb), lane);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) xv[r] = yv[r] > 0.0f ? acc[r] : 0.0f;
-            put_delta(0, kb, L.b_cat);
-        }
+        dw_rows(D_F + 1 * NB, NB, [&](int i) { return XSeg{H_F + 2 * NB + i, 32 * i, 32}; }, tens, H);
+        d_hidden(zero_init, Wg + L.w_m2, L.ld_m, 1, 2, 0, L.b_cat);
     }
     // ---- cat_layer: delta D(0), input [h2 | e1] ; d h2 -> D(1) ; d e1 -> DE (accumulators) ----
     {
         float* tens = out + L.f[4];
         const int K = H + kEmb1;
-        for (int ob = 0; ob < NB; ++ob) {
-            dw_row(D_F + 0 * NB + ob, NB + 3, [&](int i) { return i < NB ? XSeg{H_F + 1 * NB + i, 32 * i, 32}
-                                                                        : XSeg{E_F + (i - NB), H + 32 * (i - NB), i - NB < 2 ? 32 : kEmb1 - 64}; }, tens, K, 32 * ob);
-        }
-        for (int kb = 0; kb < NB; ++kb) {
+        dw_rows(D_F + 0 * NB, NB + 3, [&](int i) { return i < NB ? XSeg{H_F + 1 * NB + i, 32 * i, 32}
+                                                                 : XSeg{E_F + (i - NB), H + 32 * (i - NB), i - NB < 2 ? 32 : kEmb1 - 64}; }, tens, K);
+        d_hidden(zero_init, Wg + L.w_cat, L.ld_cat, 0, 1, 1, L.b_m1);
+        {   // d e1 (cat_layer part): blocks 0, 1 in one pass over D(0), block 2 in another
+            zero_acc(acc); zero_acc(acc1);
+            chain_bwd2(acc, acc1, NB, L.ld_cat, [&](int ob) {
+                const float* c = Wg + L.w_cat + (32 * ob + 4 * hi) * L.ld_cat + H + p31;
+                return BSeg2{c, c + 32, BLK(D_P + 0 * NB + ob)}; }, lane);
+            stacc(BLK(DE + 0), acc, lane);
+            stacc(BLK(DE + 1), acc1, lane);
             zero_acc(acc);
-            chain_bwd(acc, NB, L.ld_cat, [&](int ob) { return BSeg{Wg + L.w_cat + (32 * ob + 4 * hi) * L.ld_cat + 32 * kb + p31, BLK(D_P + 0 * NB + ob)}; }, lane);
-            ldb(yv, BLK(H_P + 1 * NB + kb), lane);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) xv[r] = yv[r] > 0.0f ? acc[r] : 0.0f;
-            put_delta(1, kb, L.b_m1);
-        }
-        for (int eb = 0; eb < 3; ++eb) {
-            zero_acc(acc);
-            const int col = eb < 2 ? 32 * eb + p31 : min(64 + p31, 88);
-            chain_bwd(acc, NB, L.ld_cat, [&](int ob) { return BSeg{Wg + L.w_cat + (32 * ob + 4 * hi) * L.ld_cat + H + col, BLK(D_P + 0 * NB + ob)}; }, lane);
-            stacc(BLK(DE + eb), acc, lane);
+            chain_bwd(acc, NB, L.ld_cat, [&](int ob) { return BSeg{Wg + L.w_cat + (32 * ob + 4 * hi) * L.ld_cat + H + min(64 + p31, 88), BLK(D_P + 0 * NB + ob)}; }, lane);
+            stacc(BLK(DE + 2), acc, lane);
         }
     }
     // ---- mid1: delta D(1), input h1 ; d h1 -> D(0) ----
     {
         float* tens = out + L.f[2];
-        for (int ob = 0; ob < NB; ++ob)
-            dw_row(D_F + 1 * NB + ob, NB, [&](int i) { return XSeg{H_F + 0 * NB + i, 32 * i, 32}; }, tens, H, 32 * ob);
-        for (int kb = 0; kb < NB; ++kb) {
-            zero_acc(acc);
-            chain_bwd(acc, NB, L.ld_m, [&](int ob) { return BSeg{Wg + L.w_m1 + (32 * ob + 4 * hi) * L.ld_m + 32 * kb + p31, BLK(D_P + 1 * NB + ob)}; }, lane);
-            ldb(yv, BLK(H_P + 0 * NB + kb), lane);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) xv[r] = yv[r] > 0.0f ? acc[r] : 0.0f;
-            put_delta(0, kb, L.b_in);
-        }
+        dw_rows(D_F + 1 * NB, NB, [&](int i) { return XSeg{H_F + 0 * NB + i, 32 * i, 32}; }, tens, H);
+        d_hidden(zero_init, Wg + L.w_m1, L.ld_m, 1, 0, 0, L.b_in);
     }
     // ---- in_layer: delta D(0), input e1 ; d e1 += ... ; encoding backward ----
     {
         float* tens = out + L.f[0];
-        for (int ob = 0; ob < NB; ++ob) {
-            dw_row(D_F + 0 * NB + ob, 3, [&](int i) { return XSeg{E_F + i, 32 * i, i < 2 ? 32 : kEmb1 - 64}; }, tens, kEmb1, 32 * ob);
-        }
-        for (int eb = 0; eb < 3; ++eb) {
-            ldb(xv, BLK(DE + eb), lane);
+        dw_rows(D_F + 0 * NB, 3, [&](int i) { return XSeg{E_F + i, 32 * i, i < 2 ? 32 : kEmb1 - 64}; }, tens, kEmb1);
+        ldb(xv, BLK(DE + 0), lane);
+        ldb(yv, BLK(DE + 1), lane);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = xv[r];
-            const int col = eb < 2 ? 32 * eb + p31 : min(64 + p31, 88);
-            chain_bwd(acc, NB, L.ld_in, [&](int ob) { return BSeg{Wg + L.w_in + (32 * ob + 4 * hi) * L.ld_in + col, BLK(D_P + 0 * NB + ob)}; }, lane);
-            ldb(yv, BLK(CFB + eb), lane);
-            if (eb == 0) pe_block_bwd<16>(dproj, acc, yv, 0, kEmb1, 0, hi);
-            else if (eb == 1) pe_block_bwd<16>(dproj, acc, yv, 0, kEmb1, 1, hi);
-            else pe_block_bwd<12>(dproj, acc, yv, 0, kEmb1, 2, hi);
-        }
+        for (int r = 0; r < 16; ++r) { acc[r] = xv[r]; acc1[r] = yv[r]; }
+        chain_bwd2(acc, acc1, NB, L.ld_in, [&](int ob) {
+            const float* c = Wg + L.w_in + (32 * ob + 4 * hi) * L.ld_in + p31;
+            return BSeg2{c, c + 32, BLK(D_P + 0 * NB + ob)}; }, lane);
+        ldb(yv, BLK(CFB + 0), lane);
+        pe_block_bwd<16>(dproj, acc, yv, 0, kEmb1, 0, hi);
+        ldb(yv, BLK(CFB + 1), lane);
+        pe_block_bwd<16>(dproj, acc1, yv, 0, kEmb1, 1, hi);
+        ldb(xv, BLK(DE + 2), lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = xv[r];
+        chain_bwd(acc, NB, L.ld_in, [&](int ob) { return BSeg{Wg + L.w_in + (32 * ob + 4 * hi) * L.ld_in + min(64 + p31, 88), BLK(D_P + 0 * NB + ob)}; }, lane);
+        ldb(yv, BLK(CFB + 2), lane);
+        pe_block_bwd<12>(dproj, acc, yv, 0, kEmb1, 2, hi);
     }
     // ---- B_layer.weight gradient ----
     {
