@@ -290,6 +290,30 @@ def test_results_are_bitwise_repeatable(name):
         lib.vmapstep_set_workgroups_per_object(old)
 
 
+def test_autograd_batch_loss_drives_torch_adamw_like_train_py():
+    """train.py:303-325 shape of use: loss tensor (+ another differentiable term) -> backward() -> torch.optim.AdamW.step()
+    on the stacked leaf tensors; gradients equal the fused call's, the extra term's gradient is added by autograd."""
+    c = cases.build_case("ragged")
+    fc, B, sc, b = _to_dev(c)
+    params = [t.clone().requires_grad_() for t in fc] + [B.clone().requires_grad_()]
+    op = step.VmapStep(c["n"], c["R"], c["S"], c["H"], device=DEV)
+    optimiser = torch.optim.AdamW(params, lr=1e-3, weight_decay=0.013)
+    loss = step.batch_loss(op, params[:14], params[14], sc, b["pcs"], b["z"], b["gt_depth"], b["gt_rgb"], b["sem"], b["depth_mask"])
+    assert loss.requires_grad and loss.dim() == 0
+    extra = 0.5 * (params[1] ** 2).sum()            # stands for `batch_loss += bg_loss` (train.py:316)
+    total = loss + extra
+    total.backward()
+    ref = _run(c)
+    assert float(loss) == pytest.approx(ref["loss"], rel=1e-6)
+    for t in range(14):
+        want = ref[f"g_fc{t}"] + (fc[1].cpu().numpy() if t == 1 else 0.0)
+        assert relerr(params[t].grad.cpu().numpy(), want) < 2e-6, t
+    assert relerr(params[14].grad.cpu().numpy(), ref["g_B"]) < 2e-6
+    before = [p.detach().clone() for p in params]
+    optimiser.step()
+    assert all(not torch.equal(a, p.detach()) for a, p in zip(before, params))
+
+
 def test_unsupported_hidden_width_fails_loudly():
     with pytest.raises(_lib.VmapStepError, match="hidden=48"):
         step.VmapStep(4, 32, 10, 48, device=DEV)

@@ -254,3 +254,31 @@ class VmapStep:
                       self._ws_ptr, self._ws_bytes, self._stream()))
         opt.step += n_steps
         return res
+
+
+class _BatchLossFn(torch.autograd.Function):
+    """``batch_loss`` of train.py:303-306 as a differentiable tensor: the fused kernel produces the loss AND all 15
+    gradients in its forward; ``backward`` hands them to autograd scaled by the incoming gradient, so the reference's
+    ``batch_loss += bg_loss; batch_loss.backward(); optimiser.step()`` (train.py:316-325) works unchanged with any
+    ``torch.optim`` optimiser."""
+
+    @staticmethod
+    def forward(ctx, op, pe_scale, batch, *params):
+        fc, B = list(params[:-1]), params[-1]
+        grads = [torch.empty_like(p) for p in params]
+        with torch.no_grad():
+            res = op.fwd_bwd([p.detach() for p in fc], B.detach(), pe_scale, *batch, grads_fc=grads[:-1], grad_B=grads[-1])
+        ctx.grads = grads
+        ctx.flags = res.flags
+        return res.loss[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None, None, None) + tuple(gr * g for gr in ctx.grads)
+
+
+def batch_loss(op: "VmapStep", fc, B, pe_scale, pcs, z, gt_depth, gt_rgb, sem, depth_mask) -> torch.Tensor:
+    """0-dim loss tensor with a grad_fn: ``batch_loss(...).backward()`` fills ``p.grad`` of the stacked parameters
+    (``fc``: the 14 stacked field tensors, ``B``: the stacked ``B_layer.weight``), like ``loss.step_batch_loss(...)``
+    followed by ``.backward()`` in the reference."""
+    return _BatchLossFn.apply(op, pe_scale, (pcs, z, gt_depth, gt_rgb, sem, depth_mask), *fc, B)
