@@ -616,7 +616,8 @@ int vmapstep_sample_frame(const vmapstep_sample_cfg* cfg, const vmapstep_sample_
     const size_t lds = (3 * (size_t)FP + vs::kWG) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(vs::frame_sample), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(vs::frame_sample), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (ea != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "hipFuncSetAttribute: %s", hipGetErrorString(ea));
         attr_set = true;
     }
     hipLaunchKernelGGL(vs::frame_sample, dim3(n_obj), dim3(vs::kWG), lds, static_cast<hipStream_t>(stream), a);
