@@ -54,8 +54,10 @@ def test_mapping_pipeline_learns_a_synthetic_scene():
     from vmap_amd.driver import HipMapper
     from vmap_amd.keyframes import FrameStore, ObjectKeyframes
     from vmap_amd.trainer import SimpleConfig, Trainer
+    import random
     dev = "cuda:0"
     torch.manual_seed(0)
+    random.seed(0)                     # the keyframe pruning draws from Python's generator (vmap.py:259-262)
     cfg = SimpleConfig(training_device=dev, hidden_feature_size=32, n_iter_per_frame=20, n_per_optim=120, win_size=5)
     ITERS, F, P, n1, n2 = cfg.n_iter_per_frame, 100, 24, 1, 9                     # 100 frames x 24 pixels = 20 x 120 rays
     store = FrameStore(12, W, H, device=dev)
