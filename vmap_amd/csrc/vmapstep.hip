@@ -88,8 +88,9 @@ int make_plan(const vmapstep_shape* sh, int max_steps, Plan& pl, const Layout& L
     if (nw < 1) nw = 1;
     if (nw > pl.NG) nw = pl.NG;
     pl.NW = nw;
-    // buffers that exist once per workgroup are sized for the largest NW a later override may ask for
-    const size_t nw_cap = pl.wide == 1 ? (size_t)std::max(nw, std::min(pl.NG, 256)) : (size_t)pl.NG;
+    // buffers that exist once per workgroup: sized for THIS plan's NW (a later change of the tuning knob that needs more
+    // is caught by the workspace size check of the call, never silently)
+    const size_t nw_cap = (size_t)nw;
     size_t o = 0;
     pl.off_stats = o; o += align_up((size_t)max_steps * sh->n_obj * 4 * sizeof(float));
     pl.off_flags = o; o += align_up((size_t)max_steps * 4 * sizeof(int));
