@@ -83,6 +83,7 @@ inline float* lds_base() { return reinterpret_cast<float*>(sim::g_block->lds.dat
 template <class T>
 inline const T& kernarg_late(const T& a) { return a; }
 
+inline float relu(float x) { return x > 0.0f ? (x < 3.4028234663852886e38f ? x : 3.4028234663852886e38f) : 0.0f; }
 inline float opaque(float x) { return x; }
 inline int opaque_iter(int x) { return x; }
 

@@ -261,7 +261,7 @@ __device__ __forceinline__ void load_bias(f32x16& acc, const float* b, int hi) {
 }
 __device__ __forceinline__ void relu_to(float (&h)[16], const f32x16& acc) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) h[r] = acc[r] > 0.0f ? acc[r] : 0.0f;
+    for (int r = 0; r < 16; ++r) h[r] = wv::relu(acc[r]);
 }
 __device__ __forceinline__ void zero_acc(f32x16& acc) {
 #pragma unroll
@@ -546,8 +546,9 @@ __device__ __forceinline__ void pe_slot(int c, const float (&t)[3], const float 
     } else if (c >= 3) {
         const int f = (c - 3) / kDirs, d = (c - 3) % kDirs;
         const float band = (float)(1 << f);
-        pre = proj[d] * band;          // exact (power of two)
-        fac = kPi * band;              // d sin(x*pi*band)/dx = cos(.) * pi * band
+        fac = kPi * band;              // d sin(x*pi*band)/dx = cos(.) * pi * band; exact: band is a power of two
+        pre = proj[d] * fac;           // == fl32(fl32(proj * band) * fl32(pi)) of embedding.py:85,88 (scaling by 2^f commutes
+                                       //    with rounding), one multiply instead of two
     }
 }
 // One 32-feature block of the encoding in P-form (+ cos * pi * 2^f for the backward).  base = first encoding
@@ -567,7 +568,7 @@ __device__ __forceinline__ void pe_block(float (&e)[16], float (&cf)[16], int ba
             float pre0, tv0, fac0, pre1, tv1, fac1;
             pe_slot(c0, t, proj, pre0, tv0, fac0);
             pe_slot(c1, t, proj, pre1, tv1, fac1);
-            arg[r] = (hi ? pre1 : pre0) * kPi;                 // fl32(xb * fl32(pi)), embedding.py:88
+            arg[r] = hi ? pre1 : pre0;                         // fl32(xb * fl32(pi)), embedding.py:88
             fac[r] = hi ? fac1 : fac0;                          // 0 for xyz / padding slots
             tv[r] = hi ? tv1 : tv0;
             is_sin[r] = hi ? (c1 >= 3) : (c0 >= 3);

@@ -87,6 +87,11 @@ __device__ __forceinline__ const T& kernarg_late(const T&) {
     return *(const T*)p;
 }
 
+// max(x, 0) for finite x as ONE instruction: v_med3_f32(x, 0, FLT_MAX).  `x > 0 ? x : 0` and fmaxf() both cost two
+// (a canonicalising v_max in front: the matrix-instruction result is not known to be free of signalling NaNs).  +inf maps
+// to FLT_MAX instead of +inf, which only matters once the "loss explode" flag (render_rays.py:88-90) is up anyway.
+__device__ __forceinline__ float relu(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 3.4028234663852886e38f); }
+
 // The value, with its origin hidden from the optimiser (no instruction).  The backward's ReLU masks test opaque(h) > 0:
 // given the plain h = max(acc, 0) the compiler proves (h > 0) == (acc > 0), evaluates all 80 masks during the forward
 // and parks them in 160 spilled SGPRs.
