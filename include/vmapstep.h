@@ -213,6 +213,15 @@ int vmapstep_query_points(int32_t hidden, const vmapstep_params* params, const v
                           const float* points, int64_t n_points, const int64_t points_stride[2],
                           float* occupancy, float* color, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Measurement hook: vmapstep_train_steps with a pair of events around every launch of the dominant kernel, in the real
+ * step sequence (prep, then main / finalize alternating); waits for the device and returns the average duration in
+ * milliseconds - the figure bench.py's roofline object uses and a rocprofv3 kernel trace of the same run reports. */
+int vmapstep_profile_train_steps(const vmapstep_shape* shape, const vmapstep_params* params, const vmapstep_tensor* pe_scale,
+                                 const vmapstep_batch* frame, int64_t ray_step, int32_t n_steps,
+                                 float color_scaling, float opacity_scaling, const vmapstep_adamw* opt,
+                                 const vmapstep_outputs* outputs, void* workspace, size_t workspace_bytes, void* stream,
+                                 float* main_kernel_ms);
+
 /* Measurement hook: step_prep once, then the dominant kernel (step_main, forward+backward) `reps` times back to
  * back on `stream` with nothing in between, so that events recorded around the call give its average launch
  * duration (bench.py's roofline figure).  Writes only to the workspace. */

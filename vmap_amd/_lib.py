@@ -74,7 +74,7 @@ EXPORTS = (
     "vmapstep_fwd_bwd", "vmapstep_render", "vmapstep_train_steps", "vmapstep_set_workgroups_per_object",
     "vmapstep_profile_main_kernel", "vmapstep_profile_phases", "vmapstep_prepare", "vmapstep_train_steps_prepared",
     "vmapstep_workspace_counts_offset", "vmapstep_fwd_bwd_prepared", "vmapstep_sample_frame",
-    "vmapstep_query_workspace_bytes", "vmapstep_query_points",
+    "vmapstep_query_workspace_bytes", "vmapstep_query_points", "vmapstep_profile_train_steps",
 )
 
 _lib = None
@@ -123,6 +123,10 @@ def load():
     lib.vmapstep_query_points.argtypes = [ctypes.c_int32, ctypes.POINTER(Params), ctypes.POINTER(Tensor), ctypes.c_int32,
                                           ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64), ctypes.c_void_p,
                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    lib.vmapstep_profile_train_steps.argtypes = [ctypes.POINTER(Shape), ctypes.POINTER(Params), ctypes.POINTER(Tensor),
+                                                 ctypes.POINTER(Batch), ctypes.c_int64, ctypes.c_int32, ctypes.c_float,
+                                                 ctypes.c_float, ctypes.POINTER(AdamW), ctypes.POINTER(Outputs),
+                                                 ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
     lib.vmapstep_profile_main_kernel.argtypes = [ctypes.POINTER(Shape), ctypes.POINTER(Params), ctypes.POINTER(Tensor),
                                                  ctypes.POINTER(Batch), ctypes.c_int32, ctypes.c_void_p,
                                                  ctypes.c_size_t, ctypes.c_void_p]
@@ -135,7 +139,7 @@ def load():
                "vmapstep_train_steps", "vmapstep_set_workgroups_per_object", "vmapstep_profile_main_kernel",
                "vmapstep_profile_phases", "vmapstep_prepare", "vmapstep_train_steps_prepared",
                "vmapstep_workspace_counts_offset", "vmapstep_fwd_bwd_prepared", "vmapstep_sample_frame",
-               "vmapstep_query_workspace_bytes", "vmapstep_query_points"):
+               "vmapstep_query_workspace_bytes", "vmapstep_query_points", "vmapstep_profile_train_steps"):
         getattr(lib, fn).restype = ctypes.c_int
     if lib.vmapstep_abi_version() != ABI_VERSION:
         raise VmapStepError(f"ABI mismatch: library {lib.vmapstep_abi_version()} != binding {ABI_VERSION}")

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "../../include/vmapstep.h"
 #include "wide_kernels.h"
@@ -20,7 +21,8 @@
 namespace {
 
 thread_local char g_err[512] = "";
-thread_local float* g_scratch_for_launch = nullptr;   // set by fill_step_args (generic-width path)
+thread_local float* g_scratch_for_launch = nullptr;
+thread_local float* g_time_main_ms = nullptr;           // measurement: train_steps_impl times every main launch with events   // set by fill_step_args (generic-width path)
 int g_nw_override = 0;
 int g_force_kernel = 0;   // measurement / test hook, hidden 128 / 256: 0 automatic, 1 step_main_gen, 2 step_main_wide<4>, 3 step_main_wide<2>
 
@@ -423,15 +425,36 @@ static int train_steps_impl(const vmapstep_shape* shape, const vmapstep_params* 
     if (!pe_scale || !pe_scale->ptr) return fail(VMAPSTEP_ERR_ARGUMENT, "pe_scale is null");
     if (!opt || !opt->exp_avg || !opt->exp_avg_sq) return fail(VMAPSTEP_ERR_ARGUMENT, "optimiser state is required");
     if (!out || !out->loss || !out->flags) return fail(VMAPSTEP_ERR_ARGUMENT, "outputs.loss / outputs.flags are required");
+    std::vector<hipEvent_t> ev;
+    if (g_time_main_ms) {
+        ev.resize(3 * (size_t)n_steps);      // per step: before main, after main, and one more right behind it (the cost of
+                                             // an event pair with nothing in between is subtracted)
+        for (auto& e : ev)
+            if (hipEventCreate(&e) != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "hipEventCreate failed");
+    }
     for (int i = 0; i < n_steps; ++i) {
         fill_step_args(a, shape, pl, L, params, pe_scale, frame, (int64_t)i * ray_step, color_scaling, opacity_scaling, ws);
         a.stats += (size_t)i * shape->n_obj * 4;
         a.flags += (size_t)i * 4;
         const bool last = i == n_steps - 1;
         if (last) { a.dbg_depth = out->render_depth; a.dbg_rgb = out->render_color; a.dbg_opacity = out->opacity; a.dbg_var = out->var; }
+        if (!ev.empty()) hipEventRecord(ev[3 * i], st);
         if ((rc = launch_main<true>(a, st))) return rc;
+        if (!ev.empty()) { hipEventRecord(ev[3 * i + 1], st); hipEventRecord(ev[3 * i + 2], st); }
         if ((rc = launch_finalize(a, L, params, last ? grads : nullptr, opt, opt->step + i + 1, true,
                                   out->loss + i, out->flags + 4 * i, st))) return rc;
+    }
+    if (!ev.empty()) {                       // measurement only: the one place this library waits for the device
+        hipEventSynchronize(ev.back());
+        double sum = 0.0;
+        for (int i = 0; i < n_steps; ++i) {
+            float ms = 0.0f, empty = 0.0f;
+            hipEventElapsedTime(&ms, ev[3 * i], ev[3 * i + 1]);
+            hipEventElapsedTime(&empty, ev[3 * i + 1], ev[3 * i + 2]);
+            sum += ms - empty;
+        }
+        *g_time_main_ms = (float)(sum / n_steps);
+        for (auto& e : ev) hipEventDestroy(e);
     }
     return VMAPSTEP_OK;
 }
@@ -460,6 +483,19 @@ int vmapstep_train_steps_prepared(const vmapstep_shape* shape, const vmapstep_pa
                                   const vmapstep_outputs* out, void* workspace, size_t workspace_bytes, void* stream) {
     return train_steps_impl(shape, params, pe_scale, frame, ray_step, n_steps, color_scaling, opacity_scaling, opt, grads,
                             out, workspace, workspace_bytes, stream, false, true, nullptr);
+}
+
+int vmapstep_profile_train_steps(const vmapstep_shape* shape, const vmapstep_params* params, const vmapstep_tensor* pe_scale,
+                                 const vmapstep_batch* frame, int64_t ray_step, int32_t n_steps,
+                                 float color_scaling, float opacity_scaling, const vmapstep_adamw* opt,
+                                 const vmapstep_outputs* out, void* workspace, size_t workspace_bytes, void* stream,
+                                 float* main_kernel_ms) {
+    if (!main_kernel_ms) return fail(VMAPSTEP_ERR_ARGUMENT, "main_kernel_ms is null");
+    g_time_main_ms = main_kernel_ms;
+    const int rc = train_steps_impl(shape, params, pe_scale, frame, ray_step, n_steps, color_scaling, opacity_scaling, opt,
+                                    nullptr, out, workspace, workspace_bytes, stream, true, true, nullptr);
+    g_time_main_ms = nullptr;
+    return rc;
 }
 
 int vmapstep_profile_main_kernel(const vmapstep_shape* shape, const vmapstep_params* params,

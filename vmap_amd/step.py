@@ -256,6 +256,25 @@ class VmapStep:
         return res
 
 
+def _profile_train_steps(self, fc, B, pe_scale, pcs, z, gt_depth, gt_rgb, sem, depth_mask, opt: "FusedAdamWState", n_steps: int) -> float:
+    """Average duration (ms) of the dominant kernel over ``n_steps`` real training steps (events around every launch,
+    in the prep / main / finalize sequence of ``train_steps``); waits for the device."""
+    pp = self._params(fc, B)
+    sc = _lib.Tensor(pe_scale.data_ptr(), pe_scale.stride(0) if pe_scale.dim() else 0)
+    bt = self._batch(pcs, z, gt_depth, gt_rgb, sem, depth_mask, rays_total=pcs.shape[1])
+    res, out = self._outputs(n_steps, False)
+    oc = opt.c_struct()
+    ms = ctypes.c_float(0.0)
+    _lib.check(self.lib.vmapstep_profile_train_steps(ctypes.byref(self.shape), ctypes.byref(pp), ctypes.byref(sc), ctypes.byref(bt),
+                                                     self.rays, n_steps, self.color_scaling, self.opacity_scaling, ctypes.byref(oc),
+                                                     ctypes.byref(out), self._ws_ptr, self._ws_bytes, self._stream(), ctypes.byref(ms)))
+    opt.step += n_steps
+    return float(ms.value)
+
+
+VmapStep.profile_train_steps = _profile_train_steps
+
+
 class _BatchLossFn(torch.autograd.Function):
     """``batch_loss`` of train.py:303-306 as a differentiable tensor: the fused kernel produces the loss AND all 15
     gradients in its forward; ``backward`` hands them to autograd scaled by the incoming gradient, so the reference's
