@@ -290,6 +290,44 @@ def test_results_are_bitwise_repeatable(name):
         lib.vmapstep_set_workgroups_per_object(old)
 
 
+def test_driver_background_on_second_stream_equals_sequential():
+    """HipMapper.train_frame_with_background: the object stack and the one-object background stack (hidden 128) train
+    side by side on two streams; both end bit-identical to training them one after the other."""
+    from vmap_amd.driver import HipMapper
+    from vmap_amd.trainer import SimpleConfig, Trainer
+    cfg = SimpleConfig(training_device=DEV, n_iter_per_frame=4)
+    iters, n, R, S, Rb, Sb = 4, 3, 24, 10, 40, 14
+
+    def build():
+        torch.manual_seed(5)
+        m = HipMapper(cfg, device=DEV)
+        for _ in range(n):
+            m.add_object(Trainer(SimpleConfig(training_device=DEV, hidden_feature_size=32)))
+        tb = Trainer(SimpleConfig(training_device=DEV, hidden_feature_size=128, obj_scale=5.0))
+        m.attach_background(tb, Rb, Sb)
+        return m, tb
+
+    ob = synth.make_batch(n, R * iters, S, seed=31)
+    bb = synth.make_batch(1, Rb * iters, Sb, seed=32)
+    keys = ("pcs", "z", "gt_depth", "gt_rgb", "sem", "depth_mask")
+    obj_batch = tuple(torch.from_numpy(ob[k]).to(DEV) for k in keys)
+    bg_batch = tuple(torch.from_numpy(bb[k]).to(DEV) for k in keys)
+    a, ta = build()
+    for _ in range(2):
+        ra, rab = a.train_frame_with_background(obj_batch, bg_batch)
+    b, tb = build()
+    for _ in range(2):
+        rb = b.train_frame(*obj_batch)
+        bgs = b.bg
+        rbb = bgs["op"].train_steps(bgs["views"][:14], bgs["views"][14], bgs["scale"], *bg_batch, opt=bgs["opt"], n_steps=iters, ray_step=Rb)
+    torch.cuda.synchronize()
+    assert torch.equal(a.slab, b.slab) and torch.equal(a.bg["slab"], b.bg["slab"])
+    assert torch.equal(ra.loss, rb.loss) and torch.equal(rab.loss, rbb.loss)
+    assert not torch.equal(a.bg["slab"], torch.zeros_like(a.bg["slab"]))
+    # the background trainer's modules are views of the trained slab
+    assert ta.fc_occ_map.in_layer[0].weight.data_ptr() == a.bg["views"][0].data_ptr() if hasattr(ta.fc_occ_map, "in_layer") else True
+
+
 def test_autograd_batch_loss_drives_torch_adamw_like_train_py():
     """train.py:303-325 shape of use: loss tensor (+ another differentiable term) -> backward() -> torch.optim.AdamW.step()
     on the stacked leaf tensors; gradients equal the fused call's, the extra term's gradient is added by autograd."""

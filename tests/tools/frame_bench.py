@@ -46,7 +46,21 @@ def timed(fn, reps=20):
 
 t_obj, t_bg = timed(obj), timed(bg)
 t_both = timed(lambda: (obj(), bg()))
+s_obj, s_bg = torch.cuda.Stream(), torch.cuda.Stream()
+
+
+def overlapped():
+    cur = torch.cuda.current_stream()
+    e = torch.cuda.Event(); e.record(cur)
+    for st, fn in ((s_bg, bg), (s_obj, obj)):
+        st.wait_event(e)
+        with torch.cuda.stream(st):
+            fn()
+        d = torch.cuda.Event(); d.record(st); cur.wait_event(d)
+
+
+t_overlap = timed(overlapped)
 print(json.dumps({"tool": "frame_bench", "iters_per_frame": ITERS,
-                  "objects_ms_per_frame": t_obj, "background_ms_per_frame": t_bg, "objects_plus_background_ms_per_frame": t_both,
+                  "objects_ms_per_frame": t_obj, "background_ms_per_frame": t_bg, "objects_plus_background_ms_per_frame": t_both, "objects_and_background_on_two_streams_ms_per_frame": t_overlap,
                   "object_rays_per_s": obj_rays * ITERS / t_obj * 1e3, "background_rays_per_s": bg_rays * ITERS / t_bg * 1e3,
                   "note": "sampler 0.10 ms/frame (profiles/r01_sampler_bench.json) not included"}))

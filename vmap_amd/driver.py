@@ -35,6 +35,8 @@ class HipMapper:
         self.op: Optional[step.VmapStep] = None
         self.flag_reduce = group_reduce          # e.g. parallel.ObjectShard(...).reduce_flags for multi-GPU
         self.frames_trained = 0
+        self.bg = None                           # the background field's own one-object stack (attach_background)
+        self._bg_stream = None
 
     # ---- object list ---------------------------------------------------------------------------------------
     def add_object(self, trainer) -> int:
@@ -83,6 +85,54 @@ class HipMapper:
                                   opt=self.opt, n_steps=iters, ray_step=rays, render=render, flag_reduce=self.flag_reduce)
         self.frames_trained += 1
         return res
+
+    # ---- background field (train.py:146-152, 308-316) ----------------------------------------------------------
+    def attach_background(self, trainer, rays: int, samples: int):
+        """The background model (``cfg.do_bg``: one field of hidden_feature_size_bg over the whole scene, its own ray
+        batch of n_per_optim_bg rays) as a second, one-object stack.  The reference adds its loss to the objects' and
+        steps one optimiser (train.py:308-325); the two sets of parameters share nothing, so here each frame's object
+        steps and background steps run side by side on two streams (measured: 6.7 -> 6.0 ms per frame at the Replica
+        shapes, profiles/r01h_frame_bench.json)."""
+        H = trainer.hidden_feature_size
+        P = layout.param_count(H)
+        slab = torch.empty(1, P, dtype=torch.float32, device=self.device)
+        offs = layout.flat_offsets(H)
+        shapes = list(layout.fc_shapes(H)) + [layout.PE_B_SHAPE]
+        views = []
+        with torch.no_grad():
+            for t, shp in enumerate(shapes):
+                views.append(slab[:, offs[t]:offs[t] + layout.numel(shp)].view((1,) + tuple(shp)))
+            for t, p in enumerate(list(trainer.fc_occ_map.parameters()) + [trainer.pe.B_layer.weight]):
+                views[t][0].copy_(p.detach())
+                p.data = views[t][0]
+        self.bg = dict(trainer=trainer, slab=slab, views=views,
+                       scale=trainer.pe.scale.detach().to(self.device).reshape(1).clone(),
+                       opt=step.FusedAdamWState(1, H, self.device, lr=self.cfg.learning_rate, weight_decay=self.cfg.weight_decay),
+                       op=step.VmapStep(1, rays, samples, H, device=self.device, max_steps=self.cfg.n_iter_per_frame))
+        self._bg_stream = torch.cuda.Stream(device=self.device)
+
+    def train_frame_with_background(self, obj_batch, bg_batch, render: bool = False):
+        """One frame of both stacks: ``obj_batch`` / ``bg_batch`` = (pcs, z, gt_depth, gt_rgb, sem, depth_mask) with the
+        leading dimensions [n, iters*R, ...] and [1, iters*R_bg, ...].  Returns (object StepResult, background StepResult);
+        the caller's stream waits for both."""
+        if self.bg is None:
+            raise RuntimeError("attach_background() first")
+        iters = self.cfg.n_iter_per_frame
+        cur = torch.cuda.current_stream(self.device)
+        fork = torch.cuda.Event()
+        fork.record(cur)
+        self._bg_stream.wait_event(fork)
+        with torch.cuda.stream(self._bg_stream):
+            b = self.bg
+            for t in bg_batch:
+                t.record_stream(self._bg_stream)
+            res_bg = b["op"].train_steps(b["views"][:14], b["views"][14], b["scale"], *bg_batch, opt=b["opt"], n_steps=iters,
+                                         ray_step=bg_batch[0].shape[1] // iters)
+            join = torch.cuda.Event()
+            join.record(self._bg_stream)
+        res = self.train_frame(*obj_batch, render=render)
+        cur.wait_event(join)
+        return res, res_bg
 
     def check_flags(self, res: step.StepResult):
         """Host-side look at the device flags of a frame (the reference exits on 'loss explode', render_rays.py:88-90)."""
