@@ -149,17 +149,6 @@ def test_sim_wide_kernel_matches_reference(nw):
             assert relerr(s[k], o[k]) < 2e-5, k
 
 
-@pytest.mark.slow
-def test_sim_wide_kernel_imap_h256():
-    """hidden 256 (two output blocks per wave) on the iMAP plumbing fixture."""
-    c = cases.build_case("imap_h256")
-    g = load_golden("imap_h256")
-    s = simlib.sim_step(c, wide=True)
-    assert abs(s["loss"] - float(g["loss"])) <= 2e-5 * abs(float(g["loss"]))
-    for k in RENDER_KEYS + GRAD_KEYS:
-        assert relerr(s[k], g[k]) < 1e-4, k
-
-
 def test_sim_bf16_weights_equal_oracle_on_rounded_weights():
     """weight_dtype = bf16 (BASELINE configs[3]/[4]): the kernels compute from the bfloat16-rounded parameter image with
     fp32 products/sums == the fp32 oracle evaluated on the rounded weights (last bullet)."""
