@@ -198,6 +198,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out), flush=True)
     if dist:
+        td.barrier()                     # rank 0 measured the kernel / printed; everybody leaves together
         td.destroy_process_group()
 
 
