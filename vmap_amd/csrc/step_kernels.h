@@ -1340,6 +1340,7 @@ struct FinalizeArgs {
     float color_w, opac_w;
     int do_adam;
     int have_grad;                     // 0: forward-only call, skip the gradient/optimiser part
+    int xcd_affine;                    // block -> object map that keeps an object on the XCD step_main used for it
     // AdamW constants, evaluated by the host in double and rounded once (as torch's Python-side scalars are)
     float decay, one_minus_beta1, beta2, one_minus_beta2, eps, step_size, bias_corr2_sqrt;
 };
@@ -1350,8 +1351,19 @@ __global__ __launch_bounds__(kWG) void step_finalize(const FinalizeArgs a) {
     // (PP % 64 == 0, 256-byte aligned) so they move as 16-byte vectors; parameter/gradient tensors are scattered
     const int quads = a.PP / 4;
     const int blocks_per_obj = (quads + kWG - 1) / kWG;
-    const int obj = blockIdx.x / blocks_per_obj;
-    const int q4 = (blockIdx.x - obj * blocks_per_obj) * kWG + threadIdx.x;
+    int obj, part;
+    if (a.xcd_affine) {
+        // same object -> XCD placement as step_main (block b runs on XCD b % 8): the partials this block sums were written
+        // through this XCD's L2 a few microseconds ago, and the image slice it writes is read there by the next step
+        const int slot = blockIdx.x >> 3;
+        const int og = slot / blocks_per_obj;
+        obj = og * 8 + (blockIdx.x & 7);
+        part = slot - og * blocks_per_obj;
+    } else {
+        obj = blockIdx.x / blocks_per_obj;
+        part = blockIdx.x - obj * blocks_per_obj;
+    }
+    const int q4 = part * kWG + threadIdx.x;
     if (a.have_grad && obj < a.n_obj && q4 < quads && 4 * q4 < a.P) {
         const int i0 = 4 * q4;
         const wv::f32x4* pg = reinterpret_cast<const wv::f32x4*>(a.part_grad + (long long)obj * a.NW * a.PP + i0);

@@ -263,7 +263,8 @@ int launch_finalize(const vk::StepArgs& a, const Layout& L, const vmapstep_param
         f.bias_corr2_sqrt = (float)std::sqrt(1.0 - std::pow(b2, (double)step_after));
     }
     const int bpo = (L.PP / 4 + vk::kWG - 1) / vk::kWG;
-    const int grid = have_grad ? a.n_obj * bpo : 1;
+    f.xcd_affine = (a.xcd_affine && have_grad) ? 1 : 0;
+    const int grid = !have_grad ? 1 : f.xcd_affine ? 8 * ((a.n_obj + 7) / 8) * bpo : a.n_obj * bpo;
     hipLaunchKernelGGL(vk::step_finalize, dim3(grid), dim3(vk::kWG), 2 * vk::kWG * sizeof(float), st, f);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "step_finalize launch: %s", hipGetErrorString(e));
