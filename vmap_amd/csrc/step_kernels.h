@@ -306,7 +306,7 @@ template <int K>
 __device__ __forceinline__ void store_quarter(float* out, const float (&q)[4], int col0, int ncols, int wave, int p31, int hi) {
     if (p31 < ncols) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) out[(8 * wave + 4 * hi + i) * K + col0 + p31] = q[i];
+        for (int i = 0; i < 4; ++i) __builtin_nontemporal_store(q[i], &out[(8 * wave + 4 * hi + i) * K + col0 + p31]);
     }
 }
 // ---- split-phase forms (the backward is software-pipelined by hand: one wave per SIMD has nobody else to hide an
