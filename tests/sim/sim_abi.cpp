@@ -108,7 +108,7 @@ extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req, int xcd
     f.step_size = (float)((double)lr / (1.0 - std::pow(0.9, step)));
     f.bias_corr2_sqrt = (float)std::sqrt(1.0 - std::pow(0.999, step));
     const int bpo = (PP / 4 + vk::kWG - 1) / vk::kWG;
-    sim::launch(n * bpo, vk::kWG, 2 * vk::kWG * 4, [&] { vk::step_finalize(f); });
+    sim::launch(n * bpo + 1, vk::kWG, 2 * vk::kWG * 4, [&] { vk::step_finalize(f); });
     return 0;
 }
 

@@ -1364,7 +1364,7 @@ __global__ __launch_bounds__(kWG) void step_finalize(const FinalizeArgs a) {
         part = blockIdx.x - obj * blocks_per_obj;
     }
     const int q4 = part * kWG + threadIdx.x;
-    if (a.have_grad && obj < a.n_obj && q4 < quads && 4 * q4 < a.P) {
+    if (a.have_grad && blockIdx.x != gridDim.x - 1 && obj < a.n_obj && q4 < quads && 4 * q4 < a.P) {
         const int i0 = 4 * q4;
         const wv::f32x4* pg = reinterpret_cast<const wv::f32x4*>(a.part_grad + (long long)obj * a.NW * a.PP + i0);
         wv::f32x4 g = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -1421,7 +1421,7 @@ __global__ __launch_bounds__(kWG) void step_finalize(const FinalizeArgs a) {
             *reinterpret_cast<wv::f32x4*>(a.v + s) = v4;
         }
     }
-    if (blockIdx.x == 0) {
+    if (blockIdx.x == gridDim.x - 1) {     // a workgroup of its own (the launch has one more than the parameter blocks)
         // per-object loss terms: thread q sums object q, q+256, ... ; then a block reduction (loss.py:59-60)
         float* red = wv::lds_base();       // kWG floats + kWG ints
         int* redi = reinterpret_cast<int*>(red + kWG);

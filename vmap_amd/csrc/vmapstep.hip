@@ -264,7 +264,8 @@ int launch_finalize(const vk::StepArgs& a, const Layout& L, const vmapstep_param
     }
     const int bpo = (L.PP / 4 + vk::kWG - 1) / vk::kWG;
     f.xcd_affine = (a.xcd_affine && have_grad) ? 1 : 0;
-    const int grid = !have_grad ? 1 : f.xcd_affine ? 8 * ((a.n_obj + 7) / 8) * bpo : a.n_obj * bpo;
+    // + 1: the loss / flag reduction has a workgroup of its own (it used to ride on block 0 and made it the straggler)
+    const int grid = (!have_grad ? 0 : f.xcd_affine ? 8 * ((a.n_obj + 7) / 8) * bpo : a.n_obj * bpo) + 1;
     hipLaunchKernelGGL(vk::step_finalize, dim3(grid), dim3(vk::kWG), 2 * vk::kWG * sizeof(float), st, f);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "step_finalize launch: %s", hipGetErrorString(e));
