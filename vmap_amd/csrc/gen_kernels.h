@@ -279,7 +279,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_gen(const GenArgs ga) {
         for (int d = 0; d < kDirs; ++d) amax = fmaxf(amax, fabsf(proj[d]));
         const bool big = wv::wave_any(!(amax * (32.0f * kPi) < kSinCosFastLimit));
 #define ENC(i, NS, base, limit, kb)                                                                      \
-        if (!big) pe_block<NS, false>(xv, yv, base, limit, kb, t, proj, hi);                             \
+        if (__builtin_expect(!big, 1)) pe_block<NS, false>(xv, yv, base, limit, kb, t, proj, hi);                             \
         else pe_block<NS, true>(xv, yv, base, limit, kb, t, proj, hi);                                   \
         stb(BLK(E_P + i), xv, lane); stb(BLK(CFB + i), yv, lane);                                        \
         toF_put(scrX, xv, p31, hi); toF_get(yv, scrX, p31, hi); stb(BLK(E_F + i), yv, lane);

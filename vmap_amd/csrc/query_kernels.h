@@ -57,7 +57,7 @@ __global__ __launch_bounds__(kWG) WV_WAVES_PER_SIMD(WPE) void field_query_h32(co
         for (int d = 0; d < kDirs; ++d) amax = fmaxf(amax, fabsf(proj[d]));
         const bool big = wv::wave_any(!(amax * (32.0f * kPi) < kSinCosFastLimit));
         float e1a[16], e1b[16], e1c[16], cf[16];
-        if (!big) {
+        if (__builtin_expect(!big, 1)) {
             pe_block<16, false>(e1a, cf, 0, kEmb1, 0, t, proj, hi);
             pe_block<16, false>(e1b, cf, 0, kEmb1, 1, t, proj, hi);
             pe_block<12, false>(e1c, cf, 0, kEmb1, 2, t, proj, hi);
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(kWG) WV_WAVES_PER_SIMD(WPE) void field_query_h32(co
             // the colour head's share of the encoding is produced here, after the first 87 features are dead, so the
             // kernel fits 168 registers (3 waves per SIMD: one wave's sincos overlaps another's matrix instructions)
             float e2a[16], e2b[16];
-            if (!big) {
+            if (__builtin_expect(!big, 1)) {
                 pe_block<16, false>(e2a, cf, kEmb1, kEmb2, 0, t, proj, hi);
                 pe_block<6, false>(e2b, cf, kEmb1, kEmb2, 1, t, proj, hi);
             } else {
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(kWG, 1) void field_query_gen(const QueryArgs a) {
         for (int d = 0; d < kDirs; ++d) amax = fmaxf(amax, fabsf(proj[d]));
         const bool big = wv::wave_any(!(amax * (32.0f * kPi) < kSinCosFastLimit));
         float e1a[16], e1b[16], e1c[16], cf[16];
-        if (!big) {
+        if (__builtin_expect(!big, 1)) {
             pe_block<16, false>(e1a, cf, 0, kEmb1, 0, t, proj, hi);
             pe_block<16, false>(e1b, cf, 0, kEmb1, 1, t, proj, hi);
             pe_block<12, false>(e1c, cf, 0, kEmb1, 2, t, proj, hi);
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(kWG, 1) void field_query_gen(const QueryArgs a) {
         }
         {
             float e2a[16], e2b[16];
-            if (!big) {
+            if (__builtin_expect(!big, 1)) {
                 pe_block<16, false>(e2a, cf, kEmb1, kEmb2, 0, t, proj, hi);
                 pe_block<6, false>(e2b, cf, kEmb1, kEmb2, 1, t, proj, hi);
             } else {

@@ -959,7 +959,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
         float amax = 0.0f;
 #pragma unroll
         for (int d = 0; d < kDirs; ++d) amax = fmaxf(amax, fabsf(proj[d]));
-        if (!wv::wave_any(!(amax * (32.0f * kPi) < kSinCosFastLimit))) {
+        if (__builtin_expect(!wv::wave_any(!(amax * (32.0f * kPi) < kSinCosFastLimit)), 1)) {   // the library path is laid out after the hot code
             pe_block<16, false>(e1a, c1a, 0, kEmb1, 0, t, proj, hi);
             pe_block<16, false>(e1b, c1b, 0, kEmb1, 1, t, proj, hi);
             pe_block<12, false>(e1c, c1c, 0, kEmb1, 2, t, proj, hi);
