@@ -638,7 +638,7 @@ template <bool BWD>
 __device__ __forceinline__ void composite_phase(const StepArgs& a, float* cb, float* loss_cells, int obj, int ray0, int nrays,
                                                 int wave, int lane, int tid, const RayMeta& pre) {
     // ---- per-ray compositing, loss and d loss / d raw  (loss.py:24-60, render_rays.py:26-96) ----
-    if (a.S <= 16) {
+    if (__builtin_expect(a.S <= 16, 1)) {
         // 16 lanes per ray: lane i of a group holds sample i; products/sums are scans and butterflies
         for (int g0 = 4 * wave; g0 < nrays; g0 += 4 * kWaves) {      // wave-uniform trip count
             const int g = g0 + (lane >> 4), i = lane & 15;
@@ -892,7 +892,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
         wgo = blockIdx.x - obj * a.NW;
     }
     unsigned* tmark = a.timing ? a.timing + ((long long)blockIdx.x * kWaves + wave) * kMarks : nullptr;
-#define VK_MARK(i) do { if (tmark && lane == 0) tmark[i] = wv::clock32(); } while (0)
+#define VK_MARK(i) do { if (__builtin_expect(tmark != nullptr, 0) && lane == 0) tmark[i] = wv::clock32(); } while (0)
     VK_MARK(0);
 
     if (BWD) {
