@@ -868,7 +868,7 @@ __global__ __launch_bounds__(kWG) void step_prep(const StepArgs a) {
 // the passes and are stored once at the end; otherwise (one pass per workgroup) each quarter is stored as soon
 // as it is reduced and no accumulator registers are held.
 // ---------------------------------------------------------------------------------------------------------
-template <bool BWD, bool MULTI>
+template <bool BWD, bool MULTI, bool STAMPS = false>      // STAMPS: the phase-clock instantiation (vmapstep_profile_phases)
 __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
     using L = Lds32;
     using F = Flat32;
@@ -891,8 +891,8 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
         obj = blockIdx.x / a.NW;
         wgo = blockIdx.x - obj * a.NW;
     }
-    unsigned* tmark = a.timing ? a.timing + ((long long)blockIdx.x * kWaves + wave) * kMarks : nullptr;
-#define VK_MARK(i) do { if (__builtin_expect(tmark != nullptr, 0) && lane == 0) tmark[i] = wv::clock32(); } while (0)
+    unsigned* tmark = STAMPS && a.timing ? a.timing + ((long long)blockIdx.x * kWaves + wave) * kMarks : nullptr;
+#define VK_MARK(i) do { if constexpr (STAMPS) { if (tmark && lane == 0) tmark[i] = wv::clock32(); } } while (0)
     VK_MARK(0);
 
     if (BWD) {

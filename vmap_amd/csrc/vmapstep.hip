@@ -157,10 +157,10 @@ void fill_step_args(vk::StepArgs& a, const vmapstep_shape* sh, const Plan& pl, c
     g_scratch_for_launch = reinterpret_cast<float*>(ws + pl.off_scratch);
 }
 
-template <bool BWD, bool MULTI>
+template <bool BWD, bool MULTI, bool STAMPS = false>
 int launch_main_v(const vk::StepArgs& a, hipStream_t st) {
     static bool attr_set = false;
-    auto kern = vk::step_main_h32<BWD, MULTI>;
+    auto kern = vk::step_main_h32<BWD, MULTI, STAMPS>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, vk::Lds32::BYTES);
@@ -548,7 +548,7 @@ int vmapstep_profile_phases(const vmapstep_shape* shape, const vmapstep_params* 
     a.timing = timing;
     *n_workgroups = a.xcd_affine ? 8 * ((shape->n_obj + 7) / 8) * pl.NW : shape->n_obj * pl.NW;
     if ((rc = launch_prep(a, 1, st))) return rc;
-    return launch_main<true>(a, st);
+    return a.NW < a.NG ? launch_main_v<true, true, true>(a, st) : launch_main_v<true, false, true>(a, st);   // the stamped build
 }
 
 int vmapstep_query_workspace_bytes(int32_t hidden, size_t* bytes) {
