@@ -1243,8 +1243,8 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
         toF_get(dF, scrD, p31, hi);
         stage_put(stg1, acc, wave, p31, hi);
         __syncthreads();
-        finish_block<MULTI, kEmb1>(qacc[11], stg1, out + F::W_IN, 64, kEmb1 - 64, wave, p31, hi);
-        zero_acc(acc); dw_mm(acc, dF, e1aF);
+        zero_acc(acc);                              // the dB chain carries the finish of block 11 like every other unit
+        dw_chain_fin<0, MULTI, kEmb1>(acc, dF, e1aF, w, nullptr, qacc[11], stg1, out + F::W_IN, 64, kEmb1 - 64, wave, p31, hi);
         stage_put(stg0, acc, wave, p31, hi);
         __syncthreads();
         if (MULTI) {
