@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--weights", default="f32", choices=["f32", "bf16"])   # bf16: BASELINE configs[3]/[4] (fp32 masters + accumulate)
     ap.add_argument("--kernel", default="auto", choices=["auto", "gen", "wide", "wide2"])   # hidden 128 / 256: which fused kernel (measurement)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--slab", action="store_true")                   # the 15 stacked tensors as views of one [n, P] slab (measurement;
+                                                                     # default: separately allocated, utils.update_vmap's own layout)
     ap.add_argument("--profile-reps", type=int, default=200)
     args = ap.parse_args()
 
@@ -102,6 +104,9 @@ def main():
     frame = synth.make_batch(n, R * ipf, S, seed=1000 * rank + 1)        # [n, iters*R, ...] like train.py:255-260
     tfc = [torch.from_numpy(a).to(dev) for a in fc]
     tB, tsc = torch.from_numpy(B).to(dev), torch.from_numpy(sc).to(dev)
+    if args.slab:
+        # the stacked parameters as views of one [n, P] slab, the way vmap_amd.driver.HipMapper re-stacks an object list
+        _, tfc, tB = layout.stack_in_slab(tfc, tB)
     fr = {k: torch.from_numpy(v).to(dev) for k, v in frame.items()}
     if args.kernel != "auto":
         from vmap_amd import _lib

@@ -93,4 +93,14 @@ inline unsigned clock32() { return (unsigned)sim::g_yields; }
 
 inline void lds_add(float* p, float v) { *p += v; }
 
+// in-launch hand-off primitives: the executor runs one workgroup at a time, so these are plain accesses and a wait that
+// is not already satisfied fails (the carried-finalize kernels are exercised on the GPU tier only)
+inline void touch_scalar4(unsigned&, unsigned&, unsigned&, unsigned&) {}
+inline void store_wt(float* p, float v) { *p = v; }
+inline float load_wt(const float* p) { return *p; }
+inline void glds16_wt(const float* g, float* lds_wave_base) { glds16(g, lds_wave_base); }
+inline void drain_vm() {}
+inline void signal_add(unsigned* c) { ++*c; }
+inline bool wait_ge(const unsigned* c, unsigned target, int) { return *c >= target; }
+
 }  // namespace wv

@@ -545,3 +545,47 @@ def test_bf16_weight_mode_equals_oracle_on_rounded_weights(name):
     torch.cuda.synchronize()
     d = (fc[2] - before).abs()
     assert 0 < float(d.max()) < 1.2e-3
+
+
+@pytest.mark.parametrize("name,nw,steps,slab", [("cfg2", 0, 20, True), ("cfg2", 0, 20, False), ("scannet_scale", 0, 20, True),
+                                                ("tiny", 0, 7, False), ("scannet_scale", 3, 5, False), ("cfg2", 2, 3, True)])
+def test_carried_finalize_is_bit_identical_to_two_kernel_steps(name, nw, steps, slab):
+    """vmapstep_train_steps has two forms of the step loop: main + finalize per step, and (when every workgroup of a
+    launch is resident at once) the finalize of step i-1 carried in the prologue of step i's launch, where the
+    workgroups of an object hand the rewritten parameter image to each other inside the launch.  Same arithmetic in the
+    same order: losses, parameters and both Adam moments must agree bit for bit over a whole frame, three frames in a
+    row (the hand-off counters are re-armed per frame).  nw = 2, 3: the multi-pass instantiation (and several rounds of
+    the carried slice per workgroup); slab: both ways the carried pass addresses the parameters."""
+    c = cases.build_case(name)
+    lib = _lib.load()
+    old = lib.vmapstep_set_workgroups_per_object(nw)
+    outs = []
+    try:
+        for knob in (-5, -6):                                    # carried finalize off / on
+            lib.vmapstep_set_workgroups_per_object(knob)
+            fc, B, sc, b = _to_dev(c)
+            if slab:                                             # parameters as views of one [n, P] slab (indexed directly)
+                _, fc, B = layout.stack_in_slab(fc, B)
+            op = step.VmapStep(c["n"], c["R"], c["S"], c["H"], device=DEV, max_steps=steps)
+            st = step.FusedAdamWState(c["n"], c["H"], DEV)
+            frame = {k: torch.cat([v.roll(i, dims=1) for i in range(steps)], dim=1).contiguous() for k, v in b.items()}
+            losses, flags = [], []
+            for _ in range(3):
+                res = op.train_steps(fc, B, sc, frame["pcs"], frame["z"], frame["gt_depth"], frame["gt_rgb"], frame["sem"],
+                                     frame["depth_mask"], opt=st, n_steps=steps)
+                losses.append(res.loss.clone())
+                flags.append(res.flags.clone())
+            torch.cuda.synchronize()
+            outs.append(dict(p=[t.clone() for t in fc + [B]], m=st.exp_avg.clone(), v=st.exp_avg_sq.clone(),
+                             losses=torch.stack(losses), flags=torch.stack(flags)))
+    finally:
+        lib.vmapstep_set_workgroups_per_object(-5)               # the default: off
+        lib.vmapstep_set_workgroups_per_object(old)
+    a, b_ = outs
+    assert int(b_["flags"][..., 3].max()) == 0                    # no hand-off timeout, no explode
+    assert torch.equal(a["flags"], b_["flags"])
+    assert torch.equal(a["losses"], b_["losses"])
+    assert bool(torch.isfinite(a["losses"]).all())
+    for x, y in zip(a["p"], b_["p"]):
+        assert torch.equal(x, y)
+    assert torch.equal(a["m"], b_["m"]) and torch.equal(a["v"], b_["v"])

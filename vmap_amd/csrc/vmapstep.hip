@@ -24,6 +24,8 @@ thread_local char g_err[512] = "";
 thread_local float* g_scratch_for_launch = nullptr;
 thread_local float* g_time_main_ms = nullptr;           // measurement: train_steps_impl times every main launch with events   // set by fill_step_args (generic-width path)
 int g_nw_override = 0;
+unsigned* g_carry_stamps = nullptr;   // diagnostics (vmapstep_debug_carry_stamps): device buffer [workgroups][8] or null
+int g_carry = -1;         // carried finalize (step_main_h32_carry): -1 = not decided yet (environment VMAPSTEP_CARRY, default off), 0 off, 1 on
 int g_force_kernel = 0;   // measurement / test hook, hidden 128 / 256: 0 automatic, 1 step_main_gen, 2 step_main_wide<4>, 3 step_main_wide<2>
 
 int fail(int code, const char* fmt, ...) {
@@ -52,11 +54,31 @@ void make_layout(int H, Layout& L) {
 
 struct Plan {
     int G, NG, NW;
-    size_t off_stats, off_flags, off_ploss, off_pgrad, off_wimg, off_scratch, total;
+    size_t off_stats, off_flags, off_ploss, off_ploss_bytes, off_cnt, off_imgtab, off_pgrad, off_wimg, off_scratch, total;
     bool generic;      // hidden != 32: step_main_gen (global-memory activations) instead of step_main_h32
     int wide;          // hidden 128 / 256: 0 = step_main_gen, 1 = step_main_wide<4> (one tile per workgroup, four waves
                        // per tile), 2 = step_main_wide<2> (four tiles per 512-thread workgroup, two waves per tile)
 };
+
+// Carried finalize (step_main_h32_carry): opt-in (VMAPSTEP_CARRY=1 or the tuning hook).  Bit-identical to the two-kernel
+// loop and measured within +-3 % of it (the 9-13 MB of partials it has to read at the top of every
+// launch and its once-per-launch code cost what the stand-alone finalize launch and its boundary cost), so it is not the
+// default: it also needs the GPU to itself (all workgroups resident at once).
+bool carry_enabled() {
+    if (g_carry < 0) {
+        const char* e = std::getenv("VMAPSTEP_CARRY");
+        g_carry = (e && e[0] == '1') ? 1 : 0;
+    }
+    return g_carry != 0;
+}
+int cu_count() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = -1;
+    }
+    return cus;
+}
 
 int make_plan(const vmapstep_shape* sh, int max_steps, Plan& pl, const Layout& L) {
     if (!sh) return fail(VMAPSTEP_ERR_ARGUMENT, "shape is null");
@@ -96,7 +118,12 @@ int make_plan(const vmapstep_shape* sh, int max_steps, Plan& pl, const Layout& L
     size_t o = 0;
     pl.off_stats = o; o += align_up((size_t)max_steps * sh->n_obj * 4 * sizeof(float));
     pl.off_flags = o; o += align_up((size_t)max_steps * 4 * sizeof(int));
-    pl.off_ploss = o; o += align_up((size_t)sh->n_obj * nw_cap * 4 * sizeof(float));
+    // loss partials: two halves used alternately by consecutive steps (the carried finalize of step i-1 reads its half
+    // while the workgroups of step i write theirs)
+    pl.off_ploss_bytes = align_up((size_t)sh->n_obj * nw_cap * 4 * sizeof(float));
+    pl.off_ploss = o; o += 2 * pl.off_ploss_bytes;
+    pl.off_cnt = o; o += align_up((size_t)sh->n_obj * 2 * sizeof(unsigned));
+    pl.off_imgtab = o; o += pl.generic ? 0 : align_up((size_t)L.PP * sizeof(int));
     pl.off_pgrad = o; o += align_up((size_t)sh->n_obj * nw_cap * L.PP * sizeof(float));
     const vk::GenLayout GL = vk::gen_layout(sh->hidden);
     pl.off_wimg = o; o += align_up((size_t)sh->n_obj * GL.imgp * sizeof(float));
@@ -151,7 +178,11 @@ void fill_step_args(vk::StepArgs& a, const vmapstep_shape* sh, const Plan& pl, c
     a.wide = pl.wide;
     a.stats = reinterpret_cast<float*>(ws + pl.off_stats);
     a.flags = reinterpret_cast<int*>(ws + pl.off_flags);
-    a.part_loss = reinterpret_cast<float*>(ws + pl.off_ploss);
+    a.part_loss = reinterpret_cast<float*>(ws + pl.off_ploss);      // half 0; the step loop of a frame alternates (ploss_half)
+    // hand-off counters and the flat -> image table exist for the carried finalize only (step_prep skips null pointers)
+    const bool carry = !pl.generic && carry_enabled();
+    a.carry_cnt = carry ? reinterpret_cast<unsigned*>(ws + pl.off_cnt) : nullptr;
+    a.img_tab = carry ? reinterpret_cast<int*>(ws + pl.off_imgtab) : nullptr;
     a.part_grad = reinterpret_cast<float*>(ws + pl.off_pgrad);
     a.wimg = reinterpret_cast<float*>(ws + pl.off_wimg);
     g_scratch_for_launch = reinterpret_cast<float*>(ws + pl.off_scratch);
@@ -172,6 +203,31 @@ int launch_main_v(const vk::StepArgs& a, hipStream_t st) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "step_main launch: %s", hipGetErrorString(e));
     return VMAPSTEP_OK;
+}
+
+// step i >= 1 of a frame with the finalize of step i-1 carried in its prologue
+template <bool MULTI>
+int launch_main_carry(const vk::StepArgs& a, const vk::CarryArgs& c, hipStream_t st) {
+    static bool attr_set = false;
+    auto kern = vk::step_main_h32_carry<MULTI>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, vk::Lds32::BYTES);
+        if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    const int grid = (a.xcd_affine ? 8 * ((a.n_obj + 7) / 8) * a.NW : a.n_obj * a.NW) + 1;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(vk::kWG), vk::Lds32::BYTES, st, a, c);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "step_main_h32_carry launch: %s", hipGetErrorString(e));
+    return VMAPSTEP_OK;
+}
+
+// The carried finalize needs every workgroup of the launch resident at once (they wait for each other): one workgroup
+// per CU (132 KB of LDS each), so n_obj * NW real workgroups must not exceed the CU count.
+bool carry_eligible(const vmapstep_shape* sh, const Plan& pl) {
+    if (!carry_enabled() || pl.generic) return false;
+    return cu_count() > 0 && (long long)sh->n_obj * pl.NW <= cu_count();
 }
 
 template <bool BWD>
@@ -231,10 +287,9 @@ int launch_prep(const vk::StepArgs& a, int n_steps, hipStream_t st) {
     return VMAPSTEP_OK;
 }
 
-int launch_finalize(const vk::StepArgs& a, const Layout& L, const vmapstep_params* params, const vmapstep_params* grads,
-                    const vmapstep_adamw* opt, int step_after, bool have_grad, float* loss_out, int* flags_out,
-                    hipStream_t st) {
-    vk::FinalizeArgs f;
+void fill_finalize_args(vk::FinalizeArgs& f, const vk::StepArgs& a, const Layout& L, const vmapstep_params* params,
+                        const vmapstep_params* grads, const vmapstep_adamw* opt, int step_after, bool have_grad,
+                        float* loss_out, int* flags_out) {
     std::memset(&f, 0, sizeof(f));
     f.n_obj = a.n_obj; f.NW = a.NW; f.PP = L.PP; f.P = L.P; f.hidden = a.hidden; f.weights_bf16 = a.weights_bf16;
     for (int t = 0; t < 16; ++t) f.offs[t] = L.offs[t];
@@ -262,8 +317,15 @@ int launch_finalize(const vk::StepArgs& a, const Layout& L, const vmapstep_param
         f.step_size = (float)(lr / (1.0 - std::pow(b1, (double)step_after)));
         f.bias_corr2_sqrt = (float)std::sqrt(1.0 - std::pow(b2, (double)step_after));
     }
-    const int bpo = (L.PP / 4 + vk::kWG - 1) / vk::kWG;
     f.xcd_affine = (a.xcd_affine && have_grad) ? 1 : 0;
+}
+
+int launch_finalize(const vk::StepArgs& a, const Layout& L, const vmapstep_params* params, const vmapstep_params* grads,
+                    const vmapstep_adamw* opt, int step_after, bool have_grad, float* loss_out, int* flags_out,
+                    hipStream_t st) {
+    vk::FinalizeArgs f;
+    fill_finalize_args(f, a, L, params, grads, opt, step_after, have_grad, loss_out, flags_out);
+    const int bpo = (L.PP / 4 + vk::kWG - 1) / vk::kWG;
     // + 1: the loss / flag reduction has a workgroup of its own (it used to ride on block 0 and made it the straggler)
     const int grid = (!have_grad ? 0 : f.xcd_affine ? 8 * ((a.n_obj + 7) / 8) * bpo : a.n_obj * bpo) + 1;
     hipLaunchKernelGGL(vk::step_finalize, dim3(grid), dim3(vk::kWG), 2 * vk::kWG * sizeof(float), st, f);
@@ -292,9 +354,14 @@ int vmapstep_set_workgroups_per_object(int32_t nw) {
     if (nw == -2) { g_force_kernel = 0; return old; }
     if (nw == -3) { g_force_kernel = 2; return old; }
     if (nw == -4) { g_force_kernel = 3; return old; }
+    if (nw == -5) { g_carry = 0; return old; }           // carried finalize off (several fused step loops sharing one GPU)
+    if (nw == -6) { g_carry = 1; return old; }
     g_nw_override = nw > 0 ? nw : 0;
     return old;
 }
+
+// diagnostics, not part of include/vmapstep.h: shader-clock stamps of the carried-finalize prologue (last carrying launch wins)
+int vmapstep_debug_carry_stamps(void* device_buffer) { g_carry_stamps = static_cast<unsigned*>(device_buffer); return 0; }
 
 int vmapstep_param_layout(int32_t hidden, int64_t sizes[VMAPSTEP_NUM_FC + 1], int64_t* params, int64_t* padded_params) {
     if (hidden < 1) return fail(VMAPSTEP_ERR_ARGUMENT, "hidden=%d", hidden);
@@ -434,17 +501,45 @@ static int train_steps_impl(const vmapstep_shape* shape, const vmapstep_params* 
         for (auto& e : ev)
             if (hipEventCreate(&e) != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "hipEventCreate failed");
     }
+    // Two forms of the loop.  Plain: main(i), finalize(i) per step.  Carried (hidden 32, all workgroups resident at once):
+    // main(0), then main(i) with finalize(i-1) in its prologue for i >= 1, then finalize(n-1) - one launch per step.
+    const bool carry = carry_eligible(shape, pl);
+    vk::StepArgs prev;
     for (int i = 0; i < n_steps; ++i) {
         fill_step_args(a, shape, pl, L, params, pe_scale, frame, (int64_t)i * ray_step, color_scaling, opacity_scaling, ws);
         a.stats += (size_t)i * shape->n_obj * 4;
         a.flags += (size_t)i * 4;
+        a.part_loss = reinterpret_cast<float*>(ws + pl.off_ploss + (size_t)(i & 1) * pl.off_ploss_bytes);
         const bool last = i == n_steps - 1;
         if (last) { a.dbg_depth = out->render_depth; a.dbg_rgb = out->render_color; a.dbg_opacity = out->opacity; a.dbg_var = out->var; }
         if (!ev.empty()) hipEventRecord(ev[3 * i], st);
-        if ((rc = launch_main<true>(a, st))) return rc;
+        if (carry && i > 0) {
+            vk::CarryArgs c;
+            fill_finalize_args(c.f, prev, L, params, nullptr, opt, opt->step + i, true, out->loss + (i - 1), out->flags + 4 * (i - 1));
+            c.stamps = g_carry_stamps;
+            vk::CarryHot& h = c.h;
+            std::memset(&h, 0, sizeof(h));
+            h.m = c.f.m; h.v = c.f.v; h.part_grad = c.f.part_grad; h.wimg = c.f.wimg; h.img_tab = a.img_tab;
+            h.cnt = a.carry_cnt; h.epoch = (unsigned)i;
+            h.NW = c.f.NW; h.PP = c.f.PP; h.weights_bf16 = c.f.weights_bf16;
+            h.decay = c.f.decay; h.one_minus_beta1 = c.f.one_minus_beta1; h.beta2 = c.f.beta2; h.one_minus_beta2 = c.f.one_minus_beta2;
+            h.eps = c.f.eps; h.step_size = c.f.step_size; h.bias_corr2_sqrt = c.f.bias_corr2_sqrt;
+            // parameters that are views of one [n, >= P] slab in flat order (vmap_amd.driver allocates them so): one base
+            // pointer instead of a per-element tensor lookup
+            h.slab = params->fc[0].ptr; h.slab_stride = params->fc[0].obj_stride;
+            for (int t = 1; t < 15 && h.slab; ++t) {
+                const vmapstep_tensor* pt = t < 14 ? &params->fc[t] : &params->pe_B;
+                if (pt->ptr != params->fc[0].ptr + L.offs[t] || pt->obj_stride != h.slab_stride) h.slab = nullptr;
+            }
+            rc = a.NW < a.NG ? launch_main_carry<true>(a, c, st) : launch_main_carry<false>(a, c, st);
+            if (rc) return rc;
+        } else if ((rc = launch_main<true>(a, st))) return rc;
         if (!ev.empty()) { hipEventRecord(ev[3 * i + 1], st); hipEventRecord(ev[3 * i + 2], st); }
-        if ((rc = launch_finalize(a, L, params, last ? grads : nullptr, opt, opt->step + i + 1, true,
-                                  out->loss + i, out->flags + 4 * i, st))) return rc;
+        if (!carry || last) {
+            if ((rc = launch_finalize(a, L, params, last ? grads : nullptr, opt, opt->step + i + 1, true,
+                                      out->loss + i, out->flags + 4 * i, st))) return rc;
+        }
+        prev = a;
     }
     if (!ev.empty()) {                       // measurement only: the one place this library waits for the device
         hipEventSynchronize(ev.back());

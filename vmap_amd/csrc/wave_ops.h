@@ -115,4 +115,35 @@ __device__ __forceinline__ unsigned clock32() { return (unsigned)__builtin_amdgc
 
 __device__ __forceinline__ void lds_add(float* p, float v) { atomicAdd(p, v); }   // ds_add_f32
 
+// four wave-uniform words are made to exist in scalar registers at this point (no instruction): pins where a block of
+// kernel arguments is fetched
+__device__ __forceinline__ void touch_scalar4(unsigned& a, unsigned& b, unsigned& c, unsigned& d) {
+    asm volatile("" : "+s"(a), "+s"(b), "+s"(c), "+s"(d));
+}
+
+// ---- hand-off between workgroups of ONE launch (MI355X_MICROARCH.md, inter-workgroup visibility: a CU's vector L1 is
+// never refreshed by another CU's stores and the XCDs' L2s are not coherent with each other).  Recipe used here:
+// write-through ("sc1") payload stores -> s_waitcnt vmcnt(0) -> workgroup barrier -> one agent-scope counter increment;
+// the consumer polls the counter with L1-bypassing loads and then reads the payload with "sc1" loads as well. ----
+__device__ __forceinline__ void store_wt(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float load_wt(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// glds16 with the sc1 cache policy (aux bit 4 on gfx940+): the copy is served past this CU's L1
+__device__ __forceinline__ void glds16_wt(const float* g, float* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 16);
+}
+// every memory instruction this wave has issued is complete (the compiler may drop the wait it would otherwise emit in
+// front of a relaxed atomic; the explicit form cannot be dropped)
+__device__ __forceinline__ void drain_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void signal_add(unsigned* c) { __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// one lane polls until *c >= target; bounded (a workgroup that is not resident cannot signal: the caller raises an error
+// flag instead of hanging the device).  Returns false on timeout.
+__device__ __forceinline__ bool wait_ge(const unsigned* c, unsigned target, int max_polls) {
+    for (int i = 0; i < max_polls; ++i) {
+        if (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return false;
+}
+
 }  // namespace wv

@@ -93,3 +93,21 @@ def step_flops(n_obj: int, R: int, S: int, H: int) -> int:
 def step_bytes(n_obj: int, R: int, S: int, H: int) -> int:
     """Algorithmic HBM bytes of one step: sample data once, weights read once, grads written once."""
     return n_obj * (R * (16 * S + 18) + 8 * param_count(H))
+
+
+def stack_in_slab(tensors, pe_B):
+    """The 15 stacked tensors re-homed as views of ONE ``[n, P]`` slab in flat order (what ``vmap_amd.driver`` does at every
+    re-stack): same shapes and values, but the per-frame step loop recognises the layout (one base pointer, object stride P)
+    and its optimiser pass indexes the slab directly instead of looking every element's tensor up.
+    Returns (slab, [14 field views], B view)."""
+    import torch
+    n = tensors[0].shape[0]
+    H = tensors[2].shape[-1]
+    offs = flat_offsets(H)
+    slab = torch.empty(n, param_count(H), dtype=torch.float32, device=tensors[0].device)
+    views = []
+    for t, src in enumerate(list(tensors) + [pe_B]):
+        v = slab[:, offs[t]:offs[t] + numel(src.shape[1:])].view(src.shape)
+        v.copy_(src)
+        views.append(v)
+    return slab, views[:-1], views[-1]
