@@ -179,10 +179,10 @@ void fill_step_args(vk::StepArgs& a, const vmapstep_shape* sh, const Plan& pl, c
     a.stats = reinterpret_cast<float*>(ws + pl.off_stats);
     a.flags = reinterpret_cast<int*>(ws + pl.off_flags);
     a.part_loss = reinterpret_cast<float*>(ws + pl.off_ploss);      // half 0; the step loop of a frame alternates (ploss_half)
-    // hand-off counters and the flat -> image table exist for the carried finalize only (step_prep skips null pointers)
+    // hand-off counters exist for the carried finalize only (step_prep skips null pointers); the flat -> image table for hidden 32
     const bool carry = !pl.generic && carry_enabled();
     a.carry_cnt = carry ? reinterpret_cast<unsigned*>(ws + pl.off_cnt) : nullptr;
-    a.img_tab = carry ? reinterpret_cast<int*>(ws + pl.off_imgtab) : nullptr;
+    a.img_tab = !pl.generic ? reinterpret_cast<int*>(ws + pl.off_imgtab) : nullptr;   // also read by step_finalize_h32
     a.part_grad = reinterpret_cast<float*>(ws + pl.off_pgrad);
     a.wimg = reinterpret_cast<float*>(ws + pl.off_wimg);
     g_scratch_for_launch = reinterpret_cast<float*>(ws + pl.off_scratch);
@@ -320,6 +320,24 @@ void fill_finalize_args(vk::FinalizeArgs& f, const vk::StepArgs& a, const Layout
     f.xcd_affine = (a.xcd_affine && have_grad) ? 1 : 0;
 }
 
+// the hot fields of a finalize (vk::CarryHot) from its FinalizeArgs
+void fill_carry_hot(vk::CarryHot& h, const vk::FinalizeArgs& f, const vk::StepArgs& a, const Layout& L, const vmapstep_params* params,
+                    unsigned epoch) {
+    std::memset(&h, 0, sizeof(h));
+    h.m = f.m; h.v = f.v; h.part_grad = f.part_grad; h.wimg = f.wimg; h.img_tab = a.img_tab;
+    h.cnt = a.carry_cnt; h.epoch = epoch;
+    h.NW = f.NW; h.PP = f.PP; h.weights_bf16 = f.weights_bf16;
+    h.decay = f.decay; h.one_minus_beta1 = f.one_minus_beta1; h.beta2 = f.beta2; h.one_minus_beta2 = f.one_minus_beta2;
+    h.eps = f.eps; h.step_size = f.step_size; h.bias_corr2_sqrt = f.bias_corr2_sqrt;
+    // parameters that are views of one [n, >= P] slab in flat order (vmap_amd.driver allocates them so): one base
+    // pointer instead of a per-element tensor lookup
+    h.slab = params->fc[0].ptr; h.slab_stride = params->fc[0].obj_stride;
+    for (int t = 1; t < 15 && h.slab; ++t) {
+        const vmapstep_tensor* pt = t < 14 ? &params->fc[t] : &params->pe_B;
+        if (pt->ptr != params->fc[0].ptr + L.offs[t] || pt->obj_stride != h.slab_stride) h.slab = nullptr;
+    }
+}
+
 int launch_finalize(const vk::StepArgs& a, const Layout& L, const vmapstep_params* params, const vmapstep_params* grads,
                     const vmapstep_adamw* opt, int step_after, bool have_grad, float* loss_out, int* flags_out,
                     hipStream_t st) {
@@ -328,6 +346,15 @@ int launch_finalize(const vk::StepArgs& a, const Layout& L, const vmapstep_param
     const int bpo = (L.PP / 4 + vk::kWG - 1) / vk::kWG;
     // + 1: the loss / flag reduction has a workgroup of its own (it used to ride on block 0 and made it the straggler)
     const int grid = (!have_grad ? 0 : f.xcd_affine ? 8 * ((a.n_obj + 7) / 8) * bpo : a.n_obj * bpo) + 1;
+    if (a.hidden == 32 && a.img_tab && f.do_adam && !grads) {
+        // the common training step at hidden 32: table-driven form (same sums, same update, a third of the instructions)
+        vk::CarryHot h;
+        fill_carry_hot(h, f, a, L, params, 0u);
+        hipLaunchKernelGGL(vk::step_finalize_h32, dim3(grid), dim3(vk::kWG), 2 * vk::kWG * sizeof(float), st, f, h);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "step_finalize_h32 launch: %s", hipGetErrorString(e));
+        return VMAPSTEP_OK;
+    }
     hipLaunchKernelGGL(vk::step_finalize, dim3(grid), dim3(vk::kWG), 2 * vk::kWG * sizeof(float), st, f);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "step_finalize launch: %s", hipGetErrorString(e));
@@ -517,20 +544,7 @@ static int train_steps_impl(const vmapstep_shape* shape, const vmapstep_params* 
             vk::CarryArgs c;
             fill_finalize_args(c.f, prev, L, params, nullptr, opt, opt->step + i, true, out->loss + (i - 1), out->flags + 4 * (i - 1));
             c.stamps = g_carry_stamps;
-            vk::CarryHot& h = c.h;
-            std::memset(&h, 0, sizeof(h));
-            h.m = c.f.m; h.v = c.f.v; h.part_grad = c.f.part_grad; h.wimg = c.f.wimg; h.img_tab = a.img_tab;
-            h.cnt = a.carry_cnt; h.epoch = (unsigned)i;
-            h.NW = c.f.NW; h.PP = c.f.PP; h.weights_bf16 = c.f.weights_bf16;
-            h.decay = c.f.decay; h.one_minus_beta1 = c.f.one_minus_beta1; h.beta2 = c.f.beta2; h.one_minus_beta2 = c.f.one_minus_beta2;
-            h.eps = c.f.eps; h.step_size = c.f.step_size; h.bias_corr2_sqrt = c.f.bias_corr2_sqrt;
-            // parameters that are views of one [n, >= P] slab in flat order (vmap_amd.driver allocates them so): one base
-            // pointer instead of a per-element tensor lookup
-            h.slab = params->fc[0].ptr; h.slab_stride = params->fc[0].obj_stride;
-            for (int t = 1; t < 15 && h.slab; ++t) {
-                const vmapstep_tensor* pt = t < 14 ? &params->fc[t] : &params->pe_B;
-                if (pt->ptr != params->fc[0].ptr + L.offs[t] || pt->obj_stride != h.slab_stride) h.slab = nullptr;
-            }
+            fill_carry_hot(c.h, c.f, a, L, params, (unsigned)i);
             rc = a.NW < a.NG ? launch_main_carry<true>(a, c, st) : launch_main_carry<false>(a, c, st);
             if (rc) return rc;
         } else if ((rc = launch_main<true>(a, st))) return rc;
