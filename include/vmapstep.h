@@ -240,7 +240,8 @@ int vmapstep_profile_phases(const vmapstep_shape* shape, const vmapstep_params* 
 /* Tuning knob (0 = automatic): workgroups per object of the fused kernel. Returns the previous value.
  * More values select the kernel of hidden 128 / 256 for measurements and tests: -1 step_main_gen (one wave per
  * tile), -3 step_main_wide<4> (one tile per workgroup, four waves per tile), -4 step_main_wide<2> (four tiles per
- * workgroup, two waves per tile), -2 the automatic choice. */
+ * workgroup, two waves per tile), -2 the automatic choice; -5 / -6 carried finalize off (default) / on; -9 / -10 the
+ * table-driven finalize for hidden 32 (step_finalize_h32) on (default) / off - both pairs exist for A/B parity tests. */
 int vmapstep_set_workgroups_per_object(int32_t nw);
 
 #ifdef __cplusplus

@@ -589,3 +589,40 @@ def test_carried_finalize_is_bit_identical_to_two_kernel_steps(name, nw, steps, 
     for x, y in zip(a["p"], b_["p"]):
         assert torch.equal(x, y)
     assert torch.equal(a["m"], b_["m"]) and torch.equal(a["v"], b_["v"])
+
+
+@pytest.mark.parametrize("name,weights,slab", [("cfg2", "f32", False), ("cfg2", "f32", True), ("scannet_scale", "bf16", False),
+                                               ("tiny", "bf16", True)])
+def test_table_driven_finalize_is_bit_identical_to_generic_finalize(name, weights, slab):
+    """step_finalize_h32 (image slot from step_prep's table, compile-time tensor offsets or one slab base) against the
+    generic step_finalize (runtime tensor search + gen_image_index per element): same ordered sums, same adamw_elem.
+    Three frames of 20 steps; steps 2..20 of a frame read the parameter image the finalize maintains (bf16: the rounded
+    copy), so losses, parameters and both moments must agree bit for bit."""
+    c = cases.build_case(name)
+    lib = _lib.load()
+    steps = 20
+    outs = []
+    try:
+        for knob in (-10, -9):                                   # generic / table-driven
+            lib.vmapstep_set_workgroups_per_object(knob)
+            fc, B, sc, b = _to_dev(c)
+            if slab:
+                _, fc, B = layout.stack_in_slab(fc, B)
+            op = step.VmapStep(c["n"], c["R"], c["S"], c["H"], device=DEV, max_steps=steps, weights=weights)
+            st = step.FusedAdamWState(c["n"], c["H"], DEV)
+            frame = {k: torch.cat([v.roll(i, dims=1) for i in range(steps)], dim=1).contiguous() for k, v in b.items()}
+            losses = []
+            for _ in range(3):
+                res = op.train_steps(fc, B, sc, frame["pcs"], frame["z"], frame["gt_depth"], frame["gt_rgb"], frame["sem"],
+                                     frame["depth_mask"], opt=st, n_steps=steps)
+                losses.append(res.loss.clone())
+            torch.cuda.synchronize()
+            outs.append(dict(p=[t.clone() for t in fc + [B]], m=st.exp_avg.clone(), v=st.exp_avg_sq.clone(), losses=torch.stack(losses)))
+    finally:
+        lib.vmapstep_set_workgroups_per_object(-9)
+    a, b_ = outs
+    assert bool(torch.isfinite(a["losses"]).all())
+    assert torch.equal(a["losses"], b_["losses"])
+    for x, y in zip(a["p"], b_["p"]):
+        assert torch.equal(x, y)
+    assert torch.equal(a["m"], b_["m"]) and torch.equal(a["v"], b_["v"])

@@ -25,6 +25,7 @@ thread_local float* g_scratch_for_launch = nullptr;
 thread_local float* g_time_main_ms = nullptr;           // measurement: train_steps_impl times every main launch with events   // set by fill_step_args (generic-width path)
 int g_nw_override = 0;
 unsigned* g_carry_stamps = nullptr;   // diagnostics (vmapstep_debug_carry_stamps): device buffer [workgroups][8] or null
+int g_fin_table = 1;      // step_finalize_h32 (table-driven finalize for hidden 32) on / off: tuning hook -9 / -10, for the A/B parity test
 int g_carry = -1;         // carried finalize (step_main_h32_carry): -1 = not decided yet (environment VMAPSTEP_CARRY, default off), 0 off, 1 on
 int g_force_kernel = 0;   // measurement / test hook, hidden 128 / 256: 0 automatic, 1 step_main_gen, 2 step_main_wide<4>, 3 step_main_wide<2>
 
@@ -346,7 +347,7 @@ int launch_finalize(const vk::StepArgs& a, const Layout& L, const vmapstep_param
     const int bpo = (L.PP / 4 + vk::kWG - 1) / vk::kWG;
     // + 1: the loss / flag reduction has a workgroup of its own (it used to ride on block 0 and made it the straggler)
     const int grid = (!have_grad ? 0 : f.xcd_affine ? 8 * ((a.n_obj + 7) / 8) * bpo : a.n_obj * bpo) + 1;
-    if (a.hidden == 32 && a.img_tab && f.do_adam && !grads) {
+    if (g_fin_table && a.hidden == 32 && a.img_tab && f.do_adam && !grads) {
         // the common training step at hidden 32: table-driven form (same sums, same update, a third of the instructions)
         vk::CarryHot h;
         fill_carry_hot(h, f, a, L, params, 0u);
@@ -383,6 +384,8 @@ int vmapstep_set_workgroups_per_object(int32_t nw) {
     if (nw == -4) { g_force_kernel = 3; return old; }
     if (nw == -5) { g_carry = 0; return old; }           // carried finalize off (several fused step loops sharing one GPU)
     if (nw == -6) { g_carry = 1; return old; }
+    if (nw == -9) { g_fin_table = 1; return old; }       // table-driven finalize for hidden 32 on (default) / off
+    if (nw == -10) { g_fin_table = 0; return old; }
     g_nw_override = nw > 0 ? nw : 0;
     return old;
 }
