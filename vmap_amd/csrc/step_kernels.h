@@ -505,8 +505,8 @@ __device__ __forceinline__ void sincos_f32(float x, float& s, float& c) {
                                         4.166664568298827e-2f), fmaf(r2, -0.5f, 1.0f));
     const float ss = (q & 1) ? cp : sp;
     const float cc = (q & 1) ? sp : cp;
-    s = (q & 2) ? -ss : ss;
-    c = ((q + 1) & 2) ? -cc : cc;
+    s = __uint_as_float(__float_as_uint(ss) ^ (((unsigned)q << 30) & 0x80000000u));          // (q & 2) ? -ss : ss
+    c = __uint_as_float(__float_as_uint(cc) ^ ((((unsigned)q + 1u) << 30) & 0x80000000u));   // ((q + 1) & 2) ? -cc : cc
 }
 
 // The same for N independent arguments in lockstep: every step is applied to all N before the next one, so the
@@ -535,8 +535,12 @@ __device__ __forceinline__ void sincos_f32xN(const float (&x)[N], float (&s)[N],
     for (int k = 0; k < N; ++k) {
         const float ss = (q[k] & 1) ? cp[k] : sp[k];
         const float cc = (q[k] & 1) ? sp[k] : cp[k];
-        s[k] = (q[k] & 2) ? -ss : ss;
-        c[k] = ((q[k] + 1) & 2) ? -cc : cc;
+        // quadrant signs as sign-bit flips (the same values as `(q & 2) ? -ss : ss` and `((q + 1) & 2) ? -cc : cc`, zeros
+        // included): bit 1 of q / of q + 1 shifted into bit 31 and xor-ed in - a shift and one three-operand bit
+        // instruction each instead of and + compare + select
+        const unsigned qu = (unsigned)q[k];
+        s[k] = __uint_as_float(__float_as_uint(ss) ^ ((qu << 30) & 0x80000000u));
+        c[k] = __uint_as_float(__float_as_uint(cc) ^ (((qu + 1u) << 30) & 0x80000000u));
     }
 }
 
