@@ -14,7 +14,8 @@ acc = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(os.path.join(ROOT, "gpurun_out", "pmc", "*", "p_counter_collection.csv")):
     for row in csv.DictReader(open(f)):
         name = row["Kernel_Name"]
-        key = ("step_main_h32" if "step_main_h32" in name else "step_finalize" if "step_finalize" in name
+        key = ("step_main_h32" if "step_main_h32" in name else "step_finalize_h32" if "step_finalize_h32" in name
+               else "step_finalize" if "step_finalize" in name
                else "step_prep" if "step_prep" in name else None)
         if key:
             acc[key][row["Counter_Name"]].append(float(row["Counter_Value"]))
