@@ -542,7 +542,7 @@ static int train_steps_impl(const vmapstep_shape* shape, const vmapstep_params* 
         a.part_loss = reinterpret_cast<float*>(ws + pl.off_ploss + (size_t)(i & 1) * pl.off_ploss_bytes);
         const bool last = i == n_steps - 1;
         if (last) { a.dbg_depth = out->render_depth; a.dbg_rgb = out->render_color; a.dbg_opacity = out->opacity; a.dbg_var = out->var; }
-        if (!ev.empty()) hipEventRecord(ev[3 * i], st);
+        if (!ev.empty() && hipEventRecord(ev[3 * i], st) != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "hipEventRecord failed");
         if (carry && i > 0) {
             vk::CarryArgs c;
             fill_finalize_args(c.f, prev, L, params, nullptr, opt, opt->step + i, true, out->loss + (i - 1), out->flags + 4 * (i - 1));
@@ -551,7 +551,8 @@ static int train_steps_impl(const vmapstep_shape* shape, const vmapstep_params* 
             rc = a.NW < a.NG ? launch_main_carry<true>(a, c, st) : launch_main_carry<false>(a, c, st);
             if (rc) return rc;
         } else if ((rc = launch_main<true>(a, st))) return rc;
-        if (!ev.empty()) { hipEventRecord(ev[3 * i + 1], st); hipEventRecord(ev[3 * i + 2], st); }
+        if (!ev.empty() && (hipEventRecord(ev[3 * i + 1], st) != hipSuccess || hipEventRecord(ev[3 * i + 2], st) != hipSuccess))
+            return fail(VMAPSTEP_ERR_DEVICE, "hipEventRecord failed");
         if (!carry || last) {
             if ((rc = launch_finalize(a, L, params, last ? grads : nullptr, opt, opt->step + i + 1, true,
                                       out->loss + i, out->flags + 4 * i, st))) return rc;
@@ -559,16 +560,17 @@ static int train_steps_impl(const vmapstep_shape* shape, const vmapstep_params* 
         prev = a;
     }
     if (!ev.empty()) {                       // measurement only: the one place this library waits for the device
-        hipEventSynchronize(ev.back());
+        bool ok = hipEventSynchronize(ev.back()) == hipSuccess;
         double sum = 0.0;
-        for (int i = 0; i < n_steps; ++i) {
+        for (int i = 0; i < n_steps && ok; ++i) {
             float ms = 0.0f, empty = 0.0f;
-            hipEventElapsedTime(&ms, ev[3 * i], ev[3 * i + 1]);
-            hipEventElapsedTime(&empty, ev[3 * i + 1], ev[3 * i + 2]);
+            ok = hipEventElapsedTime(&ms, ev[3 * i], ev[3 * i + 1]) == hipSuccess &&
+                 hipEventElapsedTime(&empty, ev[3 * i + 1], ev[3 * i + 2]) == hipSuccess;
             sum += ms - empty;
         }
+        for (auto& e : ev) ok = (hipEventDestroy(e) == hipSuccess) && ok;
+        if (!ok) return fail(VMAPSTEP_ERR_DEVICE, "event timing of the step loop failed");
         *g_time_main_ms = (float)(sum / n_steps);
-        for (auto& e : ev) hipEventDestroy(e);
     }
     return VMAPSTEP_OK;
 }
