@@ -1164,7 +1164,8 @@ __device__ __forceinline__ void step_main_body(const StepArgs& a, const CarryArg
         }
     }
     float* Gv = lds + L::VEC + wave * L::SMALL_N - L::SMALL0;   // this wave's private small-vector gradients
-    // Block -> (object, workgroup-of-object).  The dispatcher is observed to place block b on XCD b % 8; with the
+    // Block -> (object, workgroup-of-object).  The dispatcher places block b on XCD b % 8 (measured: tests/tools/xcd_probe.hip,
+    // profiles/r01m_xcd_probe.jsonl); with the
     // affine map all workgroups of an object sit on one XCD, so its parameter image is fetched into that L2 once
     // instead of once per workgroup.  Pure speed/traffic choice: any placement is correct.
     int obj, wgo;
