@@ -33,6 +33,7 @@ from vmap_amd import layout, step, synth
 
 FP32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 HBM_PEAK_GBS = 8000.0
+PREHEAT_MS_DEFAULT = 100.0
 
 
 def cpu_baseline(cfg, budget_s=18.0):
@@ -66,6 +67,34 @@ def cpu_baseline(cfg, budget_s=18.0):
     return best
 
 
+def gpu_eager_baseline(cfg, dev, budget_s=2.0):
+    """The eager PyTorch-ROCm port of the step (oracle/vmap_oracle_torch.py: the same ATen ops the reference's
+    train.py:293-326 ends up launching, without functorch) timed on THIS GPU for ~budget_s: the stand-in for 'the
+    reference single-GPU PyTorch path' the north star's ">= 5x" is measured against.  Baseline only."""
+    from oracle import vmap_oracle_torch as vt          # baseline leg only - never on the product path
+    fc, B, sc = synth.make_params(cfg["n_obj"], cfg["H"], scale=cfg["scale"], seed=0)
+    batch = synth.make_batch(cfg["n_obj"], cfg["R"], cfg["S"], seed=1)
+    tr = vt.CpuTrainer(fc, B, sc, device=dev)
+    tb = {k: torch.from_numpy(v).to(dev) for k, v in batch.items()}
+    for _ in range(5):
+        tr.step(tb)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        for _ in range(10):
+            tr.step(tb)
+        n += 10
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 2000:
+            break
+    rays = cfg["n_obj"] * cfg["R"]
+    return {"value": rays * n / el, "unit": "rays/s", "kind": "port", "ms_per_step": el / n * 1e3,
+            "sample": f"{n} eager steps (fwd+loss+bwd+torch.optim.AdamW) of the same workload on {torch.cuda.get_device_name(dev)}, "
+                      f"torch {torch.__version__}"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -79,6 +108,10 @@ def main():
     ap.add_argument("--slab", action="store_true")                   # the 15 stacked tensors as views of one [n, P] slab (measurement;
                                                                      # default: separately allocated, utils.update_vmap's own layout)
     ap.add_argument("--profile-reps", type=int, default=200)
+    ap.add_argument("--preheat-ms", type=float, default=PREHEAT_MS_DEFAULT)   # untimed device pre-heat in front of the warm-up (named in the JSON)
+    ap.add_argument("--no-gpu-baseline", action="store_true")
+    ap.add_argument("--timed-only", action="store_true")            # skip the roofline / baseline legs (for kernel traces of the timed region)
+    ap.add_argument("--unbound", action="store_true")               # marshal the arguments on every frame call (VmapStep.train_steps)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -108,10 +141,11 @@ def main():
         # the stacked parameters as views of one [n, P] slab, the way vmap_amd.driver.HipMapper re-stacks an object list
         _, tfc, tB = layout.stack_in_slab(tfc, tB)
     fr = {k: torch.from_numpy(v).to(dev) for k, v in frame.items()}
+    tuning = None
     if args.kernel != "auto":
         from vmap_amd import _lib
-        _lib.load().vmapstep_set_workgroups_per_object({"gen": -1, "wide": -3, "wide2": -4}[args.kernel])
-    op = step.VmapStep(n, R, S, H, device=dev, max_steps=ipf, weights=args.weights)
+        tuning = {"kernel": {"gen": _lib.KERNEL_GEN, "wide": _lib.KERNEL_WIDE4, "wide2": _lib.KERNEL_WIDE2}[args.kernel]}
+    op = step.VmapStep(n, R, S, H, device=dev, max_steps=ipf, weights=args.weights, tuning=tuning)
     opt = step.FusedAdamWState(n, H, dev, lr=1e-3, weight_decay=0.013)
     fargs = (fr["pcs"], fr["z"], fr["gt_depth"], fr["gt_rgb"], fr["sem"], fr["depth_mask"])
 
@@ -121,11 +155,18 @@ def main():
         from vmap_amd import parallel
         flag_reduce = parallel.ObjectShard(n * world).reduce_flags
 
+    # the frame tensors and the stacked parameters do not move between frame calls: marshal them once (BoundFrame), as
+    # driver.HipMapper does for its slab and its sampler's frame buffers
+    bound = None if args.unbound else op.bind(tfc, tB, tsc, *fargs, opt=opt, flag_reduce=flag_reduce)
+
     def run(n_steps):
         done = 0
         while done < n_steps:
             k = min(ipf, n_steps - done)
-            op.train_steps(tfc, tB, tsc, *fargs, opt=opt, n_steps=k, flag_reduce=flag_reduce)
+            if bound is not None:
+                bound.train_steps(k)
+            else:
+                op.train_steps(tfc, tB, tsc, *fargs, opt=opt, n_steps=k, flag_reduce=flag_reduce)
             done += k
 
     def barrier():
@@ -133,6 +174,15 @@ def main():
             td.barrier()
         torch.cuda.synchronize()
 
+    preheat_steps = 0
+    if args.preheat_ms > 0:
+        # Untimed device pre-heat (NOT part of the W warm-up steps and NOT timed): the same frame call repeated for
+        # ~preheat_ms so that the clocks / power state are those of a running mapper rather than of an idle chip.
+        t_ph = time.perf_counter()
+        while (time.perf_counter() - t_ph) * 1e3 < args.preheat_ms:
+            run(ipf)
+            preheat_steps += ipf
+            torch.cuda.synchronize()
     run(args.warmup)
     barrier()
     t0 = time.perf_counter()
@@ -147,22 +197,34 @@ def main():
     rays_per_step = n * R * world
     value = rays_per_step / (elapsed / args.steps)
 
+    if args.timed_only:
+        if rank == 0:
+            print(json.dumps({"value": value, "ms_per_step": ms_per_step, "steps": args.steps, "warmup": args.warmup,
+                              "preheat_ms": args.preheat_ms, "timed_only": True}), flush=True)
+        if dist:
+            td.barrier()
+            td.destroy_process_group()
+        return
     out = None
     if rank == 0:
         # ---- dominant kernel, timed live on the launch stream ----
-        # (event pairs around every launch of the dominant kernel inside the real prep / main / finalize sequence, minus
-        # the cost of an empty event pair; back-to-back launches of the kernel alone are reported next to it.  A
-        # rocprofv3 --kernel-trace of the same command reads ~2.4 us more per dispatch of this kernel: profiles/)
+        # (event pairs around every launch of the dominant kernel inside the real prep / main / finalize sequence; `frac`
+        # uses the RAW pair time, which is what a rocprofv3 --kernel-trace of the same command reports per dispatch
+        # (profiles/); the time minus the cost of an empty event pair and back-to-back launches of the kernel alone are
+        # reported next to it)
         b0 = tuple(x[:, :R] for x in fargs)
         k_ms_alone = op.profile_main_kernel(tfc, tB, tsc, *b0, reps=args.profile_reps)
         reps = max(1, args.profile_reps // ipf)
-        k_ms = sum(op.profile_train_steps(tfc, tB, tsc, *fargs, opt=opt, n_steps=ipf) for _ in range(reps)) / reps
+        pairs = [op.profile_train_steps(tfc, tB, tsc, *fargs, opt=opt, n_steps=ipf) for _ in range(reps)]
+        k_ms = sum(p[0] for p in pairs) / reps               # raw event-pair time around every launch: the roofline's duration
+        k_ms_corr = sum(p[1] for p in pairs) / reps          # minus the cost of an empty event pair
         flops = layout.step_flops(n, R, S, H)
         abytes = layout.step_bytes(n, R, S, H)
         achieved = flops / (k_ms * 1e-3) / 1e12
         # HBM-side bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE, see
         # profiles/*_pmc_counters.json); counters cannot be sampled from inside this process
         traffic = None
+        pmcs = []
         try:
             pmcs = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_counters.json"))
             if pmcs and args.config == "replica_room0_vmap":
@@ -190,15 +252,23 @@ def main():
                        "parallelism": f"objects sharded over {world} GPU(s); no per-step collective, one 4x{ipf}-int32 flag all-reduce per frame"},
             "roofline": {"bound": "mfma", "kernel": "step_main_h32<true>" if H == 32 else "step_main_gen / step_main_wide (hidden 128, 256: chosen by tile count)", "achieved": achieved,
                          "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
-                         "traffic": traffic, "kernel_ms": k_ms, "kernel_ms_back_to_back": k_ms_alone, "algorithmic_flops_per_launch": flops,
+                         "traffic": traffic,
+                         "traffic_source": ("copied from the committed rocprofv3 --pmc passes of this kernel (profiles/" + pmcs[-1] +
+                                            "), not observed in this run") if traffic is not None else None,
+                         "kernel_ms": k_ms, "kernel_ms_minus_empty_event_pair": k_ms_corr, "kernel_ms_back_to_back": k_ms_alone, "algorithmic_flops_per_launch": flops,
                          "algorithmic_bytes_per_launch": abytes,
                          "hbm_achieved_GBs": abytes / (k_ms * 1e-3) / 1e9,
                          "hbm_frac": abytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "fwd_bwd_only": {"ms_per_step_host_launched": fb_ms, "rays_per_s": n * R / (fb_ms * 1e-3)},
+            "preheat": {"ms": args.preheat_ms, "steps": preheat_steps, "timed": False},
+            "frame_call": "bound (arguments marshalled once)" if bound is not None else "marshalled per call",
         }
     if dist:
         td.barrier()
     if rank == 0:
+        if world == 1 and not args.no_gpu_baseline:
+            out["gpu_eager_baseline"] = gpu_eager_baseline(cfg, dev)
+            out["gpu_eager_baseline"]["speedup"] = value / out["gpu_eager_baseline"]["value"]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out), flush=True)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VMAPSTEP_ABI_VERSION 3
+#define VMAPSTEP_ABI_VERSION 4
 #define VMAPSTEP_NUM_FC 14 /* field-MLP tensors per object, nn.Module.parameters() order (model.py:28-49) */
 
 #define VMAPSTEP_OK 0
@@ -45,12 +45,31 @@ extern "C" {
 #define VMAPSTEP_FLAG_DROP_OPACITY 2
 #define VMAPSTEP_FLAG_EXPLODE 3      /* render_rays.py:88-90: a per-object loss term exceeded 1e5 */
 
+/* Measurement / test overrides of the automatic launch plan.  Passed PER CALL through vmapstep_shape::tuning (NULL or
+ * all-zero = automatic); the library keeps no tuning state of its own, so two operators in one process (two streams,
+ * two devices, two threads) cannot influence each other.  The plan - and with it the workspace layout - depends on these
+ * values: pass the same tuning to vmapstep_workspace_bytes and to every call that uses that workspace. */
+#define VMAPSTEP_KERNEL_AUTO 0
+#define VMAPSTEP_KERNEL_GEN 1     /* hidden 64..256: step_main_gen (one wave per 32-point tile)                      */
+#define VMAPSTEP_KERNEL_WIDE4 2   /* hidden 128/256: step_main_wide<4> (one tile per workgroup, four waves per tile) */
+#define VMAPSTEP_KERNEL_WIDE2 3   /* hidden 128/256: step_main_wide<2> (four tiles per workgroup, two waves per tile)*/
+typedef struct vmapstep_tuning {
+    int32_t workgroups_per_object; /* 0 = automatic (256 / n_obj, at most one per ray group)                      */
+    int32_t kernel;                /* VMAPSTEP_KERNEL_*                                                           */
+    int32_t generic_finalize;      /* 1: step_finalize instead of the table-driven step_finalize_h32 (A/B parity) */
+    int32_t carried_finalize;      /* 1: hidden 32, all workgroups resident: step i's launch finishes step i-1
+                                      (bit-identical, measured slower: DESIGN.md 6b); default off                 */
+    uint32_t* carry_stamps;        /* diagnostics: device buffer [workgroups][8] for the carried prologue, or NULL */
+} vmapstep_tuning;
+
 typedef struct vmapstep_shape {
     int32_t n_obj;   /* objects in the stack                         (len(obj_dict))        */
     int32_t rays;    /* rays per object per step, R                  (cfg.n_per_optim)      */
     int32_t samples; /* samples per ray, S = n_bins_cam2surface+n_bins                      */
     int32_t hidden;  /* hidden width H                               (hidden_feature_size)  */
     int32_t weight_dtype; /* VMAPSTEP_WEIGHTS_F32 or VMAPSTEP_WEIGHTS_BF16 (see below)              */
+    int32_t reserved;     /* 0                                                                       */
+    const vmapstep_tuning* tuning; /* NULL = automatic                                               */
 } vmapstep_shape;
 
 /* weight_dtype: the reference is fp32 only (AMP = False, train.py:64).  BF16 = BASELINE configs[3]/[4] "bf16 weights +
@@ -214,13 +233,14 @@ int vmapstep_query_points(int32_t hidden, const vmapstep_params* params, const v
                           float* occupancy, float* color, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Measurement hook: vmapstep_train_steps with a pair of events around every launch of the dominant kernel, in the real
- * step sequence (prep, then main / finalize alternating); waits for the device and returns the average duration in
- * milliseconds - the figure bench.py's roofline object uses and a rocprofv3 kernel trace of the same run reports. */
+ * step sequence (prep, then main / finalize alternating); waits for the device and returns the average durations in
+ * milliseconds: main_kernel_ms[0] = the raw event-pair time (what a rocprofv3 kernel trace of the same run reports,
+ * and what bench.py's roofline uses), main_kernel_ms[1] = the same minus the cost of an empty event pair. */
 int vmapstep_profile_train_steps(const vmapstep_shape* shape, const vmapstep_params* params, const vmapstep_tensor* pe_scale,
                                  const vmapstep_batch* frame, int64_t ray_step, int32_t n_steps,
                                  float color_scaling, float opacity_scaling, const vmapstep_adamw* opt,
                                  const vmapstep_outputs* outputs, void* workspace, size_t workspace_bytes, void* stream,
-                                 float* main_kernel_ms);
+                                 float main_kernel_ms[2]);
 
 /* Measurement hook: step_prep once, then the dominant kernel (step_main, forward+backward) `reps` times back to
  * back on `stream` with nothing in between, so that events recorded around the call give its average launch
@@ -236,13 +256,6 @@ int vmapstep_profile_phases(const vmapstep_shape* shape, const vmapstep_params* 
                             const vmapstep_tensor* pe_scale, const vmapstep_batch* batch,
                             uint32_t* timing, size_t timing_elems, int32_t* n_workgroups,
                             void* workspace, size_t workspace_bytes, void* stream);
-
-/* Tuning knob (0 = automatic): workgroups per object of the fused kernel. Returns the previous value.
- * More values select the kernel of hidden 128 / 256 for measurements and tests: -1 step_main_gen (one wave per
- * tile), -3 step_main_wide<4> (one tile per workgroup, four waves per tile), -4 step_main_wide<2> (four tiles per
- * workgroup, two waves per tile), -2 the automatic choice; -5 / -6 carried finalize off (default) / on; -9 / -10 the
- * table-driven finalize for hidden 32 (step_finalize_h32) on (default) / off - both pairs exist for A/B parity tests. */
-int vmapstep_set_workgroups_per_object(int32_t nw);
 
 #ifdef __cplusplus
 }

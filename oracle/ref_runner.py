@@ -151,3 +151,63 @@ def reference_step(fc_np, B_np, scale_np, batch, H, dtype=torch.float32, strateg
             out[f"p_fc{t}"] = p.detach().numpy().copy()
         out["p_B"] = pe_param[0].detach().numpy().copy()
     return out
+
+
+def reference_frame(fc_np, B_np, scale_np, frame, H, rays_per_step, n_steps, dtype=torch.float32,
+                    lr=1e-3, weight_decay=0.013):
+    """The reference's OWN step loop over one frame (train.py:270-326, vmap strategy): the per-frame sample tensors
+    ``[n, n_steps * rays_per_step, ...]`` are sliced with ``data_idx = slice(i * R, (i + 1) * R)`` on dimension 1 (strided
+    views, exactly like train.py:271-277), every step is vmap(pe) -> vmap(fc) -> loss.step_batch_loss -> backward ->
+    ``AdamW.step()`` -> ``zero_grad(set_to_none=True)`` on an optimiser built like train.py:67 + utils.py:33.
+
+    Returns the per-step losses (float64 array), the final parameters and the gradients of the FIRST step."""
+    mods = _import_reference()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        from functorch import combine_state_for_ensemble, vmap
+    loss_mod = mods["loss"]
+    fc_models, pe_models = build_reference_models(fc_np, B_np, scale_np, H, dtype)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        fc_model, fc_param, fc_buffer = combine_state_for_ensemble(fc_models)
+        pe_model, pe_param, pe_buffer = combine_state_for_ensemble(pe_models)
+    [p.requires_grad_() for p in fc_param]
+    [p.requires_grad_() for p in pe_param]
+    opt = torch.optim.AdamW([torch.autograd.Variable(torch.tensor(0.0))], lr=lr, weight_decay=weight_decay)   # train.py:67
+    opt.add_param_group({"params": fc_param})                                                                  # utils.py:33
+    opt.add_param_group({"params": pe_param})
+
+    N_pcs = torch.from_numpy(frame["pcs"]).to(dtype)
+    N_z = torch.from_numpy(frame["z"]).to(dtype)
+    N_gt_depth = torch.from_numpy(frame["gt_depth"]).to(dtype)
+    N_gt_rgb = torch.from_numpy(frame["gt_rgb"]).to(dtype)
+    N_sem = torch.from_numpy(frame["sem"])
+    N_dmask = torch.from_numpy(frame["depth_mask"]).bool()
+    R = rays_per_step
+    losses, first_grads = [], None
+    for it in range(n_steps):
+        data_idx = slice(it * R, (it + 1) * R)                                   # train.py:271
+        pcs, z = N_pcs[:, data_idx, ...], N_z[:, data_idx, ...]
+        gt_depth, gt_rgb = N_gt_depth[:, data_idx, ...], N_gt_rgb[:, data_idx, ...]
+        sem, dmask = N_sem[:, data_idx, ...], N_dmask[:, data_idx, ...]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            emb = vmap(pe_model)(pe_param, pe_buffer, pcs)                       # train.py:293
+            alpha, color = vmap(fc_model)(fc_param, fc_buffer, emb)              # train.py:294
+        l, _ = loss_mod.step_batch_loss(alpha, color, gt_depth.detach(), gt_rgb.detach(), sem.detach(), dmask.detach(),
+                                        z.detach())                             # train.py:303-306
+        if l.requires_grad:
+            l.backward()                                                         # train.py:324
+        if it == 0:
+            first_grads = [(p.grad if p.grad is not None else torch.zeros_like(p)).detach().numpy().copy()
+                           for p in list(fc_param) + list(pe_param)]
+        opt.step()                                                               # train.py:325
+        opt.zero_grad(set_to_none=True)                                          # train.py:326
+        losses.append(float(l))
+    out = {"losses": np.array(losses, dtype=np.float64)}
+    for t, p in enumerate(fc_param):
+        out[f"p_fc{t}"] = p.detach().numpy().copy()
+        out[f"g0_fc{t}"] = first_grads[t]
+    out["p_B"] = pe_param[0].detach().numpy().copy()
+    out["g0_B"] = first_grads[14]
+    return out

@@ -54,3 +54,20 @@ def input_digest(case) -> str:
     for k in ("pcs", "z", "gt_depth", "gt_rgb", "sem", "depth_mask"):
         h.update(np.ascontiguousarray(case["batch"][k]).tobytes())
     return h.hexdigest()
+
+
+# Whole-frame trajectory cases: the reference's own step loop (train.py:270-326) over [n, n_steps * R, ...] frame tensors.
+FRAME_CASES = {
+    # name: (n_obj, R, S, H, scale, param_seed, frame_seed, n_steps, objects whose final parameters are stored)
+    "cfg2_frame20":   (20, 120, 10, 32, 2.0, 20, 121, 20, None),            # BASELINE configs[1], the frame bench.py times
+    "scannet50_frame": (50, 120, 10, 32, 3.0, 90, 191, 4, (0, 7, 23, 49)),  # configs[3]: 50 objects -> multi-pass step_main at real n
+    "h64_r256_frame": (32, 256, 10, 64, 2.0, 92, 193, 3, (0, 13, 31)),      # configs[4] per-GPU shape (256 objects / 8 GPUs)
+}
+
+
+def build_frame_case(name):
+    n, R, S, H, scale, ps, bs, n_steps, keep = FRAME_CASES[name]
+    fc, B, pe_scale = synth.make_params(n, H, scale=scale, seed=ps)
+    frame = synth.make_batch(n, R * n_steps, S, seed=bs)
+    return dict(name=name, n=n, R=R, S=S, H=H, n_steps=n_steps, fc=fc, B=B, scale=pe_scale, frame=frame,
+                keep=tuple(range(n)) if keep is None else tuple(keep))

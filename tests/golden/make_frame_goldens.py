@@ -1,0 +1,54 @@
+"""Generate the whole-frame trajectory fixtures by running the REAL reference's step loop on CPU.
+
+Run in the authoring container only (needs /root/reference):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_frame_goldens.py [names...]
+
+For every case in ``tests/cases.py:FRAME_CASES`` it runs ``oracle.ref_runner.reference_frame`` (train.py:270-326: strided
+slices of the frame tensors, functorch vmap, loss.step_batch_loss, backward, AdamW(lr 1e-3, wd 0.013), zero_grad) in
+float32 and stores the per-step losses, the gradients of the first step and the final parameters of the kept objects
+(all objects for the headline frame), plus per-object / per-tensor L2 norms of the final parameters of every object; the
+float64 twin contributes its losses (the tie-breaker for how fast the two precisions drift apart).
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from oracle import ref_runner  # noqa: E402
+import cases  # noqa: E402
+
+
+def main(names=None):
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    for name in (names or cases.FRAME_CASES):
+        c = cases.build_frame_case(name)
+        keep = list(c["keep"])
+        r32 = ref_runner.reference_frame(c["fc"], c["B"], c["scale"], c["frame"], c["H"], c["R"], c["n_steps"], torch.float32)
+        r64 = ref_runner.reference_frame(c["fc"], c["B"], c["scale"], c["frame"], c["H"], c["R"], c["n_steps"], torch.float64)
+        out = {"losses": r32["losses"], "f64_losses": r64["losses"], "keep": np.array(keep)}
+        for t in list(range(14)) + ["B"]:
+            k = f"fc{t}" if t != "B" else "B"
+            out[f"p_{k}"] = r32[f"p_{k}"][keep].astype(np.float32)
+            out[f"g0_{k}"] = r32[f"g0_{k}"][keep].astype(np.float32)
+            n = r32[f"p_{k}"].shape[0]
+            out[f"pnorm_{k}"] = np.sqrt((r32[f"p_{k}"].astype(np.float64).reshape(n, -1) ** 2).sum(-1))
+            out[f"f64_pnorm_{k}"] = np.sqrt((r64[f"p_{k}"].astype(np.float64).reshape(n, -1) ** 2).sum(-1))
+        out["torch_version"] = np.array(torch.__version__)
+        path = os.path.join(HERE, f"{name}.npz")
+        np.savez_compressed(path, **out)
+        print(f"{name:16s} losses {r32['losses'][0]:.4f} .. {r32['losses'][-1]:.4f}  (f64 {r64['losses'][0]:.4f} .. {r64['losses'][-1]:.4f})"
+              f"  -> {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:] or None)

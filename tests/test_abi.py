@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in _declared_functions():
         assert hasattr(lib, name), name
-    assert lib.vmapstep_abi_version() == 3
+    assert lib.vmapstep_abi_version() == 4
 
 
 @pytest.mark.parametrize("H", [32, 64, 128, 256])
@@ -52,6 +52,27 @@ def test_workspace_and_error_reporting():
     assert lib.vmapstep_fwd_bwd(ctypes.byref(sh), None, None, None, 5.0, 10.0, None, None, None, 0, None) == -1
     with pytest.raises(_lib.VmapStepError):
         _lib.check(-1)
+
+
+def test_tuning_is_per_call_state_not_library_state():
+    """ABI v4: the plan overrides travel in vmapstep_shape::tuning; the library holds no tuning state, so sizing the
+    workspace for one operator cannot change the plan of another."""
+    lib = _lib.load()
+    auto, tuned = ctypes.c_size_t(), ctypes.c_size_t()
+    sh = _lib.Shape(20, 120, 10, 32, 0)
+    assert lib.vmapstep_workspace_bytes(ctypes.byref(sh), 20, ctypes.byref(auto)) == 0
+    t = _lib.Tuning(workgroups_per_object=2)
+    sh2 = _lib.Shape(20, 120, 10, 32, 0)
+    sh2.tuning = ctypes.pointer(t)
+    assert lib.vmapstep_workspace_bytes(ctypes.byref(sh2), 20, ctypes.byref(tuned)) == 0
+    assert tuned.value < auto.value                              # 2 instead of 10 gradient-partial rows per object
+    again = ctypes.c_size_t()
+    assert lib.vmapstep_workspace_bytes(ctypes.byref(sh), 20, ctypes.byref(again)) == 0
+    assert again.value == auto.value                             # ... and nothing of it stuck to the library
+    bad = _lib.Tuning(kernel=17)
+    sh2.tuning = ctypes.pointer(bad)
+    assert lib.vmapstep_workspace_bytes(ctypes.byref(sh2), 20, ctypes.byref(tuned)) == -1
+    assert not hasattr(lib, "vmapstep_set_workgroups_per_object")
 
 
 def test_step_operator_refuses_cpu():

@@ -27,9 +27,9 @@ def _to_dev(c):
     return fc, B, sc, b
 
 
-def _run(c, fn="fwd_bwd", op=None, **kw):
+def _run(c, fn="fwd_bwd", op=None, tuning=None, **kw):
     fc, B, sc, b = _to_dev(c)
-    op = op or step.VmapStep(c["n"], c["R"], c["S"], c["H"], device=DEV)
+    op = op or step.VmapStep(c["n"], c["R"], c["S"], c["H"], device=DEV, tuning=tuning)
     gfc = [torch.full_like(t, float("nan")) for t in fc]
     gB = torch.full_like(B, float("nan"))
     if fn == "fwd_bwd":
@@ -52,7 +52,7 @@ H32_CASES = [n for n, v in cases.CASES.items() if v[3] == 32]
 
 def test_native_library_is_loaded():
     lib = _lib.load()
-    assert lib.vmapstep_abi_version() == _lib.ABI_VERSION == 3
+    assert lib.vmapstep_abi_version() == _lib.ABI_VERSION == 4
     assert torch.cuda.is_available()
     assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
 
@@ -165,12 +165,7 @@ def test_slab_views_as_parameters():
 def test_workgroups_per_object_does_not_change_results(nw):
     c = cases.build_case("scannet_scale")      # R=120 -> 10 ray groups per object
     g = load_golden("scannet_scale")
-    lib = _lib.load()
-    old = lib.vmapstep_set_workgroups_per_object(nw)
-    try:
-        s = _run(c)
-    finally:
-        lib.vmapstep_set_workgroups_per_object(old)
+    s = _run(c, tuning={"workgroups_per_object": nw})
     for k in RENDER_KEYS + GRAD_KEYS:
         assert relerr(s[k], g[k]) < 1e-4, k
 
@@ -270,24 +265,21 @@ def test_results_are_bitwise_repeatable(name):
     backward would show up here as a flipped bit long before it moves a 1e-4 tolerance."""
     c = cases.build_case(name)
     fc, B, sc, b = _to_dev(c)
-    lib = _lib.load()
-    old = lib.vmapstep_set_workgroups_per_object(0 if name == "cfg2" else 3)      # 3 of 10 ray groups per workgroup: multi-pass
-    try:
-        op = step.VmapStep(c["n"], c["R"], c["S"], c["H"], device=DEV)
-        ref = None
-        for it in range(40):
-            gfc = [torch.full_like(t, float("nan")) for t in fc]
-            gB = torch.full_like(B, float("nan"))
-            res = op.fwd_bwd(fc, B, sc, b["pcs"], b["z"], b["gt_depth"], b["gt_rgb"], b["sem"], b["depth_mask"],
-                             grads_fc=gfc, grad_B=gB, render=True)
-            cur = [res.loss.clone(), res.render_depth.clone(), res.render_color.clone()] + gfc + [gB]
-            if ref is None:
-                ref = cur
-            else:
-                for x, y in zip(cur, ref):
-                    assert torch.equal(x, y), it
-    finally:
-        lib.vmapstep_set_workgroups_per_object(old)
+    # scannet_scale: 3 of 10 ray groups per workgroup -> the multi-pass kernel
+    op = step.VmapStep(c["n"], c["R"], c["S"], c["H"], device=DEV,
+                       tuning={"workgroups_per_object": 0 if name == "cfg2" else 3})
+    ref = None
+    for it in range(40):
+        gfc = [torch.full_like(t, float("nan")) for t in fc]
+        gB = torch.full_like(B, float("nan"))
+        res = op.fwd_bwd(fc, B, sc, b["pcs"], b["z"], b["gt_depth"], b["gt_rgb"], b["sem"], b["depth_mask"],
+                         grads_fc=gfc, grad_B=gB, render=True)
+        cur = [res.loss.clone(), res.render_depth.clone(), res.render_color.clone()] + gfc + [gB]
+        if ref is None:
+            ref = cur
+        else:
+            for x, y in zip(cur, ref):
+                assert torch.equal(x, y), it
 
 
 def test_driver_background_on_second_stream_equals_sequential():
@@ -367,23 +359,10 @@ def test_generic_width_kernel_matches_reference_fixture(name, kernel):
     workgroup / four tiles per workgroup, also with fewer workgroups than ray groups) and step_main_gen."""
     c = cases.build_case(name)
     g = load_golden(name)
-    lib = _lib.load()
-    old = 0
-    try:
-        if kernel == "gen":
-            lib.vmapstep_set_workgroups_per_object(-1)
-        if kernel in ("wide", "wide_multipass"):
-            lib.vmapstep_set_workgroups_per_object(-3)
-        if kernel in ("wide2", "wide2_multipass"):
-            lib.vmapstep_set_workgroups_per_object(-4)
-        if kernel == "wide_multipass":
-            old = lib.vmapstep_set_workgroups_per_object(3)
-        if kernel == "wide2_multipass":
-            old = lib.vmapstep_set_workgroups_per_object(1)
-        s = _run(c)
-    finally:
-        lib.vmapstep_set_workgroups_per_object(-2)
-        lib.vmapstep_set_workgroups_per_object(old)
+    tuning = {"kernel": {"gen": _lib.KERNEL_GEN, "wide": _lib.KERNEL_WIDE4, "wide_multipass": _lib.KERNEL_WIDE4,
+                         "wide2": _lib.KERNEL_WIDE2, "wide2_multipass": _lib.KERNEL_WIDE2}[kernel],
+              "workgroups_per_object": {"wide_multipass": 3, "wide2_multipass": 1}.get(kernel, 0)}
+    s = _run(c, tuning=tuning)
     assert abs(s["loss"] - float(g["loss"])) <= 2e-5 * abs(float(g["loss"]))
     for k in RENDER_KEYS:
         assert relerr(s[k], g[k]) < 2e-5, k
@@ -396,12 +375,7 @@ def test_generic_width_multi_pass_and_train_steps():
     """hidden = 64 with fewer workgroups than ray groups (partials accumulated over passes) + fused AdamW steps."""
     c = cases.build_case("h64")
     g = load_golden("h64")
-    lib = _lib.load()
-    old = lib.vmapstep_set_workgroups_per_object(2)
-    try:
-        s = _run(c)
-    finally:
-        lib.vmapstep_set_workgroups_per_object(old)
+    s = _run(c, tuning={"workgroups_per_object": 2})
     for k in RENDER_KEYS + GRAD_KEYS:
         assert relerr(s[k], g[k]) < 1e-4, k
     fc, B, sc, b = _to_dev(c)
@@ -557,30 +531,24 @@ def test_carried_finalize_is_bit_identical_to_two_kernel_steps(name, nw, steps, 
     row (the hand-off counters are re-armed per frame).  nw = 2, 3: the multi-pass instantiation (and several rounds of
     the carried slice per workgroup); slab: both ways the carried pass addresses the parameters."""
     c = cases.build_case(name)
-    lib = _lib.load()
-    old = lib.vmapstep_set_workgroups_per_object(nw)
     outs = []
-    try:
-        for knob in (-5, -6):                                    # carried finalize off / on
-            lib.vmapstep_set_workgroups_per_object(knob)
-            fc, B, sc, b = _to_dev(c)
-            if slab:                                             # parameters as views of one [n, P] slab (indexed directly)
-                _, fc, B = layout.stack_in_slab(fc, B)
-            op = step.VmapStep(c["n"], c["R"], c["S"], c["H"], device=DEV, max_steps=steps)
-            st = step.FusedAdamWState(c["n"], c["H"], DEV)
-            frame = {k: torch.cat([v.roll(i, dims=1) for i in range(steps)], dim=1).contiguous() for k, v in b.items()}
-            losses, flags = [], []
-            for _ in range(3):
-                res = op.train_steps(fc, B, sc, frame["pcs"], frame["z"], frame["gt_depth"], frame["gt_rgb"], frame["sem"],
-                                     frame["depth_mask"], opt=st, n_steps=steps)
-                losses.append(res.loss.clone())
-                flags.append(res.flags.clone())
-            torch.cuda.synchronize()
-            outs.append(dict(p=[t.clone() for t in fc + [B]], m=st.exp_avg.clone(), v=st.exp_avg_sq.clone(),
-                             losses=torch.stack(losses), flags=torch.stack(flags)))
-    finally:
-        lib.vmapstep_set_workgroups_per_object(-5)               # the default: off
-        lib.vmapstep_set_workgroups_per_object(old)
+    for carried in (0, 1):                                       # carried finalize off / on: two operators, each with its own tuning
+        fc, B, sc, b = _to_dev(c)
+        if slab:                                                 # parameters as views of one [n, P] slab (indexed directly)
+            _, fc, B = layout.stack_in_slab(fc, B)
+        op = step.VmapStep(c["n"], c["R"], c["S"], c["H"], device=DEV, max_steps=steps,
+                           tuning={"workgroups_per_object": nw, "carried_finalize": carried})
+        st = step.FusedAdamWState(c["n"], c["H"], DEV)
+        frame = {k: torch.cat([v.roll(i, dims=1) for i in range(steps)], dim=1).contiguous() for k, v in b.items()}
+        losses, flags = [], []
+        for _ in range(3):
+            res = op.train_steps(fc, B, sc, frame["pcs"], frame["z"], frame["gt_depth"], frame["gt_rgb"], frame["sem"],
+                                 frame["depth_mask"], opt=st, n_steps=steps)
+            losses.append(res.loss.clone())
+            flags.append(res.flags.clone())
+        torch.cuda.synchronize()
+        outs.append(dict(p=[t.clone() for t in fc + [B]], m=st.exp_avg.clone(), v=st.exp_avg_sq.clone(),
+                         losses=torch.stack(losses), flags=torch.stack(flags)))
     a, b_ = outs
     assert int(b_["flags"][..., 3].max()) == 0                    # no hand-off timeout, no explode
     assert torch.equal(a["flags"], b_["flags"])
@@ -599,27 +567,23 @@ def test_table_driven_finalize_is_bit_identical_to_generic_finalize(name, weight
     Three frames of 20 steps; steps 2..20 of a frame read the parameter image the finalize maintains (bf16: the rounded
     copy), so losses, parameters and both moments must agree bit for bit."""
     c = cases.build_case(name)
-    lib = _lib.load()
     steps = 20
     outs = []
-    try:
-        for knob in (-10, -9):                                   # generic / table-driven
-            lib.vmapstep_set_workgroups_per_object(knob)
-            fc, B, sc, b = _to_dev(c)
-            if slab:
-                _, fc, B = layout.stack_in_slab(fc, B)
-            op = step.VmapStep(c["n"], c["R"], c["S"], c["H"], device=DEV, max_steps=steps, weights=weights)
-            st = step.FusedAdamWState(c["n"], c["H"], DEV)
-            frame = {k: torch.cat([v.roll(i, dims=1) for i in range(steps)], dim=1).contiguous() for k, v in b.items()}
-            losses = []
-            for _ in range(3):
-                res = op.train_steps(fc, B, sc, frame["pcs"], frame["z"], frame["gt_depth"], frame["gt_rgb"], frame["sem"],
-                                     frame["depth_mask"], opt=st, n_steps=steps)
-                losses.append(res.loss.clone())
-            torch.cuda.synchronize()
-            outs.append(dict(p=[t.clone() for t in fc + [B]], m=st.exp_avg.clone(), v=st.exp_avg_sq.clone(), losses=torch.stack(losses)))
-    finally:
-        lib.vmapstep_set_workgroups_per_object(-9)
+    for generic in (1, 0):                                       # generic / table-driven
+        fc, B, sc, b = _to_dev(c)
+        if slab:
+            _, fc, B = layout.stack_in_slab(fc, B)
+        op = step.VmapStep(c["n"], c["R"], c["S"], c["H"], device=DEV, max_steps=steps, weights=weights,
+                           tuning={"generic_finalize": generic})
+        st = step.FusedAdamWState(c["n"], c["H"], DEV)
+        frame = {k: torch.cat([v.roll(i, dims=1) for i in range(steps)], dim=1).contiguous() for k, v in b.items()}
+        losses = []
+        for _ in range(3):
+            res = op.train_steps(fc, B, sc, frame["pcs"], frame["z"], frame["gt_depth"], frame["gt_rgb"], frame["sem"],
+                                 frame["depth_mask"], opt=st, n_steps=steps)
+            losses.append(res.loss.clone())
+        torch.cuda.synchronize()
+        outs.append(dict(p=[t.clone() for t in fc + [B]], m=st.exp_avg.clone(), v=st.exp_avg_sq.clone(), losses=torch.stack(losses)))
     a, b_ = outs
     assert bool(torch.isfinite(a["losses"]).all())
     assert torch.equal(a["losses"], b_["losses"])

@@ -23,17 +23,17 @@ if SLAB:
     from vmap_amd import layout
     _, tfc, tB = layout.stack_in_slab(tfc, tB)
 fr = {k: t(v) for k, v in frame.items()}
-op = step.VmapStep(n, R, S, H, device=dev, max_steps=20)
+buf = torch.zeros(512 * 8, dtype=torch.int32, device=dev)
+# two operators over the same state: the second one carries the finalize and stamps its prologue (per-operator tuning)
+op = step.VmapStep(n, R, S, H, device=dev, max_steps=20, tuning={"carried_finalize": 1})
+op_st = step.VmapStep(n, R, S, H, device=dev, max_steps=20, tuning={"carried_finalize": 1, "carry_stamps": buf.data_ptr()})
 opt = step.FusedAdamWState(n, H, dev)
 lib = _lib.load()
-buf = torch.zeros(512 * 8, dtype=torch.int32, device=dev)
 args = (tfc, tB, tsc, fr["pcs"], fr["z"], fr["gt_depth"], fr["gt_rgb"], fr["sem"], fr["depth_mask"])
 for _ in range(3):
     op.train_steps(*args, opt=opt, n_steps=20)
-lib.vmapstep_debug_carry_stamps(ctypes.c_void_p(buf.data_ptr()))
-op.train_steps(*args, opt=opt, n_steps=20)
+op_st.train_steps(*args, opt=opt, n_steps=20)
 torch.cuda.synchronize()
-lib.vmapstep_debug_carry_stamps(ctypes.c_void_p(0))
 s = (buf.cpu().numpy().astype(np.int64) & 0xFFFFFFFF).reshape(512, 8)
 s = s[s[:, 0] != 0]
 names = ["start", "trip 0: first loads issued", "trip 0: partials summed", "trip 0 done", "trip 1 done", "all waves drained + barrier", "before wait-all", "after wait-all"]

@@ -12,13 +12,23 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvmapstep.so")
 
 NUM_FC = 14
-ABI_VERSION = 3
+ABI_VERSION = 4
 WEIGHTS_F32, WEIGHTS_BF16 = 0, 1
+
+
+KERNEL_AUTO, KERNEL_GEN, KERNEL_WIDE4, KERNEL_WIDE2 = 0, 1, 2, 3
+
+
+class Tuning(ctypes.Structure):
+    """vmapstep_tuning: measurement / test overrides of the automatic launch plan, passed per call through Shape.tuning."""
+    _fields_ = [("workgroups_per_object", ctypes.c_int32), ("kernel", ctypes.c_int32), ("generic_finalize", ctypes.c_int32),
+                ("carried_finalize", ctypes.c_int32), ("carry_stamps", ctypes.c_void_p)]
 
 
 class Shape(ctypes.Structure):
     _fields_ = [("n_obj", ctypes.c_int32), ("rays", ctypes.c_int32), ("samples", ctypes.c_int32),
-                ("hidden", ctypes.c_int32), ("weight_dtype", ctypes.c_int32)]
+                ("hidden", ctypes.c_int32), ("weight_dtype", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("tuning", ctypes.POINTER(Tuning))]
 
 
 class Tensor(ctypes.Structure):
@@ -71,7 +81,7 @@ class SampleRandoms(ctypes.Structure):
 
 EXPORTS = (
     "vmapstep_last_error", "vmapstep_abi_version", "vmapstep_param_layout", "vmapstep_workspace_bytes",
-    "vmapstep_fwd_bwd", "vmapstep_render", "vmapstep_train_steps", "vmapstep_set_workgroups_per_object",
+    "vmapstep_fwd_bwd", "vmapstep_render", "vmapstep_train_steps",
     "vmapstep_profile_main_kernel", "vmapstep_profile_phases", "vmapstep_prepare", "vmapstep_train_steps_prepared",
     "vmapstep_workspace_counts_offset", "vmapstep_fwd_bwd_prepared", "vmapstep_sample_frame",
     "vmapstep_query_workspace_bytes", "vmapstep_query_points", "vmapstep_profile_train_steps",
@@ -134,9 +144,8 @@ def load():
                                             ctypes.POINTER(Batch), ctypes.c_void_p, ctypes.c_size_t,
                                             ctypes.POINTER(ctypes.c_int32), ctypes.c_void_p, ctypes.c_size_t,
                                             ctypes.c_void_p]
-    lib.vmapstep_set_workgroups_per_object.argtypes = [ctypes.c_int32]
     for fn in ("vmapstep_param_layout", "vmapstep_workspace_bytes", "vmapstep_fwd_bwd", "vmapstep_render",
-               "vmapstep_train_steps", "vmapstep_set_workgroups_per_object", "vmapstep_profile_main_kernel",
+               "vmapstep_train_steps", "vmapstep_profile_main_kernel",
                "vmapstep_profile_phases", "vmapstep_prepare", "vmapstep_train_steps_prepared",
                "vmapstep_workspace_counts_offset", "vmapstep_fwd_bwd_prepared", "vmapstep_sample_frame",
                "vmapstep_query_workspace_bytes", "vmapstep_query_points", "vmapstep_profile_train_steps"):

@@ -75,6 +75,7 @@ struct StepArgs {
     int wide;                          // 1: step_main_wide (tile per workgroup, G*S <= 32) instead of step_main_gen
     unsigned* carry_cnt;               // step_prep: [n_obj][2] hand-off counters of the carried finalize, zeroed per frame
     int* img_tab;                      // step_prep: [PP] flat parameter -> image position table (or null)
+    float* gen_scratch;                // step_main_gen / step_main_wide: per-wave (per-workgroup) register-image scratch (workspace)
 };
 
 __device__ __forceinline__ constexpr int phi(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "../../include/vmapstep.h"
@@ -21,13 +22,9 @@
 namespace {
 
 thread_local char g_err[512] = "";
-thread_local float* g_scratch_for_launch = nullptr;
-thread_local float* g_time_main_ms = nullptr;           // measurement: train_steps_impl times every main launch with events   // set by fill_step_args (generic-width path)
-int g_nw_override = 0;
-unsigned* g_carry_stamps = nullptr;   // diagnostics (vmapstep_debug_carry_stamps): device buffer [workgroups][8] or null
-int g_fin_table = 1;      // step_finalize_h32 (table-driven finalize for hidden 32) on / off: tuning hook -9 / -10, for the A/B parity test
-int g_carry = -1;         // carried finalize (step_main_h32_carry): -1 = not decided yet (environment VMAPSTEP_CARRY, default off), 0 off, 1 on
-int g_force_kernel = 0;   // measurement / test hook, hidden 128 / 256: 0 automatic, 1 step_main_gen, 2 step_main_wide<4>, 3 step_main_wide<2>
+// No tuning state lives in the library (ABI v4): overrides of the automatic plan arrive per call in vmapstep_shape::tuning.
+const vmapstep_tuning kAutoTuning = {0, VMAPSTEP_KERNEL_AUTO, 0, 0, nullptr};
+const vmapstep_tuning& tuning_of(const vmapstep_shape* sh) { return (sh && sh->tuning) ? *sh->tuning : kAutoTuning; }
 
 int fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -61,24 +58,34 @@ struct Plan {
                        // per tile), 2 = step_main_wide<2> (four tiles per 512-thread workgroup, two waves per tile)
 };
 
-// Carried finalize (step_main_h32_carry): opt-in (VMAPSTEP_CARRY=1 or the tuning hook).  Bit-identical to the two-kernel
-// loop and measured within +-3 % of it (the 9-13 MB of partials it has to read at the top of every
-// launch and its once-per-launch code cost what the stand-alone finalize launch and its boundary cost), so it is not the
-// default: it also needs the GPU to itself (all workgroups resident at once).
-bool carry_enabled() {
-    if (g_carry < 0) {
-        const char* e = std::getenv("VMAPSTEP_CARRY");
-        g_carry = (e && e[0] == '1') ? 1 : 0;
-    }
-    return g_carry != 0;
+// Per-device facts and one-time per-device function attributes.  A process may drive several GPUs (one
+// process, 8 streams): the dynamic-LDS limit of a kernel is a per-device property of the loaded code object, so "set
+// once" is keyed by (device, function); lookups take a lock (a handful per API call, next to ~40 kernel launches).
+constexpr int kMaxDevices = 64;
+std::mutex g_dev_mutex;
+int current_device() {
+    int dev = 0;
+    return hipGetDevice(&dev) == hipSuccess ? dev : -1;
 }
 int cu_count() {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = -1;
-    }
-    return cus;
+    static int cus[kMaxDevices] = {};
+    const int dev = current_device();
+    if (dev < 0 || dev >= kMaxDevices) return -1;
+    std::lock_guard<std::mutex> lk(g_dev_mutex);
+    if (!cus[dev] && hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus[dev] = -1;
+    return cus[dev];
+}
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (device, kernel)
+int ensure_dynamic_lds(const void* kernel, size_t bytes, const char* what) {
+    static std::vector<const void*> done[kMaxDevices];
+    const int dev = current_device();
+    if (dev < 0 || dev >= kMaxDevices) return fail(VMAPSTEP_ERR_DEVICE, "hipGetDevice failed");
+    std::lock_guard<std::mutex> lk(g_dev_mutex);
+    for (const void* k : done[dev]) if (k == kernel) return VMAPSTEP_OK;
+    hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "hipFuncSetAttribute(%s): %s", what, hipGetErrorString(e));
+    done[dev].push_back(kernel);
+    return VMAPSTEP_OK;
 }
 
 int make_plan(const vmapstep_shape* sh, int max_steps, Plan& pl, const Layout& L) {
@@ -97,24 +104,27 @@ int make_plan(const vmapstep_shape* sh, int max_steps, Plan& pl, const Layout& L
     // partial-gradient traffic per 32 points).  step_main_wide<2>: four tiles per 512-thread workgroup, two waves per tile
     // (twice step_main_gen's waves for the same tiles and partial traffic).  step_main_gen: one wave per tile.
     pl.wide = 0;
-    if (pl.generic && sh->hidden % 128 == 0 && g_force_kernel != 1) {
+    const vmapstep_tuning& tun = tuning_of(sh);
+    const int force = tun.kernel;
+    if (force < VMAPSTEP_KERNEL_AUTO || force > VMAPSTEP_KERNEL_WIDE2) return fail(VMAPSTEP_ERR_ARGUMENT, "tuning.kernel=%d", force);
+    if (pl.generic && sh->hidden % 128 == 0 && force != VMAPSTEP_KERNEL_GEN) {
         if (sh->samples <= vk::kWideTile) {
             const int gw = std::min(vk::kWideTile / sh->samples, sh->rays);
             const long long tiles = (long long)sh->n_obj * ((sh->rays + gw - 1) / gw);
-            if (g_force_kernel == 2 || (g_force_kernel == 0 && tiles <= 256)) pl.wide = 1;
+            if (force == VMAPSTEP_KERNEL_WIDE4 || (force == VMAPSTEP_KERNEL_AUTO && tiles <= 256)) pl.wide = 1;
         }
-        if (!pl.wide && g_force_kernel == 3) pl.wide = 2;      // measured: no gain over step_main_gen at 600 tiles (both are
+        if (!pl.wide && force == VMAPSTEP_KERNEL_WIDE2) pl.wide = 2;      // measured: no gain over step_main_gen at 600 tiles (both are
                                                                  // bound by the traffic of the per-tile register images), not automatic
     }
     pl.G = (pl.wide == 1 ? vk::kWideTile : vk::kMaxPts) / sh->samples;
     if (pl.G > sh->rays) pl.G = sh->rays;
     pl.NG = (sh->rays + pl.G - 1) / pl.G;
-    int nw = g_nw_override > 0 ? g_nw_override : 256 / sh->n_obj;
+    int nw = tun.workgroups_per_object > 0 ? tun.workgroups_per_object : 256 / sh->n_obj;
     if (nw < 1) nw = 1;
     if (nw > pl.NG) nw = pl.NG;
     pl.NW = nw;
-    // buffers that exist once per workgroup: sized for THIS plan's NW (a later change of the tuning knob that needs more
-    // is caught by the workspace size check of the call, never silently)
+    // buffers that exist once per workgroup: sized for THIS plan's NW (the tuning is part of the shape, so the sizing call
+    // and the launches see the same plan; a mismatch is caught by the workspace size check of the call, never silently)
     const size_t nw_cap = (size_t)nw;
     size_t o = 0;
     pl.off_stats = o; o += align_up((size_t)max_steps * sh->n_obj * 4 * sizeof(float));
@@ -181,24 +191,18 @@ void fill_step_args(vk::StepArgs& a, const vmapstep_shape* sh, const Plan& pl, c
     a.flags = reinterpret_cast<int*>(ws + pl.off_flags);
     a.part_loss = reinterpret_cast<float*>(ws + pl.off_ploss);      // half 0; the step loop of a frame alternates (ploss_half)
     // hand-off counters exist for the carried finalize only (step_prep skips null pointers); the flat -> image table for hidden 32
-    const bool carry = !pl.generic && carry_enabled();
+    const bool carry = !pl.generic && tuning_of(sh).carried_finalize != 0;
     a.carry_cnt = carry ? reinterpret_cast<unsigned*>(ws + pl.off_cnt) : nullptr;
     a.img_tab = !pl.generic ? reinterpret_cast<int*>(ws + pl.off_imgtab) : nullptr;   // also read by step_finalize_h32
     a.part_grad = reinterpret_cast<float*>(ws + pl.off_pgrad);
     a.wimg = reinterpret_cast<float*>(ws + pl.off_wimg);
-    g_scratch_for_launch = reinterpret_cast<float*>(ws + pl.off_scratch);
+    a.gen_scratch = reinterpret_cast<float*>(ws + pl.off_scratch);
 }
 
 template <bool BWD, bool MULTI, bool STAMPS = false>
 int launch_main_v(const vk::StepArgs& a, hipStream_t st) {
-    static bool attr_set = false;
     auto kern = vk::step_main_h32<BWD, MULTI, STAMPS>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, vk::Lds32::BYTES);
-        if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_set = true;
-    }
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), vk::Lds32::BYTES, "step_main_h32")) return rc;
     const int grid = a.xcd_affine ? 8 * ((a.n_obj + 7) / 8) * a.NW : a.n_obj * a.NW;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(vk::kWG), vk::Lds32::BYTES, st, a);
     hipError_t e = hipGetLastError();
@@ -209,14 +213,8 @@ int launch_main_v(const vk::StepArgs& a, hipStream_t st) {
 // step i >= 1 of a frame with the finalize of step i-1 carried in its prologue
 template <bool MULTI>
 int launch_main_carry(const vk::StepArgs& a, const vk::CarryArgs& c, hipStream_t st) {
-    static bool attr_set = false;
     auto kern = vk::step_main_h32_carry<MULTI>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, vk::Lds32::BYTES);
-        if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_set = true;
-    }
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), vk::Lds32::BYTES, "step_main_h32_carry")) return rc;
     const int grid = (a.xcd_affine ? 8 * ((a.n_obj + 7) / 8) * a.NW : a.n_obj * a.NW) + 1;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(vk::kWG), vk::Lds32::BYTES, st, a, c);
     hipError_t e = hipGetLastError();
@@ -227,24 +225,18 @@ int launch_main_carry(const vk::StepArgs& a, const vk::CarryArgs& c, hipStream_t
 // The carried finalize needs every workgroup of the launch resident at once (they wait for each other): one workgroup
 // per CU (132 KB of LDS each), so n_obj * NW real workgroups must not exceed the CU count.
 bool carry_eligible(const vmapstep_shape* sh, const Plan& pl) {
-    if (!carry_enabled() || pl.generic) return false;
+    if (!tuning_of(sh).carried_finalize || pl.generic) return false;
     return cu_count() > 0 && (long long)sh->n_obj * pl.NW <= cu_count();
 }
 
 template <bool BWD>
 int launch_gen(const vk::StepArgs& a, hipStream_t st) {
-    static bool attr_set = false;
     auto kern = vk::step_main_gen<BWD>;
     const vk::GenLayout GL = vk::gen_layout(a.hidden);
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           vk::LdsGen::bytes(vk::gen_layout(256).small_n));
-        if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_set = true;
-    }
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), vk::LdsGen::bytes(vk::gen_layout(256).small_n), "step_main_gen")) return rc;
     vk::GenArgs ga;
     ga.s = a;
-    ga.scratch = g_scratch_for_launch;
+    ga.scratch = a.gen_scratch;
     ga.wave_blocks = vk::gen_wave_blocks(GL.NB);
     hipLaunchKernelGGL(kern, dim3(a.n_obj * a.NW), dim3(vk::kWG), vk::LdsGen::bytes(GL.small_n), st, ga);
     hipError_t e = hipGetLastError();
@@ -255,18 +247,12 @@ int launch_gen(const vk::StepArgs& a, hipStream_t st) {
 template <bool BWD, int SPLIT>
 int launch_wide(const vk::StepArgs& a, hipStream_t st) {
     using LW = vk::LdsWide<SPLIT>;
-    static bool attr_set = false;
     auto kern = vk::step_main_wide<BWD, SPLIT>;
     const vk::GenLayout GL = vk::gen_layout(a.hidden);
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           LW::bytes(vk::gen_layout(256).small_n));
-        if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_set = true;
-    }
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LW::bytes(vk::gen_layout(256).small_n), "step_main_wide")) return rc;
     vk::GenArgs ga;
     ga.s = a;
-    ga.scratch = g_scratch_for_launch;
+    ga.scratch = a.gen_scratch;
     ga.wave_blocks = vk::gen_wave_blocks(GL.NB);
     hipLaunchKernelGGL(kern, dim3(a.n_obj * a.NW), dim3(64 * LW::NWAVES), LW::bytes(GL.small_n), st, ga);
     hipError_t e = hipGetLastError();
@@ -341,13 +327,13 @@ void fill_carry_hot(vk::CarryHot& h, const vk::FinalizeArgs& f, const vk::StepAr
 
 int launch_finalize(const vk::StepArgs& a, const Layout& L, const vmapstep_params* params, const vmapstep_params* grads,
                     const vmapstep_adamw* opt, int step_after, bool have_grad, float* loss_out, int* flags_out,
-                    hipStream_t st) {
+                    hipStream_t st, bool generic_finalize) {
     vk::FinalizeArgs f;
     fill_finalize_args(f, a, L, params, grads, opt, step_after, have_grad, loss_out, flags_out);
     const int bpo = (L.PP / 4 + vk::kWG - 1) / vk::kWG;
     // + 1: the loss / flag reduction has a workgroup of its own (it used to ride on block 0 and made it the straggler)
     const int grid = (!have_grad ? 0 : f.xcd_affine ? 8 * ((a.n_obj + 7) / 8) * bpo : a.n_obj * bpo) + 1;
-    if (g_fin_table && a.hidden == 32 && a.img_tab && f.do_adam && !grads) {
+    if (!generic_finalize && a.hidden == 32 && a.img_tab && f.do_adam && !grads) {
         // the common training step at hidden 32: table-driven form (same sums, same update, a third of the instructions)
         vk::CarryHot h;
         fill_carry_hot(h, f, a, L, params, 0u);
@@ -375,23 +361,6 @@ extern "C" {
 
 const char* vmapstep_last_error(void) { return g_err; }
 int vmapstep_abi_version(void) { return VMAPSTEP_ABI_VERSION; }
-
-int vmapstep_set_workgroups_per_object(int32_t nw) {
-    int old = g_nw_override;
-    if (nw == -1) { g_force_kernel = 1; return old; }    // hooks: kernel for hidden 128 / 256
-    if (nw == -2) { g_force_kernel = 0; return old; }
-    if (nw == -3) { g_force_kernel = 2; return old; }
-    if (nw == -4) { g_force_kernel = 3; return old; }
-    if (nw == -5) { g_carry = 0; return old; }           // carried finalize off (several fused step loops sharing one GPU)
-    if (nw == -6) { g_carry = 1; return old; }
-    if (nw == -9) { g_fin_table = 1; return old; }       // table-driven finalize for hidden 32 on (default) / off
-    if (nw == -10) { g_fin_table = 0; return old; }
-    g_nw_override = nw > 0 ? nw : 0;
-    return old;
-}
-
-// diagnostics, not part of include/vmapstep.h: shader-clock stamps of the carried-finalize prologue (last carrying launch wins)
-int vmapstep_debug_carry_stamps(void* device_buffer) { g_carry_stamps = static_cast<unsigned*>(device_buffer); return 0; }
 
 int vmapstep_param_layout(int32_t hidden, int64_t sizes[VMAPSTEP_NUM_FC + 1], int64_t* params, int64_t* padded_params) {
     if (hidden < 1) return fail(VMAPSTEP_ERR_ARGUMENT, "hidden=%d", hidden);
@@ -438,7 +407,7 @@ static int fwd_bwd_impl(const vmapstep_shape* shape, const vmapstep_params* para
     a.dbg_depth = out->render_depth; a.dbg_rgb = out->render_color; a.dbg_opacity = out->opacity; a.dbg_var = out->var;
     if (do_prep && (rc = launch_prep(a, 1, st))) return rc;
     if ((rc = launch_main<true>(a, st))) return rc;
-    return launch_finalize(a, L, params, grads, nullptr, 0, true, out->loss, out->flags, st);
+    return launch_finalize(a, L, params, grads, nullptr, 0, true, out->loss, out->flags, st, tuning_of(shape).generic_finalize != 0);
 }
 
 int vmapstep_fwd_bwd(const vmapstep_shape* shape, const vmapstep_params* params, const vmapstep_tensor* pe_scale,
@@ -489,7 +458,7 @@ int vmapstep_render(const vmapstep_shape* shape, const vmapstep_params* params, 
     a.dbg_depth = out->render_depth; a.dbg_rgb = out->render_color; a.dbg_opacity = out->opacity; a.dbg_var = out->var;
     if ((rc = launch_prep(a, 1, st))) return rc;
     if ((rc = launch_main<false>(a, st))) return rc;
-    return launch_finalize(a, L, params, nullptr, nullptr, 0, false, out->loss, out->flags, st);
+    return launch_finalize(a, L, params, nullptr, nullptr, 0, false, out->loss, out->flags, st, tuning_of(shape).generic_finalize != 0);
 }
 
 static int train_steps_impl(const vmapstep_shape* shape, const vmapstep_params* params, const vmapstep_tensor* pe_scale,
@@ -497,7 +466,7 @@ static int train_steps_impl(const vmapstep_shape* shape, const vmapstep_params* 
                             float color_scaling, float opacity_scaling, const vmapstep_adamw* opt,
                             const vmapstep_params* grads, const vmapstep_outputs* out,
                             void* workspace, size_t workspace_bytes, void* stream, bool do_prep, bool do_steps,
-                            size_t* flags_offset) {
+                            size_t* flags_offset, float* time_main_ms = nullptr) {
     int rc;
     if (!shape) return fail(VMAPSTEP_ERR_ARGUMENT, "shape is null");
     if (n_steps < 1) return fail(VMAPSTEP_ERR_ARGUMENT, "n_steps=%d", n_steps);
@@ -525,7 +494,7 @@ static int train_steps_impl(const vmapstep_shape* shape, const vmapstep_params* 
     if (!opt || !opt->exp_avg || !opt->exp_avg_sq) return fail(VMAPSTEP_ERR_ARGUMENT, "optimiser state is required");
     if (!out || !out->loss || !out->flags) return fail(VMAPSTEP_ERR_ARGUMENT, "outputs.loss / outputs.flags are required");
     std::vector<hipEvent_t> ev;
-    if (g_time_main_ms) {
+    if (time_main_ms) {
         ev.resize(3 * (size_t)n_steps);      // per step: before main, after main, and one more right behind it (the cost of
                                              // an event pair with nothing in between is subtracted)
         for (auto& e : ev)
@@ -546,7 +515,7 @@ static int train_steps_impl(const vmapstep_shape* shape, const vmapstep_params* 
         if (carry && i > 0) {
             vk::CarryArgs c;
             fill_finalize_args(c.f, prev, L, params, nullptr, opt, opt->step + i, true, out->loss + (i - 1), out->flags + 4 * (i - 1));
-            c.stamps = g_carry_stamps;
+            c.stamps = tuning_of(shape).carry_stamps;
             fill_carry_hot(c.h, c.f, a, L, params, (unsigned)i);
             rc = a.NW < a.NG ? launch_main_carry<true>(a, c, st) : launch_main_carry<false>(a, c, st);
             if (rc) return rc;
@@ -555,22 +524,24 @@ static int train_steps_impl(const vmapstep_shape* shape, const vmapstep_params* 
             return fail(VMAPSTEP_ERR_DEVICE, "hipEventRecord failed");
         if (!carry || last) {
             if ((rc = launch_finalize(a, L, params, last ? grads : nullptr, opt, opt->step + i + 1, true,
-                                      out->loss + i, out->flags + 4 * i, st))) return rc;
+                                      out->loss + i, out->flags + 4 * i, st, tuning_of(shape).generic_finalize != 0))) return rc;
         }
         prev = a;
     }
     if (!ev.empty()) {                       // measurement only: the one place this library waits for the device
         bool ok = hipEventSynchronize(ev.back()) == hipSuccess;
-        double sum = 0.0;
+        double sum_raw = 0.0, sum_empty = 0.0;
         for (int i = 0; i < n_steps && ok; ++i) {
             float ms = 0.0f, empty = 0.0f;
             ok = hipEventElapsedTime(&ms, ev[3 * i], ev[3 * i + 1]) == hipSuccess &&
                  hipEventElapsedTime(&empty, ev[3 * i + 1], ev[3 * i + 2]) == hipSuccess;
-            sum += ms - empty;
+            sum_raw += ms;
+            sum_empty += empty;
         }
         for (auto& e : ev) ok = (hipEventDestroy(e) == hipSuccess) && ok;
         if (!ok) return fail(VMAPSTEP_ERR_DEVICE, "event timing of the step loop failed");
-        *g_time_main_ms = (float)(sum / n_steps);
+        time_main_ms[0] = (float)(sum_raw / n_steps);                  // raw event-pair time around the launch
+        time_main_ms[1] = (float)((sum_raw - sum_empty) / n_steps);    // minus what an empty event pair costs
     }
     return VMAPSTEP_OK;
 }
@@ -605,13 +576,10 @@ int vmapstep_profile_train_steps(const vmapstep_shape* shape, const vmapstep_par
                                  const vmapstep_batch* frame, int64_t ray_step, int32_t n_steps,
                                  float color_scaling, float opacity_scaling, const vmapstep_adamw* opt,
                                  const vmapstep_outputs* out, void* workspace, size_t workspace_bytes, void* stream,
-                                 float* main_kernel_ms) {
+                                 float main_kernel_ms[2]) {
     if (!main_kernel_ms) return fail(VMAPSTEP_ERR_ARGUMENT, "main_kernel_ms is null");
-    g_time_main_ms = main_kernel_ms;
-    const int rc = train_steps_impl(shape, params, pe_scale, frame, ray_step, n_steps, color_scaling, opacity_scaling, opt,
-                                    nullptr, out, workspace, workspace_bytes, stream, true, true, nullptr);
-    g_time_main_ms = nullptr;
-    return rc;
+    return train_steps_impl(shape, params, pe_scale, frame, ray_step, n_steps, color_scaling, opacity_scaling, opt,
+                            nullptr, out, workspace, workspace_bytes, stream, true, true, nullptr, main_kernel_ms);
 }
 
 int vmapstep_profile_main_kernel(const vmapstep_shape* shape, const vmapstep_params* params,
@@ -701,28 +669,17 @@ int vmapstep_query_points(int32_t hidden, const vmapstep_params* params, const v
     q.n_pts = n_points; q.occ = occupancy; q.rgb = color;
     const long long chunks = (n_points + vk::kMaxPts - 1) / vk::kMaxPts;
     if (hidden == 32) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(vk::field_query_h32<2>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, vk::Lds32::IMGP * sizeof(float));
-            if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-            attr_set = true;
-        }
+        if ((rc = ensure_dynamic_lds(reinterpret_cast<const void*>(vk::field_query_h32<2>), vk::Lds32::IMGP * sizeof(float), "field_query_h32"))) return rc;
         const int grid = (int)(chunks < 512 ? chunks : 512);          // two resident workgroups per CU (236 registers each)
         hipLaunchKernelGGL(vk::field_query_h32<2>, dim3(grid), dim3(vk::kWG), vk::Lds32::IMGP * sizeof(float), st, q);
     } else {
         const int grid = (int)(chunks < 256 ? chunks : 256);
         const int nb = hidden / 32;
         const size_t lds = nb > 4 ? (size_t)nb * 1024 * vk::kWaves * sizeof(float) : 0;   // second activation set (NB > 4)
-        static bool attr_set = false;
-        if (!attr_set) {
+        if (nb > 4) {
             const void* big[4] = {reinterpret_cast<const void*>(vk::field_query_gen<5>), reinterpret_cast<const void*>(vk::field_query_gen<6>),
                                   reinterpret_cast<const void*>(vk::field_query_gen<7>), reinterpret_cast<const void*>(vk::field_query_gen<8>)};
-            for (int i = 0; i < 4; ++i) {
-                hipError_t e = hipFuncSetAttribute(big[i], hipFuncAttributeMaxDynamicSharedMemorySize, (5 + i) * 1024 * vk::kWaves * (int)sizeof(float));
-                if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-            }
-            attr_set = true;
+            if ((rc = ensure_dynamic_lds(big[nb - 5], lds, "field_query_gen"))) return rc;
         }
         switch (nb) {
             case 2: hipLaunchKernelGGL(vk::field_query_gen<2>, dim3(grid), dim3(vk::kWG), lds, st, q); break;
@@ -767,12 +724,7 @@ int vmapstep_sample_frame(const vmapstep_sample_cfg* cfg, const vmapstep_sample_
     }
     a.pcs = pcs; a.z = z; a.gt_depth = gt_depth; a.gt_rgb = gt_rgb; a.sem = sem; a.depth_mask = depth_mask;
     const size_t lds = (3 * (size_t)FP + vs::kWG) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(vs::frame_sample), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (ea != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "hipFuncSetAttribute: %s", hipGetErrorString(ea));
-        attr_set = true;
-    }
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(vs::frame_sample), 160 * 1024, "frame_sample")) return rc;
     hipLaunchKernelGGL(vs::frame_sample, dim3(n_obj), dim3(vs::kWG), lds, static_cast<hipStream_t>(stream), a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "frame_sample launch: %s", hipGetErrorString(e));

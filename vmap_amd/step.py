@@ -51,7 +51,10 @@ class VmapStep:
     """The fused step operator for a fixed (n_obj, rays, samples, hidden) problem shape."""
 
     def __init__(self, n_obj: int, rays: int, samples: int, hidden: int, device="cuda:0", max_steps: int = 32,
-                 color_scaling: float = 5.0, opacity_scaling: float = 10.0, weights: str = "f32"):
+                 color_scaling: float = 5.0, opacity_scaling: float = 10.0, weights: str = "f32", tuning: Optional[dict] = None):
+        """``tuning``: optional overrides of the automatic launch plan for measurements / A-B tests (fields of
+        ``vmapstep_tuning``: workgroups_per_object, kernel, generic_finalize, carried_finalize, carry_stamps).  They belong
+        to THIS operator (the C library keeps no tuning state)."""
         self.lib = _lib.load()
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -59,6 +62,10 @@ class VmapStep:
         if weights not in ("f32", "bf16"):
             raise ValueError("weights must be 'f32' or 'bf16'")
         self.shape = _lib.Shape(n_obj, rays, samples, hidden, _lib.WEIGHTS_BF16 if weights == "bf16" else _lib.WEIGHTS_F32)
+        self._tuning = None
+        if tuning:
+            self._tuning = _lib.Tuning(**tuning)          # kept alive by the operator; the shape points at it
+            self.shape.tuning = ctypes.pointer(self._tuning)
         self.n_obj, self.rays, self.samples, self.hidden = n_obj, rays, samples, hidden
         self.max_steps = max_steps
         self.color_scaling, self.opacity_scaling = float(color_scaling), float(opacity_scaling)
@@ -129,9 +136,9 @@ class VmapStep:
             o.opacity, o.var = res.opacity.data_ptr(), res.var.data_ptr()
         return res, o
 
-    @staticmethod
-    def _stream() -> int:
-        return torch.cuda.current_stream().cuda_stream
+    def _stream(self) -> int:
+        # the current stream of THIS operator's device (not of whatever device happens to be current)
+        return torch.cuda.current_stream(self.device).cuda_stream
 
     # ---- operators ------------------------------------------------------------------------------------
     def _ws_view(self, byte_offset: int, nbytes: int) -> torch.Tensor:
@@ -256,20 +263,70 @@ class VmapStep:
         return res
 
 
+class BoundFrame:
+    """``VmapStep.train_steps`` with the argument marshalling done ONCE: the ctypes blocks of the stacked parameters, the
+    per-frame sample tensors and the outputs are built at bind time (the tensors are kept alive here), so a frame call is
+    one C call.  For callers whose buffers do not move between frames (the slab of ``driver.HipMapper``, a sampler that
+    writes into fixed frame tensors, ``bench.py``): per-call Python shrinks from ~0.1 ms of shape checks and struct
+    filling - a tenth of a 20-step frame - to the call itself.  Outputs (loss [max_steps], flags [max_steps, 4]) are
+    reused by every call: read or copy them before the next one."""
+
+    def __init__(self, op: "VmapStep", fc, B, pe_scale, pcs, z, gt_depth, gt_rgb, sem, depth_mask, opt: "FusedAdamWState",
+                 ray_step: Optional[int] = None, render: bool = False, flag_reduce=None):
+        self.op, self.opt, self.flag_reduce = op, opt, flag_reduce
+        self.ray_step = op.rays if ray_step is None else int(ray_step)
+        self.rays_total = pcs.shape[1]
+        self._keep = (list(fc), B, pe_scale, pcs, z, gt_depth, gt_rgb, sem, depth_mask)
+        self._pp = op._params(fc, B)
+        self._sc = _lib.Tensor(pe_scale.data_ptr(), pe_scale.stride(0) if pe_scale.dim() else 0)
+        self._bt = op._batch(pcs, z, gt_depth, gt_rgb, sem, depth_mask, rays_total=self.rays_total)
+        self.result, self._out = op._outputs(op.max_steps, render)
+        self._stream = op._stream()
+
+    def train_steps(self, n_steps: int) -> StepResult:
+        op, opt = self.op, self.opt
+        if n_steps > op.max_steps or (n_steps - 1) * self.ray_step + op.rays > self.rays_total:
+            raise ValueError(f"n_steps={n_steps}: the bound frame holds {self.rays_total} rays, max_steps={op.max_steps}")
+        oc = opt.c_struct()
+        lib, sh = op.lib, ctypes.byref(op.shape)
+        fn = lib.vmapstep_train_steps
+        if self.flag_reduce is not None:
+            off = ctypes.c_size_t(0)
+            _lib.check(lib.vmapstep_prepare(sh, ctypes.byref(self._pp), ctypes.byref(self._bt), self.ray_step, n_steps,
+                                            op._ws_ptr, op._ws_bytes, ctypes.byref(off), self._stream))
+            self.flag_reduce(op._ws_view(off.value, n_steps * 16).view(torch.int32).view(n_steps, 4))
+            fn = lib.vmapstep_train_steps_prepared
+        _lib.check(fn(sh, ctypes.byref(self._pp), ctypes.byref(self._sc), ctypes.byref(self._bt), self.ray_step, n_steps,
+                      op.color_scaling, op.opacity_scaling, ctypes.byref(oc), None, ctypes.byref(self._out),
+                      op._ws_ptr, op._ws_bytes, self._stream))
+        opt.step += n_steps
+        return self.result
+
+
+def _bind(self, fc, B, pe_scale, pcs, z, gt_depth, gt_rgb, sem, depth_mask, opt: "FusedAdamWState", ray_step=None,
+          render: bool = False, flag_reduce=None) -> BoundFrame:
+    """Marshal once, call many times: see ``BoundFrame``.  Bound to the CURRENT stream of the operator's device."""
+    return BoundFrame(self, fc, B, pe_scale, pcs, z, gt_depth, gt_rgb, sem, depth_mask, opt, ray_step, render, flag_reduce)
+
+
+VmapStep.bind = _bind
+
+
 def _profile_train_steps(self, fc, B, pe_scale, pcs, z, gt_depth, gt_rgb, sem, depth_mask, opt: "FusedAdamWState", n_steps: int) -> float:
     """Average duration (ms) of the dominant kernel over ``n_steps`` real training steps (events around every launch,
-    in the prep / main / finalize sequence of ``train_steps``); waits for the device."""
+    in the prep / main / finalize sequence of ``train_steps``); waits for the device.  Returns (raw event-pair time,
+    the same minus the cost of an empty event pair)."""
     pp = self._params(fc, B)
     sc = _lib.Tensor(pe_scale.data_ptr(), pe_scale.stride(0) if pe_scale.dim() else 0)
     bt = self._batch(pcs, z, gt_depth, gt_rgb, sem, depth_mask, rays_total=pcs.shape[1])
     res, out = self._outputs(n_steps, False)
     oc = opt.c_struct()
-    ms = ctypes.c_float(0.0)
+    ms = (ctypes.c_float * 2)(0.0, 0.0)
     _lib.check(self.lib.vmapstep_profile_train_steps(ctypes.byref(self.shape), ctypes.byref(pp), ctypes.byref(sc), ctypes.byref(bt),
                                                      self.rays, n_steps, self.color_scaling, self.opacity_scaling, ctypes.byref(oc),
-                                                     ctypes.byref(out), self._ws_ptr, self._ws_bytes, self._stream(), ctypes.byref(ms)))
+                                                     ctypes.byref(out), self._ws_ptr, self._ws_bytes, self._stream(), ms))
     opt.step += n_steps
-    return float(ms.value)
+    return float(ms[0]), float(ms[1])
 
 
 VmapStep.profile_train_steps = _profile_train_steps
