@@ -32,6 +32,7 @@ import torch
 from vmap_amd import layout, step, synth
 
 FP32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2500.0   # dense (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0
 PREHEAT_MS_DEFAULT = 100.0
 
@@ -103,7 +104,8 @@ def main():
     ap.add_argument("--config", default="replica_room0_vmap", choices=list(synth.CONFIGS))
     ap.add_argument("--iters-per-frame", type=int, default=20)       # config: render.iters_per_frame
     ap.add_argument("--weights", default="f32", choices=["f32", "bf16"])   # bf16: BASELINE configs[3]/[4] (fp32 masters + accumulate)
-    ap.add_argument("--kernel", default="auto", choices=["auto", "gen", "wide", "wide2"])   # hidden 128 / 256: which fused kernel (measurement)
+    ap.add_argument("--kernel", default="auto", choices=["auto", "gen", "wide", "wide2", "f32"])   # measurement: hidden 128 / 256 kernels; f32 = hidden 32
+                                                                                                 # on the exact-fp32 matrix instruction (step_main_h32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--slab", action="store_true")                   # the 15 stacked tensors as views of one [n, P] slab (measurement;
                                                                      # default: separately allocated, utils.update_vmap's own layout)
@@ -144,7 +146,7 @@ def main():
     tuning = None
     if args.kernel != "auto":
         from vmap_amd import _lib
-        tuning = {"kernel": {"gen": _lib.KERNEL_GEN, "wide": _lib.KERNEL_WIDE4, "wide2": _lib.KERNEL_WIDE2}[args.kernel]}
+        tuning = {"kernel": {"gen": _lib.KERNEL_GEN, "wide": _lib.KERNEL_WIDE4, "wide2": _lib.KERNEL_WIDE2, "f32": _lib.KERNEL_H32_F32}[args.kernel]}
     op = step.VmapStep(n, R, S, H, device=dev, max_steps=ipf, weights=args.weights, tuning=tuning)
     opt = step.FusedAdamWState(n, H, dev, lr=1e-3, weight_decay=0.013)
     fargs = (fr["pcs"], fr["z"], fr["gt_depth"], fr["gt_rgb"], fr["sem"], fr["depth_mask"])
@@ -218,6 +220,10 @@ def main():
         pairs = [op.profile_train_steps(tfc, tB, tsc, *fargs, opt=opt, n_steps=ipf) for _ in range(reps)]
         k_ms = sum(p[0] for p in pairs) / reps               # raw event-pair time around every launch: the roofline's duration
         k_ms_corr = sum(p[1] for p in pairs) / reps          # minus the cost of an empty event pair
+        split = H == 32 and args.kernel != "f32"
+        kernel_name = ("step_main_s32 (bf16 matrix pipe, split operands: 6 products forward, 3 backward)" if split else
+                       "step_main_h32 (exact-fp32 matrix instruction)" if H == 32 else
+                       "step_main_gen / step_main_wide (hidden 128, 256: chosen by tile count)")
         flops = layout.step_flops(n, R, S, H)
         abytes = layout.step_bytes(n, R, S, H)
         achieved = flops / (k_ms * 1e-3) / 1e12
@@ -250,7 +256,7 @@ def main():
                                    f"{S} samples/ray, fwd+loss+bwd+fused AdamW, {ipf} steps per frame call",
                        "objects_per_gpu": n, "rays_per_object": R, "samples_per_ray": S, "hidden": H,
                        "parallelism": f"objects sharded over {world} GPU(s); no per-step collective, one 4x{ipf}-int32 flag all-reduce per frame"},
-            "roofline": {"bound": "mfma", "kernel": "step_main_h32<true>" if H == 32 else "step_main_gen / step_main_wide (hidden 128, 256: chosen by tile count)", "achieved": achieved,
+            "roofline": {"bound": "mfma", "kernel": kernel_name, "achieved": achieved,
                          "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
                          "traffic": traffic,
                          "traffic_source": ("copied from the committed rocprofv3 --pmc passes of this kernel (profiles/" + pmcs[-1] +
@@ -258,8 +264,13 @@ def main():
                          "kernel_ms": k_ms, "kernel_ms_minus_empty_event_pair": k_ms_corr, "kernel_ms_back_to_back": k_ms_alone, "algorithmic_flops_per_launch": flops,
                          "algorithmic_bytes_per_launch": abytes,
                          "hbm_achieved_GBs": abytes / (k_ms * 1e-3) / 1e9,
-                         "hbm_frac": abytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                         "hbm_frac": abytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "peak_note": "peak = the float32 matrix / vector rate (157.3 TFLOP/s), the rate of the path's own arithmetic type; "
+                                      "achieved = ALGORITHMIC float32 FLOPs (n R S 6 H (4H + 220)) per launch / launch duration"},
             "fwd_bwd_only": {"ms_per_step_host_launched": fb_ms, "rays_per_s": n * R / (fb_ms * 1e-3)},
+            "matrix_pipe": ({"instruction": "v_mfma_f32_32x32x16_bf16", "instructions_per_32_point_tile": 288 if args.weights == "f32" else 195,
+                             "executed_tflops": (n * ((R + (128 // S) - 1) // (128 // S)) * 4 * (288 if args.weights == "f32" else 195) * 32768) / (k_ms * 1e-3) / 1e12,
+                             "peak_tflops": BF16_MFMA_PEAK_TFLOPS} if split else None),
             "preheat": {"ms": args.preheat_ms, "steps": preheat_steps, "timed": False},
             "frame_call": "bound (arguments marshalled once)" if bound is not None else "marshalled per call",
         }

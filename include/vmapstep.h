@@ -53,6 +53,8 @@ extern "C" {
 #define VMAPSTEP_KERNEL_GEN 1     /* hidden 64..256: step_main_gen (one wave per 32-point tile)                      */
 #define VMAPSTEP_KERNEL_WIDE4 2   /* hidden 128/256: step_main_wide<4> (one tile per workgroup, four waves per tile) */
 #define VMAPSTEP_KERNEL_WIDE2 3   /* hidden 128/256: step_main_wide<2> (four tiles per workgroup, two waves per tile)*/
+#define VMAPSTEP_KERNEL_H32_F32 4 /* hidden 32: step_main_h32 on the exact-fp32 matrix instruction instead of the default
+                                     step_main_s32 (bf16 matrix pipe, split operands, float32-equivalent forward)      */
 typedef struct vmapstep_tuning {
     int32_t workgroups_per_object; /* 0 = automatic (256 / n_obj, at most one per ray group)                      */
     int32_t kernel;                /* VMAPSTEP_KERNEL_*                                                           */

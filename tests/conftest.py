@@ -22,6 +22,14 @@ def relerr(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
 
 
+def tensor_err_q(a, b, q=0.999, floor=1e-3):
+    """Per-tensor check that a systematically wrong LOW-magnitude block cannot hide under one large element: the
+    q-quantile over the tensor's elements of |a - b| / (|b| + floor * max|b|)."""
+    a = np.asarray(a, dtype=np.float64).ravel()
+    b = np.asarray(b, dtype=np.float64).ravel()
+    return float(np.quantile(np.abs(a - b) / (np.abs(b) + floor * (np.abs(b).max() + 1e-30)), q))
+
+
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
 

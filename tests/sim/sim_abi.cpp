@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "wide_kernels.h"
+#include "split_kernels.h"
 #include "sample_kernels.h"
 #include "query_kernels.h"
 
@@ -17,7 +18,9 @@ void fc_sizes(int H, int* sz) {
 
 extern "C" int vmsim_lds_bytes() { return vk::Lds32::BYTES; }
 static int g_wide = 0;
-extern "C" void vmsim_set_wide(int w) { g_wide = w; }   // hidden 128 / 256: 1 = step_main_wide<4> (G * S <= 32), 2 = step_main_wide<2>
+extern "C" void vmsim_set_wide(int w) { g_wide = w; }
+static int g_split = 0;
+extern "C" void vmsim_set_split(int on) { g_split = on; }   // hidden 32: 1 = step_main_s32 (split-bf16 matrix pipe) instead of step_main_h32   // hidden 128 / 256: 1 = step_main_wide<4> (G * S <= 32), 2 = step_main_wide<2>
 
 // fc[t]: [n][size_t] contiguous; grads: flat slab [n][P] in natural order (14 field tensors then B).
 extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req, int xcd_affine, int weights_bf16,
@@ -42,7 +45,8 @@ extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req, int xcd
     std::vector<float> stats(n * 4, NAN), part_grad((size_t)n * NW * PP, NAN), part_loss((size_t)n * NW * 4, NAN);
     std::vector<int> fl(4, -1);
     const vk::GenLayout GL = vk::gen_layout(H);
-    std::vector<float> wimg((size_t)n * GL.imgp, NAN);
+    const bool split = g_split && H == 32;
+    std::vector<float> wimg((size_t)n * (split ? vk::Img32s::BYTES / 4 : GL.imgp), NAN);
 
     vk::StepArgs a{};
     a.n_obj = n; a.R = R; a.S = S; a.G = G; a.NG = NG; a.NW = NW; a.PP = PP; a.prep_steps = 1; a.prep_ray_step = 0; a.xcd_affine = (xcd_affine && H == 32) ? 1 : 0; a.hidden = H; a.weights_bf16 = weights_bf16;
@@ -62,10 +66,22 @@ extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req, int xcd
     std::vector<int> img_tab(PP, -1);
     a.img_tab = H == 32 ? img_tab.data() : nullptr;         // flat parameter -> image position (step_finalize_h32)
 
-    sim::launch(1 + n * (vk::gen_layout(H).imgp / 1024), vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep(a); });
+    if (split) sim::launch(1 + n * vk::kSplitPackBlocks, vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep_s32(a); });
+    else sim::launch(1 + n * (vk::gen_layout(H).imgp / 1024), vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep(a); });
     const bool multi = NW < NG;
     const int grid = xcd_affine && H == 32 ? 8 * ((n + 7) / 8) * NW : n * NW;
-    if (H == 32) {
+    if (split) {
+        const int lb = vk::Img32s::LDS_BYTES;
+        if (weights_bf16) {
+            if (bwd && multi)  sim::launch(grid, vk::kWG, lb, [&] { vk::step_main_s32<true, true, false, false>(a); });
+            if (bwd && !multi) sim::launch(grid, vk::kWG, lb, [&] { vk::step_main_s32<true, false, false, false>(a); });
+            if (!bwd)          sim::launch(grid, vk::kWG, lb, [&] { vk::step_main_s32<false, false, false, false>(a); });
+        } else {
+            if (bwd && multi)  sim::launch(grid, vk::kWG, lb, [&] { vk::step_main_s32<true, true, false, true>(a); });
+            if (bwd && !multi) sim::launch(grid, vk::kWG, lb, [&] { vk::step_main_s32<true, false, false, true>(a); });
+            if (!bwd)          sim::launch(grid, vk::kWG, lb, [&] { vk::step_main_s32<false, false, false, true>(a); });
+        }
+    } else if (H == 32) {
         if (bwd && multi)  sim::launch(grid, vk::kWG, vk::Lds32::BYTES, [&] { vk::step_main_h32<true, true>(a); });
         if (bwd && !multi) sim::launch(grid, vk::kWG, vk::Lds32::BYTES, [&] { vk::step_main_h32<true, false>(a); });
         if (!bwd)          sim::launch(grid, vk::kWG, vk::Lds32::BYTES, [&] { vk::step_main_h32<false, false>(a); });
@@ -125,7 +141,8 @@ extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req, int xcd
         h.NW = f.NW; h.PP = f.PP; h.weights_bf16 = f.weights_bf16;
         h.decay = f.decay; h.one_minus_beta1 = f.one_minus_beta1; h.beta2 = f.beta2; h.one_minus_beta2 = f.one_minus_beta2;
         h.eps = f.eps; h.step_size = f.step_size; h.bias_corr2_sqrt = f.bias_corr2_sqrt;
-        sim::launch(n * bpo + 1, vk::kWG, 2 * vk::kWG * 4, [&] { vk::step_finalize_h32(f, h); });
+        if (split) sim::launch(n * bpo + 1, vk::kWG, 2 * vk::kWG * 4, [&] { vk::step_finalize_s32(f, h); });
+        else sim::launch(n * bpo + 1, vk::kWG, 2 * vk::kWG * 4, [&] { vk::step_finalize_h32(f, h); });
         return 0;
     }
     sim::launch(n * bpo + 1, vk::kWG, 2 * vk::kWG * 4, [&] { vk::step_finalize(f); });

@@ -42,6 +42,9 @@ struct Block {
     Barrier wave_bar[kMaxWaves];
     float xa[kMaxWaves][kWave];
     float xb[kMaxWaves][kWave];
+    unsigned xa4[kMaxWaves][kWave][4];      // bf16 matrix-instruction operands (four dwords per lane)
+    unsigned xb4[kMaxWaves][kWave][4];
+    const void* xp[kMaxWaves][kWave];       // per-lane addresses of a transposing LDS read
     std::vector<unsigned char> lds;
 };
 

@@ -31,6 +31,63 @@ inline f32x16 mfma32(float a, float b, f32x16 c) {
     return d;
 }
 
+// ---- bf16 matrix pipe model ----
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+inline float bf16_to_f32(unsigned h) { unsigned u = (h & 0xFFFFu) << 16; float f; std::memcpy(&f, &u, 4); return f; }
+inline unsigned f32_to_bf16_rne(float x) {
+    unsigned u; std::memcpy(&u, &x, 4);
+    if ((u & 0x7F800000u) == 0x7F800000u && (u & 0x007FFFFFu)) return (u >> 16) | 0x40u;     // NaN stays NaN
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+inline unsigned pack_bf16(float lo, float hi) { return f32_to_bf16_rne(lo) | (f32_to_bf16_rne(hi) << 16); }
+
+// v_mfma_f32_32x32x16_bf16: exact products, sum of the 16 products and C formed in double and rounded once (the hardware's
+// internal summation order is not architected; this is the most accurate model, the gpu tier checks the real thing)
+inline f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
+    const int w = sim::wave_id(), l = sim::lane_id();
+    sim::Block* B = sim::g_block;
+    for (int i = 0; i < 4; ++i) { B->xa4[w][l][i] = a[i]; B->xb4[w][l][i] = b[i]; }
+    sim::wave_barrier();
+    const int j = l & 31, hi = l >> 5;
+    f32x16 d = c;
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        double acc = c[r];
+        for (int h = 0; h < 2; ++h)
+            for (int t = 0; t < 8; ++t) {
+                const unsigned ua = B->xa4[w][32 * h + i][t >> 1], ub = B->xb4[w][32 * h + j][t >> 1];
+                const float fa = bf16_to_f32((t & 1) ? ua >> 16 : ua), fb = bf16_to_f32((t & 1) ? ub >> 16 : ub);
+                acc += (double)fa * (double)fb;
+            }
+        d[r] = (float)acc;
+    }
+    sim::wave_barrier();
+    return d;
+}
+
+// ds_read_b64_tr_b16 (see the device header): lane c of a 16-lane group gets element (c & 3) of the 4 words at lane 4j + (c >> 2)'s address
+inline u32x2 lds_tr16(const void* p) {
+    const int w = sim::wave_id(), l = sim::lane_id();
+    sim::Block* B = sim::g_block;
+    B->xp[w][l] = p;
+    sim::wave_barrier();
+    const int g = l & ~15, c = l & 15;
+    unsigned short v[4];
+    for (int j = 0; j < 4; ++j) {
+        const unsigned short* src = static_cast<const unsigned short*>(B->xp[w][g + 4 * j + (c >> 2)]);
+        v[j] = src[c & 3];
+    }
+    sim::wave_barrier();
+    u32x2 out;
+    out[0] = (unsigned)v[0] | ((unsigned)v[1] << 16);
+    out[1] = (unsigned)v[2] | ((unsigned)v[3] << 16);
+    return out;
+}
+
 inline float swap_half(float x) {
     const int w = sim::wave_id(), l = sim::lane_id();
     sim::g_block->xa[w][l] = x;
@@ -86,6 +143,7 @@ inline const T& kernarg_late(const T& a) { return a; }
 inline float relu(float x) { return x > 0.0f ? (x < 3.4028234663852886e38f ? x : 3.4028234663852886e38f) : 0.0f; }
 inline float opaque(float x) { return x; }
 inline int opaque_iter(int x) { return x; }
+inline unsigned opaque_u(unsigned x) { return x; }
 
 inline void sched_fence() {}
 

@@ -22,7 +22,8 @@ def build(force=False):
                    os.path.join(ROOT, "vmap_amd", "csrc", "gen_kernels.h"),
                    os.path.join(ROOT, "vmap_amd", "csrc", "sample_kernels.h"),
                    os.path.join(ROOT, "vmap_amd", "csrc", "query_kernels.h"),
-                   os.path.join(ROOT, "vmap_amd", "csrc", "wide_kernels.h")]
+                   os.path.join(ROOT, "vmap_amd", "csrc", "wide_kernels.h"),
+                   os.path.join(ROOT, "vmap_amd", "csrc", "split_kernels.h")]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
@@ -49,8 +50,10 @@ def _p(a, ty=ctypes.c_float):
     return a.ctypes.data_as(ctypes.POINTER(ty)) if a is not None else None
 
 
-def sim_step(case_or_fc, B=None, scale=None, batch=None, G=None, bwd=True, adam=None, NW=0, xcd_affine=1, weights_bf16=0, wide=False):
-    """Run prep + main + finalize on the simulator. Returns dict like oracle.training_step."""
+def sim_step(case_or_fc, B=None, scale=None, batch=None, G=None, bwd=True, adam=None, NW=0, xcd_affine=1, weights_bf16=0, wide=False,
+             split=False):
+    """Run prep + main + finalize on the simulator. Returns dict like oracle.training_step.
+    split: hidden 32 on the split-bf16 kernels (step_prep_s32 / step_main_s32 / step_finalize_s32)."""
     if isinstance(case_or_fc, dict):
         c = case_or_fc
         fc, B, scale, batch = c["fc"], c["B"], c["scale"], c["batch"]
@@ -60,6 +63,7 @@ def sim_step(case_or_fc, B=None, scale=None, batch=None, G=None, bwd=True, adam=
     H = fc[2].shape[-1]
     if G is None:
         G = max(1, (32 if wide in (True, 1) else 128) // S)
+    lib().vmsim_set_split(int(bool(split)))
     lib().vmsim_set_wide(int(wide))       # 0 general kernel, 1 / True step_main_wide<4>, 2 step_main_wide<2>
     fc_c = [np.ascontiguousarray(a, dtype=np.float32) for a in fc]
     sizes = [a[0].size for a in fc_c]

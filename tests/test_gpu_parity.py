@@ -9,7 +9,7 @@ import pytest
 import torch
 
 import cases
-from conftest import GRAD_KEYS, RENDER_KEYS, load_golden, relerr
+from conftest import tensor_err_q, GRAD_KEYS, RENDER_KEYS, load_golden, relerr
 from oracle import vmap_oracle as vo
 from vmap_amd import _lib, layout, step, synth
 
@@ -50,6 +50,16 @@ def _run(c, fn="fwd_bwd", op=None, tuning=None, **kw):
 H32_CASES = [n for n, v in cases.CASES.items() if v[3] == 32]
 
 
+@pytest.fixture(autouse=True, params=["split", "f32"])
+def h32_kernel(request):
+    """Every test of this module runs twice: hidden 32 on the default split-bf16 kernel (step_main_s32) and on the
+    exact-fp32 kernel (step_main_h32, tuning.kernel = KERNEL_H32_F32).  Other widths ignore the choice."""
+    old = step.VmapStep.default_tuning
+    step.VmapStep.default_tuning = {"kernel": _lib.KERNEL_H32_F32} if request.param == "f32" else None
+    yield request.param
+    step.VmapStep.default_tuning = old
+
+
 def test_native_library_is_loaded():
     lib = _lib.load()
     assert lib.vmapstep_abi_version() == _lib.ABI_VERSION == 4
@@ -69,6 +79,9 @@ def test_fwd_bwd_matches_reference_fixture(name):
     for k in GRAD_KEYS:
         assert not np.isnan(s[k]).any(), k
         assert relerr(s[k], g[k]) < gt, k
+        # second, per-tensor criterion: 99.9 % of the elements within QTOL relative to |ref| + 1e-3 max|ref| (small-magnitude
+        # entries are constrained too; the saturated case keeps its documented noise floor)
+        assert tensor_err_q(s[k], g[k]) < (2e-2 if name == "saturated" else 2e-3), k
     o = vo.training_step(c["fc"], c["B"], c["scale"], c["batch"], dtype=np.float32)
     assert s["flags"][:3].tolist() == [int(x) for x in o["drop"]]
     assert int(s["flags"][3]) == int(o["explode"])
@@ -498,7 +511,7 @@ def test_headless_driver_object_list_semantics():
 @pytest.mark.parametrize("name", ["scannet_scale", "h64"])
 def test_bf16_weight_mode_equals_oracle_on_rounded_weights(name):
     """BASELINE configs[3]/[4] 'bf16 weights + fp32 accumulate': masters fp32, image rounded to bfloat16."""
-    from conftest import round_bf16
+    from conftest import tensor_err_q, round_bf16
     from oracle import vmap_oracle_torch as vt
     c = cases.build_case(name)
     fc_r = [round_bf16(a) for a in c["fc"]]
@@ -523,13 +536,15 @@ def test_bf16_weight_mode_equals_oracle_on_rounded_weights(name):
 
 @pytest.mark.parametrize("name,nw,steps,slab", [("cfg2", 0, 20, True), ("cfg2", 0, 20, False), ("scannet_scale", 0, 20, True),
                                                 ("tiny", 0, 7, False), ("scannet_scale", 3, 5, False), ("cfg2", 2, 3, True)])
-def test_carried_finalize_is_bit_identical_to_two_kernel_steps(name, nw, steps, slab):
+def test_carried_finalize_is_bit_identical_to_two_kernel_steps(name, nw, steps, slab, h32_kernel):
     """vmapstep_train_steps has two forms of the step loop: main + finalize per step, and (when every workgroup of a
     launch is resident at once) the finalize of step i-1 carried in the prologue of step i's launch, where the
     workgroups of an object hand the rewritten parameter image to each other inside the launch.  Same arithmetic in the
     same order: losses, parameters and both Adam moments must agree bit for bit over a whole frame, three frames in a
     row (the hand-off counters are re-armed per frame).  nw = 2, 3: the multi-pass instantiation (and several rounds of
     the carried slice per workgroup); slab: both ways the carried pass addresses the parameters."""
+    if h32_kernel != "f32":
+        pytest.skip("the carried finalize is a form of the exact-fp32 kernel only")
     c = cases.build_case(name)
     outs = []
     for carried in (0, 1):                                       # carried finalize off / on: two operators, each with its own tuning
@@ -561,11 +576,13 @@ def test_carried_finalize_is_bit_identical_to_two_kernel_steps(name, nw, steps, 
 
 @pytest.mark.parametrize("name,weights,slab", [("cfg2", "f32", False), ("cfg2", "f32", True), ("scannet_scale", "bf16", False),
                                                ("tiny", "bf16", True)])
-def test_table_driven_finalize_is_bit_identical_to_generic_finalize(name, weights, slab):
+def test_table_driven_finalize_is_bit_identical_to_generic_finalize(name, weights, slab, h32_kernel):
     """step_finalize_h32 (image slot from step_prep's table, compile-time tensor offsets or one slab base) against the
     generic step_finalize (runtime tensor search + gen_image_index per element): same ordered sums, same adamw_elem.
     Three frames of 20 steps; steps 2..20 of a frame read the parameter image the finalize maintains (bf16: the rounded
     copy), so losses, parameters and both moments must agree bit for bit."""
+    if h32_kernel != "f32":
+        pytest.skip("step_finalize_h32 / step_finalize belong to the exact-fp32 kernel's image")
     c = cases.build_case(name)
     steps = 20
     outs = []
@@ -590,3 +607,86 @@ def test_table_driven_finalize_is_bit_identical_to_generic_finalize(name, weight
     for x, y in zip(a["p"], b_["p"]):
         assert torch.equal(x, y)
     assert torch.equal(a["m"], b_["m"]) and torch.equal(a["v"], b_["v"])
+
+
+FRAME_TOL = {   # (relative loss tolerance for steps < 5, for later steps, q99 / median of |final parameter - reference|)
+    # The variance-normalised depth loss is ill-conditioned at random init (the reference's own float32 and float64 runs
+    # differ by up to 30 % per step, see the fixture's f64_losses): summation-order noise is amplified step by step, so
+    # the bound widens after the first steps; the parameters themselves stay within a few Adam steps (lr = 1e-3).
+    "cfg2_frame20": (2e-4, 3e-2, 3e-4, 2e-5),
+    "scannet50_frame": (2e-4, 2e-4, 2e-5, 2e-6),
+    "h64_r256_frame": (2e-4, 2e-4, 2e-5, 2e-6),
+}
+
+
+@pytest.mark.parametrize("name", list(cases.FRAME_CASES))
+def test_frame_trajectory_matches_reference_step_loop(name):
+    """vmapstep_train_steps over a whole frame - distinct strided ray slices per step, fused AdamW - against the
+    reference's OWN loop (train.py:270-326: functorch vmap + loss.step_batch_loss + torch.optim.AdamW), fixture
+    tests/golden/<name>.npz.  cfg2_frame20 is the frame bench.py times; scannet50_frame runs the multi-pass kernel at a
+    real object count; h64_r256_frame is the per-GPU shape of BASELINE configs[4]."""
+    c = cases.build_frame_case(name)
+    g = load_golden(name)
+    n, R, S, H, steps = c["n"], c["R"], c["S"], c["H"], c["n_steps"]
+    fc = [torch.from_numpy(a).to(DEV) for a in c["fc"]]
+    B = torch.from_numpy(c["B"]).to(DEV)
+    sc = torch.from_numpy(c["scale"]).to(DEV)
+    fr = {k: torch.from_numpy(v).to(DEV) for k, v in c["frame"].items()}
+    op = step.VmapStep(n, R, S, H, device=DEV, max_steps=steps)
+    st = step.FusedAdamWState(n, H, DEV)
+    # first-step gradients (same state): fixture parity of the strided slice [0, R)
+    gfc = [torch.zeros_like(t) for t in fc]
+    gB = torch.zeros_like(B)
+    op.fwd_bwd(fc, B, sc, *(fr[k][:, :R] for k in ("pcs", "z", "gt_depth", "gt_rgb", "sem", "depth_mask")), grads_fc=gfc, grad_B=gB)
+    keep = g["keep"]
+    for t in range(15):
+        key = f"g0_fc{t}" if t < 14 else "g0_B"
+        got = (gfc[t] if t < 14 else gB).cpu().numpy()[keep]
+        assert relerr(got, g[key]) < 1e-4, key
+    res = op.train_steps(fc, B, sc, fr["pcs"], fr["z"], fr["gt_depth"], fr["gt_rgb"], fr["sem"], fr["depth_mask"], opt=st,
+                         n_steps=steps, ray_step=R)
+    torch.cuda.synchronize()
+    losses = res.loss.cpu().numpy().astype(np.float64)
+    assert int(res.flags[:, 3].max()) == 0
+    early, late, q99, med = FRAME_TOL[name]
+    rel = np.abs(losses - g["losses"]) / np.abs(g["losses"])
+    assert rel[:5].max() <= early, rel
+    assert rel.max() <= late, rel
+    diffs = []
+    for t in range(15):
+        key = f"p_fc{t}" if t < 14 else "p_B"
+        got = (fc[t] if t < 14 else B).cpu().numpy()
+        diffs.append(np.abs(got[keep].astype(np.float64) - g[key]).ravel())
+        # every object (not only the kept ones): L2 norm of the final parameters per object and tensor
+        nk = f"pnorm_fc{t}" if t < 14 else "pnorm_B"
+        pn = np.sqrt((got.astype(np.float64).reshape(n, -1) ** 2).sum(-1))
+        assert np.abs(pn - g[nk]).max() <= 2e-3 * g[nk].max(), nk
+    d = np.concatenate(diffs)
+    assert d.max() <= steps * 1e-3 * 1.2                      # an element can at most walk lr per step
+    assert np.quantile(d, 0.99) < q99 and np.median(d) < med, (np.quantile(d, 0.99), np.median(d))
+
+
+@pytest.mark.parametrize("weights", ["f32", "bf16"])
+def test_parameter_image_kept_by_finalize_equals_freshly_packed_image(weights):
+    """The finalize kernel rewrites the packed parameter image (split planes / float32 image) element by element after
+    every AdamW update; a new frame call packs it from the parameter tensors.  Two steps in ONE call (step 2 reads the
+    maintained image) must equal two calls of one step (step 2 reads a fresh pack): bit for bit."""
+    c = cases.build_case("scannet_scale")
+    outs = []
+    for split_calls in (False, True):
+        fc, B, sc, b = _to_dev(c)
+        op = step.VmapStep(c["n"], c["R"], c["S"], c["H"], device=DEV, max_steps=2, weights=weights)
+        st = step.FusedAdamWState(c["n"], c["H"], DEV)
+        frame = {k: torch.cat([v, v.roll(3, dims=1)], dim=1).contiguous() for k, v in b.items()}
+        args = (frame["pcs"], frame["z"], frame["gt_depth"], frame["gt_rgb"], frame["sem"], frame["depth_mask"])
+        if not split_calls:
+            losses = op.train_steps(fc, B, sc, *args, opt=st, n_steps=2).loss.clone()
+        else:
+            l0 = op.train_steps(fc, B, sc, *args, opt=st, n_steps=1).loss.clone()
+            l1 = op.train_steps(fc, B, sc, *(x[:, c["R"]:] for x in args), opt=st, n_steps=1).loss.clone()
+            losses = torch.cat([l0, l1])
+        torch.cuda.synchronize()
+        outs.append((losses, [t.clone() for t in fc + [B]]))
+    assert torch.equal(outs[0][0], outs[1][0])
+    for x, y in zip(outs[0][1], outs[1][1]):
+        assert torch.equal(x, y)

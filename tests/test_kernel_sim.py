@@ -167,3 +167,74 @@ def test_sim_bf16_weights_equal_oracle_on_rounded_weights():
         assert relerr(s[k], g.numpy()) < 1e-4, k
     # and it is NOT the fp32-weight result
     assert relerr(s["render_depth"], load_golden("tiny")["render_depth"]) > 1e-4
+
+
+# ---- the split-bf16 kernels (split_kernels.h: step_prep_s32 / step_main_s32 / step_finalize_s32) ----------------------
+@pytest.mark.parametrize("name", ["tiny", "ragged", "drop_depth", "drop_opacity", "drop_colour", "saturated", "exact_hit"])
+def test_sim_split_kernel_matches_reference(name):
+    """bf16 matrix instruction with split operands (6 products forward, 3 backward), owner-lane encoding with the
+    double-angle octave recurrence, transposing LDS reads, bias columns: same fixtures, same tolerances."""
+    c = cases.build_case(name)
+    g = load_golden(name)
+    s = simlib.sim_step(c, split=True)
+    rt, gt = TOL.get(name, TOL["default"])
+    assert abs(s["loss"] - float(g["loss"])) <= 2e-5 * abs(float(g["loss"]))
+    for k in RENDER_KEYS:
+        assert relerr(s[k], g[k]) < rt, k
+    for k in GRAD_KEYS:
+        assert not np.isnan(s[k]).any(), k
+        assert relerr(s[k], g[k]) < gt, k
+    o = vo.training_step(c["fc"], c["B"], c["scale"], c["batch"], dtype=np.float32)
+    assert s["flags"][:3].tolist() == [int(x) for x in o["drop"]]
+
+
+@pytest.mark.parametrize("nw,G", [(1, None), (2, 5), (3, 7)])
+def test_sim_split_pass_loop_and_group_sizes(nw, G):
+    """Several passes per workgroup: the lo planes are re-copied per pass (the staging tiles overlay them)."""
+    c = cases.build_case("ragged")
+    g = load_golden("ragged")
+    s = simlib.sim_step(c, NW=nw, G=G, split=True)
+    for k in RENDER_KEYS + GRAD_KEYS:
+        assert relerr(s[k], g[k]) < 1e-4, k
+
+
+def test_sim_split_forward_only_and_far_point():
+    c = cases.build_case("tiny")
+    g = load_golden("tiny")
+    s = simlib.sim_step(c, bwd=False, split=True)
+    for k in RENDER_KEYS:
+        assert relerr(s[k], g[k]) < 2e-5, k
+    c["batch"]["pcs"][1, 3, 4, :] = [3.0e5, -2.0e5, 1.0e5]          # library sincos for octave 0, recurrence above it
+    o = vo.training_step(c["fc"], c["B"], c["scale"], c["batch"], dtype=np.float32)
+    s = simlib.sim_step(c, split=True)
+    for k in RENDER_KEYS + GRAD_KEYS:
+        assert relerr(s[k], o[k]) < 1e-4, k
+
+
+def test_sim_split_bf16_weights_equal_oracle_on_rounded_weights():
+    from conftest import round_bf16
+    c = cases.build_case("tiny")
+    fc_r = [round_bf16(a) for a in c["fc"]]
+    B_r = round_bf16(c["B"])
+    o = vo.training_step(fc_r, B_r, c["scale"], c["batch"], dtype=np.float32)
+    s = simlib.sim_step(c, split=True, weights_bf16=1)
+    for k in RENDER_KEYS:
+        assert relerr(s[k], o[k]) < 2e-5, k
+    for k in GRAD_KEYS:
+        assert relerr(s[k], o[k]) < 2e-2, k          # numpy oracle: ReLU-kink noise bound (the ATen port is the tight comparator on the GPU tier)
+
+
+def test_sim_split_fused_adamw_and_maintained_image():
+    """step_finalize_s32: AdamW == oracle update; the planes it rewrites == the planes a fresh pack of the updated
+    parameters produces (second step from either gives the same loss)."""
+    c = cases.build_case("tiny")
+    n = c["n"]
+    flat = np.concatenate([a.reshape(n, -1) for a in c["fc"]] + [c["B"].reshape(n, -1)], axis=1).astype(np.float32)
+    P = flat.shape[1]
+    PP = (P + 63) // 64 * 64
+    state = dict(p=flat.copy(), m=np.zeros((n, PP), np.float32), v=np.zeros((n, PP), np.float32), step=1)
+    s = simlib.sim_step(c, adam=state, split=True)
+    p_ref, m_ref, v_ref = vo.adamw_update(flat, s["grads_flat"], np.zeros_like(flat), np.zeros_like(flat), 1)
+    assert relerr(state["p"], p_ref) < 1e-6
+    assert relerr(state["m"][:, :P], m_ref) < 1e-6
+    assert relerr(state["v"][:, :P], v_ref) < 1e-6

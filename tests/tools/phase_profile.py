@@ -22,13 +22,15 @@ dev = "cuda:0"
 tfc = [torch.from_numpy(a).to(dev) for a in fc]
 tB, tsc = torch.from_numpy(B).to(dev), torch.from_numpy(sc).to(dev)
 tb = {k: torch.from_numpy(v).to(dev) for k, v in batch.items()}
-op = step.VmapStep(n, R, S, H, device=dev)
+from vmap_amd import _lib  # noqa: E402
+kern = sys.argv[2] if len(sys.argv) > 2 else "split"       # split (default kernel at hidden 32) | f32
+op = step.VmapStep(n, R, S, H, device=dev, tuning={"kernel": _lib.KERNEL_H32_F32} if kern == "f32" else None)
 args = (tfc, tB, tsc, tb["pcs"], tb["z"], tb["gt_depth"], tb["gt_rgb"], tb["sem"], tb["depth_mask"])
 for _ in range(3):
     t = op.profile_phases(*args)
 t = op.profile_phases(*args).astype(np.float64)          # [WG, 4 waves, 16]
 d = np.diff(t, axis=-1)
-print(f"config {name}: {t.shape[0]} workgroups; kernel span {t.max():.0f} clocks; per-phase clocks (median / p90 / max over waves)")
+print(f"config {name} kernel {kern}: {t.shape[0]} workgroups; kernel span {t.max():.0f} clocks; per-phase clocks (median / p90 / max over waves)")
 tot = 0.0
 for i in range(15):
     x = d[:, :, i].ravel()
@@ -37,4 +39,4 @@ for i in range(15):
 print(f"  sum of medians {tot:.0f}; wave-0 first stamp spread across WGs {np.ptp(t[:, 0, 0]):.0f}; "
       f"last stamp median {np.median(t[:, :, 15]):.0f} max {t[:, :, 15].max():.0f}")
 json.dump({"config": name, "median": np.median(d.reshape(-1, 15), axis=0).tolist(), "names": NAMES[1:]},
-          open(os.path.join(ROOT, "gpurun_out", f"phases_{name}.json"), "w"))
+          open(os.path.join(ROOT, "gpurun_out", f"phases_{name}_{kern}.json"), "w"))

@@ -1,0 +1,1027 @@
+// split_kernels.h - the fused per-object training step for hidden = 32 on the bf16 matrix pipe (gfx950 / CDNA4).
+//
+// Same path, phases, reductions and ABI as step_main_h32 (step_kernels.h; train.py:293-326), but every contraction runs
+// on v_mfma_f32_32x32x16_bf16 with SPLIT operands instead of the exact-fp32 matrix instruction:
+//
+//   a float32 x is carried as up to three bfloat16 planes  x = hi + mid + lo  (hi = rne(x), mid = rne(x - hi),
+//   lo = rne(x - hi - mid): 24 significant bits, i.e. exact), a product of two such values as the sum of bf16 x bf16
+//   products (each exact in float32), accumulated in float32 by the matrix instruction:
+//     forward   W.x  = hi.hi + hi.mid + mid.hi + mid.mid + hi.lo + lo.hi     (6 products: float32-equivalent; the
+//                       dropped terms are <= 2^-24 relative) - needed: a ReLU kink or a saturated occupancy amplifies
+//                       anything coarser beyond the 1e-4 parity bar (measured on the reference fixtures)
+//     backward  d-prop and weight gradients = hi.hi + hi.mid + mid.hi          (3 products, 2^-16 per product:
+//                       gradients stay within 1e-5 of the reference fixtures, the same as the exact-fp32 kernel)
+//   Why: the exact-fp32 matrix instruction runs at the VALU rate ON the VALU lanes (64 clocks per 32x32x2, nothing else
+//   issues meanwhile); the bf16 form does 8x the K per instruction in 32 clocks on the matrix pipe proper and the wave's
+//   VALU work issues next to it (profiles/r02a_bf16_probe.jsonl).  One 32-point tile: 574 fp32 instructions = 36.7 k
+//   clocks  ->  288 bf16 instructions = 9.2 k clocks, mostly hidden behind the tile's VALU work.
+//
+// What else differs from step_main_h32:
+//   * parameter image = three bf16 planes of the five weight matrices, rows in the K-order the matrix instruction
+//     consumes (one ds_read_b128 per plane and 16-deep step), + the small float32 vectors; written by step_prep_s32,
+//     kept current by step_finalize_s32 (three 2-byte stores per parameter);
+//   * d-prop needs W^T as the A operand: read from the SAME row-major planes with ds_read_b64_tr_b16 (4x4 transpose in
+//     the LDS read path) - no transposed copy; the P->F transposes of the weight-gradient operands use it too (packed
+//     P-form quads stored with ds_write_b64, F-form read back transposed): 8 + 8 DS instructions per operand instead of 20;
+//   * the encoding's K order is free (the weight columns are permuted to match when the image is built), so it is laid out
+//     by OWNER LANE: the lane pair (p, hi) of a point splits the 21 directions 11 / 10 and each lane evaluates ONE sincos
+//     per direction and five double-angle steps (2^f scaling is exact in float32: sin(2^f a) from (sin a, cos a) is the
+//     reference's embedding.py:85-88 value up to the recurrence's rounding) - 11 sincos per lane instead of 62;
+//   * the biases of in / cat / colour layers ride in a weight column that meets a constant-1 slot of the encoding:
+//     no bias preload in the forward, and the bias gradient is a column of the weight-gradient block.
+#pragma once
+#include "step_kernels.h"
+
+namespace vk {
+
+using wv::u32x2;
+using wv::u32x4;
+
+// ---------------------------------------------------------------------------------------------------------
+// Image layout (bytes; the global image of an object and its LDS copy are identical).
+// Plane = [W_in | W_m1 | W_cat | W_m2 | W_c], each [32 rows][steps][hi][t = 0..7] bf16: element (row j, step s, hi, t)
+// is W[j][k(s, hi, t)], k(s, hi, t) = 16 s + (t & 3) + 4 hi + 8 (t >> 2) for hidden-layer inputs (the P-form register map
+// of wave_ops.h) and the slot tables below for encoding inputs.  Row pitch = 16 bytes x odd: the "lane = row"
+// ds_read_b128 of the forward is bank-conflict free.
+// ---------------------------------------------------------------------------------------------------------
+struct Img32s {
+    static constexpr int PIT_IN = 208, PIT_M = 80, PIT_CAT = 272, PIT_C = 176;      // 6 / 2 / 8 / 5 steps of 32 bytes (+16)
+    static constexpr int O_IN = 0, O_M1 = O_IN + 32 * PIT_IN, O_CAT = O_M1 + 32 * PIT_M, O_M2 = O_CAT + 32 * PIT_CAT,
+                         O_C = O_M2 + 32 * PIT_M, PLANE = O_C + 32 * PIT_C;          // 26112 bytes per plane
+    static constexpr int P_HI = 0, P_MID = PLANE, SMALL = 2 * PLANE, SMALL_BYTES = 2048, P_LO = SMALL + SMALL_BYTES,
+                         END = P_LO + PLANE, BYTES = (END + 4095) / 4096 * 4096;     // 81920: 20 rounds of 4 x 1 KiB LDS-DMA
+    static constexpr int ROUNDS = BYTES / 4096;
+    static constexpr int ELEMS = PLANE / 2;                                          // bf16 elements per plane
+    // small float32 vectors (index in floats from SMALL)
+    static constexpr int B_M1 = 0, B_M2 = 32, W_A = 64, W_OC = 96, B_A = 192, B_OC = 196, PE_B = 200, SMALL_N = 208;
+    // ---- LDS map of step_main_s32 (bytes) ----
+    static constexpr int TILE = 32 * Lds32::TP * 4;          // 4608: one float32 32x32 exchange tile = two bf16 planes [32][72 B]
+    static constexpr int TPL = TILE / 2;                     // one bf16 plane of a transpose tile
+    static constexpr int TPIT = 72;                          // bytes per point row of a bf16 transpose plane (8 x odd)
+    static constexpr int STG = P_LO;                         // staging tiles OVERLAY the lo planes (dead once the forward is done)
+    static constexpr int STG_BYTES = 2 * kWaves * TILE;
+    static constexpr int SCR = STG + STG_BYTES;              // per-wave transpose tiles: kWaves x 2
+    static constexpr int VEC = SCR + kWaves * 2 * TILE;      // per-wave small-vector gradient accumulators
+    static constexpr int CB = VEC + kWaves * SMALL_N * 4;
+    static constexpr int LOSS = CB + kMaxPts * 8 * 4;
+    static constexpr int LDS_BYTES = LOSS + kWaves * 4 * 4;
+};
+static_assert(Img32s::PLANE == 26112 && Img32s::BYTES == 81920, "image size");
+static_assert(Img32s::STG + Img32s::STG_BYTES >= Img32s::BYTES, "the staging overlay must end behind the image");
+static_assert(Img32s::LDS_BYTES <= 160 * 1024, "LDS budget");
+static_assert(Img32s::PLANE % 16 == 0 && Img32s::SMALL % 16 == 0 && Img32s::P_LO % 16 == 0, "16-byte planes");
+
+constexpr int kSlotOne = -2, kSlotPad = -1;
+// Encoding slots, by OWNER LANE.  A lane (point p, half hi) holds 48 registers of the 87-wide first group (R = 0..47,
+// consumed 8 per 16-deep step) and 24 of the 42-wide second group.  Returns the index inside the group (embedding.py:85-89
+// order: xyz, then 3 + 21 f + d), kSlotOne for the constant-1 slot that meets the bias column, kSlotPad for zero padding.
+__host__ __device__ constexpr int e1_slot(int R, int hi) {
+    if (hi == 0) return R < 44 ? 3 + 21 * (R & 3) + (R >> 2) : (R < 47 ? R - 44 : kSlotOne);     // directions 0..10, xyz, one
+    return R < 40 ? 3 + 21 * (R & 3) + 11 + (R >> 2) : kSlotPad;                                   // directions 11..20
+}
+__host__ __device__ constexpr int e2_slot(int R, int hi) {
+    if (hi == 0) return R < 22 ? 21 * (R & 1) + (R >> 1) : (R == 22 ? kSlotOne : kSlotPad);        // octaves 4, 5 of directions 0..10
+    return R < 20 ? 21 * (R & 1) + 11 + (R >> 1) : kSlotPad;
+}
+__host__ __device__ constexpr int hidden_k(int s, int hi, int t) { return 16 * s + (t & 3) + 4 * hi + 8 * (t >> 2); }
+
+// Which parameter sits at bf16 element x of a plane: tensor t (0..13 field tensors in nn.Module.parameters() order) and
+// offset o inside it; false = zero padding.
+__host__ __device__ inline bool split_image_source(int x, int& t, int& o) {
+    using I = Img32s;
+    const int byte = 2 * x;
+    int base, pit, steps, kind;          // kind: 0 in, 1 m1, 2 cat, 3 m2, 4 c
+    if (byte < I::O_M1) { base = I::O_IN; pit = I::PIT_IN; steps = 6; kind = 0; }
+    else if (byte < I::O_CAT) { base = I::O_M1; pit = I::PIT_M; steps = 2; kind = 1; }
+    else if (byte < I::O_M2) { base = I::O_CAT; pit = I::PIT_CAT; steps = 8; kind = 2; }
+    else if (byte < I::O_C) { base = I::O_M2; pit = I::PIT_M; steps = 2; kind = 3; }
+    else { base = I::O_C; pit = I::PIT_C; steps = 5; kind = 4; }
+    const int j = (byte - base) / pit, rb = (byte - base) - j * pit;
+    const int s = rb >> 5, hi = (rb >> 4) & 1, tt = (rb >> 1) & 7;
+    if (s >= steps) return false;
+    const int k = hidden_k(s, hi, tt);
+    switch (kind) {
+        case 0: {
+            const int c = e1_slot(8 * s + tt, hi);
+            if (c == kSlotPad) return false;
+            if (c == kSlotOne) { t = 1; o = j; } else { t = 0; o = j * kEmb1 + c; }
+            return true;
+        }
+        case 1: t = 2; o = j * 32 + k; return true;
+        case 2: {
+            if (s < 2) { t = 4; o = j * (32 + kEmb1) + k; return true; }
+            const int c = e1_slot(8 * (s - 2) + tt, hi);
+            if (c == kSlotPad) return false;
+            if (c == kSlotOne) { t = 5; o = j; } else { t = 4; o = j * (32 + kEmb1) + 32 + c; }
+            return true;
+        }
+        case 3: t = 6; o = j * 32 + k; return true;
+        default: {
+            if (s < 2) { t = 10; o = j * (32 + kEmb2) + k; return true; }
+            const int c = e2_slot(8 * (s - 2) + tt, hi);
+            if (c == kSlotPad) return false;
+            if (c == kSlotOne) { t = 11; o = j; } else { t = 10; o = j * (32 + kEmb2) + 32 + c; }
+            return true;
+        }
+    }
+}
+// Which parameter sits at float i of the small-vector region (false = padding)
+__host__ __device__ inline bool split_small_source(int i, int& t, int& o) {
+    using I = Img32s;
+    if (i < I::B_M2) { t = 3; o = i - I::B_M1; return true; }
+    if (i < I::W_A) { t = 7; o = i - I::B_M2; return true; }
+    if (i < I::W_OC) { t = 8; o = i - I::W_A; return true; }
+    if (i < I::B_A) { t = 12; o = i - I::W_OC; return true; }
+    if (i < I::B_OC) { t = 9; o = i - I::B_A; return o < 1; }
+    if (i < I::PE_B) { t = 13; o = i - I::B_OC; return o < 3; }
+    t = 14; o = i - I::PE_B;
+    return o < 63;
+}
+
+__device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xFFFF0000u); }
+
+// one float32 -> its three bfloat16 planes (as 16-bit patterns)
+__device__ __forceinline__ void split3_scalar(float p, unsigned& h, unsigned& m, unsigned& l) {
+    const unsigned ph = wv::pack_bf16(p, 0.0f) & 0xFFFFu;
+    const float r1 = p - bf_lo(ph);
+    const unsigned pm = wv::pack_bf16(r1, 0.0f) & 0xFFFFu;
+    const float r2 = r1 - bf_lo(pm);
+    h = ph; m = pm; l = wv::pack_bf16(r2, 0.0f) & 0xFFFFu;
+}
+// parameter value p -> its place in the image.  loc >= 0: bf16 element of the planes; loc < 0: float (loc & 0x7fffffff)
+// of the small-vector region.  bf16 weights (BASELINE configs[3]/[4]): the image holds rne_bf16(p) - one plane.
+__device__ __forceinline__ void split_image_store(char* img, int loc, float p, int weights_bf16) {
+    using I = Img32s;
+    if (loc < 0) {
+        reinterpret_cast<float*>(img + I::SMALL)[loc & 0x7FFFFFFF] = weights_bf16 ? round_bf16(p) : p;
+        return;
+    }
+    unsigned h, m, l;
+    split3_scalar(p, h, m, l);
+    if (weights_bf16) { m = 0u; l = 0u; }
+    reinterpret_cast<unsigned short*>(img + I::P_HI)[loc] = (unsigned short)h;
+    reinterpret_cast<unsigned short*>(img + I::P_MID)[loc] = (unsigned short)m;
+    reinterpret_cast<unsigned short*>(img + I::P_LO)[loc] = (unsigned short)l;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// step_prep_s32: blocks [0, prep_steps) mask statistics (as step_prep); then 13 blocks per object that build the
+// object's split image (one thread per 4 consecutive bf16 elements = 8 bytes of each plane; the last 64 threads of an
+// object's last block fill the small-vector region) and, for object 0, the flat parameter -> image location table.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kSplitPackBlocks = (Img32s::ELEMS / 4 + kWG - 1) / kWG;       // 13
+static_assert(kSplitPackBlocks * kWG - Img32s::ELEMS / 4 >= 64, "room for the small-vector threads");
+
+__global__ __launch_bounds__(kWG) void step_prep_s32(const StepArgs a) {
+    using I = Img32s;
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x < a.prep_steps) {
+        prep_stats(a, blockIdx.x, Flat32::P, (Flat32::P + 63) / 64 * 64);
+        return;
+    }
+    const int b = blockIdx.x - a.prep_steps;
+    const int k = b / kSplitPackBlocks;
+    const int q = (b - k * kSplitPackBlocks) * kWG + tid;           // quad of elements
+    char* img = reinterpret_cast<char*>(a.wimg) + (long long)k * I::BYTES;
+    constexpr int offs[16] = {Flat32::W_IN, Flat32::B_IN, Flat32::W_M1, Flat32::B_M1, Flat32::W_CAT, Flat32::B_CAT, Flat32::W_M2, Flat32::B_M2,
+                              Flat32::W_A, Flat32::B_A, Flat32::W_C, Flat32::B_C, Flat32::W_OC, Flat32::B_OC, Flat32::PE_B, Flat32::P};
+    if (q < I::ELEMS / 4) {
+        unsigned h[4], m[4], l[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int t, o;
+            float f = 0.0f;
+            if (split_image_source(4 * q + e, t, o)) {
+                f = a.fc[t].p[k * a.fc[t].stride + o];
+                if (k == 0 && a.img_tab) a.img_tab[offs[t] + o] = 4 * q + e;
+            }
+            split3_scalar(f, h[e], m[e], l[e]);
+            if (a.weights_bf16) { m[e] = 0u; l[e] = 0u; }
+        }
+        *reinterpret_cast<u32x2*>(img + I::P_HI + 8 * q) = u32x2{h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
+        *reinterpret_cast<u32x2*>(img + I::P_MID + 8 * q) = u32x2{m[0] | (m[1] << 16), m[2] | (m[3] << 16)};
+        *reinterpret_cast<u32x2*>(img + I::P_LO + 8 * q) = u32x2{l[0] | (l[1] << 16), l[2] | (l[3] << 16)};
+    } else {
+        // small float32 vectors (+ zero padding of the region and of the image tail): 64 threads x 8 floats = 2048 bytes
+        const int s0 = (q - I::ELEMS / 4) * 8;
+        if (s0 < I::SMALL_BYTES / 4) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                int t, o;
+                float f = 0.0f;
+                if (split_small_source(s0 + e, t, o)) {
+                    f = t < kNFc ? a.fc[t].p[k * a.fc[t].stride + o] : a.pe_B.p[k * a.pe_B.stride + o];
+                    if (k == 0 && a.img_tab) a.img_tab[offs[t] + o] = (int)(0x80000000u | (unsigned)(s0 + e));
+                }
+                reinterpret_cast<float*>(img + I::SMALL)[s0 + e] = a.weights_bf16 ? round_bf16(f) : f;
+            }
+            // the unused tail of the image (read by the LDS-DMA, never used) is zeroed once
+            for (int i = I::END / 4 + (q - I::ELEMS / 4); i < I::BYTES / 4; i += 64) reinterpret_cast<float*>(img)[i] = 0.0f;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// step_finalize_s32: step_finalize_h32 (same sums in the same order, same adamw_elem) writing the split image
+// ---------------------------------------------------------------------------------------------------------
+template <bool SLAB>
+__device__ __forceinline__ void finalize_quad_s32(const FinalizeArgs& f, const CarryHot& a, int obj, int q) {
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    const long long s = (long long)obj * a.PP + 4 * q;
+    const wv::f32x4* pg = reinterpret_cast<const wv::f32x4*>(a.part_grad + (long long)obj * a.NW * a.PP + 4 * q);
+    wv::f32x4 m4 = *reinterpret_cast<const wv::f32x4*>(a.m + s);
+    wv::f32x4 v4 = *reinterpret_cast<const wv::f32x4*>(a.v + s);
+    const i32x4 img = *reinterpret_cast<const i32x4*>(a.img_tab + 4 * q);
+    float* pp[4]; float pv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int i = min(4 * q + e, Flat32::P - 1);
+        if (SLAB) {
+            pp[e] = a.slab + obj * a.slab_stride + i;
+        } else {
+            int t, o;
+            flat32_tensor_of(i, t, o);
+            pp[e] = f.param[t].p + obj * f.param[t].stride + o;
+        }
+        pv[e] = *pp[e];
+    }
+    wv::f32x4 g = {0.0f, 0.0f, 0.0f, 0.0f};
+    {
+        const long long qs = a.PP / 4;
+        int u0 = 0;
+        for (; u0 + 8 <= a.NW; u0 += 8) {
+            wv::f32x4 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = pg[(u0 + u) * qs];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) g += t[u];
+        }
+        wv::f32x4 t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = u0 + u < a.NW ? pg[(u0 + u) * qs] : wv::f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (u0 + u < a.NW) g += t[u];
+    }
+    char* image = reinterpret_cast<char*>(a.wimg) + (long long)obj * Img32s::BYTES;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (4 * q + e < Flat32::P) {
+            float p = pv[e], m = m4[e], v = v4[e];
+            adamw_elem(a, g[e], p, m, v);
+            *pp[e] = p; m4[e] = m; v4[e] = v;
+            split_image_store(image, img[e], p, a.weights_bf16);
+        }
+    }
+    *reinterpret_cast<wv::f32x4*>(a.m + s) = m4;
+    *reinterpret_cast<wv::f32x4*>(a.v + s) = v4;
+}
+
+__global__ __launch_bounds__(kWG) void step_finalize_s32(const FinalizeArgs a, const CarryHot hh) {
+    const int quads = a.PP / 4;
+    const int blocks_per_obj = (quads + kWG - 1) / kWG;
+    if (blockIdx.x == gridDim.x - 1) {
+        finalize_loss(a);
+        return;
+    }
+    int obj, part;
+    if (a.xcd_affine) {
+        const int slot = blockIdx.x >> 3;
+        const int og = slot / blocks_per_obj;
+        obj = og * 8 + (blockIdx.x & 7);
+        part = slot - og * blocks_per_obj;
+    } else {
+        obj = blockIdx.x / blocks_per_obj;
+        part = blockIdx.x - obj * blocks_per_obj;
+    }
+    const int q4 = part * kWG + threadIdx.x;
+    if (obj < a.n_obj && q4 < quads && 4 * q4 < a.P) {
+        if (hh.slab) finalize_quad_s32<true>(a, hh, obj, q4);
+        else finalize_quad_s32<false>(a, hh, obj, q4);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// device helpers of step_main_s32
+// ---------------------------------------------------------------------------------------------------------
+// N float32 registers (P-form, consecutive register pairs) -> NPL packed bf16 planes of N / 2 dwords each
+template <int N, int NPL>
+__device__ __forceinline__ void split_planes(const float (&x)[N], unsigned (&h)[N / 2], unsigned (&m)[N / 2], unsigned (&l)[N / 2]) {
+#pragma unroll
+    for (int i = 0; i < N / 2; ++i) {
+        const float a = x[2 * i], b = x[2 * i + 1];
+        const unsigned ph = wv::pack_bf16(a, b);
+        h[i] = ph;
+        if (NPL >= 2) {
+            const float ra = a - bf_lo(ph), rb = b - bf_hi(ph);
+            const unsigned pm = wv::pack_bf16(ra, rb);
+            m[i] = pm;
+            if (NPL >= 3) l[i] = wv::pack_bf16(ra - bf_lo(pm), rb - bf_hi(pm));
+        }
+    }
+}
+template <int N>
+__device__ __forceinline__ u32x4 opnd(const unsigned (&u)[N], int s) { return u32x4{u[4 * s], u[4 * s + 1], u[4 * s + 2], u[4 * s + 3]}; }
+
+// forward, one 16-deep step: acc += W[:, step] . x[step]; wrow = this lane's row of the hi plane at the step (+16 hi)
+template <bool W3>
+__device__ __forceinline__ void fwd_step(f32x16& acc, const char* wrow, u32x4 xh, u32x4 xm, u32x4 xl) {
+    using I = Img32s;
+    const u32x4 wh = *reinterpret_cast<const u32x4*>(wrow + I::P_HI);
+    if (W3) {
+        const u32x4 wm = *reinterpret_cast<const u32x4*>(wrow + I::P_MID);
+        const u32x4 wl = *reinterpret_cast<const u32x4*>(wrow + I::P_LO);
+        acc = wv::mfma_bf16(wh, xl, acc);        // smallest terms first
+        acc = wv::mfma_bf16(wl, xh, acc);
+        acc = wv::mfma_bf16(wm, xm, acc);
+        acc = wv::mfma_bf16(wh, xm, acc);
+        acc = wv::mfma_bf16(wm, xh, acc);
+        acc = wv::mfma_bf16(wh, xh, acc);
+    } else {                                     // bf16 weights: one plane x the three planes of the activations
+        acc = wv::mfma_bf16(wh, xl, acc);
+        acc = wv::mfma_bf16(wh, xm, acc);
+        acc = wv::mfma_bf16(wh, xh, acc);
+    }
+}
+
+// lane coordinates of the transposing reads: 16-lane group G = lane >> 4 (half = G & 1: which 16 of the operand's 32 rows,
+// hi = G >> 1), c = lane & 15, source-lane role jj = c >> 2 (row of the 4 x 4 block), q = c & 3 (its quad of 4 elements)
+struct TrLane { int half, hi, jj, q; };
+__device__ __forceinline__ TrLane tr_lane(int lane) { return TrLane{(lane >> 4) & 1, lane >> 5, (lane & 15) >> 2, lane & 3}; }
+
+// A operand of a d-prop chain: W^T for the 32 input columns that start at 16-deep step `step0` of matrix rows at `wmat`
+// (hi plane, row pitch PIT): w[pl * 8 + s * 4 + u * 2 + {0, 1}], pl = 0 hi / 1 mid plane, s = 16-deep step over the 32
+// OUTPUT rows j, u = which four of the lane's eight j: element t = 4 u + jj' <-> j = 16 s + 8 u + 4 hi + jj'.
+template <int PIT, bool W3>
+__device__ __forceinline__ void wt_get(unsigned (&w)[16], const char* wmat, int step0, const TrLane& L) {
+    using I = Img32s;
+    const char* base = wmat + (4 * L.hi + L.jj) * PIT + (step0 + L.half) * 32 + ((L.q & 1) * 8 + (L.q >> 1) * 4) * 2;
+#pragma unroll
+    for (int pl = 0; pl < (W3 ? 2 : 1); ++pl)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const u32x2 v = wv::lds_tr16(base + (pl ? I::P_MID : I::P_HI) + (16 * s + 8 * u) * PIT);
+                w[pl * 8 + s * 4 + u * 2] = v[0];
+                w[pl * 8 + s * 4 + u * 2 + 1] = v[1];
+            }
+}
+// d-prop: acc += W^T . dY with dY = dh + dm (P-form planes): hi.mid + mid.hi + hi.hi
+template <bool W3>
+__device__ __forceinline__ void dprop_mm(f32x16& acc, const unsigned (&w)[16], const unsigned (&dh)[8], const unsigned (&dm)[8]) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const u32x4 wh = u32x4{w[4 * s], w[4 * s + 1], w[4 * s + 2], w[4 * s + 3]};
+        acc = wv::mfma_bf16(wh, opnd(dm, s), acc);
+        if (W3) {
+            const u32x4 wm = u32x4{w[8 + 4 * s], w[8 + 4 * s + 1], w[8 + 4 * s + 2], w[8 + 4 * s + 3]};
+            acc = wv::mfma_bf16(wm, opnd(dh, s), acc);
+        }
+        acc = wv::mfma_bf16(wh, opnd(dh, s), acc);
+    }
+}
+
+// P-form planes (hi, mid; NQ quads of four features per lane) -> wave-private transpose tile [plane][point][feature]
+template <int NQ>
+__device__ __forceinline__ void tile_put(char* tile, const unsigned* h, const unsigned* m, int p31, int hi) {
+    using I = Img32s;
+    wv::wave_lds_fence();   // earlier reads of this tile are ordered before the overwrite
+    char* row = tile + p31 * I::TPIT + hi * 8;
+#pragma unroll
+    for (int mq = 0; mq < NQ; ++mq) {
+        *reinterpret_cast<u32x2*>(row + 16 * mq) = u32x2{h[2 * mq], h[2 * mq + 1]};
+        *reinterpret_cast<u32x2*>(row + I::TPL + 16 * mq) = u32x2{m[2 * mq], m[2 * mq + 1]};
+    }
+    wv::wave_lds_fence();
+}
+// F-form operand (lane = feature, elements = 16 points per half): f[pl * 8 + s * 4 + u * 2 + {0, 1}]; element t = 4 u + jj'
+// of step s <-> point 16 s + 8 hi + t
+__device__ __forceinline__ void tile_get(unsigned (&f)[16], const char* tile, const TrLane& L) {
+    using I = Img32s;
+    const char* base = tile + (8 * L.hi + L.jj) * I::TPIT + (16 * L.half + 4 * L.q) * 2;
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const u32x2 v = wv::lds_tr16(base + pl * I::TPL + (16 * s + 4 * u) * I::TPIT);
+                f[pl * 8 + s * 4 + u * 2] = v[0];
+                f[pl * 8 + s * 4 + u * 2 + 1] = v[1];
+            }
+}
+// weight gradient: acc[j][k] += sum_p dY[p][j] X[p][k], both operands in F-form planes: hi.mid + mid.hi + hi.hi
+__device__ __forceinline__ void dw_mm_s(f32x16& acc, const unsigned (&dyF)[16], const unsigned (&xF)[16]) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const u32x4 ah = u32x4{dyF[4 * s], dyF[4 * s + 1], dyF[4 * s + 2], dyF[4 * s + 3]};
+        const u32x4 am = u32x4{dyF[8 + 4 * s], dyF[8 + 4 * s + 1], dyF[8 + 4 * s + 2], dyF[8 + 4 * s + 3]};
+        const u32x4 bh = u32x4{xF[4 * s], xF[4 * s + 1], xF[4 * s + 2], xF[4 * s + 3]};
+        const u32x4 bm = u32x4{xF[8 + 4 * s], xF[8 + 4 * s + 1], xF[8 + 4 * s + 2], xF[8 + 4 * s + 3]};
+        acc = wv::mfma_bf16(ah, bm, acc);
+        acc = wv::mfma_bf16(am, bh, acc);
+        acc = wv::mfma_bf16(ah, bh, acc);
+    }
+}
+// bias gradient of a layer whose input has no constant-1 slot (mid1, mid2): dY^T . ones -> every column of the result holds
+// sum_p dY[p][j]; lanes 0 and 32 add their 16 rows to the wave's small-vector accumulators
+__device__ __forceinline__ void db_ones(float* gb, const unsigned (&dyF)[16], int p31, int hi) {
+    const u32x4 ones = u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+    f32x16 acc;
+    zero_acc(acc);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        acc = wv::mfma_bf16(u32x4{dyF[8 + 4 * s], dyF[8 + 4 * s + 1], dyF[8 + 4 * s + 2], dyF[8 + 4 * s + 3]}, ones, acc);
+        acc = wv::mfma_bf16(u32x4{dyF[4 * s], dyF[4 * s + 1], dyF[4 * s + 2], dyF[4 * s + 3]}, ones, acc);
+    }
+    if (p31 == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gb[phi(r, hi)] += acc[r];
+    }
+}
+// ReLU mask from the packed hi plane of the activation: d[r] = h[r] > 0 ? v[r] : 0 (h >= 0: nonzero <=> positive)
+__device__ __forceinline__ void relu_mask(float (&d)[16], const f32x16& v, const unsigned (&hh)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const unsigned u = wv::opaque_u(hh[i]);
+        d[2 * i] = (u & 0xFFFFu) != 0u ? v[2 * i] : 0.0f;
+        d[2 * i + 1] = u > 0xFFFFu ? v[2 * i + 1] : 0.0f;
+    }
+}
+
+// where column k (= lane) of a 32-column weight-gradient block goes.  KIND 0: natural (column k of the tensor row),
+// 1: first-group encoding block blk (0..2), 2: second-group block blk (0..1).  col = column inside the tensor row (after
+// the hidden part) or -1; bias = the column is the layer's bias gradient.
+template <int KIND>
+__device__ __forceinline__ void col_target(int blk, int k, int& col, bool& bias) {
+    bias = false;
+    if (KIND == 0) { col = k; return; }
+    const int hs = (k >> 2) & 1, r = (k & 3) + 4 * (k >> 3), R = 16 * blk + r;
+    int c;
+    if (KIND == 1) c = e1_slot(R, hs);
+    else c = R < 24 ? e2_slot(R, hs) : kSlotPad;
+    bias = c == kSlotOne;
+    col = c >= 0 ? c : -1;
+}
+// this wave's quarter (rows 8 wave + 4 hi + i) of a reduced block -> the workgroup's partial gradients
+template <int K>
+__device__ __forceinline__ void store_quarter_map(float* out_w, float* out_b, const float (&q)[4], int col, bool bias, int ncols,
+                                                  int wave, int hi) {
+    if (col >= 0 && col < ncols) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) __builtin_nontemporal_store(q[i], &out_w[(8 * wave + 4 * hi + i) * K + col]);
+    } else if (bias) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) __builtin_nontemporal_store(q[i], &out_b[8 * wave + 4 * hi + i]);
+    }
+}
+
+// sin / cos of the six octaves 2^f * a of one angle: one accurate sincos + five double-angle steps.  2^f * a is exact in
+// float32, so this IS sin(fl32(2^f * proj * pi)) of embedding.py:85-88 up to the recurrence's rounding (~2^f ulp).
+template <bool BIG>
+__device__ __forceinline__ void octave_sincos(float a0, float (&s)[6], float (&c)[6]) {
+    if (BIG) sincosf(a0, &s[0], &c[0]);
+    else sincos_f32(a0, s[0], c[0]);
+#pragma unroll
+    for (int f = 1; f < 6; ++f) {
+        const float t = s[f - 1] + s[f - 1];
+        s[f] = t * c[f - 1];
+        c[f] = fmaf(-t, s[f - 1], 1.0f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// step_main_s32<BWD, MULTI, STAMPS, W3>:  W3 = float32 weights as three planes (false: bf16 weights, one plane)
+// ---------------------------------------------------------------------------------------------------------
+template <bool BWD, bool MULTI, bool STAMPS, bool W3>
+__device__ __forceinline__ void step_main_s32_body(const StepArgs& a) {
+    using I = Img32s;
+    using F = Flat32;
+    constexpr int H = 32;
+    char* lds = reinterpret_cast<char*>(wv::lds_base());
+    const char* W = lds;                                       // the image
+    const float* SM = reinterpret_cast<const float*>(lds + I::SMALL);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p31 = lane & 31, hi = lane >> 5;
+    float* Gv = reinterpret_cast<float*>(lds + I::VEC) + wave * I::SMALL_N;      // this wave's private small-vector gradients
+    int obj, wgo;
+    if (a.xcd_affine) {
+        const int slot = blockIdx.x >> 3;
+        const int og = slot / a.NW;
+        obj = og * 8 + (blockIdx.x & 7);
+        wgo = slot - og * a.NW;
+        if (obj >= a.n_obj) return;
+    } else {
+        obj = blockIdx.x / a.NW;
+        wgo = blockIdx.x - obj * a.NW;
+    }
+    unsigned* tmark = STAMPS && a.timing ? a.timing + ((long long)blockIdx.x * kWaves + wave) * kMarks : nullptr;
+#define VS_MARK(i) do { if constexpr (STAMPS) { if (tmark && lane == 0) tmark[i] = wv::clock32(); } } while (0)
+    VS_MARK(0);
+    if (BWD) {
+        for (int i = tid; i < kWaves * I::SMALL_N; i += kWG) reinterpret_cast<float*>(lds + I::VEC)[i] = 0.0f;
+    }
+    float* loss_cells = reinterpret_cast<float*>(lds + I::LOSS);
+    if (tid < kWaves * 4) loss_cells[tid] = 0.0f;
+    float* out = a.part_grad + ((long long)(obj * a.NW + wgo)) * a.PP;   // this workgroup's partial gradients
+    float qacc[13][4];      // MULTI only: this wave's quarter of every reduced weight-gradient block
+#pragma unroll
+    for (int b = 0; b < 13; ++b) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) qacc[b][i] = 0.0f;
+    }
+    float* stg0 = reinterpret_cast<float*>(lds + I::STG);
+    float* stg1 = stg0 + kWaves * Lds32::STG_TILE;
+    char* scrX = lds + I::SCR + wave * 2 * I::TILE;
+    char* scrD = scrX + I::TILE;
+    float* cb = reinterpret_cast<float*>(lds + I::CB);
+    const float* cbw = cb + wave * 32 * 8;
+    const float scale = a.pe_scale.p[obj * a.pe_scale.stride];
+    const char* gimg = reinterpret_cast<const char*>(a.wimg) + (long long)obj * I::BYTES;
+    const float* Bg = reinterpret_cast<const float*>(gimg + I::SMALL) + I::PE_B;     // B_layer.weight, from the global image
+
+    const int tid_k = tid;
+    for (int grp = wgo; grp < a.NG; grp += a.NW) {   // ---- one pass = up to kMaxPts points (whole rays) ----
+    const int tid = MULTI ? wv::opaque_iter(tid_k) : tid_k;
+    const int lane = tid & 63, wave = tid >> 6, p31 = lane & 31, hi = lane >> 5;
+    const TrLane TL = tr_lane(lane);
+    __syncthreads();                                 // previous pass finished with the composite buffer and the staging tiles
+    for (int i = tid; i < kMaxPts * 8; i += kWG) cb[i] = 0.0f;
+
+    // ---- this lane's sample point ----
+    const int ray0 = grp * a.G;
+    const int nrays = min(a.G, a.R - ray0);
+    const int npts = nrays * a.S;
+    const int pt = wave * 32 + p31;
+    const bool valid = pt < npts;
+    const int lray = valid ? pt / a.S : 0;
+    const int smp = valid ? pt - lray * a.S : 0;
+    const int ray = ray0 + lray;
+    float t[3] = {0.0f, 0.0f, 0.0f};
+    if (valid) {
+        const float* px = a.pcs + obj * a.pcs_so + ray * a.pcs_sr + smp * a.pcs_ss;
+        t[0] = px[0] / scale;              // embedding.py:83  x / self.scale
+        t[1] = px[a.pcs_sc] / scale;
+        t[2] = px[2 * a.pcs_sc] / scale;
+    }
+    // this lane's directions: hi = 0 -> 0..10, hi = 1 -> 11..20 (+ one dummy)
+    float proj[11];
+#pragma unroll
+    for (int i = 0; i < 11; ++i) {
+        const int d0 = i, d1 = i < 10 ? 11 + i : 20;
+        const float b0 = hi ? Bg[3 * d1] : Bg[3 * d0], b1 = hi ? Bg[3 * d1 + 1] : Bg[3 * d0 + 1], b2 = hi ? Bg[3 * d1 + 2] : Bg[3 * d0 + 2];
+        proj[i] = fmaf(t[2], b2, fmaf(t[1], b1, t[0] * b0));          // embedding.py:84 B_layer(tensor)
+    }
+
+    // ---- asynchronous copy of the parameter image into LDS (lands during the encoding) ----
+    if (grp == wgo) {
+        const char* src = gimg + wave * 1024 + lane * 16;
+#pragma unroll
+        for (int c = 0; c < I::ROUNDS; ++c)
+            wv::glds16(reinterpret_cast<const float*>(src + c * 4096), reinterpret_cast<float*>(lds + c * 4096 + wave * 1024));
+    } else if (W3) {
+        // later passes: the lo planes were overwritten by the staging tiles of the previous pass (26 chunks of 1 KiB; the
+        // last one runs 512 bytes into the image's zero tail / the dead staging area)
+        const char* src = gimg + I::P_LO + wave * 1024 + lane * 16;
+#pragma unroll
+        for (int c = 0; c < (I::PLANE + 4095) / 4096; ++c)
+            if (4 * c + wave < (I::PLANE + 1023) / 1024)
+                wv::glds16(reinterpret_cast<const float*>(src + c * 4096), reinterpret_cast<float*>(lds + I::P_LO + c * 4096 + wave * 1024));
+    }
+    VS_MARK(1);
+
+    // ---- encoding (embedding.py:82-91): own directions, octaves by double-angle recurrence ----
+    float e1[48], e2[24];          // values of this lane's slots (P-form registers of the two groups)
+    float cfac[11][6];             // cos * pi * 2^f of this lane's directions (backward)
+    {
+        float amax = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 11; ++i) amax = fmaxf(amax, fabsf(proj[i]));
+        const bool fast = !wv::wave_any(!(amax * (32.0f * kPi) < kSinCosFastLimit));
+#pragma unroll
+        for (int i = 0; i < 11; ++i) {
+            float s[6], c[6];
+            const float a0 = proj[i] * kPi;            // fl32(proj * fl32(pi)); the octaves 2^f * a0 are exact
+            if (__builtin_expect(fast, 1)) octave_sincos<false>(a0, s, c);
+            else octave_sincos<true>(a0, s, c);
+            const bool own = i < 10 || hi == 0;        // the eleventh direction of the hi = 1 lanes is a dummy
+#pragma unroll
+            for (int f = 0; f < 6; ++f) {
+                const float sv = own ? s[f] : 0.0f;
+                cfac[i][f] = own ? c[f] * (kPi * (float)(1 << f)) : 0.0f;
+                if (f < 4) e1[4 * i + f] = sv;
+                else e2[2 * i + (f - 4)] = sv;
+            }
+        }
+        // slots behind the directions: hi = 0: xyz + the constant one (bias column); hi = 1: zero padding
+        e1[44] = hi ? 0.0f : t[0]; e1[45] = hi ? 0.0f : t[1]; e1[46] = hi ? 0.0f : t[2]; e1[47] = hi ? 0.0f : 1.0f;
+        e2[22] = hi ? 0.0f : 1.0f; e2[23] = 0.0f;
+    }
+    unsigned e1h[24], e1m[24], e1l[24], e2h[12], e2m[12], e2l[12];
+    split_planes<48, 3>(e1, e1h, e1m, e1l);
+    split_planes<24, 3>(e2, e2h, e2m, e2l);
+    VS_MARK(2);
+    __syncthreads();        // parameter image landed (the barrier drains the LDS-DMA), composite buffer zeroed
+
+    // ---- field MLP forward (model.py:59-83) ----
+    unsigned h1h[8], h1m[8], h2h[8], h2m[8], h3h[8], h3m[8], h4h[8], h4m[8];
+    float h4[16], hc[16];
+    f32x16 acc;
+    {
+        unsigned xl[8];
+        float hf[16];
+        const char* w = W + I::O_IN + p31 * I::PIT_IN + 16 * hi;
+        zero_acc(acc);                                            // the bias rides in the column of the constant-1 slot
+#pragma unroll
+        for (int s = 0; s < 6; ++s) fwd_step<W3>(acc, w + 32 * s, opnd(e1h, s), opnd(e1m, s), opnd(e1l, s));
+        relu_to(hf, acc);                                         // :59 in_layer
+        split_planes<16, 3>(hf, h1h, h1m, xl);
+        w = W + I::O_M1 + p31 * I::PIT_M + 16 * hi;
+        load_bias(acc, SM + I::B_M1, hi);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) fwd_step<W3>(acc, w + 32 * s, opnd(h1h, s), opnd(h1m, s), opnd(xl, s));
+        relu_to(hf, acc);                                         // :60 mid1
+        split_planes<16, 3>(hf, h2h, h2m, xl);
+        w = W + I::O_CAT + p31 * I::PIT_CAT + 16 * hi;
+        zero_acc(acc);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) fwd_step<W3>(acc, w + 32 * s, opnd(h2h, s), opnd(h2m, s), opnd(xl, s));     // :63 cat((fc2, x[:emb1]))
+#pragma unroll
+        for (int s = 0; s < 6; ++s) fwd_step<W3>(acc, w + 32 * (2 + s), opnd(e1h, s), opnd(e1m, s), opnd(e1l, s));
+        relu_to(hf, acc);                                         // :64 cat_layer
+        split_planes<16, 3>(hf, h3h, h3m, xl);
+        w = W + I::O_M2 + p31 * I::PIT_M + 16 * hi;
+        load_bias(acc, SM + I::B_M2, hi);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) fwd_step<W3>(acc, w + 32 * s, opnd(h3h, s), opnd(h3m, s), opnd(xl, s));
+        relu_to(h4, acc);                                         // :67 mid2
+        split_planes<16, 3>(h4, h4h, h4m, xl);
+        w = W + I::O_C + p31 * I::PIT_C + 16 * hi;
+        zero_acc(acc);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) fwd_step<W3>(acc, w + 32 * s, opnd(h4h, s), opnd(h4m, s), opnd(xl, s));     // :81 cat((fc4, x[emb1:]))
+#pragma unroll
+        for (int s = 0; s < 3; ++s) fwd_step<W3>(acc, w + 32 * (2 + s), opnd(e2h, s), opnd(e2m, s), opnd(e2l, s));
+        relu_to(hc, acc);                                         // :81 color_linear
+    }
+    VS_MARK(3);
+    {
+        float ra = 0.0f, r0 = 0.0f, r1 = 0.0f, r2 = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = phi(r, hi);
+            ra = fmaf(SM[I::W_A + j], h4[r], ra);                 // :71 out_alpha
+            r0 = fmaf(SM[I::W_OC + j], hc[r], r0);                // :82 out_color
+            r1 = fmaf(SM[I::W_OC + H + j], hc[r], r1);
+            r2 = fmaf(SM[I::W_OC + 2 * H + j], hc[r], r2);
+        }
+        ra += wv::swap_half(ra); r0 += wv::swap_half(r0); r1 += wv::swap_half(r1); r2 += wv::swap_half(r2);
+        ra += SM[I::B_A]; r0 += SM[I::B_OC]; r1 += SM[I::B_OC + 1]; r2 += SM[I::B_OC + 2];
+        if (valid && hi == 0) {
+            float* row = cb + pt * 8;
+            row[6] = a.z[obj * a.z_so + ray * a.z_sr + smp * a.z_ss];
+            row[0] = sigmoidf_acc(ra * 10.0f);                   // :77 raw*10 ; render_rays.py:6 sigmoid
+            row[1] = sigmoidf_acc(r0);                           // :83 sigmoid(raw_color)
+            row[2] = sigmoidf_acc(r1);
+            row[3] = sigmoidf_acc(r2);
+        }
+        if (BWD) {
+            // float32 transposes of h4 / hc for the head gradients (consumed after the compositing; the tiles are idle until then)
+            toF_put(reinterpret_cast<float*>(scrX), h4, p31, hi);
+            toF_put(reinterpret_cast<float*>(scrD), hc, p31, hi);
+        }
+    }
+    VS_MARK(4);
+    __syncthreads();
+    VS_MARK(5);
+    {
+        const StepArgs& al = wv::kernarg_late(a);
+        composite_phase<BWD>(al, cb, loss_cells, obj, ray0, nrays, wave, lane, tid,
+                             load_ray_meta(al, obj, ray0 + min(4 * wave + (lane >> 4), nrays - 1)));
+    }
+    __syncthreads();
+    VS_MARK(6);
+    if (BWD) {
+    // ---- backward ----
+    float d_raw, d_c0, d_c1, d_c2;
+    {
+        const float* row = cb + pt * 8;          // pt < kMaxPts always; padding rows hold zeros
+        d_raw = row[0]; d_c0 = row[1]; d_c1 = row[2]; d_c2 = row[3];
+    }
+    unsigned xF[16], dF[16], w[16];
+    float dproj[11];
+#pragma unroll
+    for (int i = 0; i < 11; ++i) dproj[i] = 0.0f;
+    unsigned dch[8], dcm[8], d4h[8], d4m[8], xl_unused[8];
+    {
+        // heads: out_alpha / out_color weight + bias gradients (lane = hidden feature), float32 as in step_main_h32
+        float h4F[16], hcF[16];
+        toF_get(h4F, reinterpret_cast<const float*>(scrX), p31, hi);
+        toF_get(hcF, reinterpret_cast<const float*>(scrD), p31, hi);
+        float ga = 0.0f, g0 = 0.0f, g1 = 0.0f, g2 = 0.0f, sa = 0.0f, s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float* row = cbw + (r + 16 * hi) * 8;
+            const float da = row[0], q0 = row[1], q1 = row[2], q2 = row[3];
+            ga = fmaf(da, h4F[r], ga);
+            g0 = fmaf(q0, hcF[r], g0); g1 = fmaf(q1, hcF[r], g1); g2 = fmaf(q2, hcF[r], g2);
+            sa += da; s0 += q0; s1 += q1; s2 += q2;
+        }
+        ga += wv::swap_half(ga); g0 += wv::swap_half(g0); g1 += wv::swap_half(g1); g2 += wv::swap_half(g2);
+        sa += wv::swap_half(sa); s0 += wv::swap_half(s0); s1 += wv::swap_half(s1); s2 += wv::swap_half(s2);
+        if (hi == 0) {
+            Gv[I::W_A + p31] += ga;
+            Gv[I::W_OC + p31] += g0;
+            Gv[I::W_OC + H + p31] += g1;
+            Gv[I::W_OC + 2 * H + p31] += g2;
+            if (p31 == 0) {
+                Gv[I::B_A] += sa;
+                Gv[I::B_OC + 0] += s0;
+                Gv[I::B_OC + 1] += s1;
+                Gv[I::B_OC + 2] += s2;
+            }
+        }
+        // d hc = W_oc^T d rawc, through the ReLU
+        float dcp[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = phi(r, hi);
+            const float v = SM[I::W_OC + j] * d_c0 + SM[I::W_OC + H + j] * d_c1 + SM[I::W_OC + 2 * H + j] * d_c2;
+            dcp[r] = wv::opaque(hc[r]) > 0.0f ? v : 0.0f;
+        }
+        split_planes<16, 2>(dcp, dch, dcm, xl_unused);
+    }
+    f32x16 acc2;
+    float dv[16];
+    // ---- units 0..2: colour layer (delta = d hc) ----
+    tile_put<4>(scrD, dch, dcm, p31, hi);
+    tile_get(dF, scrD, TL);
+    // unit 0: x = h4;  d h4 = W_a d raw + W_c[:, :H]^T d hc
+    tile_put<4>(scrX, h4h, h4m, p31, hi);
+    tile_get(xF, scrX, TL);
+    wt_get<I::PIT_C, W3>(w, W + I::O_C, 0, TL);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[r] = SM[I::W_A + phi(r, hi)] * d_raw;
+    dprop_mm<W3>(acc2, w, dch, dcm);
+    relu_mask(dv, acc2, h4h);
+    split_planes<16, 2>(dv, d4h, d4m, xl_unused);
+    zero_acc(acc);
+    dw_mm_s(acc, dF, xF);
+    stage_put(stg0, acc, wave, p31, hi);
+    // unit 1: x = second-group slots 0..15
+    tile_put<4>(scrX, e2h, e2m, p31, hi);
+    tile_get(xF, scrX, TL);
+    wt_get<I::PIT_C, W3>(w, W + I::O_C, 2, TL);
+    zero_acc(acc2);
+    dprop_mm<W3>(acc2, w, dch, dcm);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dproj[r >> 1] += acc2[r] * cfac[r >> 1][4 + (r & 1)];          // d e2 slot R = r: direction r >> 1, octave 4 + (r & 1)
+    zero_acc(acc);
+    dw_mm_s(acc, dF, xF);
+    __syncthreads();
+    {
+        int col; bool bias;
+        col_target<0>(0, p31, col, bias);
+        if (MULTI) stage_get(qacc[0], stg0, wave, p31, hi);
+        else { float q[4] = {0, 0, 0, 0}; stage_get(q, stg0, wave, p31, hi); store_quarter_map<H + kEmb2>(out + F::W_C, nullptr, q, col, bias, 32, wave, hi); }
+    }
+    stage_put(stg1, acc, wave, p31, hi);
+    // unit 2: x = second-group slots 16..23 (half a block)
+    tile_put<2>(scrX, e2h + 8, e2m + 8, p31, hi);
+    tile_get(xF, scrX, TL);
+    wt_get<I::PIT_C, W3>(w, W + I::O_C, 4, TL);
+    zero_acc(acc2);
+    dprop_mm<W3>(acc2, w, dch, dcm);
+#pragma unroll
+    for (int r = 0; r < 6; ++r) dproj[8 + (r >> 1)] += acc2[r] * cfac[8 + (r >> 1)][4 + (r & 1)];  // slots 16..21: directions 8..10
+    zero_acc(acc);
+    dw_mm_s(acc, dF, xF);
+    __syncthreads();
+    {
+        int col; bool bias;
+        col_target<2>(0, p31, col, bias);
+        if (MULTI) stage_get(qacc[1], stg1, wave, p31, hi);
+        else { float q[4] = {0, 0, 0, 0}; stage_get(q, stg1, wave, p31, hi); store_quarter_map<H + kEmb2>(out + F::W_C + H, out + F::B_C, q, col, bias, kEmb2, wave, hi); }
+    }
+    stage_put(stg0, acc, wave, p31, hi);
+    VS_MARK(7);
+    // ---- unit 3: mid2, delta = d4, x = h3 ----
+    unsigned d3h[8], d3m[8], dF3[16];
+    tile_put<4>(scrD, d4h, d4m, p31, hi);
+    tile_get(dF, scrD, TL);
+    tile_put<4>(scrX, h3h, h3m, p31, hi);
+    tile_get(xF, scrX, TL);
+    wt_get<I::PIT_M, W3>(w, W + I::O_M2, 0, TL);
+    zero_acc(acc2);
+    dprop_mm<W3>(acc2, w, d4h, d4m);
+    relu_mask(dv, acc2, h3h);
+    split_planes<16, 2>(dv, d3h, d3m, xl_unused);
+    db_ones(Gv + I::B_M2, dF, p31, hi);
+    zero_acc(acc);
+    dw_mm_s(acc, dF, xF);
+    __syncthreads();
+    {
+        int col; bool bias;
+        col_target<2>(1, p31, col, bias);
+        if (MULTI) stage_get(qacc[2], stg0, wave, p31, hi);
+        else { float q[4] = {0, 0, 0, 0}; stage_get(q, stg0, wave, p31, hi); store_quarter_map<H + kEmb2>(out + F::W_C + H, out + F::B_C, q, col, bias, kEmb2, wave, hi); }
+    }
+    stage_put(stg1, acc, wave, p31, hi);
+    VS_MARK(8);
+    // ---- unit 4: cat_layer, delta = d3 (its F-form is kept for the three first-group blocks), x = h2 ----
+    unsigned d2h[8], d2m[8];
+    tile_put<4>(scrD, d3h, d3m, p31, hi);
+    tile_get(dF3, scrD, TL);
+    tile_put<4>(scrX, h2h, h2m, p31, hi);
+    tile_get(xF, scrX, TL);
+    wt_get<I::PIT_CAT, W3>(w, W + I::O_CAT, 0, TL);
+    zero_acc(acc2);
+    dprop_mm<W3>(acc2, w, d3h, d3m);
+    relu_mask(dv, acc2, h2h);
+    split_planes<16, 2>(dv, d2h, d2m, xl_unused);
+    zero_acc(acc);
+    dw_mm_s(acc, dF3, xF);
+    __syncthreads();
+    {
+        int col; bool bias;
+        col_target<0>(0, p31, col, bias);
+        if (MULTI) stage_get(qacc[3], stg1, wave, p31, hi);
+        else { float q[4] = {0, 0, 0, 0}; stage_get(q, stg1, wave, p31, hi); store_quarter_map<H>(out + F::W_M2, nullptr, q, col, bias, 32, wave, hi); }
+    }
+    stage_put(stg0, acc, wave, p31, hi);
+    VS_MARK(9);
+    // ---- unit 5: mid1, delta = d2, x = h1 ----
+    unsigned d1h[8], d1m[8], dF1[16];
+    tile_put<4>(scrD, d2h, d2m, p31, hi);
+    tile_get(dF, scrD, TL);
+    tile_put<4>(scrX, h1h, h1m, p31, hi);
+    tile_get(xF, scrX, TL);
+    wt_get<I::PIT_M, W3>(w, W + I::O_M1, 0, TL);
+    zero_acc(acc2);
+    dprop_mm<W3>(acc2, w, d2h, d2m);
+    relu_mask(dv, acc2, h1h);
+    split_planes<16, 2>(dv, d1h, d1m, xl_unused);
+    db_ones(Gv + I::B_M1, dF, p31, hi);
+    zero_acc(acc);
+    dw_mm_s(acc, dF, xF);
+    __syncthreads();
+    {
+        int col; bool bias;
+        col_target<0>(0, p31, col, bias);
+        if (MULTI) stage_get(qacc[4], stg0, wave, p31, hi);
+        else { float q[4] = {0, 0, 0, 0}; stage_get(q, stg0, wave, p31, hi); store_quarter_map<H + kEmb1>(out + F::W_CAT, nullptr, q, col, bias, 32, wave, hi); }
+    }
+    stage_put(stg1, acc, wave, p31, hi);
+    // delta d1 transposed once for the three in_layer blocks
+    tile_put<4>(scrD, d1h, d1m, p31, hi);
+    tile_get(dF1, scrD, TL);
+    VS_MARK(10);
+    // ---- units 6..11: the three first-group blocks feed cat_layer (delta d3) and in_layer (delta d1) ----
+    f32x16 de;
+#pragma unroll
+    for (int blk = 0; blk < 3; ++blk) {
+        tile_put<4>(scrX, e1h + 8 * blk, e1m + 8 * blk, p31, hi);
+        tile_get(xF, scrX, TL);                                   // after the last block xF = its F-form, used by the B unit
+        // cat_layer x block
+        wt_get<I::PIT_CAT, W3>(w, W + I::O_CAT, 2 + 2 * blk, TL);
+        zero_acc(de);
+        dprop_mm<W3>(de, w, d3h, d3m);
+        zero_acc(acc);
+        dw_mm_s(acc, dF3, xF);
+        __syncthreads();
+        {
+            // finishes the block staged before this one: blk 0: mid1 (W_M1); else the in_layer block blk - 1
+            float* sprev = stg1;
+            if (blk == 0) {
+                int col; bool bias;
+                col_target<0>(0, p31, col, bias);
+                if (MULTI) stage_get(qacc[5], sprev, wave, p31, hi);
+                else { float q[4] = {0, 0, 0, 0}; stage_get(q, sprev, wave, p31, hi); store_quarter_map<H>(out + F::W_M1, nullptr, q, col, bias, 32, wave, hi); }
+            } else {
+                int col; bool bias;
+                col_target<1>(blk - 1, p31, col, bias);
+                if (MULTI) stage_get(qacc[8 + blk], sprev, wave, p31, hi);
+                else { float q[4] = {0, 0, 0, 0}; stage_get(q, sprev, wave, p31, hi); store_quarter_map<kEmb1>(out + F::W_IN, out + F::B_IN, q, col, bias, kEmb1, wave, hi); }
+            }
+        }
+        stage_put(stg0, acc, wave, p31, hi);
+        // in_layer x block
+        wt_get<I::PIT_IN, W3>(w, W + I::O_IN, 2 * blk, TL);
+        dprop_mm<W3>(de, w, d1h, d1m);
+        // d(first-group slot R = 16 blk + r) -> direction R >> 2, octave R & 3 (slots 44..47: xyz / one / padding: no gradient)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int R = 16 * blk + r;
+            if (R < 44) dproj[R >> 2] += de[r] * cfac[R >> 2][R & 3];
+        }
+        zero_acc(acc);
+        dw_mm_s(acc, dF1, xF);
+        __syncthreads();
+        {
+            int col; bool bias;
+            col_target<1>(blk, p31, col, bias);
+            if (MULTI) stage_get(qacc[6 + blk], stg0, wave, p31, hi);
+            else { float q[4] = {0, 0, 0, 0}; stage_get(q, stg0, wave, p31, hi); store_quarter_map<H + kEmb1>(out + F::W_CAT + H, out + F::B_CAT, q, col, bias, kEmb1, wave, hi); }
+        }
+        stage_put(stg1, acc, wave, p31, hi);
+    }
+    VS_MARK(12);
+    // ---- unit 12: B_layer.weight gradient: dB[d][j] = sum_points dproj[d] * t[j]; t = slots 44..46 of the hi = 0 lanes
+    //      = features 24..26 of the last first-group block, whose F-form is still in xF ----
+    {
+        float dpP[16];
+        unsigned dph[8], dpm[8];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dpP[r] = r < 11 ? dproj[r] : 0.0f;          // row phi(r, hi) <-> direction hi ? 11 + r : r
+        split_planes<16, 2>(dpP, dph, dpm, xl_unused);
+        tile_put<4>(scrD, dph, dpm, p31, hi);
+        tile_get(dF, scrD, TL);
+        zero_acc(acc);
+        dw_mm_s(acc, dF, xF);
+        __syncthreads();
+        {
+            int col; bool bias;
+            col_target<1>(2, p31, col, bias);
+            if (MULTI) stage_get(qacc[11], stg1, wave, p31, hi);
+            else { float q[4] = {0, 0, 0, 0}; stage_get(q, stg1, wave, p31, hi); store_quarter_map<kEmb1>(out + F::W_IN, out + F::B_IN, q, col, bias, kEmb1, wave, hi); }
+        }
+        stage_put(stg0, acc, wave, p31, hi);
+        __syncthreads();
+        float q[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (MULTI) stage_get(qacc[12], stg0, wave, p31, hi);
+        else stage_get(q, stg0, wave, p31, hi);
+        if (!MULTI && p31 >= 24 && p31 < 27) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = 8 * wave + 4 * hi + i;                 // = phi(r, hs): hs = hi, r = i + 4 * wave
+                const int r = i + 4 * wave, d = hi ? 11 + r : r;
+                if (r < (hi ? 10 : 11)) out[F::PE_B + 3 * d + (p31 - 24)] = q[i];
+                (void)row;
+            }
+        }
+    }
+    VS_MARK(13);
+    }   // BWD
+    if (!MULTI) break;      // one pass per workgroup: no back edge
+    }   // pass loop
+    __syncthreads();
+    VS_MARK(14);
+    if (tid == 0) {
+        float* pl = a.part_loss + (obj * a.NW + wgo) * 4;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            pl[k] = (loss_cells[k] + loss_cells[4 + k]) + (loss_cells[8 + k] + loss_cells[12 + k]);
+        pl[3] = 0.0f;
+    }
+    if (!BWD) return;
+
+    // ---- write this workgroup's partial gradients in the natural flat order ----
+    if (MULTI) {
+        int col; bool bias;
+        col_target<0>(0, p31, col, bias);
+        store_quarter_map<H + kEmb2>(out + F::W_C, nullptr, qacc[0], col, false, 32, wave, hi);
+        store_quarter_map<H>(out + F::W_M2, nullptr, qacc[3], col, false, 32, wave, hi);
+        store_quarter_map<H + kEmb1>(out + F::W_CAT, nullptr, qacc[4], col, false, 32, wave, hi);
+        store_quarter_map<H>(out + F::W_M1, nullptr, qacc[5], col, false, 32, wave, hi);
+        col_target<2>(0, p31, col, bias);
+        store_quarter_map<H + kEmb2>(out + F::W_C + H, out + F::B_C, qacc[1], col, bias, kEmb2, wave, hi);
+        col_target<2>(1, p31, col, bias);
+        store_quarter_map<H + kEmb2>(out + F::W_C + H, out + F::B_C, qacc[2], col, bias, kEmb2, wave, hi);
+#pragma unroll
+        for (int blk = 0; blk < 3; ++blk) {
+            col_target<1>(blk, p31, col, bias);
+            store_quarter_map<H + kEmb1>(out + F::W_CAT + H, out + F::B_CAT, qacc[6 + blk], col, bias, kEmb1, wave, hi);
+            store_quarter_map<kEmb1>(out + F::W_IN, out + F::B_IN, qacc[9 + blk], col, bias, kEmb1, wave, hi);
+        }
+        if (p31 >= 24 && p31 < 27) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = i + 4 * wave, d = hi ? 11 + r : r;
+                if (r < (hi ? 10 : 11)) out[F::PE_B + 3 * d + (p31 - 24)] = qacc[12][i];
+            }
+        }
+    }
+    // small vectors: sum of the four waves' private accumulators (biases of mid1 / mid2, the heads)
+    for (int sv = tid; sv < I::SMALL_N; sv += kWG) {
+        const float* v = reinterpret_cast<const float*>(lds + I::VEC) + sv;
+        const float g = (v[0] + v[I::SMALL_N]) + (v[2 * I::SMALL_N] + v[3 * I::SMALL_N]);
+        int o = -1;
+        if (sv < I::B_M2) o = F::B_M1 + (sv - I::B_M1);
+        else if (sv < I::W_A) o = F::B_M2 + (sv - I::B_M2);
+        else if (sv < I::W_OC) o = F::W_A + (sv - I::W_A);
+        else if (sv < I::B_A) o = F::W_OC + (sv - I::W_OC);
+        else if (sv == I::B_A) o = F::B_A;
+        else if (sv >= I::B_OC && sv < I::B_OC + 3) o = F::B_OC + (sv - I::B_OC);
+        if (o >= 0) out[o] = g;
+    }
+    VS_MARK(15);
+#undef VS_MARK
+}
+
+template <bool BWD, bool MULTI, bool STAMPS, bool W3>
+__global__ __launch_bounds__(kWG, 1) void step_main_s32(const StepArgs a) {
+    step_main_s32_body<BWD, MULTI, STAMPS, W3>(a);
+}
+
+}  // namespace vk

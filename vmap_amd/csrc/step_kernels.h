@@ -75,6 +75,7 @@ struct StepArgs {
     int wide;                          // 1: step_main_wide (tile per workgroup, G*S <= 32) instead of step_main_gen
     unsigned* carry_cnt;               // step_prep: [n_obj][2] hand-off counters of the carried finalize, zeroed per frame
     int* img_tab;                      // step_prep: [PP] flat parameter -> image position table (or null)
+    int split;                         // 1: hidden 32 on the split-bf16 kernels (split_kernels.h); wimg is then the byte image of Img32s
     float* gen_scratch;                // step_main_gen / step_main_wide: per-wave (per-workgroup) register-image scratch (workspace)
 };
 
@@ -805,41 +806,18 @@ __device__ __forceinline__ void composite_phase(const StepArgs& a, float* cb, fl
 //                                     empty mask" switches (loss.py:16-19,38,46,56; render_rays.py:68-73)
 //   blocks [prep_steps, +n_obj*imgp/1024)  pack the objects' 15 tensors into their LDS-layout parameter images
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kWG) void step_prep(const StepArgs a) {
+// mask statistics of optimisation step `step` of the frame (one workgroup): per-object counts + the batch-wide switches
+__device__ __forceinline__ void prep_stats(const StepArgs& a, int step, int table_len_P, int table_len_PP) {
     const int tid = threadIdx.x;
-    if ((int)blockIdx.x >= a.prep_steps) {
-        // pack: imgp / 1024 workgroups per object, one 16-byte image slot per thread (destination-major: the zero
-        // padding is written by the same pass, no barrier, coalesced stores)
-        const GenLayout L = gen_layout(a.hidden);
-        const int per_obj = L.imgp / 1024;
-        const int b = blockIdx.x - a.prep_steps;
-        const int k = b / per_obj;
-        const int x0 = (b - k * per_obj) * 1024 + 4 * tid;
-        wv::f32x4 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            int t, o;
-            float f = 0.0f;
-            if (gen_image_source(L, x0 + e, t, o)) {
-                f = t < kNFc ? a.fc[t].p[k * a.fc[t].stride + o] : a.pe_B.p[k * a.pe_B.stride + o];
-                if (k == 0 && a.img_tab) a.img_tab[L.f[t] + o] = x0 + e;     // flat parameter -> image position (the inverse map, for free)
-            }
-            v[e] = a.weights_bf16 ? round_bf16(f) : f;
-        }
-        *reinterpret_cast<wv::f32x4*>(a.wimg + (long long)k * L.imgp + x0) = v;
-        return;
-    }
     // one wave per object (objects w, w+4, ...): per-lane counts over the rays, a shuffle tree, no workgroup barrier
     // per object (the old form - one block reduction per object, 20 in sequence - took 25 us per frame)
     float* lds = wv::lds_base();
     int* dropw = reinterpret_cast<int*>(lds);          // [kWaves]
     const int lane = tid & 63, wave = tid >> 6;
-    const int step = blockIdx.x;                       // one workgroup per optimisation step of the frame
     if (step == 0 && a.carry_cnt)
         for (int i = tid; i < 2 * a.n_obj; i += kWG) a.carry_cnt[i] = 0u;
     if (step == 0 && a.img_tab) {                      // padding entries; the real ones are written by the pack blocks of object 0
-        const GenLayout L = gen_layout(a.hidden);
-        for (int i = L.P + tid; i < L.PP; i += kWG) a.img_tab[i] = 0;
+        for (int i = table_len_P + tid; i < table_len_PP; i += kWG) a.img_tab[i] = 0;
     }
     const unsigned char* sem = a.sem + step * a.prep_ray_step * a.sem_sr;
     const unsigned char* dmask = a.dmask + step * a.prep_ray_step * a.dm_sr;
@@ -876,6 +854,34 @@ __global__ __launch_bounds__(kWG) void step_prep(const StepArgs a) {
         for (int w = 0; w < kWaves; ++w) d |= dropw[w];
         flags[0] = d & 1; flags[1] = (d >> 1) & 1; flags[2] = (d >> 2) & 1; flags[3] = 0;
     }
+}
+
+__global__ __launch_bounds__(kWG) void step_prep(const StepArgs a) {
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x >= a.prep_steps) {
+        // pack: imgp / 1024 workgroups per object, one 16-byte image slot per thread (destination-major: the zero
+        // padding is written by the same pass, no barrier, coalesced stores)
+        const GenLayout L = gen_layout(a.hidden);
+        const int per_obj = L.imgp / 1024;
+        const int b = blockIdx.x - a.prep_steps;
+        const int k = b / per_obj;
+        const int x0 = (b - k * per_obj) * 1024 + 4 * tid;
+        wv::f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int t, o;
+            float f = 0.0f;
+            if (gen_image_source(L, x0 + e, t, o)) {
+                f = t < kNFc ? a.fc[t].p[k * a.fc[t].stride + o] : a.pe_B.p[k * a.pe_B.stride + o];
+                if (k == 0 && a.img_tab) a.img_tab[L.f[t] + o] = x0 + e;     // flat parameter -> image position (the inverse map, for free)
+            }
+            v[e] = a.weights_bf16 ? round_bf16(f) : f;
+        }
+        *reinterpret_cast<wv::f32x4*>(a.wimg + (long long)k * L.imgp + x0) = v;
+        return;
+    }
+    const GenLayout LL = gen_layout(a.hidden);
+    prep_stats(a, blockIdx.x, LL.P, LL.PP);
 }
 
 // ---------------------------------------------------------------------------------------------------------

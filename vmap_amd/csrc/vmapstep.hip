@@ -16,6 +16,7 @@
 
 #include "../../include/vmapstep.h"
 #include "wide_kernels.h"
+#include "split_kernels.h"
 #include "sample_kernels.h"
 #include "query_kernels.h"
 
@@ -54,6 +55,7 @@ struct Plan {
     int G, NG, NW;
     size_t off_stats, off_flags, off_ploss, off_ploss_bytes, off_cnt, off_imgtab, off_pgrad, off_wimg, off_scratch, total;
     bool generic;      // hidden != 32: step_main_gen (global-memory activations) instead of step_main_h32
+    bool split;        // hidden 32 on the bf16 matrix pipe with split operands (step_main_s32; the default at hidden 32)
     int wide;          // hidden 128 / 256: 0 = step_main_gen, 1 = step_main_wide<4> (one tile per workgroup, four waves
                        // per tile), 2 = step_main_wide<2> (four tiles per 512-thread workgroup, two waves per tile)
 };
@@ -106,7 +108,9 @@ int make_plan(const vmapstep_shape* sh, int max_steps, Plan& pl, const Layout& L
     pl.wide = 0;
     const vmapstep_tuning& tun = tuning_of(sh);
     const int force = tun.kernel;
-    if (force < VMAPSTEP_KERNEL_AUTO || force > VMAPSTEP_KERNEL_WIDE2) return fail(VMAPSTEP_ERR_ARGUMENT, "tuning.kernel=%d", force);
+    if (force < VMAPSTEP_KERNEL_AUTO || force > VMAPSTEP_KERNEL_H32_F32) return fail(VMAPSTEP_ERR_ARGUMENT, "tuning.kernel=%d", force);
+    pl.split = !pl.generic && force != VMAPSTEP_KERNEL_H32_F32;
+    if (pl.split && tun.carried_finalize) return fail(VMAPSTEP_ERR_UNSUPPORTED, "the carried finalize exists for the exact-fp32 kernel only (tuning.kernel = VMAPSTEP_KERNEL_H32_F32)");
     if (pl.generic && sh->hidden % 128 == 0 && force != VMAPSTEP_KERNEL_GEN) {
         if (sh->samples <= vk::kWideTile) {
             const int gw = std::min(vk::kWideTile / sh->samples, sh->rays);
@@ -137,7 +141,7 @@ int make_plan(const vmapstep_shape* sh, int max_steps, Plan& pl, const Layout& L
     pl.off_imgtab = o; o += pl.generic ? 0 : align_up((size_t)L.PP * sizeof(int));
     pl.off_pgrad = o; o += align_up((size_t)sh->n_obj * nw_cap * L.PP * sizeof(float));
     const vk::GenLayout GL = vk::gen_layout(sh->hidden);
-    pl.off_wimg = o; o += align_up((size_t)sh->n_obj * GL.imgp * sizeof(float));
+    pl.off_wimg = o; o += align_up(pl.split ? (size_t)sh->n_obj * vk::Img32s::BYTES : (size_t)sh->n_obj * GL.imgp * sizeof(float));
     pl.off_scratch = o;
     if (pl.generic)   // register-image scratch: per wave (step_main_gen) or per workgroup (step_main_wide)
         o += align_up((size_t)sh->n_obj * nw_cap * (pl.wide == 1 ? 1 : vk::kWaves) * vk::gen_wave_blocks(GL.NB) * vk::kBlk * sizeof(float));
@@ -187,6 +191,7 @@ void fill_step_args(vk::StepArgs& a, const vmapstep_shape* sh, const Plan& pl, c
     a.hidden = sh->hidden;
     a.weights_bf16 = sh->weight_dtype == VMAPSTEP_WEIGHTS_BF16 ? 1 : 0;
     a.wide = pl.wide;
+    a.split = pl.split ? 1 : 0;
     a.stats = reinterpret_cast<float*>(ws + pl.off_stats);
     a.flags = reinterpret_cast<int*>(ws + pl.off_flags);
     a.part_loss = reinterpret_cast<float*>(ws + pl.off_ploss);      // half 0; the step loop of a frame alternates (ploss_half)
@@ -260,13 +265,37 @@ int launch_wide(const vk::StepArgs& a, hipStream_t st) {
     return VMAPSTEP_OK;
 }
 
+template <bool BWD, bool MULTI, bool STAMPS, bool W3>
+int launch_split_v(const vk::StepArgs& a, hipStream_t st) {
+    auto kern = vk::step_main_s32<BWD, MULTI, STAMPS, W3>;
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), vk::Img32s::LDS_BYTES, "step_main_s32")) return rc;
+    const int grid = a.xcd_affine ? 8 * ((a.n_obj + 7) / 8) * a.NW : a.n_obj * a.NW;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(vk::kWG), vk::Img32s::LDS_BYTES, st, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "step_main_s32 launch: %s", hipGetErrorString(e));
+    return VMAPSTEP_OK;
+}
+template <bool BWD, bool STAMPS = false>
+int launch_split(const vk::StepArgs& a, hipStream_t st) {
+    const bool multi = a.NW < a.NG;
+    if (a.weights_bf16) return multi ? launch_split_v<BWD, true, STAMPS, false>(a, st) : launch_split_v<BWD, false, STAMPS, false>(a, st);
+    return multi ? launch_split_v<BWD, true, STAMPS, true>(a, st) : launch_split_v<BWD, false, STAMPS, true>(a, st);
+}
+
 template <bool BWD>
 int launch_main(const vk::StepArgs& a, hipStream_t st) {
+    if (a.split) return launch_split<BWD>(a, st);
     if (a.hidden != 32) return a.wide == 1 ? launch_wide<BWD, 4>(a, st) : a.wide == 2 ? launch_wide<BWD, 2>(a, st) : launch_gen<BWD>(a, st);
     return a.NW < a.NG ? launch_main_v<BWD, true>(a, st) : launch_main_v<BWD, false>(a, st);
 }
 
 int launch_prep(const vk::StepArgs& a, int n_steps, hipStream_t st) {
+    if (a.split) {
+        hipLaunchKernelGGL(vk::step_prep_s32, dim3(n_steps + a.n_obj * vk::kSplitPackBlocks), dim3(vk::kWG), 3 * vk::kWG * sizeof(int), st, a);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "step_prep_s32 launch: %s", hipGetErrorString(e));
+        return VMAPSTEP_OK;
+    }
     const int pack_blocks = a.n_obj * (vk::gen_layout(a.hidden).imgp / 1024);
     hipLaunchKernelGGL(vk::step_prep, dim3(n_steps + pack_blocks), dim3(vk::kWG), 3 * vk::kWG * sizeof(int), st, a);
     hipError_t e = hipGetLastError();
@@ -333,6 +362,22 @@ int launch_finalize(const vk::StepArgs& a, const Layout& L, const vmapstep_param
     const int bpo = (L.PP / 4 + vk::kWG - 1) / vk::kWG;
     // + 1: the loss / flag reduction has a workgroup of its own (it used to ride on block 0 and made it the straggler)
     const int grid = (!have_grad ? 0 : f.xcd_affine ? 8 * ((a.n_obj + 7) / 8) * bpo : a.n_obj * bpo) + 1;
+    if (a.split && f.do_adam) {
+        // split image: the table-driven finalize is the only writer of the planes.  A caller that also wants the gradients of
+        // this step gets them from a gradient-only pass of the generic kernel first (same ordered sums).
+        if (grads) {
+            vk::FinalizeArgs fg = f;
+            fg.do_adam = 0;
+            hipLaunchKernelGGL(vk::step_finalize, dim3(grid), dim3(vk::kWG), 2 * vk::kWG * sizeof(float), st, fg);
+            std::memset(f.grad, 0, sizeof(f.grad));
+        }
+        vk::CarryHot h;
+        fill_carry_hot(h, f, a, L, params, 0u);
+        hipLaunchKernelGGL(vk::step_finalize_s32, dim3(grid), dim3(vk::kWG), 2 * vk::kWG * sizeof(float), st, f, h);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "step_finalize_s32 launch: %s", hipGetErrorString(e));
+        return VMAPSTEP_OK;
+    }
     if (!generic_finalize && a.hidden == 32 && a.img_tab && f.do_adam && !grads) {
         // the common training step at hidden 32: table-driven form (same sums, same update, a third of the instructions)
         vk::CarryHot h;
@@ -630,6 +675,7 @@ int vmapstep_profile_phases(const vmapstep_shape* shape, const vmapstep_params* 
     a.timing = timing;
     *n_workgroups = a.xcd_affine ? 8 * ((shape->n_obj + 7) / 8) * pl.NW : shape->n_obj * pl.NW;
     if ((rc = launch_prep(a, 1, st))) return rc;
+    if (a.split) return launch_split<true, true>(a, st);
     return a.NW < a.NG ? launch_main_v<true, true, true>(a, st) : launch_main_v<true, false, true>(a, st);   // the stamped build
 }
 

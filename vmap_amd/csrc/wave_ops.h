@@ -24,6 +24,36 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
+// ---- bf16 matrix pipe (split-bf16 step kernel, split_kernels.h) ----
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+
+// D = A(32x16) * B(16x32) + C on v_mfma_f32_32x32x16_bf16: bf16 operands, fp32 accumulate, 32 cycles per SIMD (1/16 of the
+// exact-fp32 form per MAC) and - unlike the fp32 form - issued next to VALU work of the same wave (measured:
+// profiles/r02a_bf16_probe.jsonl: up to ~6 VALU instructions per matrix instruction are free).
+//   a: lane l supplies A[i = l & 31][k = 8 * (l >> 5) + t], t = 0..7 as four dwords of two bf16 each (low half first)
+//   b: lane l supplies B[k = 8 * (l >> 5) + t][j = l & 31]
+//   c/d: as mfma32
+__device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+// two floats -> one dword of two bfloat16 (round to nearest even), lo in the low half: one v_cvt_pk_bf16_f32
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+// ds_read_b64_tr_b16: within each 16-lane group, lane c receives element (c & 3) of the four consecutive 16-bit words lane
+// 4 * j + (c >> 2) points at, for j = 0..3 (measured: profiles/r02a_bf16_probe.jsonl) - a 4 x 4 transpose across lanes.
+// `p` must be 8-byte aligned.
+__device__ __forceinline__ u32x2 lds_tr16(const void* p) {
+    const s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
+    return __builtin_bit_cast(u32x2, v);
+}
+
 // value held by the partner lane in the other 32-lane half of the wave (lane ^ 32): v_permlane32_swap + select
 // (VALU only; the ds_bpermute form costs an LDS round trip of ~100 cycles that one wave per SIMD cannot hide)
 __device__ __forceinline__ float swap_half(float x) {
@@ -96,6 +126,11 @@ __device__ __forceinline__ float relu(float x) { return __builtin_amdgcn_fmed3f(
 // given the plain h = max(acc, 0) the compiler proves (h > 0) == (acc > 0), evaluates all 80 masks during the forward
 // and parks them in 160 spilled SGPRs.
 __device__ __forceinline__ float opaque(float x) {
+    asm("" : "+v"(x));
+    return x;
+}
+
+__device__ __forceinline__ unsigned opaque_u(unsigned x) {
     asm("" : "+v"(x));
     return x;
 }

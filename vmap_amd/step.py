@@ -50,6 +50,10 @@ class FusedAdamWState:
 class VmapStep:
     """The fused step operator for a fixed (n_obj, rays, samples, hidden) problem shape."""
 
+    # measurement / test hook: plan overrides merged UNDER every new operator's own ``tuning`` (Python-side default only;
+    # the C library keeps no tuning state)
+    default_tuning: Optional[dict] = None
+
     def __init__(self, n_obj: int, rays: int, samples: int, hidden: int, device="cuda:0", max_steps: int = 32,
                  color_scaling: float = 5.0, opacity_scaling: float = 10.0, weights: str = "f32", tuning: Optional[dict] = None):
         """``tuning``: optional overrides of the automatic launch plan for measurements / A-B tests (fields of
@@ -63,6 +67,7 @@ class VmapStep:
             raise ValueError("weights must be 'f32' or 'bf16'")
         self.shape = _lib.Shape(n_obj, rays, samples, hidden, _lib.WEIGHTS_BF16 if weights == "bf16" else _lib.WEIGHTS_F32)
         self._tuning = None
+        tuning = {**(type(self).default_tuning or {}), **(tuning or {})}
         if tuning:
             self._tuning = _lib.Tuning(**tuning)          # kept alive by the operator; the shape points at it
             self.shape.tuning = ctypes.pointer(self._tuning)
