@@ -144,8 +144,12 @@ inline float relu(float x) { return x > 0.0f ? (x < 3.4028234663852886e38f ? x :
 inline float opaque(float x) { return x; }
 inline int opaque_iter(int x) { return x; }
 inline unsigned opaque_u(unsigned x) { return x; }
+inline float after(float x, float) { return x; }
+inline unsigned after_u(unsigned x, unsigned) { return x; }
 
 inline void sched_fence() {}
+template <int NM, int NV>
+inline void interleave_mfma_valu() {}
 
 inline unsigned clock32() { return (unsigned)sim::g_yields; }
 

@@ -79,9 +79,9 @@ def test_fwd_bwd_matches_reference_fixture(name):
     for k in GRAD_KEYS:
         assert not np.isnan(s[k]).any(), k
         assert relerr(s[k], g[k]) < gt, k
-        # second, per-tensor criterion: 99.9 % of the elements within QTOL relative to |ref| + 1e-3 max|ref| (small-magnitude
+        # second, per-tensor criterion: 99.9 % of the elements within 5e-3 of |ref| + 1e-3 max|ref| (i.e. 5e-6 of the tensor's max for its smallest entries) (small-magnitude
         # entries are constrained too; the saturated case keeps its documented noise floor)
-        assert tensor_err_q(s[k], g[k]) < (2e-2 if name == "saturated" else 2e-3), k
+        assert tensor_err_q(s[k], g[k]) < (2e-2 if name == "saturated" else 5e-3), k
     o = vo.training_step(c["fc"], c["B"], c["scale"], c["batch"], dtype=np.float32)
     assert s["flags"][:3].tolist() == [int(x) for x in o["drop"]]
     assert int(s["flags"][3]) == int(o["explode"])

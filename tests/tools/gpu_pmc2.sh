@@ -1,0 +1,12 @@
+# hardware counters of the step kernels (separate --pmc passes, kernel trace only)
+set -x
+mkdir -p gpurun_out/pmc
+export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+cd /tmp
+for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU" "GRBM_GUI_ACTIVE"; do
+  tag=$(echo $C | tr ' ' '_' | cut -c1-40)
+  timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/gpurun_out/pmc/$tag -o p -- python $R/tests/tools/run_steps.py replica_room0_vmap 40 > $R/gpurun_out/pmc/$tag.log 2>&1
+  echo "$tag rc=$?"
+done
+cd $R; python tests/tools/pmc_summary.py > gpurun_out/pmc/summary.json; head -c 3000 gpurun_out/pmc/summary.json

@@ -14,13 +14,15 @@ acc = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(os.path.join(ROOT, "gpurun_out", "pmc", "*", "p_counter_collection.csv")):
     for row in csv.DictReader(open(f)):
         name = row["Kernel_Name"]
-        key = ("step_main_h32" if "step_main_h32" in name else "step_finalize_h32" if "step_finalize_h32" in name
+        key = ("step_main_s32" if "step_main_s32" in name else "step_finalize_s32" if "step_finalize_s32" in name
+               else "step_prep_s32" if "step_prep_s32" in name
+               else "step_main_h32" if "step_main_h32" in name else "step_finalize_h32" if "step_finalize_h32" in name
                else "step_finalize" if "step_finalize" in name
                else "step_prep" if "step_prep" in name else None)
         if key:
             acc[key][row["Counter_Name"]].append(float(row["Counter_Value"]))
 out = {k: {c: sum(v) / len(v) for c, v in sorted(cs.items())} for k, cs in acc.items()}
-m = out.get("step_main_h32", {})
+m = out.get("step_main_s32", out.get("step_main_h32", {}))
 notes = {"units": "FETCH_SIZE/WRITE_SIZE in KiB per dispatch (rocprofv3), other counters summed over the chip per dispatch",
          "collection": "rocprofv3 --kernel-trace --pmc <group> in 7 separate passes over tests/tools/run_steps.py replica_room0_vmap 40"}
 if "FETCH_SIZE" in m and "WRITE_SIZE" in m:

@@ -345,6 +345,45 @@ __device__ __forceinline__ void fwd_step(f32x16& acc, const char* wrow, u32x4 xh
     }
 }
 
+// NS consecutive 16-deep steps of a layer with the weight rows of step s + 1 requested before the matrix instructions of
+// step s are issued (one wave per SIMD: a read issued right in front of its use is a fully exposed LDS round trip)
+template <bool W3, int NS>
+__device__ __forceinline__ void fwd_chain(f32x16& acc, const char* wrow, const unsigned* xh, const unsigned* xm, const unsigned* xl) {
+    using I = Img32s;
+    u32x4 wh = *reinterpret_cast<const u32x4*>(wrow + I::P_HI), wm = wh, wl = wh;
+    if (W3) {
+        wm = *reinterpret_cast<const u32x4*>(wrow + I::P_MID);
+        wl = *reinterpret_cast<const u32x4*>(wrow + I::P_LO);
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        u32x4 nh = wh, nm = wm, nl = wl;
+        if (s + 1 < NS) {
+            nh = *reinterpret_cast<const u32x4*>(wrow + 32 * (s + 1) + I::P_HI);
+            if (W3) {
+                nm = *reinterpret_cast<const u32x4*>(wrow + 32 * (s + 1) + I::P_MID);
+                nl = *reinterpret_cast<const u32x4*>(wrow + 32 * (s + 1) + I::P_LO);
+            }
+        }
+        const u32x4 bh = u32x4{xh[4 * s], xh[4 * s + 1], xh[4 * s + 2], xh[4 * s + 3]};
+        const u32x4 bm = u32x4{xm[4 * s], xm[4 * s + 1], xm[4 * s + 2], xm[4 * s + 3]};
+        const u32x4 bl = u32x4{xl[4 * s], xl[4 * s + 1], xl[4 * s + 2], xl[4 * s + 3]};
+        if (W3) {
+            acc = wv::mfma_bf16(wh, bl, acc);        // smallest terms first
+            acc = wv::mfma_bf16(wl, bh, acc);
+            acc = wv::mfma_bf16(wm, bm, acc);
+            acc = wv::mfma_bf16(wh, bm, acc);
+            acc = wv::mfma_bf16(wm, bh, acc);
+            acc = wv::mfma_bf16(wh, bh, acc);
+        } else {
+            acc = wv::mfma_bf16(wh, bl, acc);
+            acc = wv::mfma_bf16(wh, bm, acc);
+            acc = wv::mfma_bf16(wh, bh, acc);
+        }
+        wh = nh; wm = nm; wl = nl;
+    }
+}
+
 // lane coordinates of the transposing reads: 16-lane group G = lane >> 4 (half = G & 1: which 16 of the operand's 32 rows,
 // hi = G >> 1), c = lane & 15, source-lane role jj = c >> 2 (row of the 4 x 4 block), q = c & 3 (its quad of 4 elements)
 struct TrLane { int half, hi, jj, q; };
@@ -478,6 +517,156 @@ __device__ __forceinline__ void store_quarter_map(float* out_w, float* out_b, co
     }
 }
 
+// after the workgroup barrier that follows a block's staging: reduce this wave's quarter over the four staged tiles and
+// store it (single pass) or keep it (MULTI)
+template <int KIND, int K, bool MULTI>
+__device__ __forceinline__ void finish_block_s(float (&qp)[4], const float* stage, float* out_w, float* out_b, int blk, int ncols,
+                                               int wave, int p31, int hi) {
+    int col; bool bias;
+    col_target<KIND>(blk, p31, col, bias);
+    if (MULTI) {
+        stage_get(qp, stage, wave, p31, hi);
+    } else {
+        float q[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        stage_get(q, stage, wave, p31, hi);
+        store_quarter_map<K>(out_w, out_b, q, col, bias, ncols, wave, hi);
+    }
+}
+
+
+// ---- matrix chains with VALU work interleaved BY HAND.  One wave per SIMD issues in order: a matrix instruction that waits
+// for the pipe blocks everything behind it, so independent VALU work hides behind matrix instructions only when the two are
+// interleaved in the instruction stream (<= 6 VALU per bf16 matrix instruction are free: profiles/r02a_bf16_probe.jsonl).
+// Every helper takes a callable vc(i) that is invoked right after matrix instruction i, between scheduling fences. ----
+template <bool W3, class VC>
+__device__ __forceinline__ void mm_dprop_il(f32x16& acc, const unsigned (&w)[16], const unsigned (&dh)[8], const unsigned (&dm)[8], VC&& vc) {
+    constexpr int PS = W3 ? 3 : 2;
+    wv::sched_fence();
+#pragma unroll
+    for (int i = 0; i < 2 * PS; ++i) {
+        const int s = i / PS, k = i % PS;
+        const u32x4 wh = u32x4{w[4 * s], w[4 * s + 1], w[4 * s + 2], w[4 * s + 3]};
+        const u32x4 wm = u32x4{w[8 + 4 * s], w[8 + 4 * s + 1], w[8 + 4 * s + 2], w[8 + 4 * s + 3]};
+        if (k == 0) acc = wv::mfma_bf16(wh, opnd(dm, s), acc);
+        else if (W3 && k == 1) acc = wv::mfma_bf16(wm, opnd(dh, s), acc);
+        else acc = wv::mfma_bf16(wh, opnd(dh, s), acc);
+        wv::sched_fence();
+        vc(i);
+        wv::sched_fence();
+    }
+}
+constexpr int kDpropMM(bool w3) { return w3 ? 6 : 4; }
+// weight-gradient chain (6 matrix instructions), optionally followed by the 4 of the ones-column bias gradient (DB)
+template <bool DB, class VC>
+__device__ __forceinline__ void mm_dw_il(f32x16& acc, f32x16& accb, const unsigned (&dyF)[16], const unsigned (&xF)[16], VC&& vc) {
+    const u32x4 ones = u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+    wv::sched_fence();
+#pragma unroll
+    for (int i = 0; i < (DB ? 10 : 6); ++i) {
+        if (i < 6) {
+            const int s = i / 3, k = i % 3;
+            const u32x4 ah = u32x4{dyF[4 * s], dyF[4 * s + 1], dyF[4 * s + 2], dyF[4 * s + 3]};
+            const u32x4 am = u32x4{dyF[8 + 4 * s], dyF[8 + 4 * s + 1], dyF[8 + 4 * s + 2], dyF[8 + 4 * s + 3]};
+            const u32x4 bh = u32x4{xF[4 * s], xF[4 * s + 1], xF[4 * s + 2], xF[4 * s + 3]};
+            const u32x4 bm = u32x4{xF[8 + 4 * s], xF[8 + 4 * s + 1], xF[8 + 4 * s + 2], xF[8 + 4 * s + 3]};
+            acc = k == 0 ? wv::mfma_bf16(ah, bm, acc) : k == 1 ? wv::mfma_bf16(am, bh, acc) : wv::mfma_bf16(ah, bh, acc);
+        } else {
+            const int s = (i - 6) / 2, k = (i - 6) % 2;
+            const u32x4 a = k == 0 ? u32x4{dyF[8 + 4 * s], dyF[8 + 4 * s + 1], dyF[8 + 4 * s + 2], dyF[8 + 4 * s + 3]}
+                                   : u32x4{dyF[4 * s], dyF[4 * s + 1], dyF[4 * s + 2], dyF[4 * s + 3]};
+            accb = wv::mfma_bf16(a, ones, accb);
+        }
+        wv::sched_fence();
+        vc(i);
+        wv::sched_fence();
+    }
+}
+// ReLU mask + two-plane split of register pair j of a d-prop result (the VALU work of a hidden unit, one chunk per pair)
+__device__ __forceinline__ void mask_split_pair(int j, const f32x16& v, const unsigned (&hh)[8], unsigned (&dh)[8], unsigned (&dm)[8], float dep) {
+    const unsigned u = wv::opaque_u(hh[j]);
+    const float a = (u & 0xFFFFu) != 0u ? wv::after(v[2 * j], dep) : 0.0f;
+    const float b = u > 0xFFFFu ? v[2 * j + 1] : 0.0f;
+    const unsigned ph = wv::pack_bf16(a, b);
+    dh[j] = ph;
+    dm[j] = wv::pack_bf16(a - bf_lo(ph), b - bf_hi(ph));
+}
+// finishing a staged block in two chunks: 0 = the four 16-byte reads of this wave's quarter, 1 = sum + store (or keep, MULTI)
+struct FinState { wv::f32x4 t0, t1, t2, t3; };
+template <int KIND, int K, bool MULTI>
+__device__ __forceinline__ void fin_chunk(int j, FinState& st, float (&qp)[4], const float* stage, float* out_w, float* out_b, int blk,
+                                          int ncols, int wave, int p31, int hi) {
+    if (j == 0) {
+        const float* rd = stage + p31 * Lds32::TP + 8 * wave + 4 * hi;
+        st.t0 = *reinterpret_cast<const wv::f32x4*>(rd);
+        st.t1 = *reinterpret_cast<const wv::f32x4*>(rd + Lds32::STG_TILE);
+        st.t2 = *reinterpret_cast<const wv::f32x4*>(rd + 2 * Lds32::STG_TILE);
+        st.t3 = *reinterpret_cast<const wv::f32x4*>(rd + 3 * Lds32::STG_TILE);
+    } else {
+        if (MULTI) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) qp[i] += (st.t0[i] + st.t1[i]) + (st.t2[i] + st.t3[i]);
+        } else {
+            float q[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) q[i] = 0.0f + ((st.t0[i] + st.t1[i]) + (st.t2[i] + st.t3[i]));
+            int col; bool bias;
+            col_target<KIND>(blk, p31, col, bias);
+            store_quarter_map<K>(out_w, out_b, q, col, bias, ncols, wave, hi);
+        }
+    }
+}
+
+// One "gap" of the forward: the ReLU + three-plane split of a layer's 16 outputs (16 half-pair chunks of 6-7 VALU
+// instructions) interleaved with NS 16-deep steps of an encoding half that does not depend on them (6 / 3 matrix
+// instructions per step).  wrowB = the lane's weight row of the hi plane at the first of those steps.
+template <bool W3, int NS>
+__device__ __forceinline__ void gap_fill(f32x16& accB, const char* wrowB, const unsigned* xh, const unsigned* xm, const unsigned* xl,
+                                         const f32x16& accA, float (&hf)[16], unsigned (&hh)[8], unsigned (&hm)[8], unsigned (&hl)[8]) {
+    using I = Img32s;
+    constexpr int PS = W3 ? 6 : 3, NM = NS * PS;
+    u32x4 wh[NS], wm[NS], wl[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        wh[s] = *reinterpret_cast<const u32x4*>(wrowB + 32 * s + I::P_HI);
+        if (W3) {
+            wm[s] = *reinterpret_cast<const u32x4*>(wrowB + 32 * s + I::P_MID);
+            wl[s] = *reinterpret_cast<const u32x4*>(wrowB + 32 * s + I::P_LO);
+        }
+    }
+    float ra[8], rb[8];
+    wv::sched_fence();
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+        const int s = m / PS, k = m % PS;
+        const u32x4 bh = u32x4{xh[4 * s], xh[4 * s + 1], xh[4 * s + 2], xh[4 * s + 3]};
+        const u32x4 bm = u32x4{xm[4 * s], xm[4 * s + 1], xm[4 * s + 2], xm[4 * s + 3]};
+        const u32x4 bl = u32x4{xl[4 * s], xl[4 * s + 1], xl[4 * s + 2], xl[4 * s + 3]};
+        if (W3) {
+            accB = k == 0 ? wv::mfma_bf16(wh[s], bl, accB) : k == 1 ? wv::mfma_bf16(wl[s], bh, accB) : k == 2 ? wv::mfma_bf16(wm[s], bm, accB)
+                 : k == 3 ? wv::mfma_bf16(wh[s], bm, accB) : k == 4 ? wv::mfma_bf16(wm[s], bh, accB) : wv::mfma_bf16(wh[s], bh, accB);
+        } else {
+            accB = k == 0 ? wv::mfma_bf16(wh[s], bl, accB) : k == 1 ? wv::mfma_bf16(wh[s], bm, accB) : wv::mfma_bf16(wh[s], bh, accB);
+        }
+        wv::sched_fence();
+#pragma unroll
+        for (int c = m * 16 / NM; c < (m + 1) * 16 / NM; ++c) {
+            const int i = c >> 1;
+            if ((c & 1) == 0) {
+                const float a = wv::relu(wv::after(accA[2 * i], accB[0])), b = wv::relu(accA[2 * i + 1]);   // behind matrix instruction m
+                hf[2 * i] = a; hf[2 * i + 1] = b;
+                const unsigned ph = wv::pack_bf16(a, b);
+                hh[i] = ph;
+                ra[i] = a - bf_lo(ph); rb[i] = b - bf_hi(ph);
+            } else {
+                const unsigned pm = wv::pack_bf16(wv::after(ra[i], accB[0]), rb[i]);
+                hm[i] = pm;
+                hl[i] = wv::pack_bf16(ra[i] - bf_lo(pm), rb[i] - bf_hi(pm));
+            }
+        }
+        wv::sched_fence();
+    }
+}
+
 // sin / cos of the six octaves 2^f * a of one angle: one accurate sincos + five double-angle steps.  2^f * a is exact in
 // float32, so this IS sin(fl32(2^f * proj * pi)) of embedding.py:85-88 up to the recurrence's rounding (~2^f ulp).
 template <bool BIG>
@@ -558,23 +747,12 @@ __device__ __forceinline__ void step_main_s32_body(const StepArgs& a) {
     const int lray = valid ? pt / a.S : 0;
     const int smp = valid ? pt - lray * a.S : 0;
     const int ray = ray0 + lray;
-    float t[3] = {0.0f, 0.0f, 0.0f};
+    float px3[3] = {0.0f, 0.0f, 0.0f};
     if (valid) {
         const float* px = a.pcs + obj * a.pcs_so + ray * a.pcs_sr + smp * a.pcs_ss;
-        t[0] = px[0] / scale;              // embedding.py:83  x / self.scale
-        t[1] = px[a.pcs_sc] / scale;
-        t[2] = px[2 * a.pcs_sc] / scale;
+        px3[0] = px[0]; px3[1] = px[a.pcs_sc]; px3[2] = px[2 * a.pcs_sc];
     }
-    // this lane's directions: hi = 0 -> 0..10, hi = 1 -> 11..20 (+ one dummy)
-    float proj[11];
-#pragma unroll
-    for (int i = 0; i < 11; ++i) {
-        const int d0 = i, d1 = i < 10 ? 11 + i : 20;
-        const float b0 = hi ? Bg[3 * d1] : Bg[3 * d0], b1 = hi ? Bg[3 * d1 + 1] : Bg[3 * d0 + 1], b2 = hi ? Bg[3 * d1 + 2] : Bg[3 * d0 + 2];
-        proj[i] = fmaf(t[2], b2, fmaf(t[1], b1, t[0] * b0));          // embedding.py:84 B_layer(tensor)
-    }
-
-    // ---- asynchronous copy of the parameter image into LDS (lands during the encoding) ----
+    // ---- asynchronous copy of the parameter image into LDS (issued behind the loads of the sample point, whose latency its 20 instructions cover; lands during the encoding) ----
     if (grp == wgo) {
         const char* src = gimg + wave * 1024 + lane * 16;
 #pragma unroll
@@ -589,6 +767,16 @@ __device__ __forceinline__ void step_main_s32_body(const StepArgs& a) {
             if (4 * c + wave < (I::PLANE + 1023) / 1024)
                 wv::glds16(reinterpret_cast<const float*>(src + c * 4096), reinterpret_cast<float*>(lds + I::P_LO + c * 4096 + wave * 1024));
     }
+    const float t[3] = {px3[0] / scale, px3[1] / scale, px3[2] / scale};          // embedding.py:83  x / self.scale (0 for padding lanes)
+    // this lane's directions: hi = 0 -> 0..10, hi = 1 -> 11..20 (+ one dummy)
+    float proj[11];
+#pragma unroll
+    for (int i = 0; i < 11; ++i) {
+        const int d0 = i, d1 = i < 10 ? 11 + i : 20;
+        const float b0 = hi ? Bg[3 * d1] : Bg[3 * d0], b1 = hi ? Bg[3 * d1 + 1] : Bg[3 * d0 + 1], b2 = hi ? Bg[3 * d1 + 2] : Bg[3 * d0 + 2];
+        proj[i] = fmaf(t[2], b2, fmaf(t[1], b1, t[0] * b0));          // embedding.py:84 B_layer(tensor)
+    }
+
     VS_MARK(1);
 
     // ---- encoding (embedding.py:82-91): own directions, octaves by double-angle recurrence ----
@@ -629,41 +817,32 @@ __device__ __forceinline__ void step_main_s32_body(const StepArgs& a) {
     float h4[16], hc[16];
     f32x16 acc;
     {
+        // The layer-to-layer chain (matrix chain -> ReLU -> split into planes -> next matrix chain) would leave the matrix pipe
+        // idle while the ~100 VALU instructions of a split run; the encoding halves of cat_layer and color_linear do not
+        // depend on any hidden layer, so their 54 matrix instructions are interleaved with the four splits (gap_fill).
         unsigned xl[8];
         float hf[16];
+        f32x16 accE, accC;
         const char* w = W + I::O_IN + p31 * I::PIT_IN + 16 * hi;
+        const char* wcat = W + I::O_CAT + p31 * I::PIT_CAT + 16 * hi;
+        const char* wc = W + I::O_C + p31 * I::PIT_C + 16 * hi;
         zero_acc(acc);                                            // the bias rides in the column of the constant-1 slot
-#pragma unroll
-        for (int s = 0; s < 6; ++s) fwd_step<W3>(acc, w + 32 * s, opnd(e1h, s), opnd(e1m, s), opnd(e1l, s));
-        relu_to(hf, acc);                                         // :59 in_layer
-        split_planes<16, 3>(hf, h1h, h1m, xl);
+        fwd_chain<W3, 6>(acc, w, e1h, e1m, e1l);
+        zero_acc(accE);
+        gap_fill<W3, 3>(accE, wcat + 32 * 2, e1h, e1m, e1l, acc, hf, h1h, h1m, xl);                 // :59 in_layer -> h1 | :63 x[:emb1] half, steps 0..2
         w = W + I::O_M1 + p31 * I::PIT_M + 16 * hi;
         load_bias(acc, SM + I::B_M1, hi);
-#pragma unroll
-        for (int s = 0; s < 2; ++s) fwd_step<W3>(acc, w + 32 * s, opnd(h1h, s), opnd(h1m, s), opnd(xl, s));
-        relu_to(hf, acc);                                         // :60 mid1
-        split_planes<16, 3>(hf, h2h, h2m, xl);
-        w = W + I::O_CAT + p31 * I::PIT_CAT + 16 * hi;
-        zero_acc(acc);
-#pragma unroll
-        for (int s = 0; s < 2; ++s) fwd_step<W3>(acc, w + 32 * s, opnd(h2h, s), opnd(h2m, s), opnd(xl, s));     // :63 cat((fc2, x[:emb1]))
-#pragma unroll
-        for (int s = 0; s < 6; ++s) fwd_step<W3>(acc, w + 32 * (2 + s), opnd(e1h, s), opnd(e1m, s), opnd(e1l, s));
-        relu_to(hf, acc);                                         // :64 cat_layer
-        split_planes<16, 3>(hf, h3h, h3m, xl);
+        fwd_chain<W3, 2>(acc, w, h1h, h1m, xl);
+        gap_fill<W3, 3>(accE, wcat + 32 * 5, e1h + 12, e1m + 12, e1l + 12, acc, hf, h2h, h2m, xl);  // :60 mid1 -> h2 | steps 3..5
+        fwd_chain<W3, 2>(accE, wcat, h2h, h2m, xl);                                                  // :63 cat((fc2, x[:emb1]))
+        zero_acc(accC);
+        gap_fill<W3, 2>(accC, wc + 32 * 2, e2h, e2m, e2l, accE, hf, h3h, h3m, xl);                  // :64 cat_layer -> h3 | :81 x[emb1:] half, steps 0, 1
         w = W + I::O_M2 + p31 * I::PIT_M + 16 * hi;
         load_bias(acc, SM + I::B_M2, hi);
-#pragma unroll
-        for (int s = 0; s < 2; ++s) fwd_step<W3>(acc, w + 32 * s, opnd(h3h, s), opnd(h3m, s), opnd(xl, s));
-        relu_to(h4, acc);                                         // :67 mid2
-        split_planes<16, 3>(h4, h4h, h4m, xl);
-        w = W + I::O_C + p31 * I::PIT_C + 16 * hi;
-        zero_acc(acc);
-#pragma unroll
-        for (int s = 0; s < 2; ++s) fwd_step<W3>(acc, w + 32 * s, opnd(h4h, s), opnd(h4m, s), opnd(xl, s));     // :81 cat((fc4, x[emb1:]))
-#pragma unroll
-        for (int s = 0; s < 3; ++s) fwd_step<W3>(acc, w + 32 * (2 + s), opnd(e2h, s), opnd(e2m, s), opnd(e2l, s));
-        relu_to(hc, acc);                                         // :81 color_linear
+        fwd_chain<W3, 2>(acc, w, h3h, h3m, xl);
+        gap_fill<W3, 1>(accC, wc + 32 * 4, e2h + 8, e2m + 8, e2l + 8, acc, h4, h4h, h4m, xl);       // :67 mid2 -> h4 | step 2
+        fwd_chain<W3, 2>(accC, wc, h4h, h4m, xl);                                                    // :81 cat((fc4, x[emb1:]))
+        relu_to(hc, accC);                                        // :81 color_linear
     }
     VS_MARK(3);
     {
@@ -709,7 +888,7 @@ __device__ __forceinline__ void step_main_s32_body(const StepArgs& a) {
         const float* row = cb + pt * 8;          // pt < kMaxPts always; padding rows hold zeros
         d_raw = row[0]; d_c0 = row[1]; d_c1 = row[2]; d_c2 = row[3];
     }
-    unsigned xF[16], dF[16], w[16];
+    unsigned dF[16];
     float dproj[11];
 #pragma unroll
     for (int i = 0; i < 11; ++i) dproj[i] = 0.0f;
@@ -752,183 +931,191 @@ __device__ __forceinline__ void step_main_s32_body(const StepArgs& a) {
         }
         split_planes<16, 2>(dcp, dch, dcm, xl_unused);
     }
-    f32x16 acc2;
-    float dv[16];
-    // ---- units 0..2: colour layer (delta = d hc) ----
+    // ---- 13 units, one 32x32 weight-gradient block each.  Per unit two matrix chains, each with VALU work interleaved by
+    // hand (one wave per SIMD issues in order):
+    //   A: d-prop chain  W^T . delta          next to  finishing the block staged two units ago + staging the last block
+    //   B: weight-gradient chain  delta^T . x  next to  the VALU work on A's result (ReLU mask + split of the next delta,
+    //                                                   or the encoding's d(projection) sums)
+    // and the operands are requested ONE UNIT AHEAD: transposed weight columns (wA / wB), the F-form of the next input block
+    // (xA / xB; the tile is refilled as soon as its previous content has been read); a new delta is transposed behind B. ----
+    f32x16 acc2, accb;
+    FinState fs;
+    unsigned wA[16], wB[16], xA[16], xB[16];
+    unsigned d3h[8], d3m[8], d2h[8], d2m[8], d1h[8], d1m[8], dF3[16], dF1[16];
+    constexpr int NA = kDpropMM(W3);
+    const auto nothing = [](int) {};
+#define VS_FIN(KIND, K, QI, STG, OW, OB, BLK, NC)                                                                             \
+    [&](int i) {                                                                                                              \
+        if (i == 0) fin_chunk<KIND, K, MULTI>(0, fs, qacc[QI], STG, OW, OB, BLK, NC, wave, p31, hi);                          \
+        if (i == NA - 3) fin_chunk<KIND, K, MULTI>(1, fs, qacc[QI], STG, OW, OB, BLK, NC, wave, p31, hi);                     \
+    }
     tile_put<4>(scrD, dch, dcm, p31, hi);
-    tile_get(dF, scrD, TL);
-    // unit 0: x = h4;  d h4 = W_a d raw + W_c[:, :H]^T d hc
     tile_put<4>(scrX, h4h, h4m, p31, hi);
-    tile_get(xF, scrX, TL);
-    wt_get<I::PIT_C, W3>(w, W + I::O_C, 0, TL);
+    wt_get<I::PIT_C, W3>(wA, W + I::O_C, 0, TL);
+    tile_get(dF, scrD, TL);                                       // F(d hc): the delta of units 0..2
+    tile_get(xA, scrX, TL);                                       // F(h4)
+    tile_put<4>(scrX, e2h, e2m, p31, hi);                         // x of unit 1
+    wt_get<I::PIT_C, W3>(wB, W + I::O_C, 2, TL);
+    // unit 0: colour layer x h4;  d h4 = W_a d raw + W_c[:, :H]^T d hc
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc2[r] = SM[I::W_A + phi(r, hi)] * d_raw;
-    dprop_mm<W3>(acc2, w, dch, dcm);
-    relu_mask(dv, acc2, h4h);
-    split_planes<16, 2>(dv, d4h, d4m, xl_unused);
+    mm_dprop_il<W3>(acc2, wA, dch, dcm, nothing);
+    tile_get(xB, scrX, TL);                                       // F(second-group slots 0..15)
     zero_acc(acc);
-    dw_mm_s(acc, dF, xF);
-    stage_put(stg0, acc, wave, p31, hi);
+    mm_dw_il<false>(acc, accb, dF, xA, [&](int i) {
+#pragma unroll
+        for (int j = i * 8 / 6; j < (i + 1) * 8 / 6; ++j) mask_split_pair(j, acc2, h4h, d4h, d4m, acc[0]);
+    });
+    tile_put<2>(scrX, e2h + 8, e2m + 8, p31, hi);                 // x of unit 2 (half a block)
+    wt_get<I::PIT_C, W3>(wA, W + I::O_C, 4, TL);
+    tile_put<4>(scrD, d4h, d4m, p31, hi);                         // delta of unit 3 (F(d hc) stays in dF for units 1, 2)
+    __syncthreads();
     // unit 1: x = second-group slots 0..15
-    tile_put<4>(scrX, e2h, e2m, p31, hi);
-    tile_get(xF, scrX, TL);
-    wt_get<I::PIT_C, W3>(w, W + I::O_C, 2, TL);
     zero_acc(acc2);
-    dprop_mm<W3>(acc2, w, dch, dcm);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) dproj[r >> 1] += acc2[r] * cfac[r >> 1][4 + (r & 1)];          // d e2 slot R = r: direction r >> 1, octave 4 + (r & 1)
+    mm_dprop_il<W3>(acc2, wB, dch, dcm, [&](int i) { if (i == NA - 1) stage_put(stg0, acc, wave, p31, hi); });       // block 0
+    tile_get(xA, scrX, TL);                                       // F(second-group slots 16..23)
+    tile_put<4>(scrX, h3h, h3m, p31, hi);                         // x of unit 3
+    wt_get<I::PIT_M, W3>(wB, W + I::O_M2, 0, TL);
     zero_acc(acc);
-    dw_mm_s(acc, dF, xF);
+    mm_dw_il<false>(acc, accb, dF, xB, [&](int i) {
+        if (i < 4) {
+#pragma unroll
+            for (int r = 4 * i; r < 4 * i + 4; ++r) dproj[r >> 1] += wv::after(acc2[r], acc[0]) * cfac[r >> 1][4 + (r & 1)];     // slot R = r: direction r >> 1, octave 4 + (r & 1)
+        }
+    });
     __syncthreads();
-    {
-        int col; bool bias;
-        col_target<0>(0, p31, col, bias);
-        if (MULTI) stage_get(qacc[0], stg0, wave, p31, hi);
-        else { float q[4] = {0, 0, 0, 0}; stage_get(q, stg0, wave, p31, hi); store_quarter_map<H + kEmb2>(out + F::W_C, nullptr, q, col, bias, 32, wave, hi); }
-    }
-    stage_put(stg1, acc, wave, p31, hi);
-    // unit 2: x = second-group slots 16..23 (half a block)
-    tile_put<2>(scrX, e2h + 8, e2m + 8, p31, hi);
-    tile_get(xF, scrX, TL);
-    wt_get<I::PIT_C, W3>(w, W + I::O_C, 4, TL);
+    // unit 2: x = second-group slots 16..23
     zero_acc(acc2);
-    dprop_mm<W3>(acc2, w, dch, dcm);
-#pragma unroll
-    for (int r = 0; r < 6; ++r) dproj[8 + (r >> 1)] += acc2[r] * cfac[8 + (r >> 1)][4 + (r & 1)];  // slots 16..21: directions 8..10
-    zero_acc(acc);
-    dw_mm_s(acc, dF, xF);
-    __syncthreads();
     {
-        int col; bool bias;
-        col_target<2>(0, p31, col, bias);
-        if (MULTI) stage_get(qacc[1], stg1, wave, p31, hi);
-        else { float q[4] = {0, 0, 0, 0}; stage_get(q, stg1, wave, p31, hi); store_quarter_map<H + kEmb2>(out + F::W_C + H, out + F::B_C, q, col, bias, kEmb2, wave, hi); }
+        auto fin = VS_FIN(0, H + kEmb2, 0, stg0, out + F::W_C, nullptr, 0, 32);
+        mm_dprop_il<W3>(acc2, wA, dch, dcm, [&](int i) { fin(i); if (i == NA - 1) stage_put(stg1, acc, wave, p31, hi); });   // block 1
     }
-    stage_put(stg0, acc, wave, p31, hi);
+    tile_get(xB, scrX, TL);                                       // F(h3)
+    tile_put<4>(scrX, h2h, h2m, p31, hi);                         // x of unit 4
+    wt_get<I::PIT_CAT, W3>(wA, W + I::O_CAT, 0, TL);
+    zero_acc(acc);
+    mm_dw_il<false>(acc, accb, dF, xA, [&](int i) {
+        if (i < 3) {
+#pragma unroll
+            for (int r = 2 * i; r < 2 * i + 2; ++r) dproj[8 + (r >> 1)] += wv::after(acc2[r], acc[0]) * cfac[8 + (r >> 1)][4 + (r & 1)];   // slots 16..21: directions 8..10
+        }
+    });
+    tile_get(dF, scrD, TL);                                       // F(d4)
+    __syncthreads();
     VS_MARK(7);
-    // ---- unit 3: mid2, delta = d4, x = h3 ----
-    unsigned d3h[8], d3m[8], dF3[16];
-    tile_put<4>(scrD, d4h, d4m, p31, hi);
-    tile_get(dF, scrD, TL);
-    tile_put<4>(scrX, h3h, h3m, p31, hi);
-    tile_get(xF, scrX, TL);
-    wt_get<I::PIT_M, W3>(w, W + I::O_M2, 0, TL);
+    // unit 3: mid2, delta = d4, x = h3
     zero_acc(acc2);
-    dprop_mm<W3>(acc2, w, d4h, d4m);
-    relu_mask(dv, acc2, h3h);
-    split_planes<16, 2>(dv, d3h, d3m, xl_unused);
-    db_ones(Gv + I::B_M2, dF, p31, hi);
-    zero_acc(acc);
-    dw_mm_s(acc, dF, xF);
-    __syncthreads();
     {
-        int col; bool bias;
-        col_target<2>(1, p31, col, bias);
-        if (MULTI) stage_get(qacc[2], stg0, wave, p31, hi);
-        else { float q[4] = {0, 0, 0, 0}; stage_get(q, stg0, wave, p31, hi); store_quarter_map<H + kEmb2>(out + F::W_C + H, out + F::B_C, q, col, bias, kEmb2, wave, hi); }
+        auto fin = VS_FIN(2, H + kEmb2, 1, stg1, out + F::W_C + H, out + F::B_C, 0, kEmb2);
+        mm_dprop_il<W3>(acc2, wB, d4h, d4m, [&](int i) { fin(i); if (i == NA - 1) stage_put(stg0, acc, wave, p31, hi); });   // block 2
     }
-    stage_put(stg1, acc, wave, p31, hi);
-    VS_MARK(8);
-    // ---- unit 4: cat_layer, delta = d3 (its F-form is kept for the three first-group blocks), x = h2 ----
-    unsigned d2h[8], d2m[8];
+    tile_get(xA, scrX, TL);                                       // F(h2)
+    tile_put<4>(scrX, h1h, h1m, p31, hi);                         // x of unit 5
+    wt_get<I::PIT_M, W3>(wB, W + I::O_M1, 0, TL);
+    zero_acc(acc);
+    zero_acc(accb);
+    mm_dw_il<true>(acc, accb, dF, xB, [&](int i) {
+#pragma unroll
+        for (int j = i * 8 / 10; j < (i + 1) * 8 / 10; ++j) mask_split_pair(j, acc2, h3h, d3h, d3m, i < 6 ? acc[0] : accb[0]);
+    });
+    if (p31 == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Gv[I::B_M2 + phi(r, hi)] += accb[r];
+    }
     tile_put<4>(scrD, d3h, d3m, p31, hi);
-    tile_get(dF3, scrD, TL);
-    tile_put<4>(scrX, h2h, h2m, p31, hi);
-    tile_get(xF, scrX, TL);
-    wt_get<I::PIT_CAT, W3>(w, W + I::O_CAT, 0, TL);
-    zero_acc(acc2);
-    dprop_mm<W3>(acc2, w, d3h, d3m);
-    relu_mask(dv, acc2, h2h);
-    split_planes<16, 2>(dv, d2h, d2m, xl_unused);
-    zero_acc(acc);
-    dw_mm_s(acc, dF3, xF);
+    tile_get(dF3, scrD, TL);                                      // F(d3): kept for the three first-group blocks
     __syncthreads();
+    VS_MARK(8);
+    // unit 4: cat_layer, delta = d3, x = h2
+    zero_acc(acc2);
     {
-        int col; bool bias;
-        col_target<0>(0, p31, col, bias);
-        if (MULTI) stage_get(qacc[3], stg1, wave, p31, hi);
-        else { float q[4] = {0, 0, 0, 0}; stage_get(q, stg1, wave, p31, hi); store_quarter_map<H>(out + F::W_M2, nullptr, q, col, bias, 32, wave, hi); }
+        auto fin = VS_FIN(2, H + kEmb2, 2, stg0, out + F::W_C + H, out + F::B_C, 1, kEmb2);
+        mm_dprop_il<W3>(acc2, wA, d3h, d3m, [&](int i) { fin(i); if (i == NA - 1) stage_put(stg1, acc, wave, p31, hi); });   // block 3
     }
-    stage_put(stg0, acc, wave, p31, hi);
-    VS_MARK(9);
-    // ---- unit 5: mid1, delta = d2, x = h1 ----
-    unsigned d1h[8], d1m[8], dF1[16];
+    tile_get(xB, scrX, TL);                                       // F(h1)
+    tile_put<4>(scrX, e1h, e1m, p31, hi);                         // x of units 6, 7
+    wt_get<I::PIT_CAT, W3>(wA, W + I::O_CAT, 2, TL);
+    zero_acc(acc);
+    mm_dw_il<false>(acc, accb, dF3, xA, [&](int i) {
+#pragma unroll
+        for (int j = i * 8 / 6; j < (i + 1) * 8 / 6; ++j) mask_split_pair(j, acc2, h2h, d2h, d2m, acc[0]);
+    });
     tile_put<4>(scrD, d2h, d2m, p31, hi);
-    tile_get(dF, scrD, TL);
-    tile_put<4>(scrX, h1h, h1m, p31, hi);
-    tile_get(xF, scrX, TL);
-    wt_get<I::PIT_M, W3>(w, W + I::O_M1, 0, TL);
-    zero_acc(acc2);
-    dprop_mm<W3>(acc2, w, d2h, d2m);
-    relu_mask(dv, acc2, h1h);
-    split_planes<16, 2>(dv, d1h, d1m, xl_unused);
-    db_ones(Gv + I::B_M1, dF, p31, hi);
-    zero_acc(acc);
-    dw_mm_s(acc, dF, xF);
+    tile_get(dF, scrD, TL);                                       // F(d2)
     __syncthreads();
+    VS_MARK(9);
+    // unit 5: mid1, delta = d2, x = h1
+    zero_acc(acc2);
     {
-        int col; bool bias;
-        col_target<0>(0, p31, col, bias);
-        if (MULTI) stage_get(qacc[4], stg0, wave, p31, hi);
-        else { float q[4] = {0, 0, 0, 0}; stage_get(q, stg0, wave, p31, hi); store_quarter_map<H + kEmb1>(out + F::W_CAT, nullptr, q, col, bias, 32, wave, hi); }
+        auto fin = VS_FIN(0, H, 3, stg1, out + F::W_M2, nullptr, 0, 32);
+        mm_dprop_il<W3>(acc2, wB, d2h, d2m, [&](int i) { fin(i); if (i == NA - 1) stage_put(stg0, acc, wave, p31, hi); });   // block 4
     }
-    stage_put(stg1, acc, wave, p31, hi);
-    // delta d1 transposed once for the three in_layer blocks
+    tile_get(xA, scrX, TL);                                       // F(first-group block 0)
+    wt_get<I::PIT_IN, W3>(wB, W + I::O_IN, 0, TL);
+    zero_acc(acc);
+    zero_acc(accb);
+    mm_dw_il<true>(acc, accb, dF, xB, [&](int i) {
+#pragma unroll
+        for (int j = i * 8 / 10; j < (i + 1) * 8 / 10; ++j) mask_split_pair(j, acc2, h1h, d1h, d1m, i < 6 ? acc[0] : accb[0]);
+    });
+    if (p31 == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Gv[I::B_M1 + phi(r, hi)] += accb[r];
+    }
     tile_put<4>(scrD, d1h, d1m, p31, hi);
-    tile_get(dF1, scrD, TL);
+    tile_get(dF1, scrD, TL);                                      // F(d1): kept for the three in_layer blocks
+    __syncthreads();
     VS_MARK(10);
-    // ---- units 6..11: the three first-group blocks feed cat_layer (delta d3) and in_layer (delta d1) ----
+    // units 6..11: the three first-group blocks feed cat_layer (delta d3, weights wA) and in_layer (delta d1, weights wB);
+    // the block's F-form alternates between xA and xB
     f32x16 de;
 #pragma unroll
     for (int blk = 0; blk < 3; ++blk) {
-        tile_put<4>(scrX, e1h + 8 * blk, e1m + 8 * blk, p31, hi);
-        tile_get(xF, scrX, TL);                                   // after the last block xF = its F-form, used by the B unit
-        // cat_layer x block
-        wt_get<I::PIT_CAT, W3>(w, W + I::O_CAT, 2 + 2 * blk, TL);
+        unsigned (&xc)[16] = (blk & 1) ? xB : xA;
+        unsigned (&xn)[16] = (blk & 1) ? xA : xB;
+        // cat_layer x block: finishes block 4 (blk 0) or the cat block of the previous round; stages the last in / mid1 block
         zero_acc(de);
-        dprop_mm<W3>(de, w, d3h, d3m);
-        zero_acc(acc);
-        dw_mm_s(acc, dF3, xF);
-        __syncthreads();
-        {
-            // finishes the block staged before this one: blk 0: mid1 (W_M1); else the in_layer block blk - 1
-            float* sprev = stg1;
-            if (blk == 0) {
-                int col; bool bias;
-                col_target<0>(0, p31, col, bias);
-                if (MULTI) stage_get(qacc[5], sprev, wave, p31, hi);
-                else { float q[4] = {0, 0, 0, 0}; stage_get(q, sprev, wave, p31, hi); store_quarter_map<H>(out + F::W_M1, nullptr, q, col, bias, 32, wave, hi); }
-            } else {
-                int col; bool bias;
-                col_target<1>(blk - 1, p31, col, bias);
-                if (MULTI) stage_get(qacc[8 + blk], sprev, wave, p31, hi);
-                else { float q[4] = {0, 0, 0, 0}; stage_get(q, sprev, wave, p31, hi); store_quarter_map<kEmb1>(out + F::W_IN, out + F::B_IN, q, col, bias, kEmb1, wave, hi); }
-            }
+        if (blk == 0) {
+            auto fin = VS_FIN(0, H + kEmb1, 4, stg0, out + F::W_CAT, nullptr, 0, 32);
+            mm_dprop_il<W3>(de, wA, d3h, d3m, [&](int i) { fin(i); if (i == NA - 1) stage_put(stg1, acc, wave, p31, hi); });   // block 5
+        } else {
+            auto fin = VS_FIN(1, H + kEmb1, 6 + blk - 1, stg0, out + F::W_CAT + H, out + F::B_CAT, blk - 1, kEmb1);
+            mm_dprop_il<W3>(de, wA, d3h, d3m, [&](int i) { fin(i); if (i == NA - 1) stage_put(stg1, acc, wave, p31, hi); });   // block 9 + blk - 1
         }
-        stage_put(stg0, acc, wave, p31, hi);
-        // in_layer x block
-        wt_get<I::PIT_IN, W3>(w, W + I::O_IN, 2 * blk, TL);
-        dprop_mm<W3>(de, w, d1h, d1m);
-        // d(first-group slot R = 16 blk + r) -> direction R >> 2, octave R & 3 (slots 44..47: xyz / one / padding: no gradient)
+        if (blk < 2) {
+            tile_put<4>(scrX, e1h + 8 * (blk + 1), e1m + 8 * (blk + 1), p31, hi);
+            wt_get<I::PIT_CAT, W3>(wA, W + I::O_CAT, 2 + 2 * (blk + 1), TL);
+            tile_get(xn, scrX, TL);
+        }
+        zero_acc(acc);
+        mm_dw_il<false>(acc, accb, dF3, xc, nothing);
+        __syncthreads();
+        // in_layer x block: finishes the mid1 block (blk 0) or the previous round's in block; stages this round's cat block
+        if (blk == 0) {
+            auto fin = VS_FIN(0, H, 5, stg1, out + F::W_M1, nullptr, 0, 32);
+            mm_dprop_il<W3>(de, wB, d1h, d1m, [&](int i) { fin(i); if (i == NA - 1) stage_put(stg0, acc, wave, p31, hi); });   // block 6 + blk
+        } else {
+            auto fin = VS_FIN(1, kEmb1, 9 + blk - 1, stg1, out + F::W_IN, out + F::B_IN, blk - 1, kEmb1);
+            mm_dprop_il<W3>(de, wB, d1h, d1m, [&](int i) { fin(i); if (i == NA - 1) stage_put(stg0, acc, wave, p31, hi); });   // block 6 + blk
+        }
+        if (blk < 2) wt_get<I::PIT_IN, W3>(wB, W + I::O_IN, 2 * (blk + 1), TL);
+        zero_acc(acc);
+        mm_dw_il<false>(acc, accb, dF1, xc, [&](int i) {
+            // d(first-group slot R = 16 blk + r) -> direction R >> 2, octave R & 3 (slots 44..47: xyz / one / padding: no gradient)
+            if (i < 4) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int R = 16 * blk + r;
-            if (R < 44) dproj[R >> 2] += de[r] * cfac[R >> 2][R & 3];
-        }
-        zero_acc(acc);
-        dw_mm_s(acc, dF1, xF);
+                for (int r = 4 * i; r < 4 * i + 4; ++r) {
+                    const int R = 16 * blk + r;
+                    if (R < 44) dproj[R >> 2] += wv::after(de[r], acc[0]) * cfac[R >> 2][R & 3];
+                }
+            }
+        });
         __syncthreads();
-        {
-            int col; bool bias;
-            col_target<1>(blk, p31, col, bias);
-            if (MULTI) stage_get(qacc[6 + blk], stg0, wave, p31, hi);
-            else { float q[4] = {0, 0, 0, 0}; stage_get(q, stg0, wave, p31, hi); store_quarter_map<H + kEmb1>(out + F::W_CAT + H, out + F::B_CAT, q, col, bias, kEmb1, wave, hi); }
-        }
-        stage_put(stg1, acc, wave, p31, hi);
     }
+    VS_MARK(11);
     VS_MARK(12);
     // ---- unit 12: B_layer.weight gradient: dB[d][j] = sum_points dproj[d] * t[j]; t = slots 44..46 of the hi = 0 lanes
-    //      = features 24..26 of the last first-group block, whose F-form is still in xF ----
+    //      = features 24..26 of the last first-group block, whose F-form is still in xA ----
     {
         float dpP[16];
         unsigned dph[8], dpm[8];
@@ -937,15 +1124,14 @@ __device__ __forceinline__ void step_main_s32_body(const StepArgs& a) {
         split_planes<16, 2>(dpP, dph, dpm, xl_unused);
         tile_put<4>(scrD, dph, dpm, p31, hi);
         tile_get(dF, scrD, TL);
+        // finish the last cat block (staged in stg0), stage the last in block
+        fin_chunk<1, H + kEmb1, MULTI>(0, fs, qacc[8], stg0, out + F::W_CAT + H, out + F::B_CAT, 2, kEmb1, wave, p31, hi);
+        stage_put(stg1, acc, wave, p31, hi);                      // block 11
+        fin_chunk<1, H + kEmb1, MULTI>(1, fs, qacc[8], stg0, out + F::W_CAT + H, out + F::B_CAT, 2, kEmb1, wave, p31, hi);
         zero_acc(acc);
-        dw_mm_s(acc, dF, xF);
+        mm_dw_il<false>(acc, accb, dF, xA, nothing);
         __syncthreads();
-        {
-            int col; bool bias;
-            col_target<1>(2, p31, col, bias);
-            if (MULTI) stage_get(qacc[11], stg1, wave, p31, hi);
-            else { float q[4] = {0, 0, 0, 0}; stage_get(q, stg1, wave, p31, hi); store_quarter_map<kEmb1>(out + F::W_IN, out + F::B_IN, q, col, bias, kEmb1, wave, hi); }
-        }
+        finish_block_s<1, kEmb1, MULTI>(qacc[11], stg1, out + F::W_IN, out + F::B_IN, 2, kEmb1, wave, p31, hi);
         stage_put(stg0, acc, wave, p31, hi);
         __syncthreads();
         float q[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -954,13 +1140,12 @@ __device__ __forceinline__ void step_main_s32_body(const StepArgs& a) {
         if (!MULTI && p31 >= 24 && p31 < 27) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int row = 8 * wave + 4 * hi + i;                 // = phi(r, hs): hs = hi, r = i + 4 * wave
-                const int r = i + 4 * wave, d = hi ? 11 + r : r;
+                const int r = i + 4 * wave, d = hi ? 11 + r : r;          // row 8 wave + 4 hi + i = phi(r, hi)
                 if (r < (hi ? 10 : 11)) out[F::PE_B + 3 * d + (p31 - 24)] = q[i];
-                (void)row;
             }
         }
     }
+#undef VS_FIN
     VS_MARK(13);
     }   // BWD
     if (!MULTI) break;      // one pass per workgroup: no back edge

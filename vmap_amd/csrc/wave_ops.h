@@ -135,6 +135,18 @@ __device__ __forceinline__ unsigned opaque_u(unsigned x) {
     return x;
 }
 
+// Ordering ties for hand-interleaved instruction streams (no instruction): the returned copy of x exists only after y does,
+// so work that consumes the copy cannot be scheduled in front of the producer of y.  (Scheduling fences alone do not pin
+// side-effect-free arithmetic: it is placed before instruction scheduling sees the fences.)
+__device__ __forceinline__ float after(float x, float y) {
+    asm volatile("" : "+v"(x) : "v"(y));
+    return x;
+}
+__device__ __forceinline__ unsigned after_u(unsigned x, unsigned y) {
+    asm volatile("" : "+v"(x) : "v"(y));
+    return x;
+}
+
 // An integer the optimiser must assume changes at every execution (no instruction).  step_main_h32's multi-pass loop
 // re-derives its lane coordinates from opaque_iter(threadIdx.x): otherwise every lane mask and LDS address of the
 // 6000-instruction body is loop-invariant, gets hoisted in front of the loop and is kept in (spilled) registers.
@@ -145,6 +157,19 @@ __device__ __forceinline__ int opaque_iter(int x) {
 
 // nothing may be moved across this point by the instruction scheduler (hand-placed software pipelining)
 __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+
+// Scheduling-region directive: the next instructions of the region are emitted as NM groups of {1 matrix instruction, NV VALU
+// instructions} (LLVM sched_group_barrier; masks: VALU 0x2, MFMA 0x8).  One wave per SIMD issues in order: a matrix
+// instruction that waits for the pipe blocks the VALU work behind it, so independent VALU work only hides behind matrix
+// instructions when it is INTERLEAVED with them (<= 6 per bf16 matrix instruction are free, profiles/r02a_bf16_probe.jsonl).
+template <int NM, int NV>
+__device__ __forceinline__ void interleave_mfma_valu() {
+#pragma unroll
+    for (int i = 0; i < NM; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x2, NV, 0);
+    }
+}
 
 __device__ __forceinline__ unsigned clock32() { return (unsigned)__builtin_amdgcn_s_memtime(); }
 
