@@ -112,6 +112,9 @@ def main():
     ap.add_argument("--profile-reps", type=int, default=200)
     ap.add_argument("--preheat-ms", type=float, default=PREHEAT_MS_DEFAULT)   # untimed device pre-heat in front of the warm-up (named in the JSON)
     ap.add_argument("--no-gpu-baseline", action="store_true")
+    ap.add_argument("--with-background", action="store_true")      # also train the SHARED background model (train.py:308-316; hidden 128,
+                                                                     # 1200 rays / step split over the ranks, ONE gradient all-reduce per
+                                                                     # step) next to the objects, on a second stream; reported separately
     ap.add_argument("--timed-only", action="store_true")            # skip the roofline / baseline legs (for kernel traces of the timed region)
     ap.add_argument("--unbound", action="store_true")               # marshal the arguments on every frame call (VmapStep.train_steps)
     args = ap.parse_args()
@@ -176,6 +179,48 @@ def main():
             td.barrier()
         torch.cuda.synchronize()
 
+    # ---- the shared background model (the north star's one collective): replicas + ray sharding ----
+    bg = None
+    if args.with_background:
+        from vmap_amd import fields, parallel
+        bcfg = synth.CONFIGS["background"]
+        torch.manual_seed(7)                                          # the same replica on every rank
+        bfc = fields.OccupancyMap(hidden_size=bcfg["H"])
+        bfc.apply(fields.init_weights)
+        bpe = fields.UniDirsEmbed(max_deg=5, scale=bcfg["scale"])
+        bR = bcfg["R"] // world                                       # this rank's share of the 1200 background rays of a step
+        bframe = synth.make_batch(1, bcfg["R"] * ipf, bcfg["S"], seed=77)
+        idx = np.concatenate([np.arange(i * bcfg["R"] + rank, i * bcfg["R"] + bR * world, world) for i in range(ipf)])
+        bloc = tuple(torch.from_numpy(np.ascontiguousarray(bframe[k][0][idx])).to(dev) for k in ("pcs", "z", "gt_depth", "gt_rgb", "sem", "depth_mask"))
+        bg_stream = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(bg_stream):
+            bg = parallel.SharedBackgroundHip(bfc, bpe, bR, bcfg["S"], dev, max_steps=ipf)
+        bg_info = {"hidden": bcfg["H"], "rays_per_step_all_ranks": bR * world, "rays_per_step_this_rank": bR, "samples_per_ray": bcfg["S"],
+                   "collectives": "per frame: one all_reduce(SUM) of the [steps, 4] mask counts; per step: ONE all_reduce(SUM) of "
+                                  f"[gradient slab | loss] = {bg.buf.numel() * 4} bytes between two launches"}
+
+    def run_with_bg(n_steps):
+        """objects on the current stream, the background frame on its own stream, joined per frame call"""
+        done = 0
+        cur = torch.cuda.current_stream(dev)
+        while done < n_steps:
+            k = min(ipf, n_steps - done)
+            fork = torch.cuda.Event()
+            fork.record(cur)
+            bg_stream.wait_event(fork)
+            with torch.cuda.stream(bg_stream):
+                bg.prepare_frame(*bloc, n_steps=k)
+                for i in range(k):
+                    bg.step_prepared(i)
+                join = torch.cuda.Event()
+                join.record(bg_stream)
+            if bound is not None:
+                bound.train_steps(k)
+            else:
+                op.train_steps(tfc, tB, tsc, *fargs, opt=opt, n_steps=k, flag_reduce=flag_reduce)
+            cur.wait_event(join)
+            done += k
+
     preheat_steps = 0
     if args.preheat_ms > 0:
         # Untimed device pre-heat (NOT part of the W warm-up steps and NOT timed): the same frame call repeated for
@@ -199,14 +244,40 @@ def main():
     rays_per_step = n * R * world
     value = rays_per_step / (elapsed / args.steps)
 
+    with_bg = None
+    if bg is not None:
+        run_with_bg(args.warmup)
+        barrier()
+        t0 = time.perf_counter()
+        run_with_bg(args.steps)
+        barrier()
+        el_bg = time.perf_counter() - t0
+        if dist:
+            t = torch.tensor([el_bg], dtype=torch.float64, device=dev)
+            td.all_reduce(t, op=td.ReduceOp.MAX)
+            el_bg = float(t.item())
+        with_bg = dict(bg_info, ms_per_step=el_bg / args.steps * 1e3,
+                       object_rays_per_s=rays_per_step / (el_bg / args.steps),
+                       object_plus_background_rays_per_s=(rays_per_step + bg_info["rays_per_step_all_ranks"]) / (el_bg / args.steps))
     if args.timed_only:
-        if rank == 0:
-            print(json.dumps({"value": value, "ms_per_step": ms_per_step, "steps": args.steps, "warmup": args.warmup,
-                              "preheat_ms": args.preheat_ms, "timed_only": True}), flush=True)
         if dist:
             td.barrier()
             td.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"value": value, "ms_per_step": ms_per_step, "steps": args.steps, "warmup": args.warmup,
+                              "preheat_ms": args.preheat_ms, "timed_only": True}), flush=True)
         return
+    # who took part (so that a scaling run can show its N ranks): device of every rank + the RCCL version torch links
+    devices = [torch.cuda.get_device_name(dev) + f" (cuda:{local_rank})"]
+    rccl_version = None
+    if dist:
+        gathered = [None] * world
+        td.all_gather_object(gathered, devices[0])
+        devices = gathered
+        try:
+            rccl_version = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception:
+            rccl_version = None
     out = None
     if rank == 0:
         # ---- dominant kernel, timed live on the launch stream ----
@@ -272,6 +343,8 @@ def main():
                              "executed_tflops": (n * ((R + (128 // S) - 1) // (128 // S)) * 4 * (288 if args.weights == "f32" else 195) * 32768) / (k_ms * 1e-3) / 1e12,
                              "peak_tflops": BF16_MFMA_PEAK_TFLOPS} if split else None),
             "preheat": {"ms": args.preheat_ms, "steps": preheat_steps, "timed": False},
+            "with_background": with_bg,
+            "world": {"world_size": world, "devices": devices, "rccl": rccl_version},
             "frame_call": "bound (arguments marshalled once)" if bound is not None else "marshalled per call",
         }
     if dist:
@@ -282,10 +355,12 @@ def main():
             out["gpu_eager_baseline"]["speedup"] = value / out["gpu_eager_baseline"]["value"]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
-        print(json.dumps(out), flush=True)
     if dist:
-        td.barrier()                     # rank 0 measured the kernel / printed; everybody leaves together
-        td.destroy_process_group()
+        td.barrier()                     # rank 0 measured the kernel / the baselines; everybody leaves together
+        td.destroy_process_group()       # (RCCL prints its version banner on stdout: the JSON line comes after it, last)
+    if rank == 0:
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -168,11 +168,20 @@ int vmapstep_prepare(const vmapstep_shape* shape, const vmapstep_params* params,
  * (N_depth&obj, N_obj, N_sem, 0).  A RAY-sharded caller (the shared background model, train.py:308-316, trained
  * data-parallel) sum-reduces them over ranks and rewrites the switches (count == 0) before the prepared calls. */
 int vmapstep_workspace_counts_offset(const vmapstep_shape* shape, int32_t max_steps, size_t* counts_offset);
-/* vmapstep_fwd_bwd on a prepared workspace (step 0 of the prepared frame). */
+/* vmapstep_fwd_bwd for step `step_index` of a prepared frame: `batch` is that step's ray batch (the caller applies the
+ * slice), the mask counts / switches are the (possibly reduced) ones vmapstep_prepare wrote for that step, and the
+ * packed parameter image is the one vmapstep_prepare built and vmapstep_adamw_apply keeps current. */
 int vmapstep_fwd_bwd_prepared(const vmapstep_shape* shape, const vmapstep_params* params, const vmapstep_tensor* pe_scale,
-                              const vmapstep_batch* batch, float color_scaling, float opacity_scaling,
+                              const vmapstep_batch* batch, int32_t step_index, float color_scaling, float opacity_scaling,
                               const vmapstep_params* grads, const vmapstep_outputs* out,
                               void* workspace, size_t workspace_bytes, void* stream);
+/* torch.optim.AdamW's update of `params` from EXTERNALLY provided gradients (train.py:325 for a model whose gradients
+ * were summed over ranks by the caller: the shared background model, train.py:308-316): `grad_slab` holds, per object,
+ * the gradients in flat parameter order (the 14 field tensors then B_layer.weight), one row of grad_stride =
+ * padded_params floats (vmapstep_param_layout) per object, 16-byte aligned.  Also rewrites the packed parameter image in `workspace`, so that the next
+ * vmapstep_fwd_bwd_prepared of the frame reads the updated weights.  opt->step = updates already applied. */
+int vmapstep_adamw_apply(const vmapstep_shape* shape, const vmapstep_params* params, const float* grad_slab,
+                         int64_t grad_stride, const vmapstep_adamw* opt, void* workspace, size_t workspace_bytes, void* stream);
 int vmapstep_train_steps_prepared(const vmapstep_shape* shape, const vmapstep_params* params,
                                   const vmapstep_tensor* pe_scale, const vmapstep_batch* frame, int64_t ray_step,
                                   int32_t n_steps, float color_scaling, float opacity_scaling,

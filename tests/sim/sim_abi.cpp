@@ -161,7 +161,8 @@ extern "C" int vmsim_sample(const vs::SampleObject* objs, int n_obj, int W, int 
     a.seed_lo = (unsigned)seed; a.seed_hi = (unsigned)(seed >> 32); a.frame_counter = frame_counter;
     a.rnd.kf_ids = kf_ids; a.rnd.u_w = u_w; a.rnd.u_h = u_h; a.rnd.u_z = u_z; a.rnd.g_z = g_z;
     a.pcs = pcs; a.z = z; a.gt_depth = gt_depth; a.gt_rgb = gt_rgb; a.sem = sem; a.depth_mask = dmask;
-    sim::launch(n_obj, vs::kWG, (3 * (size_t)F * P + vs::kWG) * 4, [&] { vs::frame_sample(a); });
+    if ((long long)F * P <= vs::kMaxStagedRays) sim::launch(n_obj, vs::kWG, (3 * (size_t)F * P + vs::kWG) * 4, [&] { vs::frame_sample<true>(a); });
+    else sim::launch(n_obj, vs::kWG, vs::kWG * 4, [&] { vs::frame_sample<false>(a); });
     return 0;
 }
 extern "C" int vmsim_sample_object_size() { return (int)sizeof(vs::SampleObject); }

@@ -430,35 +430,36 @@ def test_prepared_split_applies_externally_reduced_flags():
     assert relerr(gB.cpu().numpy(), o["g_B"]) < 1e-4
 
 
-def test_shared_background_hip_equals_pytorch_background():
-    """The background model (hidden 128, 14 samples; train.py:308-316) on the HIP path vs the PyTorch ops path of
-    vmap_amd.parallel (world size 1: the collectives are identities, the count/flag plumbing is exercised)."""
+def test_shared_background_hip_tracks_the_aten_port_over_a_frame():
+    """The background model (hidden 128, 14 samples; train.py:308-316) through parallel.SharedBackgroundHip at world size 1
+    (the collectives are identities; the per-frame count plumbing, vmapstep_fwd_bwd_prepared(step i) and
+    vmapstep_adamw_apply are exercised) against the ATen port of the oracle: 4 distinct steps of one frame."""
+    from oracle import vmap_oracle_torch as vt
     from vmap_amd import fields, parallel
+    H, R, S, steps = 128, 60, 14, 4
     torch.manual_seed(4)
-    H, R, S = 128, 60, 14
-
-    def make():
-        torch.manual_seed(4)
-        fc = fields.OccupancyMap(hidden_size=H)
-        fc.apply(fields.init_weights)
-        pe = fields.UniDirsEmbed(max_deg=5, scale=5.0)
-        return fc, pe
-
-    b = synth.make_batch(1, R, S, seed=9)
-    bt = {k: torch.from_numpy(v[0]) for k, v in b.items()}
-    fc_ref, pe_ref = make()
-    ref = parallel.SharedBackground(fc_ref, pe_ref)
-    fc_hip, pe_hip = make()
-    hip = parallel.SharedBackgroundHip(fc_hip, pe_hip, R, S, DEV)
-    bd = {k: v.to(DEV) for k, v in bt.items()}
-    for it in range(2):
-        l_ref = float(ref.step(bt["pcs"], bt["z"], bt["gt_depth"], bt["gt_rgb"], bt["sem"], bt["depth_mask"]))
-        l_hip = float(hip.step(bd["pcs"], bd["z"], bd["gt_depth"], bd["gt_rgb"], bd["sem"], bd["depth_mask"]))
-        assert l_hip == pytest.approx(l_ref, rel=5e-5)
+    fc = fields.OccupancyMap(hidden_size=H)
+    fc.apply(fields.init_weights)
+    pe = fields.UniDirsEmbed(max_deg=5, scale=5.0)
+    fc_np = [p.detach().numpy()[None].copy() for p in fc.parameters()]
+    B_np = pe.B_layer.weight.detach().numpy()[None].copy()
+    sc_np = np.array([5.0], dtype=np.float32)
+    b = synth.make_batch(1, R * steps, S, seed=9)
+    ref = vt.CpuTrainer(fc_np, B_np, sc_np)
+    ref_losses = []
+    for i in range(steps):
+        l, _, _ = ref.step({k: np.ascontiguousarray(v[:, i * R:(i + 1) * R]) for k, v in b.items()})
+        ref_losses.append(float(l))
+    hip = parallel.SharedBackgroundHip(fc, pe, R, S, DEV, max_steps=steps)
+    bd = {k: torch.from_numpy(v[0]).to(DEV) for k, v in b.items()}
+    losses = hip.train_frame(bd["pcs"], bd["z"], bd["gt_depth"], bd["gt_rgb"], bd["sem"], bd["depth_mask"], steps).cpu().numpy()
+    assert hip.opt.step == steps
+    for i in range(steps):
+        assert losses[i] == pytest.approx(ref_losses[i], rel=2e-4), i
     hip.write_back()
-    for p, q in zip(list(fc_hip.parameters()) + list(pe_hip.parameters()), ref.params):
-        d = (p.detach().cpu() - q.detach()).abs()
-        assert float(d.max()) <= 2 * 1.1e-3 and float(d.median()) < 1e-6
+    for p, q in zip(list(fc.parameters()) + [pe.B_layer.weight], ref.fc + [ref.B]):
+        d = (p.detach().cpu() - q.detach()[0]).abs()
+        assert float(d.max()) <= steps * 1.1e-3 and float(d.median()) < 1e-6
 
 
 def test_headless_driver_object_list_semantics():

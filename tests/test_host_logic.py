@@ -75,3 +75,59 @@ def test_shard_objects_partitions_every_object_once():
             owned = [ensemble.shard_objects(n, ws, r) for r in range(ws)]
             assert sorted(sum(owned, [])) == list(range(n))
             assert max(map(len, owned)) - min(map(len, owned)) <= 1
+
+
+import os
+import sys
+
+import pytest
+
+_REF = os.environ.get("VMAP_REFERENCE_ROOT", "/root/reference")
+
+
+@pytest.mark.skipif(not os.path.isdir(_REF), reason="the reference tree exists in the authoring container only")
+def test_state_dicts_interchange_with_the_reference_modules_both_ways():
+    """fields.OccupancyMap / fields.UniDirsEmbed against the REAL model.OccupancyMap (model.py:16-49) and
+    embedding.UniDirsEmbed (embedding.py:43-80): same parameter / buffer names, order and shapes (what utils.update_vmap
+    stacks and what a checkpoint stores), strict load_state_dict in both directions, identical forward values."""
+    sys.dont_write_bytecode = True
+    if _REF not in sys.path:
+        sys.path.insert(0, _REF)
+    import importlib
+    ref_model = importlib.import_module("model")
+    ref_emb = importlib.import_module("embedding")
+    assert os.path.dirname(ref_model.__file__) == _REF
+    for H in (32, 128):
+        torch.manual_seed(H)
+        theirs = ref_model.OccupancyMap(layout.EMB1, layout.EMB2, hidden_size=H)
+        theirs.apply(ref_model.init_weights)
+        ours = fields.OccupancyMap(hidden_size=H)
+        assert [n for n, _ in ours.named_parameters()] == [n for n, _ in theirs.named_parameters()] == list(layout.FC_NAMES)
+        assert [tuple(p.shape) for p in ours.parameters()] == [tuple(p.shape) for p in theirs.parameters()]
+        ours.load_state_dict(theirs.state_dict(), strict=True)              # reference checkpoint -> our module
+        emb = torch.randn(7, 5, layout.EMB1 + layout.EMB2)
+        with torch.no_grad():
+            a_t, c_t = theirs(emb)
+            a_o, c_o = ours(emb)
+        assert torch.equal(a_t, a_o) and torch.equal(c_t, c_o)
+        with torch.no_grad():
+            for p in ours.parameters():
+                p.mul_(1.25)
+        theirs.load_state_dict(ours.state_dict(), strict=True)              # our checkpoint -> reference module
+        for p, q in zip(theirs.parameters(), ours.parameters()):
+            assert torch.equal(p, q)
+    for scale in (2.0, 5.0):
+        pe_t = ref_emb.UniDirsEmbed(max_deg=5, scale=scale)
+        pe_o = fields.UniDirsEmbed(max_deg=5, scale=scale)
+        assert list(pe_t.state_dict().keys()) == list(pe_o.state_dict().keys())
+        assert [n for n, _ in pe_t.named_parameters()] == [n for n, _ in pe_o.named_parameters()] == ["B_layer.weight"]
+        assert [n for n, _ in pe_t.named_buffers()] == [n for n, _ in pe_o.named_buffers()]
+        assert torch.equal(pe_t.B_layer.weight, pe_o.B_layer.weight)       # the icosahedron table (embedding.py:51-73)
+        assert torch.equal(pe_t.frequency_bands, pe_o.frequency_bands) and float(pe_t.scale) == float(pe_o.scale)
+        with torch.no_grad():
+            pe_o.B_layer.weight.add_(0.01)
+        pe_t.load_state_dict(pe_o.state_dict(), strict=True)
+        pe_o.load_state_dict(pe_t.state_dict(), strict=True)
+        x = torch.randn(11, 3)
+        with torch.no_grad():
+            assert torch.equal(pe_t(x), pe_o(x))

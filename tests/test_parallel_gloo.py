@@ -13,6 +13,7 @@ import torch.multiprocessing as mp
 import cases
 from conftest import GRAD_KEYS, relerr
 from oracle import vmap_oracle as vo
+import bg_twin
 from vmap_amd import fields, parallel, synth
 
 
@@ -75,23 +76,36 @@ def _make_bg(seed=3, H=16):
     return fc, pe
 
 
-def _bg_batch(R=64, S=14):
-    b = synth.make_batch(1, R, S, seed=9)
-    return {k: torch.from_numpy(v[0]) for k, v in b.items()}
+def _bg_batch(R=64, S=14, steps=3):
+    """A whole frame of the background model: `steps` optimisation steps of R rays each ([steps * R, ...])."""
+    b = synth.make_batch(1, R * steps, S, seed=9)
+    out = {k: torch.from_numpy(v[0]) for k, v in b.items()}
+    out["sem"][R:2 * R][::2] = 2            # step 1: every ray of rank 0's shard is 'unknown' ...
+    out["sem"][R:2 * R][1::2] = 1           # ... and none of rank 1's: only the per-frame count reduction makes the step consistent
+    return out
+
+
+BG_R, BG_STEPS = 64, 3
 
 
 def _worker_bg(rank, world, port, ret):
     _init(rank, world, port)
     try:
         fc, pe = _make_bg()
-        bg = parallel.SharedBackground(fc, pe)
+        bg = bg_twin.SharedBackground(fc, pe)
         b = _bg_batch()
-        sl = bg.ray_slice(b["z"].shape[0])
+        # this rank's rays of every step: rank, rank + world, ... inside each step's R rays
+        idx = torch.cat([torch.arange(i * BG_R + rank, (i + 1) * BG_R, world) for i in range(BG_STEPS)])
+        loc = {k: v[idx] for k, v in b.items()}
+        Rl = BG_R // world
+        bg.prepare_frame(loc["sem"], loc["depth_mask"], BG_STEPS)          # ONE count collective per frame
         losses = []
-        for _ in range(3):
-            losses.append(float(bg.step(b["pcs"][sl], b["z"][sl], b["gt_depth"][sl], b["gt_rgb"][sl], b["sem"][sl],
-                                        b["depth_mask"][sl])))
-        ret[rank] = dict(losses=losses, params=[p.detach().numpy().copy() for p in bg.params])
+        for i in range(BG_STEPS):
+            sl = slice(i * Rl, (i + 1) * Rl)
+            losses.append(float(bg.step(loc["pcs"][sl], loc["z"][sl], loc["gt_depth"][sl], loc["gt_rgb"][sl], loc["sem"][sl],
+                                        loc["depth_mask"][sl], step_index=i)))   # ONE gradient collective per step
+        ret[rank] = dict(losses=losses, params=[p.detach().numpy().copy() for p in bg.params],
+                         counts=bg.frame_counts.numpy().copy())
     finally:
         dist.destroy_process_group()
 
@@ -102,10 +116,16 @@ def test_shared_background_allreduce_equals_full_batch_training():
     ret = mgr.dict()
     mp.spawn(_worker_bg, args=(world, port, ret), nprocs=world, join=True)
     fc, pe = _make_bg()
-    bg = parallel.SharedBackground(fc, pe)          # world_size 1: plain full-batch training
+    bg = bg_twin.SharedBackground(fc, pe)          # world_size 1: plain full-batch training
     b = _bg_batch()
-    ref_losses = [float(bg.step(b["pcs"], b["z"], b["gt_depth"], b["gt_rgb"], b["sem"], b["depth_mask"])) for _ in range(3)]
+    bg.prepare_frame(b["sem"], b["depth_mask"], BG_STEPS)
+    ref_losses = []
+    for i in range(BG_STEPS):
+        sl = slice(i * BG_R, (i + 1) * BG_R)
+        ref_losses.append(float(bg.step(b["pcs"][sl], b["z"][sl], b["gt_depth"][sl], b["gt_rgb"][sl], b["sem"][sl], b["depth_mask"][sl],
+                                        step_index=i)))
     for r in range(world):
+        assert np.array_equal(ret[r]["counts"], bg.frame_counts.numpy())          # global counts on every rank, for every step
         assert ret[r]["losses"] == pytest.approx(ref_losses, rel=1e-5)
         for p, q in zip(ret[r]["params"], bg.params):
             d = np.abs(p - q.detach().numpy())

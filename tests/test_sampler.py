@@ -149,3 +149,55 @@ def test_gpu_sampler_test_mode_equals_oracle_and_feeds_training():
     res = op.train_steps(tfc, tB, tsc, a["pcs"], a["z"], a["gt_depth"], a["gt_rgb"], a["sem"], a["depth_mask"], opt=st, n_steps=iters)
     torch.cuda.synchronize()
     assert torch.isfinite(res.loss).all()
+
+
+def _bg_frame_scene():
+    """The background object's frame of the stock Replica / ScanNet configs: n_iter_per_frame * win_size_bg = 200 frame
+    slots x n_samples_per_frame_bg = 120 pixels = 24000 rays, n_bins_cam2surface_bg = 5 (train.py:197, cfg.py:67-69):
+    more rays than the kernel's LDS staging area holds."""
+    sc = sampler_cases.build_scene("bg")
+    return dict(sc, F=200, P=120, n1=5)
+
+
+def test_sim_sampler_background_frame_size_equals_oracle():
+    """24000 rays of one object: the unstaged form of frame_sample (phase A evaluated twice) against the oracle, test mode."""
+    sc = _bg_frame_scene()
+    rnd = sampler_cases.draw_randoms(sc)
+    out = simlib.sim_sample([sc], [rnd], eps=EPS, stop_eps=STOP)
+    _check_against_oracle(out, 0, _oracle(sc, rnd))
+
+
+@pytest.mark.gpu
+def test_gpu_sampler_background_frame_size():
+    """vmapstep_sample_frame at F * P = 24000 (refused with VMAPSTEP_ERR_UNSUPPORTED before): test mode == oracle; Philox
+    mode reproducible; the frame trains the background-shaped field (hidden 128, 1200 rays x 19 samples per step)."""
+    import torch
+    from vmap_amd import sampler, step, synth
+    dev = "cuda:0"
+    sc = _bg_frame_scene()
+    rnd = sampler_cases.draw_randoms(sc)
+    fx, fy, cx, cy = sc["intr"]
+    smp = sampler.FrameSampler(sc["W"], sc["H"], sc["F"], sc["P"], sc["n1"], sc["n2"], fx, fy, cx, cy,
+                               min_depth=sc["min_bound"], surface_eps=EPS, stop_eps=STOP, device=dev, seed=5)
+    smp.set_objects([dict(rgbs=torch.from_numpy(sc["rgbs"]).to(dev), depth=torch.from_numpy(sc["depth"]).to(dev),
+                          t_wc=torch.from_numpy(sc["t_wc"]).to(dev), bbox=torch.from_numpy(sc["bbox"]).to(dev),
+                          n_keyframes=sc["K"], last2=sc["last2"], center=sc["center"])])
+    tr = {k: torch.from_numpy(rnd[k][None].astype(np.int32 if k == "kf_ids" else np.float32)).to(dev)
+          for k in ("kf_ids", "u_w", "u_h", "u_z", "g_z")}
+    out = {k: v.cpu().numpy() for k, v in smp.sample(test_randoms=tr).items()}
+    _check_against_oracle(out, 0, _oracle(sc, rnd))
+    smp.frame_counter = 1
+    a = smp.sample()
+    smp.frame_counter = 1
+    b = smp.sample()
+    for k in a:
+        assert torch.equal(a[k], b[k])
+    S = sc["n1"] + sc["n2"]
+    fc, B, sc_ = synth.make_params(1, 128, scale=5.0, seed=2)
+    tfc = [torch.from_numpy(x).to(dev) for x in fc]
+    op = step.VmapStep(1, 1200, S, 128, device=dev, max_steps=20)
+    st = step.FusedAdamWState(1, 128, dev)
+    res = op.train_steps(tfc, torch.from_numpy(B).to(dev), torch.from_numpy(sc_).to(dev), a["pcs"], a["z"], a["gt_depth"], a["gt_rgb"],
+                         a["sem"], a["depth_mask"], opt=st, n_steps=20)
+    torch.cuda.synchronize()
+    assert torch.isfinite(res.loss).all()

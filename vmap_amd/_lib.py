@@ -84,7 +84,7 @@ EXPORTS = (
     "vmapstep_fwd_bwd", "vmapstep_render", "vmapstep_train_steps",
     "vmapstep_profile_main_kernel", "vmapstep_profile_phases", "vmapstep_prepare", "vmapstep_train_steps_prepared",
     "vmapstep_workspace_counts_offset", "vmapstep_fwd_bwd_prepared", "vmapstep_sample_frame",
-    "vmapstep_query_workspace_bytes", "vmapstep_query_points", "vmapstep_profile_train_steps",
+    "vmapstep_query_workspace_bytes", "vmapstep_query_points", "vmapstep_profile_train_steps", "vmapstep_adamw_apply",
 )
 
 _lib = None
@@ -124,7 +124,11 @@ def load():
                                      ctypes.c_int32, ctypes.c_void_p, ctypes.c_size_t,
                                      ctypes.POINTER(ctypes.c_size_t), ctypes.c_void_p]
     lib.vmapstep_train_steps_prepared.argtypes = lib.vmapstep_train_steps.argtypes
-    lib.vmapstep_fwd_bwd_prepared.argtypes = lib.vmapstep_fwd_bwd.argtypes
+    lib.vmapstep_fwd_bwd_prepared.argtypes = [ctypes.POINTER(Shape), ctypes.POINTER(Params), ctypes.POINTER(Tensor),
+                                              ctypes.POINTER(Batch), ctypes.c_int32, ctypes.c_float, ctypes.c_float, ctypes.POINTER(Params),
+                                              ctypes.POINTER(Outputs), ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    lib.vmapstep_adamw_apply.argtypes = [ctypes.POINTER(Shape), ctypes.POINTER(Params), ctypes.c_void_p, ctypes.c_int64,
+                                         ctypes.POINTER(AdamW), ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
     lib.vmapstep_workspace_counts_offset.argtypes = [ctypes.POINTER(Shape), ctypes.c_int32, ctypes.POINTER(ctypes.c_size_t)]
     lib.vmapstep_sample_frame.argtypes = [ctypes.POINTER(SampleCfg), ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
@@ -148,7 +152,7 @@ def load():
                "vmapstep_train_steps", "vmapstep_profile_main_kernel",
                "vmapstep_profile_phases", "vmapstep_prepare", "vmapstep_train_steps_prepared",
                "vmapstep_workspace_counts_offset", "vmapstep_fwd_bwd_prepared", "vmapstep_sample_frame",
-               "vmapstep_query_workspace_bytes", "vmapstep_query_points", "vmapstep_profile_train_steps"):
+               "vmapstep_query_workspace_bytes", "vmapstep_query_points", "vmapstep_profile_train_steps", "vmapstep_adamw_apply"):
         getattr(lib, fn).restype = ctypes.c_int
     if lib.vmapstep_abi_version() != ABI_VERSION:
         raise VmapStepError(f"ABI mismatch: library {lib.vmapstep_abi_version()} != binding {ABI_VERSION}")

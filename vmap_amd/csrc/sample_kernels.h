@@ -79,19 +79,11 @@ __device__ __forceinline__ float lin01(int i, int nb) {
     return i < (nb + 1) / 2 ? step * (float)i : 1.0f - step * (float)(nb - i);
 }
 
-__global__ __launch_bounds__(kWG) void frame_sample(const SampleArgs a) {
-    float* lds = wv::lds_base();
-    const int tid = threadIdx.x, k = blockIdx.x;
-    const SampleObject ob = a.objs[k];
-    const int FP = a.F * a.P, S = a.n1 + a.n2;
-    float* s_dep = lds;                                      // [FP]
-    unsigned* s_pix = reinterpret_cast<unsigned*>(lds + FP); // [FP]  iw | ih << 12 | kf << 24
-    unsigned* s_rgba = s_pix + FP;                           // [FP]
-    float* s_red = reinterpret_cast<float*>(s_rgba + FP);    // [kWG]
-
-    // ---- A: pixel choice + gathers ----
-    float dmax = -3.0e38f;
-    for (int ray = tid; ray < FP; ray += kWG) {
+// Phase A for one ray: keyframe slot of its frame, pixel inside that keyframe's box, the two gathers.  A pure function of
+// (object, ray, counters): frames with more rays than the LDS staging area holds evaluate it twice instead of staging.
+__device__ __forceinline__ void pick_pixel(const SampleArgs& a, const SampleObject& ob, int k, int ray, int FP,
+                                           unsigned& pix_code, unsigned& rgba_out, float& d_out) {
+    {
         const int f = ray / a.P;
         int kf;
         float uw, uh;
@@ -122,10 +114,38 @@ __global__ __launch_bounds__(kWG) void frame_sample(const SampleArgs a) {
             const int id = ob.inst[pix];
             rgba = (rgba & 0x00FFFFFFu) | (id == ob.obj_id ? (1u << 24) : id == -1 ? (2u << 24) : 0u);
         }
-        const float d = ob.depth[pix];                                               // vmap.py:354
-        s_dep[ray] = d;
-        s_pix[ray] = (unsigned)iw | ((unsigned)ih << 12) | ((unsigned)slot << 24);
-        s_rgba[ray] = rgba;
+        d_out = ob.depth[pix];                                                       // vmap.py:354
+        pix_code = (unsigned)iw | ((unsigned)ih << 12) | ((unsigned)slot << 24);
+        rgba_out = rgba;
+    }
+}
+
+// STAGED: phase A's per-ray results are kept in LDS for phase C (3 dwords per ray: F * P <= kMaxStagedRays); otherwise phase C
+// evaluates phase A again (the background model's frame: 200 frames x 120 pixels = 24000 rays, train.py:197, cfg.py:67-69).
+constexpr int kMaxStagedRays = 12000;
+template <bool STAGED>
+__global__ __launch_bounds__(kWG) void frame_sample(const SampleArgs a) {
+    float* lds = wv::lds_base();
+    const int tid = threadIdx.x, k = blockIdx.x;
+    const SampleObject ob = a.objs[k];
+    const int FP = a.F * a.P, S = a.n1 + a.n2;
+    const int NST = STAGED ? FP : 0;
+    float* s_dep = lds;                                       // [FP]
+    unsigned* s_pix = reinterpret_cast<unsigned*>(lds + NST); // [FP]  iw | ih << 12 | kf << 24
+    unsigned* s_rgba = s_pix + NST;                           // [FP]
+    float* s_red = reinterpret_cast<float*>(s_rgba + NST);    // [kWG]
+
+    // ---- A: pixel choice + gathers ----
+    float dmax = -3.0e38f;
+    for (int ray = tid; ray < FP; ray += kWG) {
+        unsigned px, rgba;
+        float d;
+        pick_pixel(a, ob, k, ray, FP, px, rgba, d);
+        if (STAGED) {
+            s_dep[ray] = d;
+            s_pix[ray] = px;
+            s_rgba[ray] = rgba;
+        }
         dmax = fmaxf(dmax, d);
     }
     // ---- B: max sampled depth of this object (vmap.py:391) ----
@@ -139,9 +159,11 @@ __global__ __launch_bounds__(kWG) void frame_sample(const SampleArgs a) {
 
     // ---- C: depth samples and points ----
     for (int ray = tid; ray < FP; ray += kWG) {
-        const unsigned px = s_pix[ray], rgba = s_rgba[ray];
+        unsigned px, rgba;
+        float d;
+        if (STAGED) { px = s_pix[ray]; rgba = s_rgba[ray]; d = s_dep[ray]; }
+        else pick_pixel(a, ob, k, ray, FP, px, rgba, d);
         const int iw = px & 0xFFF, ih = (px >> 12) & 0xFFF, kf = px >> 24;       // kf = slot of the pose
-        const float d = s_dep[ray];
         const unsigned state = rgba >> 24;
         const bool invalid = d <= a.min_bound;                                        // vmap.py:389
         const bool is_obj = state == 1u;

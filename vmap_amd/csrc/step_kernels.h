@@ -1000,6 +1000,7 @@ __device__ __forceinline__ void finalize_quad(const FinalizeArgs& a, const GenLa
 // per-object loss terms: thread q sums object q, q+256, ... ; then a block reduction (loss.py:59-60).  One whole
 // workgroup; uses the first 2 KiB of its LDS.  flags_in[3] != 0 (a carried finalize that timed out) is passed on as bit 1.
 __device__ __forceinline__ void finalize_loss(const FinalizeArgs& a) {
+    if (!a.loss_out) return;           // optimiser-only call (vmapstep_adamw_apply): no loss partials to reduce (uniform exit)
     float* red = wv::lds_base();       // kWG floats + kWG ints
     int* redi = reinterpret_cast<int*>(red + kWG);
     float loss = 0.0f;

@@ -36,6 +36,7 @@ int fail(int code, const char* fmt, ...) {
 }
 
 constexpr size_t kAlign = 256;
+constexpr int kMaxFrameSteps = 256;      // optimisation steps per API call (the flag array has this fixed capacity)
 size_t align_up(size_t x) { return (x + kAlign - 1) / kAlign * kAlign; }
 
 struct Layout {
@@ -130,9 +131,10 @@ int make_plan(const vmapstep_shape* sh, int max_steps, Plan& pl, const Layout& L
     // buffers that exist once per workgroup: sized for THIS plan's NW (the tuning is part of the shape, so the sizing call
     // and the launches see the same plan; a mismatch is caught by the workspace size check of the call, never silently)
     const size_t nw_cap = (size_t)nw;
+    // Every offset is independent of the step count (only the total grows with it): a frame prepared for n steps, a single
+    // prepared step of it and the optimiser-only call address the same buffers.  The per-step arrays come last.
+    if (max_steps > kMaxFrameSteps) return fail(VMAPSTEP_ERR_UNSUPPORTED, "steps per call %d > %d", max_steps, kMaxFrameSteps);
     size_t o = 0;
-    pl.off_stats = o; o += align_up((size_t)max_steps * sh->n_obj * 4 * sizeof(float));
-    pl.off_flags = o; o += align_up((size_t)max_steps * 4 * sizeof(int));
     // loss partials: two halves used alternately by consecutive steps (the carried finalize of step i-1 reads its half
     // while the workgroups of step i write theirs)
     pl.off_ploss_bytes = align_up((size_t)sh->n_obj * nw_cap * 4 * sizeof(float));
@@ -145,6 +147,8 @@ int make_plan(const vmapstep_shape* sh, int max_steps, Plan& pl, const Layout& L
     pl.off_scratch = o;
     if (pl.generic)   // register-image scratch: per wave (step_main_gen) or per workgroup (step_main_wide)
         o += align_up((size_t)sh->n_obj * nw_cap * (pl.wide == 1 ? 1 : vk::kWaves) * vk::gen_wave_blocks(GL.NB) * vk::kBlk * sizeof(float));
+    pl.off_flags = o; o += align_up((size_t)kMaxFrameSteps * 4 * sizeof(int));
+    pl.off_stats = o; o += align_up((size_t)max_steps * sh->n_obj * 4 * sizeof(float));
     pl.total = o;
     return VMAPSTEP_OK;
 }
@@ -432,13 +436,15 @@ int vmapstep_workspace_bytes(const vmapstep_shape* shape, int32_t max_steps, siz
 static int fwd_bwd_impl(const vmapstep_shape* shape, const vmapstep_params* params, const vmapstep_tensor* pe_scale,
                         const vmapstep_batch* batch, float color_scaling, float opacity_scaling,
                         const vmapstep_params* grads, const vmapstep_outputs* out,
-                        void* workspace, size_t workspace_bytes, void* stream, bool do_prep) {
+                        void* workspace, size_t workspace_bytes, void* stream, bool do_prep, int step_index = 0) {
     int rc;
     if (!shape) return fail(VMAPSTEP_ERR_ARGUMENT, "shape is null");
     Layout L;
     make_layout(shape->hidden, L);
     Plan pl;
-    if ((rc = make_plan(shape, 1, pl, L))) return rc;
+    if (step_index < 0) return fail(VMAPSTEP_ERR_ARGUMENT, "step_index=%d", step_index);
+    // the workspace of a prepared frame holds at least step_index + 1 steps; no offset depends on the step count
+    if ((rc = make_plan(shape, step_index + 1, pl, L))) return rc;
     if ((rc = check_params(params, "params", false))) return rc;
     if ((rc = check_params(grads, "grads", true))) return rc;
     if ((rc = check_batch(batch))) return rc;
@@ -449,6 +455,8 @@ static int fwd_bwd_impl(const vmapstep_shape* shape, const vmapstep_params* para
     vk::StepArgs a;
     fill_step_args(a, shape, pl, L, params, pe_scale, batch, 0, color_scaling, opacity_scaling, static_cast<char*>(workspace));
     a.prep_steps = 1; a.prep_ray_step = 0;
+    a.stats += (size_t)step_index * shape->n_obj * 4;
+    a.flags += (size_t)step_index * 4;
     a.dbg_depth = out->render_depth; a.dbg_rgb = out->render_color; a.dbg_opacity = out->opacity; a.dbg_var = out->var;
     if (do_prep && (rc = launch_prep(a, 1, st))) return rc;
     if ((rc = launch_main<true>(a, st))) return rc;
@@ -464,11 +472,41 @@ int vmapstep_fwd_bwd(const vmapstep_shape* shape, const vmapstep_params* params,
 }
 
 int vmapstep_fwd_bwd_prepared(const vmapstep_shape* shape, const vmapstep_params* params, const vmapstep_tensor* pe_scale,
-                              const vmapstep_batch* batch, float color_scaling, float opacity_scaling,
+                              const vmapstep_batch* batch, int32_t step_index, float color_scaling, float opacity_scaling,
                               const vmapstep_params* grads, const vmapstep_outputs* out,
                               void* workspace, size_t workspace_bytes, void* stream) {
     return fwd_bwd_impl(shape, params, pe_scale, batch, color_scaling, opacity_scaling, grads, out, workspace,
-                        workspace_bytes, stream, false);
+                        workspace_bytes, stream, false, step_index);
+}
+
+int vmapstep_adamw_apply(const vmapstep_shape* shape, const vmapstep_params* params, const float* grad_slab,
+                         int64_t grad_stride, const vmapstep_adamw* opt, void* workspace, size_t workspace_bytes, void* stream) {
+    int rc;
+    if (!shape) return fail(VMAPSTEP_ERR_ARGUMENT, "shape is null");
+    Layout L;
+    make_layout(shape->hidden, L);
+    Plan pl;
+    if ((rc = make_plan(shape, 1, pl, L))) return rc;
+    if ((rc = check_params(params, "params", false))) return rc;
+    if (!grad_slab || grad_stride != L.PP || reinterpret_cast<uintptr_t>(grad_slab) % 16)
+        return fail(VMAPSTEP_ERR_ARGUMENT, "grad_slab: need 16-byte aligned rows of padded_params = %d floats (vmapstep_param_layout)", L.PP);
+    if (!opt || !opt->exp_avg || !opt->exp_avg_sq) return fail(VMAPSTEP_ERR_ARGUMENT, "optimiser state is required");
+    if (!workspace || reinterpret_cast<uintptr_t>(workspace) % kAlign || workspace_bytes < pl.total)
+        return fail(VMAPSTEP_ERR_WORKSPACE, "workspace too small / misaligned for this shape's parameter image");
+    // the gradient slab plays the role of ONE row of partial gradients per object (NW = 1, row pitch = grad_stride): the
+    // finalize kernels' ordered sum degenerates to a copy, their AdamW update and image rewrite are what is wanted
+    vk::StepArgs a;
+    std::memset(&a, 0, sizeof(a));
+    char* ws = static_cast<char*>(workspace);
+    a.n_obj = shape->n_obj; a.NW = 1; a.PP = L.PP; a.hidden = shape->hidden;
+    a.weights_bf16 = shape->weight_dtype == VMAPSTEP_WEIGHTS_BF16 ? 1 : 0;
+    a.split = pl.split ? 1 : 0;
+    a.xcd_affine = 0;
+    a.part_grad = const_cast<float*>(grad_slab);
+    a.wimg = reinterpret_cast<float*>(ws + pl.off_wimg);
+    a.img_tab = !pl.generic ? reinterpret_cast<int*>(ws + pl.off_imgtab) : nullptr;
+    return launch_finalize(a, L, params, nullptr, opt, opt->step + 1, true, nullptr, nullptr, static_cast<hipStream_t>(stream),
+                           tuning_of(shape).generic_finalize != 0);
 }
 
 int vmapstep_workspace_counts_offset(const vmapstep_shape* shape, int32_t max_steps, size_t* counts_offset) {
@@ -754,8 +792,8 @@ int vmapstep_sample_frame(const vmapstep_sample_cfg* cfg, const vmapstep_sample_
     const long long FP = (long long)cfg->frames * cfg->samples_per_frame;
     if (n_obj < 1 || cfg->frames < 1 || cfg->samples_per_frame < 1 || cfg->n_bins_cam2surface < 1 || cfg->n_bins < 1)
         return fail(VMAPSTEP_ERR_ARGUMENT, "bad sampler shape");
-    if (S > vs::kMaxS || cfg->n_bins > 16 || cfg->width > 4095 || cfg->height > 4095 || FP > 12000)
-        return fail(VMAPSTEP_ERR_UNSUPPORTED, "sampler limits: S<=32, n_bins<=16, W,H<=4095, F*P<=12000");
+    if (S > vs::kMaxS || cfg->n_bins > 16 || cfg->width > 4095 || cfg->height > 4095 || FP > (1 << 24))
+        return fail(VMAPSTEP_ERR_UNSUPPORTED, "sampler limits: S<=32, n_bins<=16, W,H<=4095, F*P<=2^24");
     vs::SampleArgs a;
     std::memset(&a, 0, sizeof(a));
     a.objs = reinterpret_cast<const vs::SampleObject*>(objects_device);
@@ -769,9 +807,14 @@ int vmapstep_sample_frame(const vmapstep_sample_cfg* cfg, const vmapstep_sample_
         a.rnd.u_z = test_randoms->u_z; a.rnd.g_z = test_randoms->g_z;
     }
     a.pcs = pcs; a.z = z; a.gt_depth = gt_depth; a.gt_rgb = gt_rgb; a.sem = sem; a.depth_mask = depth_mask;
-    const size_t lds = (3 * (size_t)FP + vs::kWG) * sizeof(float);
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(vs::frame_sample), 160 * 1024, "frame_sample")) return rc;
-    hipLaunchKernelGGL(vs::frame_sample, dim3(n_obj), dim3(vs::kWG), lds, static_cast<hipStream_t>(stream), a);
+    if (FP <= vs::kMaxStagedRays) {
+        const size_t lds = (3 * (size_t)FP + vs::kWG) * sizeof(float);
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(vs::frame_sample<true>), 160 * 1024, "frame_sample")) return rc;
+        hipLaunchKernelGGL(vs::frame_sample<true>, dim3(n_obj), dim3(vs::kWG), lds, static_cast<hipStream_t>(stream), a);
+    } else {
+        // more rays per object than the staging area holds (the background model's frame): phase A is evaluated twice
+        hipLaunchKernelGGL(vs::frame_sample<false>, dim3(n_obj), dim3(vs::kWG), vs::kWG * sizeof(float), static_cast<hipStream_t>(stream), a);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "frame_sample launch: %s", hipGetErrorString(e));
     return VMAPSTEP_OK;

@@ -79,8 +79,13 @@ class HipMapper:
         iters = self.cfg.n_iter_per_frame
         rays = pcs.shape[1] // iters
         samples = pcs.shape[2]
-        if self._dirty or self.op is None or (self.op.rays, self.op.samples) != (rays, samples):
-            self.restack(rays, samples)
+        if self._dirty or self.op is None:
+            self.restack(rays, samples)                  # the object list changed: new stack, Adam restart (utils.py:33)
+        elif (self.op.rays, self.op.samples) != (rays, samples):
+            # only the batch shape changed: a new operator (workspace sized for the shape); slab, views and the optimiser state
+            # stay - the reference restarts the moments only when update_vmap re-stacks the object list
+            self.op = step.VmapStep(len(self.trainers), rays, samples, self.trainers[0].hidden_feature_size, device=self.device,
+                                    max_steps=self.cfg.n_iter_per_frame)
         res = self.op.train_steps(self.views[:14], self.views[14], self.scale, pcs, z, gt_depth, gt_rgb, sem, depth_mask,
                                   opt=self.opt, n_steps=iters, ray_step=rays, render=render, flag_reduce=self.flag_reduce)
         self.frames_trained += 1
@@ -132,6 +137,10 @@ class HipMapper:
             join.record(self._bg_stream)
         res = self.train_frame(*obj_batch, render=render)
         cur.wait_event(join)
+        # the background outputs were allocated from the background stream's pool: tell the allocator the caller's stream
+        # reads them, so the blocks are not handed to the next frame's background work while they are still in use
+        res_bg.loss.record_stream(cur)
+        res_bg.flags.record_stream(cur)
         return res, res_bg
 
     def check_flags(self, res: step.StepResult):

@@ -92,6 +92,6 @@ class FrameSampler:
                                                   out["pcs"].data_ptr(), out["z"].data_ptr(), out["gt_depth"].data_ptr(),
                                                   out["gt_rgb"].data_ptr(), out["sem"].data_ptr(), out["depth_mask"].data_ptr(),
                                                   self.seed, self.frame_counter, ctypes.byref(rnd) if rnd is not None else None,
-                                                  torch.cuda.current_stream().cuda_stream))
+                                                  torch.cuda.current_stream(self.device).cuda_stream))
         self.frame_counter += 1
         return out

@@ -151,13 +151,12 @@ class VmapStep:
         return self.workspace[start:start + nbytes]
 
     def fwd_bwd(self, fc, B, pe_scale, pcs, z, gt_depth, gt_rgb, sem, depth_mask, grads_fc=None, grad_B=None,
-                render: bool = False, count_reduce=None) -> StepResult:
+                render: bool = False, prepared_step: Optional[int] = None) -> StepResult:
         """Loss + gradients of all 15 stacked tensors (train.py:293-306 + :324). Gradients are written to
         ``grads_fc``/``grad_B`` if given, else into freshly allocated ``p.grad`` of the parameters.
 
-        ``count_reduce``: optional callable(counts float32 [n, 4], flags int32 [4]) for RAY-sharded data parallelism
-        (shared background model): it sums the mask counts over ranks in place and rewrites the empty-mask switches;
-        the call is then vmapstep_prepare -> count_reduce -> vmapstep_fwd_bwd_prepared."""
+        ``prepared_step``: run step i of a frame prepared with ``prepare_frame`` (mask counts / switches possibly reduced
+        over ranks by the caller, parameter image kept current by ``adamw_apply``); the batch tensors are that step's slice."""
         if grads_fc is None:
             grads_fc = []
             for p in list(fc) + [B]:
@@ -170,21 +169,44 @@ class VmapStep:
         sc = _lib.Tensor(pe_scale.data_ptr(), pe_scale.stride(0) if pe_scale.dim() else 0)
         bt = self._batch(pcs, z, gt_depth, gt_rgb, sem, depth_mask)
         res, out = self._outputs(1, render)
-        fn = self.lib.vmapstep_fwd_bwd
-        if count_reduce is not None:
-            foff, coff = ctypes.c_size_t(0), ctypes.c_size_t(0)
-            _lib.check(self.lib.vmapstep_prepare(ctypes.byref(self.shape), ctypes.byref(pp), ctypes.byref(bt), 0, 1,
-                                                 self._ws_ptr, self._ws_bytes, ctypes.byref(foff), self._stream()))
-            _lib.check(self.lib.vmapstep_workspace_counts_offset(ctypes.byref(self.shape), 1, ctypes.byref(coff)))
-            counts = self._ws_view(coff.value, self.n_obj * 16).view(torch.float32).view(self.n_obj, 4)
-            flags = self._ws_view(foff.value, 16).view(torch.int32)
-            count_reduce(counts, flags)
-            fn = self.lib.vmapstep_fwd_bwd_prepared
-        _lib.check(fn(ctypes.byref(self.shape), ctypes.byref(pp), ctypes.byref(sc),
-                      ctypes.byref(bt), self.color_scaling, self.opacity_scaling,
-                      ctypes.byref(gp), ctypes.byref(out), self._ws_ptr, self._ws_bytes,
-                      self._stream()))
+        if prepared_step is not None:
+            _lib.check(self.lib.vmapstep_fwd_bwd_prepared(ctypes.byref(self.shape), ctypes.byref(pp), ctypes.byref(sc), ctypes.byref(bt),
+                                                          int(prepared_step), self.color_scaling, self.opacity_scaling,
+                                                          ctypes.byref(gp), ctypes.byref(out), self._ws_ptr, self._ws_bytes, self._stream()))
+        else:
+            _lib.check(self.lib.vmapstep_fwd_bwd(ctypes.byref(self.shape), ctypes.byref(pp), ctypes.byref(sc), ctypes.byref(bt),
+                                                 self.color_scaling, self.opacity_scaling, ctypes.byref(gp), ctypes.byref(out),
+                                                 self._ws_ptr, self._ws_bytes, self._stream()))
         return res
+
+    def prepare_frame(self, fc, B, pcs, z, gt_depth, gt_rgb, sem, depth_mask, n_steps: int, ray_step: Optional[int] = None):
+        """vmapstep_prepare for a whole frame ([n, rays_total, ...] tensors): packs the parameter image and computes the
+        per-step mask counts and empty-mask switches.  Returns (counts float32 [n_steps, n, 4], flags int32 [n_steps, 4]) as
+        VIEWS of the workspace: a ray-sharded caller sums the counts over ranks and rewrites the flags in place, an
+        object-sharded one max-reduces the flags - ONE collective per frame either way."""
+        if n_steps > self.max_steps:
+            raise ValueError(f"n_steps={n_steps} > max_steps={self.max_steps} this operator was sized for")
+        ray_step = self.rays if ray_step is None else int(ray_step)
+        pp = self._params(fc, B)
+        bt = self._batch(pcs, z, gt_depth, gt_rgb, sem, depth_mask, rays_total=pcs.shape[1])
+        foff, coff = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        _lib.check(self.lib.vmapstep_prepare(ctypes.byref(self.shape), ctypes.byref(pp), ctypes.byref(bt), ray_step, n_steps,
+                                             self._ws_ptr, self._ws_bytes, ctypes.byref(foff), self._stream()))
+        _lib.check(self.lib.vmapstep_workspace_counts_offset(ctypes.byref(self.shape), n_steps, ctypes.byref(coff)))
+        counts = self._ws_view(coff.value, n_steps * self.n_obj * 16).view(torch.float32).view(n_steps, self.n_obj, 4)
+        flags = self._ws_view(foff.value, n_steps * 16).view(torch.int32).view(n_steps, 4)
+        return counts, flags
+
+    def adamw_apply(self, fc, B, grad_slab: torch.Tensor, opt: "FusedAdamWState"):
+        """torch.optim.AdamW's update from an externally reduced gradient slab ([n, padded_params] float32, flat parameter
+        order) + rewrite of the packed parameter image (vmapstep_adamw_apply); ``opt.step`` is advanced."""
+        if tuple(grad_slab.shape) != (self.n_obj, opt.padded) or grad_slab.dtype != torch.float32 or not grad_slab.is_contiguous():
+            raise ValueError(f"grad_slab: need contiguous float32 {(self.n_obj, opt.padded)}")
+        pp = self._params(fc, B)
+        oc = opt.c_struct()
+        _lib.check(self.lib.vmapstep_adamw_apply(ctypes.byref(self.shape), ctypes.byref(pp), grad_slab.data_ptr(), opt.padded,
+                                                 ctypes.byref(oc), self._ws_ptr, self._ws_bytes, self._stream()))
+        opt.step += 1
 
     def render(self, fc, B, pe_scale, pcs, z, gt_depth, gt_rgb, sem, depth_mask) -> StepResult:
         """Forward + loss only: rendered depth / colour / opacity / variance (loss.py:24-31)."""

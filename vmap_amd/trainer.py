@@ -31,18 +31,15 @@ class Trainer:
 
     @torch.no_grad()
     def eval_points(self, points: torch.Tensor, chunk_size: int = 100000):
-        """Occupancy and colour at arbitrary points of this object's frame (trainer.py:77-95).  On the GPU this is ONE
-        launch of the HIP query kernel (vmapstep_query_points); on the CPU the modules' PyTorch forward in chunks like
-        the reference."""
-        if points.is_cuda and self.hidden_feature_size % 32 == 0 and 32 <= self.hidden_feature_size <= 256:
-            occ, color = self._eval_points_hip(points)
-        else:
-            alphas, colors = [], []
-            for k in range(0, points.shape[0], chunk_size):
-                a, c = self.fc_occ_map(self.pe(points[k:k + chunk_size]))
-                alphas.append(a.squeeze(-1))
-                colors.append(c)
-            occ, color = torch.sigmoid(torch.cat(alphas)), torch.cat(colors)
+        """Occupancy and colour at arbitrary points of this object's frame (trainer.py:77-95): ONE launch of the HIP query
+        kernel (vmapstep_query_points).  There is no CPU / PyTorch-ops path: points on another device, or a hidden width
+        the kernels do not implement, raise (``chunk_size`` is accepted for signature compatibility and unused)."""
+        from . import _lib
+        if not points.is_cuda:
+            raise _lib.VmapStepError("Trainer.eval_points runs on the GPU only (no CPU fallback): move the points to the training device")
+        if self.hidden_feature_size % 32 != 0 or not 32 <= self.hidden_feature_size <= 256:
+            raise _lib.VmapStepError(f"hidden width {self.hidden_feature_size}: supported widths are multiples of 32 up to 256")
+        occ, color = self._eval_points_hip(points)
         if occ.max() == 0:
             return None
         return occ, color
@@ -71,7 +68,7 @@ class Trainer:
         strides = (ctypes.c_int64 * 2)(pts.stride(0), pts.stride(1))
         _lib.check(lib.vmapstep_query_points(self.hidden_feature_size, ctypes.byref(pp), ctypes.byref(sc), 0, pts.data_ptr(), n,
                                              strides, occ.data_ptr(), col.data_ptr(), ws_ptr, nb.value,
-                                             torch.cuda.current_stream().cuda_stream))
+                                             torch.cuda.current_stream(dev).cuda_stream))
         return occ, col
 
 
