@@ -1,6 +1,7 @@
-# quick perf loop: phase clocks + short bench (no CPU baseline) + kernel-level rocprof durations
-mkdir -p gpurun_out; export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-timeout 300 python tests/tools/phase_profile.py > gpurun_out/phases.txt 2>&1; cat gpurun_out/phases.txt
-timeout 300 python bench.py --steps 400 --warmup 40 --no-cpu-baseline > gpurun_out/bench_quick.log 2>&1; tail -1 gpurun_out/bench_quick.log
-timeout 300 python bench.py --config scannet0024_vmap --steps 200 --warmup 20 --no-cpu-baseline > gpurun_out/bench_quick_scannet.log 2>&1; tail -1 gpurun_out/bench_quick_scannet.log
+set -x
+mkdir -p gpurun_out/quick
+export TMPDIR=/tmp
+O=gpurun_out/quick
+( timeout 600 python -m pytest tests -m gpu -q -x ) > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest_gpu.log
+timeout 300 python bench.py --no-cpu-baseline --no-gpu-baseline > $O/bench.json 2> $O/bench.err; tail -1 $O/bench.json | head -c 260; echo
+timeout 300 python tests/tools/phase_profile.py replica_room0_vmap split > $O/phases.txt 2>&1; tail -17 $O/phases.txt

@@ -9,7 +9,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvmapstep.so")
+LIB_PATH = os.environ.get("VMAPSTEP_LIBRARY", os.path.join(_HERE, "libvmapstep.so"))   # override: measurement builds only
 
 NUM_FC = 14
 ABI_VERSION = 4

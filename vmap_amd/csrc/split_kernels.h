@@ -32,6 +32,14 @@
 #pragma once
 #include "step_kernels.h"
 
+// Measurement builds only (tests/tools/build_exp.sh; results are WRONG with any of these defined):
+//   VS_EXP_NOBARRIER  the backward's workgroup barriers removed    VS_EXP_NOFIN  no staging / finishing of weight-gradient blocks
+#if defined(VS_EXP_NOBARRIER)
+#define VS_BWD_BARRIER() do {} while (0)
+#else
+#define VS_BWD_BARRIER() __syncthreads()
+#endif
+
 namespace vk {
 
 using wv::u32x2;
@@ -584,7 +592,8 @@ __device__ __forceinline__ void mm_dw_il(f32x16& acc, f32x16& accb, const unsign
 // ReLU mask + two-plane split of register pair j of a d-prop result (the VALU work of a hidden unit, one chunk per pair)
 __device__ __forceinline__ void mask_split_pair(int j, const f32x16& v, const unsigned (&hh)[8], unsigned (&dh)[8], unsigned (&dm)[8], float dep) {
     const unsigned u = wv::opaque_u(hh[j]);
-    const float a = (u & 0xFFFFu) != 0u ? wv::after(v[2 * j], dep) : 0.0f;
+    const float va = wv::after(v[2 * j], dep);           // (the tie sits outside the select: inside it the select becomes a branch)
+    const float a = (u & 0xFFFFu) != 0u ? va : 0.0f;
     const float b = u > 0xFFFFu ? v[2 * j + 1] : 0.0f;
     const unsigned ph = wv::pack_bf16(a, b);
     dh[j] = ph;
@@ -944,11 +953,15 @@ __device__ __forceinline__ void step_main_s32_body(const StepArgs& a) {
     unsigned d3h[8], d3m[8], d2h[8], d2m[8], d1h[8], d1m[8], dF3[16], dF1[16];
     constexpr int NA = kDpropMM(W3);
     const auto nothing = [](int) {};
+#if defined(VS_EXP_NOFIN)
+#define VS_FIN(KIND, K, QI, STG, OW, OB, BLK, NC) [&](int) {}
+#else
 #define VS_FIN(KIND, K, QI, STG, OW, OB, BLK, NC)                                                                             \
     [&](int i) {                                                                                                              \
         if (i == 0) fin_chunk<KIND, K, MULTI>(0, fs, qacc[QI], STG, OW, OB, BLK, NC, wave, p31, hi);                          \
         if (i == NA - 3) fin_chunk<KIND, K, MULTI>(1, fs, qacc[QI], STG, OW, OB, BLK, NC, wave, p31, hi);                     \
     }
+#endif
     tile_put<4>(scrD, dch, dcm, p31, hi);
     tile_put<4>(scrX, h4h, h4m, p31, hi);
     wt_get<I::PIT_C, W3>(wA, W + I::O_C, 0, TL);
@@ -969,7 +982,7 @@ __device__ __forceinline__ void step_main_s32_body(const StepArgs& a) {
     tile_put<2>(scrX, e2h + 8, e2m + 8, p31, hi);                 // x of unit 2 (half a block)
     wt_get<I::PIT_C, W3>(wA, W + I::O_C, 4, TL);
     tile_put<4>(scrD, d4h, d4m, p31, hi);                         // delta of unit 3 (F(d hc) stays in dF for units 1, 2)
-    __syncthreads();
+    VS_BWD_BARRIER();
     // unit 1: x = second-group slots 0..15
     zero_acc(acc2);
     mm_dprop_il<W3>(acc2, wB, dch, dcm, [&](int i) { if (i == NA - 1) stage_put(stg0, acc, wave, p31, hi); });       // block 0
@@ -983,7 +996,7 @@ __device__ __forceinline__ void step_main_s32_body(const StepArgs& a) {
             for (int r = 4 * i; r < 4 * i + 4; ++r) dproj[r >> 1] += wv::after(acc2[r], acc[0]) * cfac[r >> 1][4 + (r & 1)];     // slot R = r: direction r >> 1, octave 4 + (r & 1)
         }
     });
-    __syncthreads();
+    VS_BWD_BARRIER();
     // unit 2: x = second-group slots 16..23
     zero_acc(acc2);
     {
@@ -1001,7 +1014,7 @@ __device__ __forceinline__ void step_main_s32_body(const StepArgs& a) {
         }
     });
     tile_get(dF, scrD, TL);                                       // F(d4)
-    __syncthreads();
+    VS_BWD_BARRIER();
     VS_MARK(7);
     // unit 3: mid2, delta = d4, x = h3
     zero_acc(acc2);
@@ -1024,7 +1037,7 @@ __device__ __forceinline__ void step_main_s32_body(const StepArgs& a) {
     }
     tile_put<4>(scrD, d3h, d3m, p31, hi);
     tile_get(dF3, scrD, TL);                                      // F(d3): kept for the three first-group blocks
-    __syncthreads();
+    VS_BWD_BARRIER();
     VS_MARK(8);
     // unit 4: cat_layer, delta = d3, x = h2
     zero_acc(acc2);
@@ -1042,7 +1055,7 @@ __device__ __forceinline__ void step_main_s32_body(const StepArgs& a) {
     });
     tile_put<4>(scrD, d2h, d2m, p31, hi);
     tile_get(dF, scrD, TL);                                       // F(d2)
-    __syncthreads();
+    VS_BWD_BARRIER();
     VS_MARK(9);
     // unit 5: mid1, delta = d2, x = h1
     zero_acc(acc2);
@@ -1064,7 +1077,7 @@ __device__ __forceinline__ void step_main_s32_body(const StepArgs& a) {
     }
     tile_put<4>(scrD, d1h, d1m, p31, hi);
     tile_get(dF1, scrD, TL);                                      // F(d1): kept for the three in_layer blocks
-    __syncthreads();
+    VS_BWD_BARRIER();
     VS_MARK(10);
     // units 6..11: the three first-group blocks feed cat_layer (delta d3, weights wA) and in_layer (delta d1, weights wB);
     // the block's F-form alternates between xA and xB
@@ -1089,7 +1102,7 @@ __device__ __forceinline__ void step_main_s32_body(const StepArgs& a) {
         }
         zero_acc(acc);
         mm_dw_il<false>(acc, accb, dF3, xc, nothing);
-        __syncthreads();
+        VS_BWD_BARRIER();
         // in_layer x block: finishes the mid1 block (blk 0) or the previous round's in block; stages this round's cat block
         if (blk == 0) {
             auto fin = VS_FIN(0, H, 5, stg1, out + F::W_M1, nullptr, 0, 32);
@@ -1110,7 +1123,7 @@ __device__ __forceinline__ void step_main_s32_body(const StepArgs& a) {
                 }
             }
         });
-        __syncthreads();
+        VS_BWD_BARRIER();
     }
     VS_MARK(11);
     VS_MARK(12);
@@ -1130,10 +1143,10 @@ __device__ __forceinline__ void step_main_s32_body(const StepArgs& a) {
         fin_chunk<1, H + kEmb1, MULTI>(1, fs, qacc[8], stg0, out + F::W_CAT + H, out + F::B_CAT, 2, kEmb1, wave, p31, hi);
         zero_acc(acc);
         mm_dw_il<false>(acc, accb, dF, xA, nothing);
-        __syncthreads();
+        VS_BWD_BARRIER();
         finish_block_s<1, kEmb1, MULTI>(qacc[11], stg1, out + F::W_IN, out + F::B_IN, 2, kEmb1, wave, p31, hi);
         stage_put(stg0, acc, wave, p31, hi);
-        __syncthreads();
+        VS_BWD_BARRIER();
         float q[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         if (MULTI) stage_get(qacc[12], stg0, wave, p31, hi);
         else stage_get(q, stg0, wave, p31, hi);
