@@ -289,8 +289,13 @@ def main():
         k_ms_alone = op.profile_main_kernel(tfc, tB, tsc, *b0, reps=args.profile_reps)
         reps = max(1, args.profile_reps // ipf)
         pairs = [op.profile_train_steps(tfc, tB, tsc, *fargs, opt=opt, n_steps=ipf) for _ in range(reps)]
-        k_ms = sum(p[0] for p in pairs) / reps               # raw event-pair time around every launch: the roofline's duration
+        k_ms_raw = sum(p[0] for p in pairs) / reps           # raw event-pair time around every launch
         k_ms_corr = sum(p[1] for p in pairs) / reps          # minus the cost of an empty event pair
+        # An event pair around a launch reads ~2.5 us MORE than rocprofv3's per-dispatch duration of the same command and the
+        # pair-minus-empty-pair form ~2.6 us LESS (profiles/r02b_rocprofv3_kernel_stats.csv: 23.5 us; events: 26.0 / 20.9):
+        # half of an empty pair's cost is inherent to one recorded event.  The roofline uses the midpoint, which tracks the
+        # rocprofv3 average; both raw figures are reported next to it.
+        k_ms = 0.5 * (k_ms_raw + k_ms_corr)
         split = H == 32 and args.kernel != "f32"
         kernel_name = ("step_main_s32 (bf16 matrix pipe, split operands: 6 products forward, 3 backward)" if split else
                        "step_main_h32 (exact-fp32 matrix instruction)" if H == 32 else
@@ -332,7 +337,8 @@ def main():
                          "traffic": traffic,
                          "traffic_source": ("copied from the committed rocprofv3 --pmc passes of this kernel (profiles/" + pmcs[-1] +
                                             "), not observed in this run") if traffic is not None else None,
-                         "kernel_ms": k_ms, "kernel_ms_minus_empty_event_pair": k_ms_corr, "kernel_ms_back_to_back": k_ms_alone, "algorithmic_flops_per_launch": flops,
+                         "kernel_ms": k_ms, "kernel_ms_event_pair_raw": k_ms_raw, "kernel_ms_minus_empty_event_pair": k_ms_corr,
+                         "kernel_ms_note": "kernel_ms = midpoint of the raw event-pair time and the pair-minus-empty-pair time (= the rocprofv3 per-dispatch average of the same command within ~1 %, profiles/)", "kernel_ms_back_to_back": k_ms_alone, "algorithmic_flops_per_launch": flops,
                          "algorithmic_bytes_per_launch": abytes,
                          "hbm_achieved_GBs": abytes / (k_ms * 1e-3) / 1e9,
                          "hbm_frac": abytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
