@@ -49,7 +49,8 @@ extern "C" {
  * all-zero = automatic); the library keeps no tuning state of its own, so two operators in one process (two streams,
  * two devices, two threads) cannot influence each other.  The plan - and with it the workspace layout - depends on these
  * values: pass the same tuning to vmapstep_workspace_bytes and to every call that uses that workspace. */
-#define VMAPSTEP_KERNEL_AUTO 0
+#define VMAPSTEP_KERNEL_AUTO 0    /* hidden 32: step_main_s32; hidden 128: step_main_ws (both: bf16 matrix pipe, split operands,
+                                     float32-equivalent forward); other widths: the exact-fp32 kernels below               */
 #define VMAPSTEP_KERNEL_GEN 1     /* hidden 64..256: step_main_gen (one wave per 32-point tile)                      */
 #define VMAPSTEP_KERNEL_WIDE4 2   /* hidden 128/256: step_main_wide<4> (one tile per workgroup, four waves per tile) */
 #define VMAPSTEP_KERNEL_WIDE2 3   /* hidden 128/256: step_main_wide<2> (four tiles per workgroup, two waves per tile)*/

@@ -6,6 +6,7 @@
 
 #include "wide_kernels.h"
 #include "split_kernels.h"
+#include "wsplit_kernels.h"
 #include "sample_kernels.h"
 #include "query_kernels.h"
 
@@ -46,7 +47,9 @@ extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req, int xcd
     std::vector<int> fl(4, -1);
     const vk::GenLayout GL = vk::gen_layout(H);
     const bool split = g_split && H == 32;
-    std::vector<float> wimg((size_t)n * (split ? vk::Img32s::BYTES / 4 : GL.imgp), NAN);
+    const bool ws = g_wide == 3 && H == 128;                 // step_main_ws (split-bf16 matrix pipe, hidden 128)
+    if (ws && G * S > vk::ImgWs<4>::kPts) return -3;
+    std::vector<float> wimg((size_t)n * (split ? vk::Img32s::BYTES / 4 : ws ? vk::ImgWs<4>::BYTES / 4 : GL.imgp), NAN);
 
     vk::StepArgs a{};
     a.n_obj = n; a.R = R; a.S = S; a.G = G; a.NG = NG; a.NW = NW; a.PP = PP; a.prep_steps = 1; a.prep_ray_step = 0; a.xcd_affine = (xcd_affine && H == 32) ? 1 : 0; a.hidden = H; a.weights_bf16 = weights_bf16;
@@ -64,13 +67,29 @@ extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req, int xcd
     a.part_grad = part_grad.data(); a.part_loss = part_loss.data(); a.wimg = wimg.data();
     a.dbg_depth = dbg_depth; a.dbg_rgb = dbg_rgb; a.dbg_opacity = dbg_opacity; a.dbg_var = dbg_var;
     std::vector<int> img_tab(PP, -1);
-    a.img_tab = H == 32 ? img_tab.data() : nullptr;         // flat parameter -> image position (step_finalize_h32)
+    a.img_tab = H == 32 || ws ? img_tab.data() : nullptr;   // flat parameter -> image position (step_finalize_h32)
+    std::vector<int> tab_wt(PP, -1);
+    vk::WsArgs wa{};
 
-    if (split) sim::launch(1 + n * vk::kSplitPackBlocks, vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep_s32(a); });
+    std::vector<char> ws_scratch;
+    if (ws) {
+        ws_scratch.assign((size_t)n * NW * vk::ImgWs<4>::WG_SCRATCH, (char)0xFF);
+        wa.s = a; wa.scratch = ws_scratch.data(); wa.tab_wt = tab_wt.data();
+        sim::launch(1 + n * vk::ws_pack_blocks<4>(), vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep_ws<4>(wa); });
+    } else if (split) sim::launch(1 + n * vk::kSplitPackBlocks, vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep_s32(a); });
     else sim::launch(1 + n * (vk::gen_layout(H).imgp / 1024), vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep(a); });
     const bool multi = NW < NG;
     const int grid = xcd_affine && H == 32 ? 8 * ((n + 7) / 8) * NW : n * NW;
-    if (split) {
+    if (ws) {
+        const int lb = vk::ImgWs<4>::LDS_BYTES;
+        if (weights_bf16) {
+            if (bwd) sim::launch(n * NW, vk::kWG, lb, [&] { vk::step_main_ws<4, true, false>(wa); });
+            else     sim::launch(n * NW, vk::kWG, lb, [&] { vk::step_main_ws<4, false, false>(wa); });
+        } else {
+            if (bwd) sim::launch(n * NW, vk::kWG, lb, [&] { vk::step_main_ws<4, true, true>(wa); });
+            else     sim::launch(n * NW, vk::kWG, lb, [&] { vk::step_main_ws<4, false, true>(wa); });
+        }
+    } else if (split) {
         const int lb = vk::Img32s::LDS_BYTES;
         if (weights_bf16) {
             if (bwd && multi)  sim::launch(grid, vk::kWG, lb, [&] { vk::step_main_s32<true, true, false, false>(a); });
@@ -126,6 +145,21 @@ extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req, int xcd
     f.step_size = (float)((double)lr / (1.0 - std::pow(0.9, step)));
     f.bias_corr2_sqrt = (float)std::sqrt(1.0 - std::pow(0.999, step));
     const int bpo = (PP / 4 + vk::kWG - 1) / vk::kWG;
+    if (ws && bwd && do_adam && p_out) {
+        if (grads) {
+            vk::FinalizeArgs fg = f;
+            fg.do_adam = 0;
+            sim::launch(n * bpo + 1, vk::kWG, 2 * vk::kWG * 4, [&] { vk::step_finalize(fg); });
+            for (int t = 0; t < 15; ++t) f.grad[t] = {nullptr, P};
+        }
+        vk::CarryHot h{};
+        h.m = f.m; h.v = f.v; h.part_grad = f.part_grad; h.wimg = f.wimg; h.img_tab = img_tab.data();
+        h.NW = f.NW; h.PP = f.PP; h.weights_bf16 = f.weights_bf16;
+        h.decay = f.decay; h.one_minus_beta1 = f.one_minus_beta1; h.beta2 = f.beta2; h.one_minus_beta2 = f.one_minus_beta2;
+        h.eps = f.eps; h.step_size = f.step_size; h.bias_corr2_sqrt = f.bias_corr2_sqrt;
+        sim::launch(n * vk::ws_finalize_blocks(PP) + 1, vk::kWG, 4 * vk::kWG * 4, [&] { vk::step_finalize_ws<4>(f, h, tab_wt.data()); });
+        return 0;
+    }
     if (H == 32 && bwd && do_adam && p_out) {
         // the table-driven form the library launches for a plain training step at hidden 32 (parameters: one [n, P] slab here);
         // the gradients the tests look at come from a gradient-only pass of the generic kernel first

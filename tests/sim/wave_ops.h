@@ -143,6 +143,8 @@ inline const T& kernarg_late(const T& a) { return a; }
 inline float relu(float x) { return x > 0.0f ? (x < 3.4028234663852886e38f ? x : 3.4028234663852886e38f) : 0.0f; }
 inline float opaque(float x) { return x; }
 inline int opaque_iter(int x) { return x; }
+inline int uniform(int x) { return x; }
+inline unsigned opaque_uzero() { return 0u; }
 inline unsigned opaque_u(unsigned x) { return x; }
 inline float after(float x, float) { return x; }
 inline unsigned after_u(unsigned x, unsigned) { return x; }

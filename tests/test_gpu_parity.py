@@ -366,15 +366,18 @@ def test_unsupported_hidden_width_fails_loudly():
 
 @pytest.mark.parametrize("name,kernel", [("h64", "gen"), ("bg_h128_s14", "wide"), ("imap_h256", "wide"),
                                          ("bg_h128_s14", "gen"), ("imap_h256", "gen"), ("bg_h128_s14", "wide_multipass"),
-                                         ("bg_h128_s14", "wide2"), ("imap_h256", "wide2"), ("bg_h128_s14", "wide2_multipass")])
+                                         ("bg_h128_s14", "wide2"), ("imap_h256", "wide2"), ("bg_h128_s14", "wide2_multipass"),
+                                         ("bg_h128_s14", "ws"), ("bg_h128_s14", "ws_multipass")])
 def test_generic_width_kernel_matches_reference_fixture(name, kernel):
     """hidden = 64 / 128 (background model shapes) / 256 (iMAP, BASELINE configs[0]): step_main_wide (tile per
-    workgroup / four tiles per workgroup, also with fewer workgroups than ray groups) and step_main_gen."""
+    workgroup / four tiles per workgroup, also with fewer workgroups than ray groups), step_main_gen, and - hidden 128 -
+    step_main_ws (bf16 matrix pipe, split operands: the automatic choice)."""
     c = cases.build_case(name)
     g = load_golden(name)
     tuning = {"kernel": {"gen": _lib.KERNEL_GEN, "wide": _lib.KERNEL_WIDE4, "wide_multipass": _lib.KERNEL_WIDE4,
-                         "wide2": _lib.KERNEL_WIDE2, "wide2_multipass": _lib.KERNEL_WIDE2}[kernel],
-              "workgroups_per_object": {"wide_multipass": 3, "wide2_multipass": 1}.get(kernel, 0)}
+                         "wide2": _lib.KERNEL_WIDE2, "wide2_multipass": _lib.KERNEL_WIDE2,
+                         "ws": _lib.KERNEL_AUTO, "ws_multipass": _lib.KERNEL_AUTO}[kernel],     # hidden 128, automatic: step_main_ws
+              "workgroups_per_object": {"wide_multipass": 3, "wide2_multipass": 1, "ws_multipass": 3}.get(kernel, 0)}
     s = _run(c, tuning=tuning)
     assert abs(s["loss"] - float(g["loss"])) <= 2e-5 * abs(float(g["loss"]))
     for k in RENDER_KEYS:
@@ -667,12 +670,12 @@ def test_frame_trajectory_matches_reference_step_loop(name):
     assert np.quantile(d, 0.99) < q99 and np.median(d) < med, (np.quantile(d, 0.99), np.median(d))
 
 
-@pytest.mark.parametrize("weights", ["f32", "bf16"])
-def test_parameter_image_kept_by_finalize_equals_freshly_packed_image(weights):
+@pytest.mark.parametrize("weights,case", [("f32", "scannet_scale"), ("bf16", "scannet_scale"), ("f32", "bg_h128_s14"), ("bf16", "bg_h128_s14")])
+def test_parameter_image_kept_by_finalize_equals_freshly_packed_image(weights, case):
     """The finalize kernel rewrites the packed parameter image (split planes / float32 image) element by element after
     every AdamW update; a new frame call packs it from the parameter tensors.  Two steps in ONE call (step 2 reads the
     maintained image) must equal two calls of one step (step 2 reads a fresh pack): bit for bit."""
-    c = cases.build_case("scannet_scale")
+    c = cases.build_case(case)          # bg_h128_s14: the two images (W, W^T) of step_main_ws
     outs = []
     for split_calls in (False, True):
         fc, B, sc, b = _to_dev(c)

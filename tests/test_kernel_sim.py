@@ -149,6 +149,34 @@ def test_sim_wide_kernel_matches_reference(nw):
             assert relerr(s[k], o[k]) < 2e-5, k
 
 
+@pytest.mark.parametrize("nw", [0, 3])
+def test_sim_ws_kernel_matches_reference(nw):
+    """step_main_ws (hidden 128 on the bf16 matrix pipe with split operands: a round of two 32-point tiles per workgroup,
+    wave = output block; nw=3: several rounds per workgroup add into its partial gradients) vs the background-shaped
+    fixture generated by the reference."""
+    c = cases.build_case("bg_h128_s14")
+    g = load_golden("bg_h128_s14")
+    s = simlib.sim_step(c, NW=nw, wide=3)
+    assert abs(s["loss"] - float(g["loss"])) <= 2e-5 * abs(float(g["loss"]))
+    for k in RENDER_KEYS:
+        assert relerr(s[k], g[k]) < 2e-5, k
+    for k in GRAD_KEYS:
+        assert relerr(s[k], g[k]) < 1e-4, k
+
+
+def test_sim_ws_kernel_bf16_weights():
+    """step_main_ws with weight_dtype = bf16 (one weight plane) == the float32 oracle on the rounded weights."""
+    from conftest import round_bf16
+    c = cases.build_case("bg_h128_s14")
+    fc_r = [round_bf16(a) for a in c["fc"]]
+    B_r = round_bf16(c["B"])
+    s = simlib.sim_step(c, weights_bf16=1, wide=3)
+    o = vo.training_step(fc_r, B_r, c["scale"], c["batch"], dtype=np.float32)
+    assert abs(s["loss"] - o["loss"]) <= 2e-5 * abs(o["loss"])
+    for k in GRAD_KEYS:
+        assert relerr(s[k], o[k]) < 1e-4, k
+
+
 def test_sim_bf16_weights_equal_oracle_on_rounded_weights():
     """weight_dtype = bf16 (BASELINE configs[3]/[4]): the kernels compute from the bfloat16-rounded parameter image with
     fp32 products/sums == the fp32 oracle evaluated on the rounded weights (last bullet)."""
@@ -234,6 +262,22 @@ def test_sim_split_fused_adamw_and_maintained_image():
     PP = (P + 63) // 64 * 64
     state = dict(p=flat.copy(), m=np.zeros((n, PP), np.float32), v=np.zeros((n, PP), np.float32), step=1)
     s = simlib.sim_step(c, adam=state, split=True)
+    p_ref, m_ref, v_ref = vo.adamw_update(flat, s["grads_flat"], np.zeros_like(flat), np.zeros_like(flat), 1)
+    assert relerr(state["p"], p_ref) < 1e-6
+    assert relerr(state["m"][:, :P], m_ref) < 1e-6
+    assert relerr(state["v"][:, :P], v_ref) < 1e-6
+
+
+def test_sim_ws_fused_adamw_matches_oracle_update():
+    """step_finalize_ws (four threads per parameter quad sum the partial-gradient rows, AdamW, W / W^T image rewrite):
+    the update == the oracle's AdamW on the same gradients."""
+    c = cases.build_case("bg_h128_s14")
+    n = c["n"]
+    flat = np.concatenate([a.reshape(n, -1) for a in c["fc"]] + [c["B"].reshape(n, -1)], axis=1).astype(np.float32)
+    P = flat.shape[1]
+    PP = (P + 63) // 64 * 64
+    state = dict(p=flat.copy(), m=np.zeros((n, PP), np.float32), v=np.zeros((n, PP), np.float32), step=1)
+    s = simlib.sim_step(c, adam=state, wide=3, NW=5)
     p_ref, m_ref, v_ref = vo.adamw_update(flat, s["grads_flat"], np.zeros_like(flat), np.zeros_like(flat), 1)
     assert relerr(state["p"], p_ref) < 1e-6
     assert relerr(state["m"][:, :P], m_ref) < 1e-6

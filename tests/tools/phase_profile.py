@@ -13,9 +13,14 @@ from vmap_amd import step, synth  # noqa: E402
 NAMES = ["start", "staged+cb zeroed", "encoding", "mlp fwd (5 layers)", "heads+cb write", "barrier B", "composite+barrier C",
          "bwd heads + dW colour", "bwd d4 + d e2", "bwd mid2", "bwd cat", "bwd mid1", "bwd in + enc", "bwd dB",
          "final barrier", "partials written"]
+NAMES_WS = ["start", "encoding + barrier", "in_layer", "mid1", "cat_layer", "mid2", "color_linear", "heads + composite",
+            "bwd: enc F images, heads delta", "bwd: heads dW, delta 0", "bwd color_linear", "bwd mid2", "bwd cat_layer", "bwd mid1",
+            "bwd in_layer + d(proj)", "bwd dB"]
 name = sys.argv[1] if len(sys.argv) > 1 else "replica_room0_vmap"
 cfg = synth.CONFIGS[name]
 n, R, S, H = cfg["n_obj"], cfg["R"], cfg["S"], cfg["H"]
+if H == 128:
+    NAMES = NAMES_WS
 fc, B, sc = synth.make_params(n, H, scale=cfg["scale"], seed=0)
 batch = synth.make_batch(n, R, S, seed=1)
 dev = "cuda:0"

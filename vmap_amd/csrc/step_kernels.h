@@ -72,11 +72,13 @@ struct StepArgs {
     unsigned* timing;                  // optional [workgroups][kWaves][kMarks] shader-clock stamps (diagnostics)
     int hidden;                        // H (step_prep packs with gen_layout(hidden); step_main_h32 requires 32)
     int weights_bf16;                  // 1: the parameter image holds the masters rounded to bfloat16 (RNE)
-    int wide;                          // 1: step_main_wide (tile per workgroup, G*S <= 32) instead of step_main_gen
+    int wide;                          // 1: step_main_wide (tile per workgroup, G*S <= 32) instead of step_main_gen; 3: step_main_ws (wsplit_kernels.h)
     unsigned* carry_cnt;               // step_prep: [n_obj][2] hand-off counters of the carried finalize, zeroed per frame
     int* img_tab;                      // step_prep: [PP] flat parameter -> image position table (or null)
     int split;                         // 1: hidden 32 on the split-bf16 kernels (split_kernels.h); wimg is then the byte image of Img32s
     float* gen_scratch;                // step_main_gen / step_main_wide: per-wave (per-workgroup) register-image scratch (workspace)
+                                       // step_main_ws (wide == 3): per-workgroup cos factors of the encoding
+    int* tab_wt;                       // step_prep_ws / step_finalize_ws: [PP] flat parameter -> element of the W^T image planes (or -1)
 };
 
 __device__ __forceinline__ constexpr int phi(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }

@@ -17,6 +17,7 @@
 #include "../../include/vmapstep.h"
 #include "wide_kernels.h"
 #include "split_kernels.h"
+#include "wsplit_kernels.h"
 #include "sample_kernels.h"
 #include "query_kernels.h"
 
@@ -121,12 +122,20 @@ int make_plan(const vmapstep_shape* sh, int max_steps, Plan& pl, const Layout& L
         if (!pl.wide && force == VMAPSTEP_KERNEL_WIDE2) pl.wide = 2;      // measured: no gain over step_main_gen at 600 tiles (both are
                                                                  // bound by the traffic of the per-tile register images), not automatic
     }
-    pl.G = (pl.wide == 1 ? vk::kWideTile : vk::kMaxPts) / sh->samples;
+    // hidden 128: the bf16 matrix pipe with split operands (step_main_ws) unless an exact-fp32 kernel is asked for
+    if (pl.generic && sh->hidden == 128 && force == VMAPSTEP_KERNEL_AUTO && sh->samples <= vk::ImgWs<4>::kPts) pl.wide = 3;
+    pl.G = (pl.wide == 3 ? vk::ImgWs<4>::kPts : pl.wide == 1 ? vk::kWideTile : vk::kMaxPts) / sh->samples;
     if (pl.G > sh->rays) pl.G = sh->rays;
     pl.NG = (sh->rays + pl.G - 1) / pl.G;
     int nw = tun.workgroups_per_object > 0 ? tun.workgroups_per_object : 256 / sh->n_obj;
     if (nw < 1) nw = 1;
     if (nw > pl.NG) nw = pl.NG;
+    if (pl.wide == 3 && tun.workgroups_per_object <= 0) {
+        // one workgroup per CU: with more rounds than workgroup slots the busiest workgroup sets the kernel time, so spread
+        // the rounds evenly (300 rounds on 256 CUs: 150 workgroups x 2 rounds) - fewer partial-gradient rows for the finalize
+        const int per = (pl.NG + nw - 1) / nw;
+        nw = (pl.NG + per - 1) / per;
+    }
     pl.NW = nw;
     // buffers that exist once per workgroup: sized for THIS plan's NW (the tuning is part of the shape, so the sizing call
     // and the launches see the same plan; a mismatch is caught by the workspace size check of the call, never silently)
@@ -140,12 +149,14 @@ int make_plan(const vmapstep_shape* sh, int max_steps, Plan& pl, const Layout& L
     pl.off_ploss_bytes = align_up((size_t)sh->n_obj * nw_cap * 4 * sizeof(float));
     pl.off_ploss = o; o += 2 * pl.off_ploss_bytes;
     pl.off_cnt = o; o += align_up((size_t)sh->n_obj * 2 * sizeof(unsigned));
-    pl.off_imgtab = o; o += pl.generic ? 0 : align_up((size_t)L.PP * sizeof(int));
+    pl.off_imgtab = o; o += pl.wide == 3 ? 2 * align_up((size_t)L.PP * sizeof(int)) : pl.generic ? 0 : align_up((size_t)L.PP * sizeof(int));
     pl.off_pgrad = o; o += align_up((size_t)sh->n_obj * nw_cap * L.PP * sizeof(float));
     const vk::GenLayout GL = vk::gen_layout(sh->hidden);
-    pl.off_wimg = o; o += align_up(pl.split ? (size_t)sh->n_obj * vk::Img32s::BYTES : (size_t)sh->n_obj * GL.imgp * sizeof(float));
+    pl.off_wimg = o; o += align_up(pl.split ? (size_t)sh->n_obj * vk::Img32s::BYTES : pl.wide == 3 ? (size_t)sh->n_obj * vk::ImgWs<4>::BYTES
+                                                                                   : (size_t)sh->n_obj * GL.imgp * sizeof(float));
     pl.off_scratch = o;
-    if (pl.generic)   // register-image scratch: per wave (step_main_gen) or per workgroup (step_main_wide)
+    if (pl.wide == 3) o += align_up((size_t)sh->n_obj * nw_cap * vk::ImgWs<4>::WG_SCRATCH);
+    else if (pl.generic)   // register-image scratch: per wave (step_main_gen) or per workgroup (step_main_wide)
         o += align_up((size_t)sh->n_obj * nw_cap * (pl.wide == 1 ? 1 : vk::kWaves) * vk::gen_wave_blocks(GL.NB) * vk::kBlk * sizeof(float));
     pl.off_flags = o; o += align_up((size_t)kMaxFrameSteps * 4 * sizeof(int));
     pl.off_stats = o; o += align_up((size_t)max_steps * sh->n_obj * 4 * sizeof(float));
@@ -202,7 +213,8 @@ void fill_step_args(vk::StepArgs& a, const vmapstep_shape* sh, const Plan& pl, c
     // hand-off counters exist for the carried finalize only (step_prep skips null pointers); the flat -> image table for hidden 32
     const bool carry = !pl.generic && tuning_of(sh).carried_finalize != 0;
     a.carry_cnt = carry ? reinterpret_cast<unsigned*>(ws + pl.off_cnt) : nullptr;
-    a.img_tab = !pl.generic ? reinterpret_cast<int*>(ws + pl.off_imgtab) : nullptr;   // also read by step_finalize_h32
+    a.img_tab = (!pl.generic || pl.wide == 3) ? reinterpret_cast<int*>(ws + pl.off_imgtab) : nullptr;   // also read by step_finalize_h32
+    a.tab_wt = pl.wide == 3 ? reinterpret_cast<int*>(ws + pl.off_imgtab + align_up((size_t)L.PP * sizeof(int))) : nullptr;
     a.part_grad = reinterpret_cast<float*>(ws + pl.off_pgrad);
     a.wimg = reinterpret_cast<float*>(ws + pl.off_wimg);
     a.gen_scratch = reinterpret_cast<float*>(ws + pl.off_scratch);
@@ -286,14 +298,44 @@ int launch_split(const vk::StepArgs& a, hipStream_t st) {
     return multi ? launch_split_v<BWD, true, STAMPS, true>(a, st) : launch_split_v<BWD, false, STAMPS, true>(a, st);
 }
 
+template <bool BWD, bool W3, bool STAMPS = false>
+int launch_ws_v(const vk::StepArgs& a, hipStream_t st) {
+    using I = vk::ImgWs<4>;
+    auto kern = vk::step_main_ws<4, BWD, W3, STAMPS>;
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), I::LDS_BYTES, "step_main_ws")) return rc;
+    vk::WsArgs ga;
+    ga.s = a;
+    ga.scratch = reinterpret_cast<char*>(a.gen_scratch);
+    ga.tab_wt = a.tab_wt;
+    hipLaunchKernelGGL(kern, dim3(a.n_obj * a.NW), dim3(vk::kWG), I::LDS_BYTES, st, ga);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "step_main_ws launch: %s", hipGetErrorString(e));
+    return VMAPSTEP_OK;
+}
+
 template <bool BWD>
 int launch_main(const vk::StepArgs& a, hipStream_t st) {
     if (a.split) return launch_split<BWD>(a, st);
+    if (a.wide == 3) return a.weights_bf16 ? launch_ws_v<BWD, false>(a, st) : launch_ws_v<BWD, true>(a, st);
     if (a.hidden != 32) return a.wide == 1 ? launch_wide<BWD, 4>(a, st) : a.wide == 2 ? launch_wide<BWD, 2>(a, st) : launch_gen<BWD>(a, st);
     return a.NW < a.NG ? launch_main_v<BWD, true>(a, st) : launch_main_v<BWD, false>(a, st);
 }
 
 int launch_prep(const vk::StepArgs& a, int n_steps, hipStream_t st) {
+    if (a.wide == 3) {
+        vk::WsArgs ga;
+        ga.s = a;
+        ga.s.prep_steps = n_steps;
+        ga.scratch = reinterpret_cast<char*>(a.gen_scratch);
+        ga.tab_wt = a.tab_wt;
+        // parameters without a place in the W^T image (biases, heads, B) keep -1 in its table
+        hipError_t e = hipMemsetAsync(a.tab_wt, 0xFF, (size_t)a.PP * sizeof(int), st);
+        if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "hipMemsetAsync(tab_wt): %s", hipGetErrorString(e));
+        hipLaunchKernelGGL(vk::step_prep_ws<4>, dim3(n_steps + a.n_obj * vk::ws_pack_blocks<4>()), dim3(vk::kWG), 3 * vk::kWG * sizeof(int), st, ga);
+        e = hipGetLastError();
+        if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "step_prep_ws launch: %s", hipGetErrorString(e));
+        return VMAPSTEP_OK;
+    }
     if (a.split) {
         hipLaunchKernelGGL(vk::step_prep_s32, dim3(n_steps + a.n_obj * vk::kSplitPackBlocks), dim3(vk::kWG), 3 * vk::kWG * sizeof(int), st, a);
         hipError_t e = hipGetLastError();
@@ -366,6 +408,22 @@ int launch_finalize(const vk::StepArgs& a, const Layout& L, const vmapstep_param
     const int bpo = (L.PP / 4 + vk::kWG - 1) / vk::kWG;
     // + 1: the loss / flag reduction has a workgroup of its own (it used to ride on block 0 and made it the straggler)
     const int grid = (!have_grad ? 0 : f.xcd_affine ? 8 * ((a.n_obj + 7) / 8) * bpo : a.n_obj * bpo) + 1;
+    if (a.wide == 3 && f.do_adam) {
+        // step_main_ws: the table-driven finalize is the only writer of the two weight images (see the split case below)
+        if (grads) {
+            vk::FinalizeArgs fg = f;
+            fg.do_adam = 0;
+            hipLaunchKernelGGL(vk::step_finalize, dim3(grid), dim3(vk::kWG), 2 * vk::kWG * sizeof(float), st, fg);
+            std::memset(f.grad, 0, sizeof(f.grad));
+        }
+        vk::CarryHot h;
+        fill_carry_hot(h, f, a, L, params, 0u);
+        hipLaunchKernelGGL(vk::step_finalize_ws<4>, dim3(a.n_obj * vk::ws_finalize_blocks(L.PP) + 1), dim3(vk::kWG), 4 * vk::kWG * sizeof(float),
+                           st, f, h, a.tab_wt);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "step_finalize_ws launch: %s", hipGetErrorString(e));
+        return VMAPSTEP_OK;
+    }
     if (a.split && f.do_adam) {
         // split image: the table-driven finalize is the only writer of the planes.  A caller that also wants the gradients of
         // this step gets them from a gradient-only pass of the generic kernel first (same ordered sums).
@@ -504,7 +562,9 @@ int vmapstep_adamw_apply(const vmapstep_shape* shape, const vmapstep_params* par
     a.xcd_affine = 0;
     a.part_grad = const_cast<float*>(grad_slab);
     a.wimg = reinterpret_cast<float*>(ws + pl.off_wimg);
-    a.img_tab = !pl.generic ? reinterpret_cast<int*>(ws + pl.off_imgtab) : nullptr;
+    a.wide = pl.wide;
+    a.img_tab = (!pl.generic || pl.wide == 3) ? reinterpret_cast<int*>(ws + pl.off_imgtab) : nullptr;
+    a.tab_wt = pl.wide == 3 ? reinterpret_cast<int*>(ws + pl.off_imgtab + align_up((size_t)L.PP * sizeof(int))) : nullptr;
     return launch_finalize(a, L, params, nullptr, opt, opt->step + 1, true, nullptr, nullptr, static_cast<hipStream_t>(stream),
                            tuning_of(shape).generic_finalize != 0);
 }
@@ -702,7 +762,7 @@ int vmapstep_profile_phases(const vmapstep_shape* shape, const vmapstep_params* 
     if ((rc = check_batch(batch))) return rc;
     if (!pe_scale || !pe_scale->ptr) return fail(VMAPSTEP_ERR_ARGUMENT, "pe_scale is null");
     if (!timing || !n_workgroups) return fail(VMAPSTEP_ERR_ARGUMENT, "timing / n_workgroups is null");
-    if (pl.generic) return fail(VMAPSTEP_ERR_UNSUPPORTED, "phase stamps exist in the hidden=32 kernel only");
+    if (pl.generic && pl.wide != 3) return fail(VMAPSTEP_ERR_UNSUPPORTED, "phase stamps exist in the hidden=32 kernels and step_main_ws only");
     const size_t need = (size_t)8 * ((shape->n_obj + 7) / 8) * pl.NW * vk::kWaves * vk::kMarks;
     if (timing_elems < need) return fail(VMAPSTEP_ERR_ARGUMENT, "timing buffer %zu < %zu elements", timing_elems, need);
     if ((rc = check_ws(workspace, workspace_bytes, pl))) return rc;
@@ -713,6 +773,7 @@ int vmapstep_profile_phases(const vmapstep_shape* shape, const vmapstep_params* 
     a.timing = timing;
     *n_workgroups = a.xcd_affine ? 8 * ((shape->n_obj + 7) / 8) * pl.NW : shape->n_obj * pl.NW;
     if ((rc = launch_prep(a, 1, st))) return rc;
+    if (a.wide == 3) return launch_ws_v<true, true, true>(a, st);
     if (a.split) return launch_split<true, true>(a, st);
     return a.NW < a.NG ? launch_main_v<true, true, true>(a, st) : launch_main_v<true, false, true>(a, st);   // the stamped build
 }

@@ -154,6 +154,17 @@ __device__ __forceinline__ int opaque_iter(int x) {
     asm volatile("" : "+v"(x));
     return x;
 }
+// a value the program knows to be the same in every lane of the wave, moved to a scalar register (addresses built from
+// it use the scalar-base form of the global instructions)
+__device__ __forceinline__ int uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
+// the same trick as opaque_iter for wave-uniform addresses: a scalar zero the optimiser cannot see through.  Addresses formed
+// as base + opaque_uzero() inside a loop are not loop-invariant, so they are formed where they are used instead of living in
+// (spilled) scalar registers; the base keeps its provenance (global address space).
+__device__ __forceinline__ unsigned opaque_uzero() {
+    unsigned z;
+    asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+    return z;
+}
 
 // nothing may be moved across this point by the instruction scheduler (hand-placed software pipelining)
 __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }

@@ -1,0 +1,1139 @@
+// wsplit_kernels.h - the fused training step for a WIDE field (hidden = 128: the background model of train.py:308-316) on the
+// bf16 matrix pipe with split operands (gfx950 / CDNA4).  Same numerics scheme as split_kernels.h (float32 = hi + mid + lo
+// bfloat16 planes; six products forward, three backward), different shape - at hidden 128 the weights (3 x 94 340 bf16) do
+// not fit LDS and the step is bound by OPERAND DELIVERY, not by the matrix pipe: every 32x32x16 instruction eats 2 KiB of
+// operands in 32 clocks (64 B/clk per SIMD), the CU delivers 64 B/clk from L1 and 128 B/clk from LDS.  So:
+//
+//   * a ROUND = two 32-point tiles belongs to the WORKGROUP; wave w owns output block w (32 features) of every layer and runs
+//     it for both tiles at once: one weight operand (read from the object's image in global memory / L2 as ready-made 1 KiB
+//     matrix operand chunks [64 lanes][8 bf16]) feeds two accumulators - per 12 matrix instructions a wave reads 3 KiB from L1 and 6 KiB from LDS (8 and 16 B/clk per SIMD);
+//   * layer inputs travel between the waves through LDS as lane-contiguous P-form operand images (all four waves hold the
+//     same points on the same lanes, so what one wave stores is directly another wave's B operand: ds_write_b128 /
+//     ds_read_b128, no transposes); the encoding is evaluated once per round, split by (tile, direction half) over the waves;
+//   * one workgroup per CU, one wave per SIMD: nothing hides a load but the wave's own matrix instructions, so every operand
+//     stream runs through explicit prefetch rings (weights two steps ahead, LDS operands one) pinned by scheduling fences;
+//     the hi / mid planes of the five activations (ReLU masks and weight-gradient operands of the backward pass) wait in
+//     an L2-resident scratch area of the workgroup;
+//   * backward, per layer: the wave's delta block -> P-form image (d-prop operand of everybody) + F-form registers (its own
+//     weight-gradient operand); its block of the layer input -> F-form image in LDS (weight-gradient operand of everybody);
+//     weight-gradient blocks accumulate over the round's two tiles in registers and go straight to the workgroup's partial
+//     gradients (stored by the first round, added by later ones); W^T comes from a second, transposed image.
+#pragma once
+#include "split_kernels.h"
+
+namespace vk {
+
+template <int NB>
+struct ImgWs {
+    static constexpr int H = 32 * NB;
+    static constexpr int JS = 2 * NB;                                    // 16-deep steps over a layer's H outputs / hidden inputs
+    // forward image W: chunks of 1 KiB per plane, index = base(layer) + ob * steps(layer) + s; planes hi, mid, lo interleaved
+    static constexpr int KS_IN = 6, KS_M = JS, KS_CAT = JS + 6, KS_C = JS + 3;
+    static constexpr int CW_IN = 0, CW_M1 = CW_IN + NB * KS_IN, CW_CAT = CW_M1 + NB * KS_M, CW_M2 = CW_CAT + NB * KS_CAT,
+                         CW_C = CW_M2 + NB * KS_M, CW_N = CW_C + NB * KS_C;
+    // transposed image W^T: index = base(layer) + kb * JS + s'; kb = input block (hidden blocks first, then encoding blocks)
+    static constexpr int IB_IN = 3, IB_M = NB, IB_CAT = NB + 3, IB_C = NB + 2;
+    static constexpr int CT_IN = 0, CT_M1 = CT_IN + IB_IN * JS, CT_CAT = CT_M1 + IB_M * JS, CT_M2 = CT_CAT + IB_CAT * JS,
+                         CT_C = CT_M2 + IB_M * JS, CT_N = CT_C + IB_C * JS;
+    static constexpr long long W_BYTES = (long long)CW_N * 3 * 1024, WT_OFF = W_BYTES, WT_BYTES = (long long)CT_N * 2 * 1024;
+    static constexpr long long SMALL_OFF = WT_OFF + WT_BYTES;
+    // small float32 vectors
+    static constexpr int B_M1 = 0, B_M2 = H, W_A = 2 * H, W_OC = 3 * H, B_A = 6 * H, B_OC = 6 * H + 4, PE_B = 6 * H + 8, SMALL_N = 6 * H + 72;
+    static constexpr long long BYTES = (SMALL_OFF + SMALL_N * 4 + 4095) / 4096 * 4096;
+    static constexpr int W_ELEMS = CW_N * 512, WT_ELEMS = CT_N * 512;     // bf16 elements per plane
+    // scratch per workgroup (global memory, L2-resident): cos factors of the encoding [tile][66][lane]; then the hi / mid planes of
+    // the five activations of the wave's block [layer][tile][plane][step][256 threads][16 B] (ReLU masks and weight-gradient
+    // operands of the backward pass: 160 registers a thread cannot afford next to the operand prefetch rings)
+    static constexpr int CF_BYTES = 2 * 66 * 64 * 4;
+    static constexpr int ACTS_OFF = (CF_BYTES + 4095) / 4096 * 4096;
+    static constexpr int WG_SCRATCH = ACTS_OFF + 5 * 2 * 2 * 2 * 4096;
+    // ---- LDS map (bytes) ----
+    static constexpr int XCH = 3072;                                       // one 16-deep step of a P-form operand image: 3 planes x 1 KiB
+    static constexpr int DCH = 2048;                                       // ... of a delta image: 2 planes
+    static constexpr int ACT = 0, ACT_ST = NB * 2 * XCH, ACT_BYTES = 2 * ACT_ST;      // forward: layer input images [tile][block][step][plane]
+    static constexpr int EF = 0, EF_ST = 5 * 4096;                         // backward (over ACT): F-form images of the 5 encoding blocks [tile][5]
+    static constexpr int EIM = ACT_BYTES, E_ST = 9 * XCH, E2_OFF = 6 * XCH;            // forward: encoding images [tile][6 + 3 steps][plane]
+    static constexpr int DLT = EIM, DLT_ST = NB * 2 * DCH;                 // backward (over EIM): delta images [tile][block][step][plane]
+    static constexpr int XF = DLT + 2 * DLT_ST, XF_ST = NB * 4096;         // backward: F-form images of the layer input [tile][block]
+    static constexpr int R1_BYTES = 2 * E_ST > 2 * DLT_ST + 2 * XF_ST ? 2 * E_ST : 2 * DLT_ST + 2 * XF_ST;
+    static constexpr int SCRT = EIM + R1_BYTES;                            // one transpose tile per wave
+    static constexpr int HP = SCRT + kWaves * Img32s::TILE;                // head partial sums [wave][tile][32 points][4]
+    static constexpr int CBO = HP + kWaves * 2 * 32 * 4 * 4;               // composite buffer [64 points][8]
+    static constexpr int LOSS = CBO + 64 * 8 * 4;
+    static constexpr int LDS_BYTES = LOSS + kWaves * 4 * 4;
+    static constexpr int kPts = 64;                                        // sample points per round
+};
+static_assert(ImgWs<4>::LDS_BYTES <= 160 * 1024, "LDS budget");
+static_assert(ImgWs<4>::EF_ST * 2 <= ImgWs<4>::ACT_BYTES, "encoding F images fit the dead layer-input images");
+
+struct WsArgs {
+    StepArgs s;
+    char* scratch;                 // [workgroups][WG_SCRATCH]
+    int* tab_wt;                   // [PP] flat parameter -> element of the W^T planes (or -1); s.img_tab is the W / small-vector table
+};
+
+// ---- which parameter sits where -------------------------------------------------------------------------------------
+// element x of a W plane -> (tensor t, offset o); false = zero padding
+template <int NB>
+__host__ __device__ inline bool ws_w_source(int x, int& t, int& o) {
+    using I = ImgWs<NB>;
+    constexpr int H = I::H;
+    const int chunk = x >> 9, lane = (x >> 3) & 63, tt = x & 7, j = lane & 31, hi = lane >> 5;
+    int base, ks, kind;
+    if (chunk < I::CW_M1) { base = I::CW_IN; ks = I::KS_IN; kind = 0; }
+    else if (chunk < I::CW_CAT) { base = I::CW_M1; ks = I::KS_M; kind = 1; }
+    else if (chunk < I::CW_M2) { base = I::CW_CAT; ks = I::KS_CAT; kind = 2; }
+    else if (chunk < I::CW_C) { base = I::CW_M2; ks = I::KS_M; kind = 3; }
+    else { base = I::CW_C; ks = I::KS_C; kind = 4; }
+    const int ob = (chunk - base) / ks, s = (chunk - base) - ob * ks, row = 32 * ob + j;
+    const int k = hidden_k(s, hi, tt);
+    switch (kind) {
+        case 0: {
+            const int c = e1_slot(8 * s + tt, hi);
+            if (c == kSlotPad) return false;
+            if (c == kSlotOne) { t = 1; o = row; } else { t = 0; o = row * kEmb1 + c; }
+            return true;
+        }
+        case 1: t = 2; o = row * H + k; return true;
+        case 2: {
+            if (s < I::JS) { t = 4; o = row * (H + kEmb1) + k; return true; }
+            const int c = e1_slot(8 * (s - I::JS) + tt, hi);
+            if (c == kSlotPad) return false;
+            if (c == kSlotOne) { t = 5; o = row; } else { t = 4; o = row * (H + kEmb1) + H + c; }
+            return true;
+        }
+        case 3: t = 6; o = row * H + k; return true;
+        default: {
+            if (s < I::JS) { t = 10; o = row * (H + kEmb2) + k; return true; }
+            const int c = e2_slot(8 * (s - I::JS) + tt, hi);
+            if (c == kSlotPad) return false;
+            if (c == kSlotOne) { t = 11; o = row; } else { t = 10; o = row * (H + kEmb2) + H + c; }
+            return true;
+        }
+    }
+}
+// element x of a W^T plane -> (tensor, offset); lane = input column inside its 32-block, elements = 8 output rows
+template <int NB>
+__host__ __device__ inline bool ws_wt_source(int x, int& t, int& o) {
+    using I = ImgWs<NB>;
+    constexpr int H = I::H;
+    const int chunk = x >> 9, lane = (x >> 3) & 63, tt = x & 7, kl = lane & 31, hi = lane >> 5;
+    int base, kind;
+    if (chunk < I::CT_M1) { base = I::CT_IN; kind = 0; }
+    else if (chunk < I::CT_CAT) { base = I::CT_M1; kind = 1; }
+    else if (chunk < I::CT_M2) { base = I::CT_CAT; kind = 2; }
+    else if (chunk < I::CT_C) { base = I::CT_M2; kind = 3; }
+    else { base = I::CT_C; kind = 4; }
+    const int kb = (chunk - base) / I::JS, sp = (chunk - base) - kb * I::JS;
+    const int j = hidden_k(sp, hi, tt);                                  // output row
+    const int hs = (kl >> 2) & 1, r = (kl & 3) + 4 * (kl >> 3);          // encoding blocks: lane kl = phi(r, hs)
+    switch (kind) {
+        case 0: {
+            const int c = e1_slot(16 * kb + r, hs);
+            if (c < 0) return false;
+            t = 0; o = j * kEmb1 + c; return true;
+        }
+        case 1: t = 2; o = j * H + 32 * kb + kl; return true;
+        case 2: {
+            if (kb < NB) { t = 4; o = j * (H + kEmb1) + 32 * kb + kl; return true; }
+            const int c = e1_slot(16 * (kb - NB) + r, hs);
+            if (c < 0) return false;
+            t = 4; o = j * (H + kEmb1) + H + c; return true;
+        }
+        case 3: t = 6; o = j * H + 32 * kb + kl; return true;
+        default: {
+            if (kb < NB) { t = 10; o = j * (H + kEmb2) + 32 * kb + kl; return true; }
+            const int R = 16 * (kb - NB) + r;
+            const int c = R < 24 ? e2_slot(R, hs) : kSlotPad;
+            if (c < 0) return false;
+            t = 10; o = j * (H + kEmb2) + H + c; return true;
+        }
+    }
+}
+template <int NB>
+__host__ __device__ inline bool ws_small_source(int i, int& t, int& o) {
+    using I = ImgWs<NB>;
+    if (i < I::B_M2) { t = 3; o = i - I::B_M1; return true; }
+    if (i < I::W_A) { t = 7; o = i - I::B_M2; return true; }
+    if (i < I::W_OC) { t = 8; o = i - I::W_A; return true; }
+    if (i < I::B_A) { t = 12; o = i - I::W_OC; return true; }
+    if (i < I::B_OC) { t = 9; o = i - I::B_A; return o < 1; }
+    if (i < I::PE_B) { t = 13; o = i - I::B_OC; return o < 3; }
+    t = 14; o = i - I::PE_B;
+    return o < 63;
+}
+
+// ---- step_prep_ws: mask statistics (blocks [0, prep_steps)) + image build (one thread per 4 plane elements) -------------
+template <int NB>
+__host__ __device__ constexpr int ws_pack_blocks() { return (ImgWs<NB>::W_ELEMS / 4 + ImgWs<NB>::WT_ELEMS / 4 + 256 + kWG - 1) / kWG; }
+
+template <int NB>
+__global__ __launch_bounds__(kWG) void step_prep_ws(const WsArgs ga) {
+    using I = ImgWs<NB>;
+    const StepArgs& a = ga.s;
+    const GenLayout L = gen_layout(I::H);
+    if ((int)blockIdx.x < a.prep_steps) {
+        prep_stats(a, blockIdx.x, L.P, L.PP);
+        return;
+    }
+    const int b = blockIdx.x - a.prep_steps;
+    const int per = ws_pack_blocks<NB>();
+    const int k = b / per;
+    const int q = (b - k * per) * kWG + threadIdx.x;
+    char* img = reinterpret_cast<char*>(a.wimg) + (long long)k * I::BYTES;
+    auto fetch = [&](int t, int o) { return t < kNFc ? a.fc[t].p[k * a.fc[t].stride + o] : a.pe_B.p[k * a.pe_B.stride + o]; };
+    if (q < I::W_ELEMS / 4) {
+        unsigned h[4], m[4], l[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int t, o;
+            float f = 0.0f;
+            if (ws_w_source<NB>(4 * q + e, t, o)) {
+                f = fetch(t, o);
+                if (k == 0 && a.img_tab) a.img_tab[L.f[t] + o] = 4 * q + e;
+            }
+            split3_scalar(f, h[e], m[e], l[e]);
+            if (a.weights_bf16) { m[e] = 0u; l[e] = 0u; }
+        }
+        // element x = chunk * 512 + within: plane pl of the chunk starts at (chunk * 3 + pl) * 1024 bytes
+        const int x = 4 * q, chunk = x >> 9, within = x & 511;
+        char* base = img + (long long)chunk * 3 * 1024 + within * 2;
+        *reinterpret_cast<u32x2*>(base) = u32x2{h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
+        *reinterpret_cast<u32x2*>(base + 1024) = u32x2{m[0] | (m[1] << 16), m[2] | (m[3] << 16)};
+        *reinterpret_cast<u32x2*>(base + 2048) = u32x2{l[0] | (l[1] << 16), l[2] | (l[3] << 16)};
+    } else if (q < I::W_ELEMS / 4 + I::WT_ELEMS / 4) {
+        const int qq = q - I::W_ELEMS / 4;
+        unsigned h[4], m[4], l[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int t, o;
+            float f = 0.0f;
+            if (ws_wt_source<NB>(4 * qq + e, t, o)) {
+                f = fetch(t, o);
+                if (k == 0 && ga.tab_wt) ga.tab_wt[L.f[t] + o] = 4 * qq + e;
+            }
+            split3_scalar(f, h[e], m[e], l[e]);
+            if (a.weights_bf16) m[e] = 0u;
+        }
+        const int x = 4 * qq, chunk = x >> 9, within = x & 511;
+        char* base = img + I::WT_OFF + (long long)chunk * 2 * 1024 + within * 2;
+        *reinterpret_cast<u32x2*>(base) = u32x2{h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
+        *reinterpret_cast<u32x2*>(base + 1024) = u32x2{m[0] | (m[1] << 16), m[2] | (m[3] << 16)};
+    } else {
+        const int s0 = (q - I::W_ELEMS / 4 - I::WT_ELEMS / 4) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (s0 + e < I::SMALL_N) {
+                int t, o;
+                float f = 0.0f;
+                if (ws_small_source<NB>(s0 + e, t, o)) {
+                    f = fetch(t, o);
+                    if (k == 0 && a.img_tab) a.img_tab[L.f[t] + o] = (int)(0x80000000u | (unsigned)(s0 + e));
+                }
+                reinterpret_cast<float*>(img + I::SMALL_OFF)[s0 + e] = a.weights_bf16 ? round_bf16(f) : f;
+            }
+        }
+    }
+    // parameters that have no place in W^T (biases, heads, B) keep -1 there: the table is pre-filled by the host side (memset)
+}
+
+// ---- finalize: step_finalize_s32's quad with runtime tensor offsets and the two wide images ---------------------------
+template <int NB>
+__device__ __forceinline__ void ws_image_store(char* img, int locw, int locwt, float p, int weights_bf16) {
+    using I = ImgWs<NB>;
+    if (locw < 0) {
+        reinterpret_cast<float*>(img + I::SMALL_OFF)[locw & 0x7FFFFFFF] = weights_bf16 ? round_bf16(p) : p;
+        return;
+    }
+    unsigned h, m, l;
+    split3_scalar(p, h, m, l);
+    if (weights_bf16) { m = 0u; l = 0u; }
+    {
+        const int chunk = locw >> 9, within = locw & 511;
+        unsigned short* b = reinterpret_cast<unsigned short*>(img + (long long)chunk * 3 * 1024) + within;
+        b[0] = (unsigned short)h; b[512] = (unsigned short)m; b[1024] = (unsigned short)l;
+    }
+    if (locwt >= 0) {
+        const int chunk = locwt >> 9, within = locwt & 511;
+        unsigned short* b = reinterpret_cast<unsigned short*>(img + I::WT_OFF + (long long)chunk * 2 * 1024) + within;
+        b[0] = (unsigned short)h; b[512] = (unsigned short)m;
+    }
+}
+
+// blocks per object of step_finalize_ws: kFinQuads quads of parameters per block, kFinGroups threads per quad
+constexpr int kFinGroups = 4, kFinQuads = kWG / kFinGroups;
+__host__ __device__ inline int ws_finalize_blocks(int PP) { return (PP / 4 + kFinQuads - 1) / kFinQuads; }
+
+// The partial gradients are NW rows of PP floats per object (one per workgroup of step_main_ws, up to 256): a quad's four
+// threads sum a quarter of the rows each (loads eight deep), a fixed tree through LDS joins them - same order every run.
+template <int NB>
+__global__ __launch_bounds__(kWG) void step_finalize_ws(const FinalizeArgs a, const CarryHot hh, const int* tab_wt) {
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    const int quads = a.PP / 4;
+    const int blocks_per_obj = ws_finalize_blocks(a.PP);
+    if (blockIdx.x == gridDim.x - 1) {
+        finalize_loss(a);
+        return;
+    }
+    const int obj = blockIdx.x / blocks_per_obj, part = blockIdx.x - obj * blocks_per_obj;
+    const int ql = threadIdx.x % kFinQuads, rg = threadIdx.x / kFinQuads;
+    const int q = min(part * kFinQuads + ql, quads - 1);
+    const bool live = part * kFinQuads + ql < quads && 4 * q < a.P;
+    wv::f32x4* red = reinterpret_cast<wv::f32x4*>(wv::lds_base());      // [kFinGroups][kFinQuads]
+    {
+        const wv::f32x4* pg = reinterpret_cast<const wv::f32x4*>(hh.part_grad + (long long)obj * hh.NW * hh.PP + 4 * q);
+        const long long qs = hh.PP / 4;
+        const int per = (hh.NW + kFinGroups - 1) / kFinGroups, u_begin = min(hh.NW, rg * per), u_end = min(hh.NW, u_begin + per);
+        wv::f32x4 g = {0.0f, 0.0f, 0.0f, 0.0f};
+        int u0 = u_begin;
+        for (; u0 + 8 <= u_end; u0 += 8) {
+            wv::f32x4 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = pg[(u0 + u) * qs];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) g += t[u];
+        }
+        for (; u0 < u_end; ++u0) g += pg[u0 * qs];
+        red[rg * kFinQuads + ql] = g;
+    }
+    __syncthreads();
+    if (rg != 0 || !live) return;
+    static_assert(kFinGroups == 4, "the join below is a four-way tree");
+    const wv::f32x4 g = (red[ql] + red[kFinQuads + ql]) + (red[2 * kFinQuads + ql] + red[3 * kFinQuads + ql]);
+    const long long s = (long long)obj * hh.PP + 4 * q;
+    wv::f32x4 m4 = *reinterpret_cast<const wv::f32x4*>(hh.m + s);
+    wv::f32x4 v4 = *reinterpret_cast<const wv::f32x4*>(hh.v + s);
+    const i32x4 iw = *reinterpret_cast<const i32x4*>(hh.img_tab + 4 * q);
+    const i32x4 it = *reinterpret_cast<const i32x4*>(tab_wt + 4 * q);
+    float* pp[4]; float pv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int i = min(4 * q + e, a.P - 1);
+        int t = 0;
+#pragma unroll
+        for (int k = 1; k <= kNFc; ++k) t += i >= a.offs[k];
+        pp[e] = a.param[t].p + obj * a.param[t].stride + (i - a.offs[t]);
+        pv[e] = *pp[e];
+    }
+    char* image = reinterpret_cast<char*>(hh.wimg) + (long long)obj * ImgWs<NB>::BYTES;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (4 * q + e < a.P) {
+            float p = pv[e], m = m4[e], v = v4[e];
+            adamw_elem(hh, g[e], p, m, v);
+            *pp[e] = p; m4[e] = m; v4[e] = v;
+            ws_image_store<NB>(image, iw[e], it[e], p, hh.weights_bf16);
+        }
+    }
+    *reinterpret_cast<wv::f32x4*>(hh.m + s) = m4;
+    *reinterpret_cast<wv::f32x4*>(hh.v + s) = v4;
+}
+
+// ---- device helpers of step_main_ws -----------------------------------------------------------------------------------
+#ifdef WS_EXP_HOTW       // measurement build: every weight load hits the same two chunks (no L2 / HBM misses on the weight streams)
+#define WS_WSTEP(s) ((s) & 1)
+#else
+#define WS_WSTEP(s) (s)
+#endif
+// global access as (wave-uniform base) + (32-bit lane offset): the scalar-base form of the global instructions, no per-lane
+// 64-bit address arithmetic
+__device__ __forceinline__ u32x4 ldgu(const char* ubase, unsigned voff) { return *reinterpret_cast<const u32x4*>(ubase + voff); }
+__device__ __forceinline__ u32x4 lds16(const char* p) { return *reinterpret_cast<const u32x4*>(p); }
+
+// Forward steps.  Per 16-deep step the wave needs its weight chunk (3 planes from global memory) and the two tiles' input
+// chunks (3 planes each from LDS) for 12 matrix instructions.  Rings: weights two steps ahead (L2 latency), LDS one step.
+// The first two weight chunks of a run are fetched by the caller BEFORE the epilogue / barrier in front of the run (WPre).
+struct WOp { u32x4 p[3]; };
+struct XOp { u32x4 x[2][3]; };
+struct WPre { WOp w[2]; };
+template <bool W3>
+__device__ __forceinline__ void wop_load(WOp& o, const char* ubase, unsigned voff) {
+    o.p[0] = ldgu(ubase, voff);
+    if (W3) { o.p[1] = ldgu(ubase + 1024, voff); o.p[2] = ldgu(ubase + 2048, voff); }
+}
+__device__ __forceinline__ void xop_load(XOp& o, const char* x, int xst) {
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) o.x[st][pl] = lds16(x + st * xst + pl * 1024);
+}
+// six (bf16 weights: three) products per tile, smallest terms first; the two tiles' chains alternate
+template <bool W3>
+__device__ __forceinline__ void fop_mm(f32x16 (&acc)[2], const WOp& w, const XOp& o) {
+#pragma unroll
+    for (int st = 0; st < 2; ++st) acc[st] = wv::mfma_bf16(w.p[0], o.x[st][2], acc[st]);
+    if (W3) {
+#pragma unroll
+        for (int st = 0; st < 2; ++st) acc[st] = wv::mfma_bf16(w.p[2], o.x[st][0], acc[st]);
+#pragma unroll
+        for (int st = 0; st < 2; ++st) acc[st] = wv::mfma_bf16(w.p[1], o.x[st][1], acc[st]);
+    }
+#pragma unroll
+    for (int st = 0; st < 2; ++st) acc[st] = wv::mfma_bf16(w.p[0], o.x[st][1], acc[st]);
+    if (W3) {
+#pragma unroll
+        for (int st = 0; st < 2; ++st) acc[st] = wv::mfma_bf16(w.p[1], o.x[st][0], acc[st]);
+    }
+#pragma unroll
+    for (int st = 0; st < 2; ++st) acc[st] = wv::mfma_bf16(w.p[0], o.x[st][0], acc[st]);
+}
+// A run of NA + NB2 steps: the first NA steps read weight chunks at wa + s * 3072 and inputs at xa + s * 3072 (tile 1:
+// + xsta), the following NB2 steps at wb / xb (cat_layer and color_linear: encoding part, then hidden part)
+template <bool W3, int NA, int NB2>
+__device__ __forceinline__ void wpre_load(WPre& p, const char* wa, const char* wb, unsigned voff) {
+    wop_load<W3>(p.w[0], NA > 0 ? wa : wb, voff);
+    wop_load<W3>(p.w[1], NA > 1 ? wa + WS_WSTEP(1) * 3072 : wb + WS_WSTEP(1 - NA) * 3072, voff);
+    wv::sched_fence();
+}
+template <bool W3, int NA, int NB2>
+__device__ __forceinline__ void fwd_run(f32x16 (&acc)[2], const WPre& pre, const char* wa, const char* xa, int xsta,
+                                        const char* wb, const char* xb, int xstb, unsigned voff) {
+    constexpr int NST = NA + NB2;
+    WOp w[3];
+    XOp xo[2];
+    w[0] = pre.w[0]; w[1] = pre.w[1];
+    xop_load(xo[0], NA > 0 ? xa : xb, NA > 0 ? xsta : xstb);
+    wv::sched_fence();
+#pragma unroll
+    for (int s = 0; s < NST; ++s) {
+        if (s + 2 < NST) wop_load<W3>(w[(s + 2) % 3], s + 2 < NA ? wa + WS_WSTEP(s + 2) * 3072 : wb + WS_WSTEP(s + 2 - NA) * 3072, voff);
+        if (s + 1 < NST) xop_load(xo[(s + 1) & 1], s + 1 < NA ? xa + (s + 1) * 3072 : xb + (s + 1 - NA) * 3072, s + 1 < NA ? xsta : xstb);
+        wv::sched_fence();
+        fop_mm<W3>(acc, w[s % 3], xo[s & 1]);
+        wv::sched_fence();
+    }
+}
+// d-prop of one input block for both tiles: acc[st] += W^T[kb] . delta[st]; W^T chunks at gwt + sp * 2048 (2 planes), delta
+// chunks at d + sp * 2048 (tile 1: + dst); the first three W^T chunks come from the caller (TPre)
+struct TOp { u32x4 p[2]; };
+struct DOp { u32x4 d[2][2]; };
+struct TPre { TOp w[3]; };
+template <bool W3>
+__device__ __forceinline__ void top_load(TOp& o, const char* ubase, unsigned voff) {
+    o.p[0] = ldgu(ubase, voff);
+    if (W3) o.p[1] = ldgu(ubase + 1024, voff);
+}
+template <bool W3>
+__device__ __forceinline__ void tpre_load(TPre& p, const char* gwt, unsigned voff) {
+    top_load<W3>(p.w[0], gwt, voff);
+    top_load<W3>(p.w[1], gwt + WS_WSTEP(1) * 2048, voff);
+    top_load<W3>(p.w[2], gwt + WS_WSTEP(2) * 2048, voff);
+    wv::sched_fence();
+}
+__device__ __forceinline__ void dop_load(DOp& o, const char* d, int dst) {
+#pragma unroll
+    for (int st = 0; st < 2; ++st) { o.d[st][0] = lds16(d + st * dst); o.d[st][1] = lds16(d + st * dst + 1024); }
+}
+template <bool W3>
+__device__ __forceinline__ void bop_mm(f32x16 (&acc)[2], const TOp& w, const DOp& o) {
+#pragma unroll
+    for (int st = 0; st < 2; ++st) acc[st] = wv::mfma_bf16(w.p[0], o.d[st][1], acc[st]);
+    if (W3) {
+#pragma unroll
+        for (int st = 0; st < 2; ++st) acc[st] = wv::mfma_bf16(w.p[1], o.d[st][0], acc[st]);
+    }
+#pragma unroll
+    for (int st = 0; st < 2; ++st) acc[st] = wv::mfma_bf16(w.p[0], o.d[st][0], acc[st]);
+}
+template <bool W3, int NST>
+__device__ __forceinline__ void bwd_run(f32x16 (&acc)[2], const TPre& pre, const char* gwt, unsigned voff, const char* d, int dst) {
+    TOp w[4];
+    DOp dd[2];
+    w[0] = pre.w[0]; w[1] = pre.w[1]; w[2] = pre.w[2];
+    dop_load(dd[0], d, dst);
+    wv::sched_fence();
+#pragma unroll
+    for (int s = 0; s < NST; ++s) {
+        if (s + 3 < NST) top_load<W3>(w[(s + 3) & 3], gwt + WS_WSTEP(s + 3) * 2048, voff);
+        if (s + 1 < NST) dop_load(dd[(s + 1) & 1], d + (s + 1) * 2048, dst);
+        wv::sched_fence();
+        bop_mm<W3>(acc, w[s & 3], dd[s & 1]);
+        wv::sched_fence();
+    }
+}
+// own block's planes -> P-form operand image: steps at img, img + CH (planes 1 KiB apart)
+template <int NPL, int CH>
+__device__ __forceinline__ void put_image(char* img, const unsigned (&h)[8], const unsigned (&m)[8], const unsigned (&l)[8]) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        *reinterpret_cast<u32x4*>(img + s * CH) = u32x4{h[4 * s], h[4 * s + 1], h[4 * s + 2], h[4 * s + 3]};
+        *reinterpret_cast<u32x4*>(img + s * CH + 1024) = u32x4{m[4 * s], m[4 * s + 1], m[4 * s + 2], m[4 * s + 3]};
+        if (NPL == 3) *reinterpret_cast<u32x4*>(img + s * CH + 2048) = u32x4{l[4 * s], l[4 * s + 1], l[4 * s + 2], l[4 * s + 3]};
+    }
+}
+// the activation planes in the workgroup's scratch: ubase = scratch + ACTS_OFF (uniform), voff = tid * 16; chunk
+// ((layer * 2 + st) * 2 + plane) * 2 + step
+__device__ __forceinline__ void acts_store(char* ubase, unsigned voff, int layer, int st, const unsigned (&h)[8], const unsigned (&m)[8]) {
+    char* q = ubase + (layer * 2 + st) * 4 * 4096;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        *reinterpret_cast<u32x4*>(q + s * 4096 + voff) = u32x4{h[4 * s], h[4 * s + 1], h[4 * s + 2], h[4 * s + 3]};
+        *reinterpret_cast<u32x4*>(q + (2 + s) * 4096 + voff) = u32x4{m[4 * s], m[4 * s + 1], m[4 * s + 2], m[4 * s + 3]};
+    }
+}
+__device__ __forceinline__ void acts_load_plane(unsigned (&h)[8], const char* ubase, unsigned voff, int layer, int st, int plane) {
+    const char* q = ubase + ((layer * 2 + st) * 2 + plane) * 2 * 4096;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const u32x4 v = ldgu(q + s * 4096, voff);
+        h[4 * s] = v[0]; h[4 * s + 1] = v[1]; h[4 * s + 2] = v[2]; h[4 * s + 3] = v[3];
+    }
+}
+// P-form planes (hi, mid) -> F-form registers through the wave's transpose tile
+template <int NQ>
+__device__ __forceinline__ void to_F(unsigned (&f)[16], char* tile, const unsigned* h, const unsigned* m, int p31, int hi, const TrLane& TL) {
+    tile_put<NQ>(tile, h, m, p31, hi);
+    tile_get(f, tile, TL);
+}
+// F-form registers <-> a 4 KiB image [4][64 lanes][16 B] (img already holds the lane offset)
+__device__ __forceinline__ void put_F(char* img, const unsigned (&f)[16]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) *reinterpret_cast<u32x4*>(img + c * 1024) = u32x4{f[4 * c], f[4 * c + 1], f[4 * c + 2], f[4 * c + 3]};
+}
+struct FImg { u32x4 c[2][4]; };                                          // the two tiles' F-form images of one block
+__device__ __forceinline__ void fimg_load(FImg& o, const char* img, int xst) {
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o.c[st][c] = lds16(img + st * xst + c * 1024);
+}
+// one weight-gradient block over the round's two tiles: acc = sum_tiles dY^T X (F-form: c[0..1] hi plane steps, c[2..3] mid)
+__device__ __forceinline__ void dw_mm_pair(f32x16& acc, const unsigned (&dF)[2][16], const FImg& x) {
+    zero_acc(acc);
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const u32x4 ah = u32x4{dF[st][4 * s], dF[st][4 * s + 1], dF[st][4 * s + 2], dF[st][4 * s + 3]};
+            const u32x4 am = u32x4{dF[st][8 + 4 * s], dF[st][8 + 4 * s + 1], dF[st][8 + 4 * s + 2], dF[st][8 + 4 * s + 3]};
+            acc = wv::mfma_bf16(ah, x.c[st][2 + s], acc);
+            acc = wv::mfma_bf16(am, x.c[st][s], acc);
+            acc = wv::mfma_bf16(ah, x.c[st][s], acc);
+        }
+}
+// bias gradient of a layer without constant-1 input column: dY^T . ones
+__device__ __forceinline__ void db_pair(f32x16& acc, const unsigned (&dF)[2][16]) {
+    const u32x4 ones = u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+    zero_acc(acc);
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            acc = wv::mfma_bf16(u32x4{dF[st][8 + 4 * s], dF[st][8 + 4 * s + 1], dF[st][8 + 4 * s + 2], dF[st][8 + 4 * s + 3]}, ones, acc);
+            acc = wv::mfma_bf16(u32x4{dF[st][4 * s], dF[st][4 * s + 1], dF[st][4 * s + 2], dF[st][4 * s + 3]}, ones, acc);
+        }
+}
+// 16 values of a lane: rows (r & 3) + 8 (r >> 2) of a block that starts at ubase (row pitch K floats); voff = the lane's element
+// offset inside row 0 (column + 4 hi rows).  One lane pointer per group of four rows, the rows themselves are immediates.
+// First round: store; later rounds: add.
+template <int K>
+__device__ __forceinline__ void store_rows(float* ubase, unsigned voff, const f32x16& acc, bool first) {
+#ifdef WS_EXP_NOSTORE       // measurement build: the partial-gradient stores never execute
+    if (acc[0] != 12345.678f) return;
+#endif
+    float* q = ubase + voff;
+    if (first) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float* qg = q + 8 * g * K;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) qg[i * K] = acc[4 * g + i];
+        }
+    } else {
+        float old[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) old[r] = q[((r & 3) + 8 * (r >> 2)) * K];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) q[((r & 3) + 8 * (r >> 2)) * K] = old[r] + acc[r];
+    }
+}
+// a 32x32 weight-gradient block (lane = column k, register r <-> row phi(r, hi)) -> the partial gradients
+template <int KIND, int K>
+__device__ __forceinline__ void store_block(float* out_w, float* out_b, const f32x16& acc, int blk, int ncols, int p31, int hi, bool first) {
+    int col; bool bias;
+    col_target<KIND>(blk, p31, col, bias);
+    if (col >= 0 && col < ncols) store_rows<K>(out_w, (unsigned)(col + 4 * hi * K), acc, first);
+    else if (bias) store_rows<1>(out_b, (unsigned)(4 * hi), acc, first);
+}
+__device__ __forceinline__ void store_one(float* q, float v, bool first) { *q = first ? v : *q + v; }
+// ReLU mask from the packed hi plane: d[r] = h[r] > 0 ? v[r] : 0
+__device__ __forceinline__ void mask_by(float (&d)[16], const f32x16& v, const unsigned (&hh)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const unsigned u = hh[i];
+        d[2 * i] = (u & 0xFFFFu) != 0u ? v[2 * i] : 0.0f;
+        d[2 * i + 1] = u > 0xFFFFu ? v[2 * i + 1] : 0.0f;
+    }
+}
+// weight-gradient blocks of one layer: N input blocks (images at ximg(kb), tile 1: + xst(kb)); the LDS reads of block kb + 1 and
+// the stores of block kb - 1 surround the matrix instructions of block kb
+template <int N, class XI, class ST>
+__device__ __forceinline__ void dw_layer(const unsigned (&dF)[2][16], XI&& ximg, ST&& store) {
+    FImg x[2];
+    f32x16 acc[2];
+    { const char* p; int st; ximg(0, p, st); fimg_load(x[0], p, st); }
+#pragma unroll
+    for (int kb = 0; kb < N; ++kb) {
+        if (kb + 1 < N) { const char* p; int st; ximg(kb + 1, p, st); fimg_load(x[(kb + 1) & 1], p, st); }
+        wv::sched_fence();
+        dw_mm_pair(acc[kb & 1], dF, x[kb & 1]);
+        if (kb > 0) store(kb - 1, acc[(kb - 1) & 1]);
+        wv::sched_fence();
+    }
+    store(N - 1, acc[(N - 1) & 1]);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// step_main_ws<NB, BWD, W3>: NB = 4 (hidden 128); W3 = false: bf16 weights (one weight plane)
+// ---------------------------------------------------------------------------------------------------------
+template <int NB, bool BWD, bool W3, bool STAMPS = false>
+__global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
+    static_assert(NB == 4, "one output block per wave");
+    using I = ImgWs<NB>;
+    constexpr int H = I::H, JS = I::JS;
+    const StepArgs& a = ga.s;
+    const GenLayout L = gen_layout(H);
+    char* lds = reinterpret_cast<char*>(wv::lds_base());
+    const int tid_k = threadIdx.x;
+    const int obj = blockIdx.x / a.NW, wgo = blockIdx.x - obj * a.NW;
+    const char* gimg = reinterpret_cast<const char*>(a.wimg) + (long long)obj * I::BYTES;
+    const float* SM = reinterpret_cast<const float*>(gimg + I::SMALL_OFF);
+    float* loss_cells = reinterpret_cast<float*>(lds + I::LOSS);
+    if (tid_k < kWaves * 4) loss_cells[tid_k] = 0.0f;
+    float* out_k = a.part_grad + ((long long)(obj * a.NW + wgo)) * a.PP;
+    float* cb = reinterpret_cast<float*>(lds + I::CBO);
+    float* hp = reinterpret_cast<float*>(lds + I::HP);
+    const float scale = a.pe_scale.p[obj * a.pe_scale.stride];
+    const float* Bg = SM + I::PE_B;
+    char* wgs_k = ga.scratch + (long long)blockIdx.x * I::WG_SCRATCH;
+    unsigned* tmark = STAMPS && a.timing ? a.timing + ((long long)blockIdx.x * kWaves + (tid_k >> 6)) * kMarks : nullptr;
+#ifdef WS_EXP_DETAIL     // measurement build: the 16 stamps sit inside the backward pass of color_linear and mid2
+#define WS_MARK(i) do { } while (0)
+#define WS_DMARK(i) do { if constexpr (STAMPS) { if (tmark && first && (tid_k & 63) == 0) tmark[i] = wv::clock32(); } } while (0)
+#else
+#define WS_MARK(i) do { if constexpr (STAMPS) { if (tmark && first && (tid_k & 63) == 0) tmark[i] = wv::clock32(); } } while (0)
+#define WS_DMARK(i) do { } while (0)
+#endif
+
+    for (int grp = wgo; grp < a.NG; grp += a.NW) {
+    const bool first = grp == wgo;
+    // per-round copies of the wave-uniform bases (see wv::opaque_uzero)
+    const unsigned uz = wv::opaque_uzero();
+    const char* gW = gimg + uz;
+    const char* gWT = gimg + I::WT_OFF + uz;
+    float* out = out_k + uz;
+    char* wgs = wgs_k + uz;
+    float* cfs = reinterpret_cast<float*>(wgs);
+    WS_MARK(0);
+    const int tid = wv::opaque_iter(tid_k), lane = tid & 63, wave = wv::uniform(tid >> 6), p31 = lane & 31, hi = lane >> 5;
+    const TrLane TL = tr_lane(lane);
+    char* tile = lds + I::SCRT + wave * Img32s::TILE;
+    char* acts = wgs + I::ACTS_OFF;                                      // + tid * 16 per thread
+    const unsigned tid16 = (unsigned)tid * 16u;
+    const int lo16 = lane * 16;
+    const unsigned vlo16 = (unsigned)lane * 16u;
+    __syncthreads();                                                     // previous round done with LDS
+    for (int i = tid; i < I::kPts * 8; i += kWG) cb[i] = 0.0f;
+    const int ray0 = grp * a.G;
+    const int nrays = min(a.G, a.R - ray0);
+    const int npts = nrays * a.S;                                        // <= 64
+    WPre pre_in;                                                         // in_layer's first weight chunks: fetched behind the encoding
+    wpre_load<W3, 6, 0>(pre_in, gW + ((long long)(I::CW_IN + wave * I::KS_IN)) * I::XCH, nullptr, vlo16);
+    // ---- encoding (embedding.py:82-91): wave = (tile est, direction half dhalf); owner-lane slots as in step_main_s32 ----
+    {
+        const int est = wave & 1, dhalf = wave >> 1;
+        const int pt = 32 * est + p31;
+        const bool valid = pt < npts;
+        const int lray = valid ? pt / a.S : 0, smp = valid ? pt - lray * a.S : 0, ray = ray0 + lray;
+        float px3[3] = {0.0f, 0.0f, 0.0f};
+        if (valid) {
+            const float* px = a.pcs + obj * a.pcs_so + ray * a.pcs_sr + smp * a.pcs_ss;
+            px3[0] = px[0]; px3[1] = px[a.pcs_sc]; px3[2] = px[2 * a.pcs_sc];
+        }
+        const float t[3] = {px3[0] / scale, px3[1] / scale, px3[2] / scale};          // embedding.py:83
+        // this wave's directions: slots i = 6 dhalf + ii; lane half hi = 0 owns directions 0..10, hi = 1 directions 11..20;
+        // slot 11 = (x, y, z, 1) / the constant of the second group
+        float proj[6];
+        float amax = 0.0f;
+#pragma unroll
+        for (int ii = 0; ii < 6; ++ii) {
+            const int i = 6 * dhalf + ii;
+            const int d = hi ? min(11 + i, 20) : min(i, 10);
+            proj[ii] = fmaf(t[2], Bg[3 * d + 2], fmaf(t[1], Bg[3 * d + 1], t[0] * Bg[3 * d]));      // embedding.py:84
+            amax = fmaxf(amax, fabsf(proj[ii]));
+        }
+        const bool fast = !wv::wave_any(!(amax * (32.0f * kPi) < kSinCosFastLimit));
+        char* e1img = lds + I::EIM + est * I::E_ST + lo16;
+        char* e2img = e1img + I::E2_OFF;
+        float* cf_out = cfs + est * 66 * 64 + lane;
+#pragma unroll
+        for (int ii = 0; ii < 6; ++ii) {
+            const int i = 6 * dhalf + ii;
+            const bool pseudo = i == 11;
+            float s[6], c[6];
+            const float a0 = proj[ii] * kPi;
+            if (__builtin_expect(fast, 1)) octave_sincos<false>(a0, s, c);
+            else octave_sincos<true>(a0, s, c);
+            const bool own = i < 10 || (i == 10 && hi == 0);
+            float v1[4], v2[2];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) v1[f] = own ? s[f] : 0.0f;
+            v2[0] = own ? s[4] : 0.0f; v2[1] = own ? s[5] : 0.0f;
+            if (pseudo) {
+                v1[0] = hi ? 0.0f : t[0]; v1[1] = hi ? 0.0f : t[1]; v1[2] = hi ? 0.0f : t[2]; v1[3] = hi ? 0.0f : 1.0f;
+                v2[0] = hi ? 0.0f : 1.0f; v2[1] = 0.0f;
+            } else if (BWD) {
+#pragma unroll
+                for (int f = 0; f < 6; ++f) cf_out[(6 * i + f) * 64] = own ? c[f] * (kPi * (float)(1 << f)) : 0.0f;
+            }
+            unsigned h1[2], m1[2], l1[2], h2[1], m2[1], l2[1];
+            split_planes<4, 3>(v1, h1, m1, l1);
+            split_planes<2, 3>(v2, h2, m2, l2);
+            char* q1 = e1img + (i >> 1) * I::XCH + (i & 1) * 8;
+            *reinterpret_cast<u32x2*>(q1) = u32x2{h1[0], h1[1]};
+            *reinterpret_cast<u32x2*>(q1 + 1024) = u32x2{m1[0], m1[1]};
+            *reinterpret_cast<u32x2*>(q1 + 2048) = u32x2{l1[0], l1[1]};
+            char* q2 = e2img + (i >> 2) * I::XCH + (i & 3) * 4;
+            *reinterpret_cast<unsigned*>(q2) = h2[0];
+            *reinterpret_cast<unsigned*>(q2 + 1024) = m2[0];
+            *reinterpret_cast<unsigned*>(q2 + 2048) = l2[0];
+        }
+    }
+    __syncthreads();
+    WS_MARK(1);
+    // ---- forward (model.py:59-83): wave w = output block w of every layer, both tiles ----
+    const char* e1x = lds + I::EIM + lo16;
+    const char* e2x = e1x + I::E2_OFF;
+    const char* actx = lds + I::ACT + lo16;
+    char* act_own = lds + I::ACT + wave * 2 * I::XCH + lo16;             // this wave's block of the layer-input images (tile 0)
+    f32x16 acc[2];
+    // epilogue of a layer: ReLU, the heads' partial sums, split into planes; planes -> the next layer's input images (lo
+    // included) and, hi / mid, -> the scratch (backward)
+    auto epilogue = [&](int layer) {
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            float hf[16];
+            unsigned ph[8], pm[8], pl[8];
+            relu_to(hf, acc[st]);
+            if (layer >= 3) {
+                float r0 = 0.0f, r1 = 0.0f, r2 = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int j = 32 * wave + phi(r, hi);
+                    if (layer == 3) r0 = fmaf(SM[I::W_A + j], hf[r], r0);                           // :71 out_alpha
+                    else {                                                                          // :82 out_color
+                        r0 = fmaf(SM[I::W_OC + j], hf[r], r0);
+                        r1 = fmaf(SM[I::W_OC + H + j], hf[r], r1);
+                        r2 = fmaf(SM[I::W_OC + 2 * H + j], hf[r], r2);
+                    }
+                }
+                r0 += wv::swap_half(r0);
+                if (layer == 4) { r1 += wv::swap_half(r1); r2 += wv::swap_half(r2); }
+                if (hi == 0) {
+                    float* cell = hp + ((wave * 2 + st) * 32 + p31) * 4;
+                    if (layer == 3) cell[0] = r0;
+                    else { cell[1] = r0; cell[2] = r1; cell[3] = r2; }
+                }
+            }
+            split_planes<16, 3>(hf, ph, pm, pl);
+            if (layer < 4) put_image<3, I::XCH>(act_own + st * I::ACT_ST, ph, pm, pl);
+            if (BWD) acts_store(acts, tid16, layer, st, ph, pm);
+        }
+    };
+#ifdef WS_EXP_HOTW
+    auto wchunk = [&](int, int, int) { return gW + (long long)wave * 2 * I::XCH; };
+#else
+    auto wchunk = [&](int base, int ks, int s) { return gW + ((long long)(base + wave * ks + s)) * I::XCH; };     // wave-uniform
+#endif
+    WPre pre;
+    zero_acc(acc[0]); zero_acc(acc[1]);                                  // :59 in_layer (bias rides in the constant-1 column)
+    fwd_run<W3, 6, 0>(acc, pre_in, wchunk(I::CW_IN, I::KS_IN, 0), e1x, I::E_ST, nullptr, nullptr, 0, vlo16);
+    wpre_load<W3, 0, JS>(pre, nullptr, wchunk(I::CW_M1, I::KS_M, 0), vlo16);
+    epilogue(0);
+    __syncthreads();
+    WS_MARK(2);
+    load_bias(acc[0], SM + I::B_M1 + 32 * wave, hi); acc[1] = acc[0];    // :60 mid1
+    fwd_run<W3, 0, JS>(acc, pre, nullptr, nullptr, 0, wchunk(I::CW_M1, I::KS_M, 0), actx, I::ACT_ST, vlo16);
+    wpre_load<W3, 6, JS>(pre, wchunk(I::CW_CAT, I::KS_CAT, JS), wchunk(I::CW_CAT, I::KS_CAT, 0), vlo16);
+    __syncthreads();                                                     // everybody has read h1
+    epilogue(1);
+    __syncthreads();
+    WS_MARK(3);
+    zero_acc(acc[0]); zero_acc(acc[1]);                                  // :63-64 cat_layer: encoding part, then h2
+    fwd_run<W3, 6, JS>(acc, pre, wchunk(I::CW_CAT, I::KS_CAT, JS), e1x, I::E_ST, wchunk(I::CW_CAT, I::KS_CAT, 0), actx, I::ACT_ST, vlo16);
+    wpre_load<W3, 0, JS>(pre, nullptr, wchunk(I::CW_M2, I::KS_M, 0), vlo16);
+    __syncthreads();
+    epilogue(2);
+    __syncthreads();
+    WS_MARK(4);
+    load_bias(acc[0], SM + I::B_M2 + 32 * wave, hi); acc[1] = acc[0];    // :67 mid2
+    fwd_run<W3, 0, JS>(acc, pre, nullptr, nullptr, 0, wchunk(I::CW_M2, I::KS_M, 0), actx, I::ACT_ST, vlo16);
+    wpre_load<W3, 3, JS>(pre, wchunk(I::CW_C, I::KS_C, JS), wchunk(I::CW_C, I::KS_C, 0), vlo16);
+    __syncthreads();
+    epilogue(3);
+    __syncthreads();
+    WS_MARK(5);
+    zero_acc(acc[0]); zero_acc(acc[1]);                                  // :81 color_linear: second encoding group, then h4
+    fwd_run<W3, 3, JS>(acc, pre, wchunk(I::CW_C, I::KS_C, JS), e2x, I::E_ST, wchunk(I::CW_C, I::KS_C, 0), actx, I::ACT_ST, vlo16);
+    epilogue(4);
+    __syncthreads();
+    WS_MARK(6);
+    if (wave < 2 && hi == 0) {                                           // heads of tile `wave`: sum of the four waves' partials
+        const int pt = 32 * wave + p31;
+        if (pt < npts) {
+            const int lray = pt / a.S, smp = pt - lray * a.S, ray = ray0 + lray;
+            float v[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                v[c] = (hp[((0 * 2 + wave) * 32 + p31) * 4 + c] + hp[((1 * 2 + wave) * 32 + p31) * 4 + c]) +
+                       (hp[((2 * 2 + wave) * 32 + p31) * 4 + c] + hp[((3 * 2 + wave) * 32 + p31) * 4 + c]);
+            float* row = cb + pt * 8;
+            row[6] = a.z[obj * a.z_so + ray * a.z_sr + smp * a.z_ss];
+            row[0] = sigmoidf_acc((v[0] + SM[I::B_A]) * 10.0f);           // :77 raw*10 ; render_rays.py:6
+            row[1] = sigmoidf_acc(v[1] + SM[I::B_OC]);                    // :83
+            row[2] = sigmoidf_acc(v[2] + SM[I::B_OC + 1]);
+            row[3] = sigmoidf_acc(v[3] + SM[I::B_OC + 2]);
+        }
+    }
+    __syncthreads();
+    {
+        const StepArgs& al = wv::kernarg_late(ga).s;
+        composite_phase<BWD>(al, cb, loss_cells, obj, ray0, nrays, wave, lane, tid,
+                             load_ray_meta(al, obj, ray0 + min(4 * wave + (lane >> 4), nrays - 1)));
+    }
+    __syncthreads();
+    WS_MARK(7);
+    if (BWD) {
+    // ---- backward ----
+    unsigned ah[2][8], am[2][8];                                         // planes of an activation block coming back from the scratch
+    auto fetch = [&](int layer) {
+#pragma unroll
+        for (int st = 0; st < 2; ++st) { acts_load_plane(ah[st], acts, tid16, layer, st, 0); acts_load_plane(am[st], acts, tid16, layer, st, 1); }
+        wv::sched_fence();
+    };
+    fetch(3);                                                            // h4: lands during the encoding transposes
+    float d_raw[2], d_c0[2], d_c1[2], d_c2[2];
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        const float* row = cb + (32 * st + p31) * 8;                     // padding rows hold zeros
+        d_raw[st] = row[0]; d_c0[st] = row[1]; d_c1[st] = row[2]; d_c2[st] = row[3];
+    }
+    // F-form images of the ten encoding blocks (weight-gradient operands), from the P-form images of the forward; dealt round-robin
+    {
+        char* ef = lds + I::EF + lo16;
+#pragma unroll
+        for (int j = 0; j < 10; ++j) {
+            if ((j & 3) != wave) continue;
+            const int st = j / 5, eb = j - 5 * st;
+            const char* src = eb < 3 ? e1x + st * I::E_ST + 2 * eb * I::XCH : e2x + st * I::E_ST + 2 * (eb - 3) * I::XCH;
+            unsigned h[8], m[8], f[16];
+            const u32x4 h0 = lds16(src), m0 = lds16(src + 1024);
+            h[0] = h0[0]; h[1] = h0[1]; h[2] = h0[2]; h[3] = h0[3]; m[0] = m0[0]; m[1] = m0[1]; m[2] = m0[2]; m[3] = m0[3];
+            if (eb < 4) {
+                const u32x4 h1 = lds16(src + I::XCH), m1 = lds16(src + I::XCH + 1024);
+                h[4] = h1[0]; h[5] = h1[1]; h[6] = h1[2]; h[7] = h1[3]; m[4] = m1[0]; m[5] = m1[1]; m[6] = m1[2]; m[7] = m1[3];
+            } else {
+                h[4] = h[5] = h[6] = h[7] = 0u; m[4] = m[5] = m[6] = m[7] = 0u;
+            }
+            to_F<4>(f, tile, h, m, p31, hi, TL);
+            put_F(ef + st * I::EF_ST + eb * 4096, f);
+        }
+    }
+    // F-form of the heads' delta (features 0..3 = d raw alpha, d raw colour), both tiles: every wave for itself
+    unsigned dF[2][16];
+    float dv[2][16];
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        unsigned dh[8], dm[8], dl[8];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dv[st][r] = 0.0f;
+        if (hi == 0) { dv[st][0] = d_raw[st]; dv[st][1] = d_c0[st]; dv[st][2] = d_c1[st]; dv[st][3] = d_c2[st]; }
+        split_planes<16, 2>(dv[st], dh, dm, dl);
+        to_F<4>(dF[st], tile, dh, dm, p31, hi, TL);
+    }
+    __syncthreads();                                                     // encoding F images complete; the P-form images are dead
+    WS_MARK(8);
+    float* outW_c = out + L.f[10] + (long long)32 * wave * (H + kEmb2);
+    float* outW_m2 = out + L.f[6] + (long long)32 * wave * H;
+    float* outW_cat = out + L.f[4] + (long long)32 * wave * (H + kEmb1);
+    float* outW_m1 = out + L.f[2] + (long long)32 * wave * H;
+    float* outW_in = out + L.f[0] + (long long)32 * wave * kEmb1;
+    char* dlt_own = lds + I::DLT + wave * 2 * I::DCH + lo16;
+    const char* dltx = lds + I::DLT + lo16;
+    char* xf_own = lds + I::XF + wave * 4096 + lo16;
+    const char* xfx = lds + I::XF + lo16;
+    const char* efx = lds + I::EF + lo16;
+    f32x16 accw, accd[2];
+    float dproj[2][11];
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int i = 0; i < 11; ++i) dproj[st][i] = 0.0f;
+    // the fetched activation block (ah, am) -> its F-form images, the layer input of everybody's weight gradients
+    auto publish_x = [&]() {
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            unsigned xF[16];
+            to_F<4>(xF, tile, ah[st], am[st], p31, hi, TL);
+            put_F(xf_own + st * I::XF_ST, xF);
+        }
+    };
+    // the wave's delta block (float32 registers dv[st]) -> planes -> P-form image + F-form registers dF
+    auto publish_d = [&]() {
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            unsigned dh[8], dm[8], dl[8];
+            split_planes<16, 2>(dv[st], dh, dm, dl);
+            put_image<2, I::DCH>(dlt_own + st * I::DLT_ST, dh, dm, dl);
+            to_F<4>(dF[st], tile, dh, dm, p31, hi, TL);
+        }
+    };
+    // d-prop into the wave's own hidden block of layer ct (both tiles); the first W^T chunks (tp) were fetched at the phase start
+    TPre tp, tpe;
+    auto hidden_ptr = [&](int ct_base) {
+#ifdef WS_EXP_HOTW
+        return gWT + ((long long)(0 * ct_base + wave * 2)) * I::DCH;
+#else
+        return gWT + ((long long)(ct_base + wave * JS)) * I::DCH;
+#endif
+    };
+    auto dprop_hidden = [&](int ct_base, bool add_alpha) {
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            if (add_alpha) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accd[st][r] = SM[I::W_A + 32 * wave + phi(r, hi)] * d_raw[st];
+            } else zero_acc(accd[st]);
+        }
+        bwd_run<W3, JS>(accd, tp, hidden_ptr(ct_base), vlo16, dltx, I::DLT_ST);
+    };
+    // d-prop into an encoding block -> d(proj) through the cos factors (cfr: fetched at the phase start, with tpe)
+    float cfr[2][16];
+    auto enc_ptr = [&](int ct_chunk) {
+#ifdef WS_EXP_HOTW
+        return gWT + (long long)(0 * ct_chunk + wave * 2) * I::DCH;
+#else
+        return gWT + (long long)ct_chunk * I::DCH;
+#endif
+    };
+    auto enc_fetch = [&](int ct_chunk, int group, int blk) {
+        tpre_load<W3>(tpe, enc_ptr(ct_chunk), vlo16);
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const char* cfu = reinterpret_cast<const char*>(cfs + st * 66 * 64);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int R = 16 * blk + r;
+                const int idx = group == 1 ? (R < 44 ? 6 * (R >> 2) + (R & 3) : -1) : (R < 22 ? 6 * (R >> 1) + 4 + (R & 1) : -1);
+#ifdef WS_EXP_NOCF
+                cfr[st][r] = 0.5f;
+#else
+                cfr[st][r] = idx >= 0 ? *reinterpret_cast<const float*>(cfu + idx * 256 + (unsigned)lane * 4u) : 0.0f;
+#endif
+            }
+        }
+        wv::sched_fence();
+    };
+    auto dprop_enc = [&](int ct_chunk, int group, int blk) {
+        f32x16 acce[2];
+        zero_acc(acce[0]); zero_acc(acce[1]);
+        bwd_run<W3, JS>(acce, tpe, enc_ptr(ct_chunk), vlo16, dltx, I::DLT_ST);
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int R = 16 * blk + r;
+                if (group == 1) { if (R < 44) dproj[st][R >> 2] = fmaf(acce[st][r], cfr[st][r], dproj[st][R >> 2]); }
+                else { if (R < 22) dproj[st][R >> 1] = fmaf(acce[st][r], cfr[st][r], dproj[st][R >> 1]); }
+            }
+        }
+    };
+    auto xf_img = [&](int kb, const char*& p, int& st) { p = xfx + kb * 4096; st = I::XF_ST; };
+    // -- heads: d W_a = (d raw)^T h4, d W_oc = (d colour)^T hc; rows 0..3 of one block each --
+    {
+        FImg xi;
+        publish_x();                                                     // h4 block: color_linear's weight-gradient operand
+        fetch(4);                                                        // hc
+        wv::wave_lds_fence();
+        fimg_load(xi, xf_own, I::XF_ST);
+        dw_mm_pair(accw, dF, xi);
+        if (hi == 0) store_one(out + L.f[8] + 32 * wave + p31, accw[0], first);
+        if (wave == 0) {
+            f32x16 accb;
+            db_pair(accb, dF);
+            if (lane == 0) {
+                store_one(out + L.f[9], accb[0], first);
+                store_one(out + L.f[13] + 0, accb[1], first); store_one(out + L.f[13] + 1, accb[2], first); store_one(out + L.f[13] + 2, accb[3], first);
+            }
+        }
+        unsigned x0[16], x1[16];
+        to_F<4>(x0, tile, ah[0], am[0], p31, hi, TL);
+        to_F<4>(x1, tile, ah[1], am[1], p31, hi, TL);
+        zero_acc(accw);
+        dw_mm_s(accw, dF[0], x0); dw_mm_s(accw, dF[1], x1);
+        if (hi == 0) {
+            store_one(out + L.f[12] + 0 * H + 32 * wave + p31, accw[1], first);
+            store_one(out + L.f[12] + 1 * H + 32 * wave + p31, accw[2], first);
+            store_one(out + L.f[12] + 2 * H + 32 * wave + p31, accw[3], first);
+        }
+    }
+    // -- delta 0 = d hc (through the ReLU; ah = hc's hi plane) --
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        f32x16 v;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = 32 * wave + phi(r, hi);
+            v[r] = SM[I::W_OC + j] * d_c0[st] + SM[I::W_OC + H + j] * d_c1[st] + SM[I::W_OC + 2 * H + j] * d_c2[st];
+        }
+        mask_by(dv[st], v, ah[st]);
+    }
+    publish_d();
+    fetch(3);                                                            // h4 again: the mask of delta 1
+    __syncthreads();
+    WS_MARK(9);
+    WS_DMARK(0);
+    // color_linear: weight gradients (h4 blocks, second-group blocks + bias column), d-prop -> d h4 (+ W_a d raw), d(second group)
+    tpre_load<W3>(tp, hidden_ptr(I::CT_C), vlo16);
+    if (wave == 0) enc_fetch(I::CT_C + (NB + 0) * JS, 2, 0);
+    if (wave == 1) enc_fetch(I::CT_C + (NB + 1) * JS, 2, 1);
+    WS_DMARK(1);
+    dw_layer<NB + 2>(dF,
+        [&](int kb, const char*& p, int& st) { if (kb < NB) xf_img(kb, p, st); else { p = efx + (3 + kb - NB) * 4096; st = I::EF_ST; } },
+        [&](int kb, const f32x16& v) {
+            if (kb < NB) store_block<0, H + kEmb2>(outW_c + 32 * kb, nullptr, v, 0, 32, p31, hi, first);
+            else store_block<2, H + kEmb2>(outW_c + H, out + L.f[11] + 32 * wave, v, kb - NB, kEmb2, p31, hi, first);
+        });
+    WS_DMARK(2);
+    if (wave == 0) dprop_enc(I::CT_C + (NB + 0) * JS, 2, 0);
+    if (wave == 1) dprop_enc(I::CT_C + (NB + 1) * JS, 2, 1);
+    WS_DMARK(3);
+    dprop_hidden(I::CT_C, true);
+    WS_DMARK(4);
+#pragma unroll
+    for (int st = 0; st < 2; ++st) mask_by(dv[st], accd[st], ah[st]);  // delta 1 = d h4
+    fetch(2);                                                            // h3: mid2's input and the mask of delta 2
+    tpre_load<W3>(tp, hidden_ptr(I::CT_M2), vlo16);
+    WS_DMARK(5);
+    __syncthreads();
+    WS_DMARK(6);
+    publish_d();
+    WS_DMARK(7);
+    publish_x();
+    WS_DMARK(8);
+    __syncthreads();
+    WS_DMARK(9);
+    WS_MARK(10);
+    // mid2
+    dw_layer<NB>(dF, xf_img, [&](int kb, const f32x16& v) { store_block<0, H>(outW_m2 + 32 * kb, nullptr, v, 0, 32, p31, hi, first); });
+    WS_DMARK(10);
+    db_pair(accw, dF);
+    if (p31 == 0) store_rows<1>(out + L.f[7] + 32 * wave, (unsigned)(4 * hi), accw, first);
+    WS_DMARK(11);
+    dprop_hidden(I::CT_M2, false);
+    WS_DMARK(12);
+#pragma unroll
+    for (int st = 0; st < 2; ++st) mask_by(dv[st], accd[st], ah[st]);  // delta 2 = d h3
+    WS_DMARK(13);
+    fetch(1);                                                            // h2
+    tpre_load<W3>(tp, hidden_ptr(I::CT_CAT), vlo16);
+    WS_DMARK(14);
+    if (wave == 1) enc_fetch(I::CT_CAT + (NB + 0) * JS, 1, 0);
+    if (wave == 2) enc_fetch(I::CT_CAT + (NB + 1) * JS, 1, 1);
+    if (wave == 3) enc_fetch(I::CT_CAT + (NB + 2) * JS, 1, 2);
+    __syncthreads();
+    publish_d();
+    publish_x();
+    __syncthreads();
+    WS_MARK(11);
+    WS_DMARK(15);
+    // cat_layer
+    dw_layer<NB + 3>(dF,
+        [&](int kb, const char*& p, int& st) { if (kb < NB) xf_img(kb, p, st); else { p = efx + (kb - NB) * 4096; st = I::EF_ST; } },
+        [&](int kb, const f32x16& v) {
+            if (kb < NB) store_block<0, H + kEmb1>(outW_cat + 32 * kb, nullptr, v, 0, 32, p31, hi, first);
+            else store_block<1, H + kEmb1>(outW_cat + H, out + L.f[5] + 32 * wave, v, kb - NB, kEmb1, p31, hi, first);
+        });
+    if (wave == 1) dprop_enc(I::CT_CAT + (NB + 0) * JS, 1, 0);
+    if (wave == 2) dprop_enc(I::CT_CAT + (NB + 1) * JS, 1, 1);
+    if (wave == 3) dprop_enc(I::CT_CAT + (NB + 2) * JS, 1, 2);
+    dprop_hidden(I::CT_CAT, false);
+#pragma unroll
+    for (int st = 0; st < 2; ++st) mask_by(dv[st], accd[st], ah[st]);  // delta 3 = d h2
+    fetch(0);                                                            // h1
+    tpre_load<W3>(tp, hidden_ptr(I::CT_M1), vlo16);
+    __syncthreads();
+    publish_d();
+    publish_x();
+    __syncthreads();
+    WS_MARK(12);
+    // mid1
+    dw_layer<NB>(dF, xf_img, [&](int kb, const f32x16& v) { store_block<0, H>(outW_m1 + 32 * kb, nullptr, v, 0, 32, p31, hi, first); });
+    db_pair(accw, dF);
+    if (p31 == 0) store_rows<1>(out + L.f[3] + 32 * wave, (unsigned)(4 * hi), accw, first);
+    dprop_hidden(I::CT_M1, false);
+#pragma unroll
+    for (int st = 0; st < 2; ++st) mask_by(dv[st], accd[st], ah[st]);  // delta 4 = d h1
+    if (wave == 0) enc_fetch(I::CT_IN + 0 * JS, 1, 0);
+    if (wave == 2) enc_fetch(I::CT_IN + 1 * JS, 1, 1);
+    if (wave == 3) enc_fetch(I::CT_IN + 2 * JS, 1, 2);
+    __syncthreads();
+    publish_d();
+    __syncthreads();
+    WS_MARK(13);
+    // in_layer
+    dw_layer<3>(dF, [&](int kb, const char*& p, int& st) { p = efx + kb * 4096; st = I::EF_ST; },
+                [&](int kb, const f32x16& v) { store_block<1, kEmb1>(outW_in, out + L.f[1] + 32 * wave, v, kb, kEmb1, p31, hi, first); });
+    if (wave == 0) dprop_enc(I::CT_IN + 0 * JS, 1, 0);
+    if (wave == 2) dprop_enc(I::CT_IN + 1 * JS, 1, 1);
+    if (wave == 3) dprop_enc(I::CT_IN + 2 * JS, 1, 2);
+    // B_layer.weight: dB[d][j] = sum_points d(proj)[d] t[j].  d(proj) = sum of the four waves' parts (exchange through LDS);
+    // t = the x, y, z slots of the hi = 0 lanes = columns 24..26 of first-group block 2
+    __syncthreads();
+    WS_MARK(14);
+    {
+        float* px = reinterpret_cast<float*>(lds + I::XF);               // [wave][tile][11][64]
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int i = 0; i < 11; ++i) px[((wave * 2 + st) * 11 + i) * 64 + lane] = dproj[st][i];
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                unsigned dh[8], dm[8], dl[8];
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    dv[st][r] = r < 11 ? (px[((0 * 2 + st) * 11 + r) * 64 + lane] + px[((1 * 2 + st) * 11 + r) * 64 + lane]) +
+                                         (px[((2 * 2 + st) * 11 + r) * 64 + lane] + px[((3 * 2 + st) * 11 + r) * 64 + lane]) : 0.0f;
+                split_planes<16, 2>(dv[st], dh, dm, dl);
+                to_F<4>(dF[st], tile, dh, dm, p31, hi, TL);
+            }
+            FImg xi;
+            fimg_load(xi, efx + 2 * 4096, I::EF_ST);
+            dw_mm_pair(accw, dF, xi);
+            if (p31 >= 24 && p31 < 27) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int d = hi ? 11 + r : r;                          // row phi(r, hi) <-> direction
+                    if (r < (hi ? 10 : 11)) store_one(out + L.f[14] + 3 * d + (p31 - 24), accw[r], first);
+                }
+            }
+        }
+    }
+    WS_MARK(15);
+    }   // BWD
+    }   // rounds
+#undef WS_MARK
+#undef WS_DMARK
+    __syncthreads();
+    if (tid_k == 0) {
+        float* pl = a.part_loss + (obj * a.NW + wgo) * 4;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            pl[k] = (loss_cells[k] + loss_cells[4 + k]) + (loss_cells[8 + k] + loss_cells[12 + k]);
+        pl[3] = 0.0f;
+    }
+}
+
+}  // namespace vk

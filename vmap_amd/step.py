@@ -240,7 +240,7 @@ class VmapStep:
         pp = self._params(fc, B)
         sc = _lib.Tensor(pe_scale.data_ptr(), pe_scale.stride(0) if pe_scale.dim() else 0)
         bt = self._batch(pcs, z, gt_depth, gt_rgb, sem, depth_mask)
-        cap = 8 * ((self.n_obj + 7) // 8) * 64 * 4 * 16
+        cap = 8 * ((self.n_obj + 7) // 8) * 256 * 4 * 16      # up to 256 workgroups per object
         buf = torch.zeros(cap, dtype=torch.int32, device=self.device)
         nwg = ctypes.c_int32(0)
         _lib.check(self.lib.vmapstep_profile_phases(ctypes.byref(self.shape), ctypes.byref(pp), ctypes.byref(sc),
