@@ -297,8 +297,10 @@ def main():
         # rocprofv3 average; both raw figures are reported next to it.
         k_ms = 0.5 * (k_ms_raw + k_ms_corr)
         split = H == 32 and args.kernel != "f32"
+        ws = H == 128 and args.kernel == "auto" and S <= 64
         kernel_name = ("step_main_s32 (bf16 matrix pipe, split operands: 6 products forward, 3 backward)" if split else
                        "step_main_h32 (exact-fp32 matrix instruction)" if H == 32 else
+                       "step_main_ws (hidden 128: bf16 matrix pipe, split operands, two 32-point tiles per workgroup round)" if ws else
                        "step_main_gen / step_main_wide (hidden 128, 256: chosen by tile count)")
         flops = layout.step_flops(n, R, S, H)
         abytes = layout.step_bytes(n, R, S, H)
@@ -347,7 +349,10 @@ def main():
             "fwd_bwd_only": {"ms_per_step_host_launched": fb_ms, "rays_per_s": n * R / (fb_ms * 1e-3)},
             "matrix_pipe": ({"instruction": "v_mfma_f32_32x32x16_bf16", "instructions_per_32_point_tile": 288 if args.weights == "f32" else 195,
                              "executed_tflops": (n * ((R + (128 // S) - 1) // (128 // S)) * 4 * (288 if args.weights == "f32" else 195) * 32768) / (k_ms * 1e-3) / 1e12,
-                             "peak_tflops": BF16_MFMA_PEAK_TFLOPS} if split else None),
+                             "peak_tflops": BF16_MFMA_PEAK_TFLOPS} if split else
+                            {"instruction": "v_mfma_f32_32x32x16_bf16", "instructions_per_64_point_round": 4 * (1185 if args.weights == "f32" else 807),
+                             "executed_tflops": (n * ((R + (64 // S) - 1) // (64 // S)) * 4 * (1185 if args.weights == "f32" else 807) * 32768) / (k_ms * 1e-3) / 1e12,
+                             "peak_tflops": BF16_MFMA_PEAK_TFLOPS} if ws else None),
             "preheat": {"ms": args.preheat_ms, "steps": preheat_steps, "timed": False},
             "with_background": with_bg,
             "world": {"world_size": world, "devices": devices, "rccl": rccl_version},

@@ -5,7 +5,7 @@ R=$PWD
 O=$PWD/gpurun_out/ws
 ( timeout 300 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "generic_width or parameter_image or shared_background" ) > $O/pytest_ws.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest_ws.log
 timeout 120 python bench.py --config background --no-cpu-baseline --no-gpu-baseline --steps 200 --warmup 20 > $O/bench_bg_auto.json 2> $O/bench_bg_auto.err < /dev/null; tail -1 $O/bench_bg_auto.json | head -c 330; echo
-VMAPSTEP_LIBRARY=$R/vmap_amd/libvmapstep_WS_EXP_DETAIL.so timeout 120 python tests/tools/phase_profile.py background > $O/phases_bg_DETAIL.txt 2>&1 < /dev/null; tail -18 $O/phases_bg_DETAIL.txt
+timeout 120 python tests/tools/phase_profile.py background > $O/phases_bg.txt 2>&1 < /dev/null; tail -18 $O/phases_bg.txt
 cd /tmp
 timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bg -- python $R/bench.py --config background --timed-only --steps 100 --warmup 10 > $O/prof_run.log 2>&1 < /dev/null
 cd $R

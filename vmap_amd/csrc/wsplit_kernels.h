@@ -335,6 +335,13 @@ __global__ __launch_bounds__(kWG) void step_finalize_ws(const FinalizeArgs a, co
 #else
 #define WS_WSTEP(s) (s)
 #endif
+// block_io of a layer for a runtime (wave-uniform) mode; A / B: the hidden-block / encoding-block form, M = the mode
+#define WS_IO3(mode, is_a, A, B)                                                              \
+    do {                                                                                       \
+        if ((mode) == 0) { constexpr int M = 0; if (is_a) { A; } else { B; } }                  \
+        else if ((mode) == 1) { constexpr int M = 1; if (is_a) { A; } else { B; } }             \
+        else { constexpr int M = 2; if (is_a) { A; } else { B; } }                              \
+    } while (0)
 // global access as (wave-uniform base) + (32-bit lane offset): the scalar-base form of the global instructions, no per-lane
 // 64-bit address arithmetic
 __device__ __forceinline__ u32x4 ldgu(const char* ubase, unsigned voff) { return *reinterpret_cast<const u32x4*>(ubase + voff); }
@@ -525,35 +532,37 @@ __device__ __forceinline__ void db_pair(f32x16& acc, const unsigned (&dF)[2][16]
 }
 // 16 values of a lane: rows (r & 3) + 8 (r >> 2) of a block that starts at ubase (row pitch K floats); voff = the lane's element
 // offset inside row 0 (column + 4 hi rows).  One lane pointer per group of four rows, the rows themselves are immediates.
-// First round: store; later rounds: add.
-template <int K>
-__device__ __forceinline__ void store_rows(float* ubase, unsigned voff, const f32x16& acc, bool first) {
+// MODE 0: store (a workgroup's first round); 1: read the values of the earlier rounds into old; 2: store old + acc.
+template <int K, int MODE>
+__device__ __forceinline__ void rows_io(float* ubase, unsigned voff, const f32x16& acc, float (&old)[16]) {
 #ifdef WS_EXP_NOSTORE       // measurement build: the partial-gradient stores never execute
     if (acc[0] != 12345.678f) return;
 #endif
     float* q = ubase + voff;
-    if (first) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float* qg = q + 8 * g * K;
+    for (int g = 0; g < 4; ++g) {
+        float* qg = q + 8 * g * K;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) qg[i * K] = acc[4 * g + i];
+        for (int i = 0; i < 4; ++i) {
+            if (MODE == 0) qg[i * K] = acc[4 * g + i];
+            else if (MODE == 1) old[4 * g + i] = qg[i * K];
+            else qg[i * K] = old[4 * g + i] + acc[4 * g + i];
         }
-    } else {
-        float old[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) old[r] = q[((r & 3) + 8 * (r >> 2)) * K];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) q[((r & 3) + 8 * (r >> 2)) * K] = old[r] + acc[r];
     }
 }
+template <int K>
+__device__ __forceinline__ void store_rows(float* ubase, unsigned voff, const f32x16& acc, bool first) {
+    float old[16];
+    if (first) rows_io<K, 0>(ubase, voff, acc, old);
+    else { rows_io<K, 1>(ubase, voff, acc, old); rows_io<K, 2>(ubase, voff, acc, old); }
+}
 // a 32x32 weight-gradient block (lane = column k, register r <-> row phi(r, hi)) -> the partial gradients
-template <int KIND, int K>
-__device__ __forceinline__ void store_block(float* out_w, float* out_b, const f32x16& acc, int blk, int ncols, int p31, int hi, bool first) {
+template <int KIND, int K, int MODE>
+__device__ __forceinline__ void block_io(float* out_w, float* out_b, const f32x16& acc, float (&old)[16], int blk, int ncols, int p31, int hi) {
     int col; bool bias;
     col_target<KIND>(blk, p31, col, bias);
-    if (col >= 0 && col < ncols) store_rows<K>(out_w, (unsigned)(col + 4 * hi * K), acc, first);
-    else if (bias) store_rows<1>(out_b, (unsigned)(4 * hi), acc, first);
+    if (col >= 0 && col < ncols) rows_io<K, MODE>(out_w, (unsigned)(col + 4 * hi * K), acc, old);
+    else if (bias) rows_io<1, MODE>(out_b, (unsigned)(4 * hi), acc, old);
 }
 __device__ __forceinline__ void store_one(float* q, float v, bool first) { *q = first ? v : *q + v; }
 // ReLU mask from the packed hi plane: d[r] = h[r] > 0 ? v[r] : 0
@@ -565,22 +574,25 @@ __device__ __forceinline__ void mask_by(float (&d)[16], const f32x16& v, const u
         d[2 * i + 1] = u > 0xFFFFu ? v[2 * i + 1] : 0.0f;
     }
 }
-// weight-gradient blocks of one layer: N input blocks (images at ximg(kb), tile 1: + xst(kb)); the LDS reads of block kb + 1 and
-// the stores of block kb - 1 surround the matrix instructions of block kb
-template <int N, class XI, class ST>
-__device__ __forceinline__ void dw_layer(const unsigned (&dF)[2][16], XI&& ximg, ST&& store) {
+// weight-gradient blocks of one layer: N input blocks (images at ximg(kb), tile 1: + xst(kb)).  Stage kb: LDS reads of block
+// kb + 1 and (later rounds) the global reads of block kb's earlier sums go out, the matrix instructions of block kb run, the
+// stores of block kb - 1 retire.  io(mode, kb, acc, old): block_io of the layer.
+template <int N, class XI, class IO>
+__device__ __forceinline__ void dw_layer(const unsigned (&dF)[2][16], bool first, XI&& ximg, IO&& io) {
     FImg x[2];
     f32x16 acc[2];
+    float old[2][16];
     { const char* p; int st; ximg(0, p, st); fimg_load(x[0], p, st); }
 #pragma unroll
     for (int kb = 0; kb < N; ++kb) {
         if (kb + 1 < N) { const char* p; int st; ximg(kb + 1, p, st); fimg_load(x[(kb + 1) & 1], p, st); }
+        if (!first) io(1, kb, acc[kb & 1], old[kb & 1]);
         wv::sched_fence();
         dw_mm_pair(acc[kb & 1], dF, x[kb & 1]);
-        if (kb > 0) store(kb - 1, acc[(kb - 1) & 1]);
+        if (kb > 0) io(first ? 0 : 2, kb - 1, acc[(kb - 1) & 1], old[(kb - 1) & 1]);
         wv::sched_fence();
     }
-    store(N - 1, acc[(N - 1) & 1]);
+    io(first ? 0 : 2, N - 1, acc[(N - 1) & 1], old[(N - 1) & 1]);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -637,6 +649,14 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     const int ray0 = grp * a.G;
     const int nrays = min(a.G, a.R - ray0);
     const int npts = nrays * a.S;                                        // <= 64
+    // compositing inputs (depth of this lane's sample, ground truth of the ray this lane composites): fetched at the top of the
+    // round, where the encoding covers them (their scalar loads would otherwise serialise with the LDS operand reads)
+    float zv = 0.0f;
+    if (wave < 2 && hi == 0 && 32 * wave + p31 < npts) {
+        const int pt = 32 * wave + p31, lray = pt / a.S, smp = pt - lray * a.S;
+        zv = a.z[obj * a.z_so + (ray0 + lray) * a.z_sr + smp * a.z_ss];
+    }
+    const RayMeta rmeta = load_ray_meta(a, obj, ray0 + min(4 * wave + (lane >> 4), nrays - 1));
     WPre pre_in;                                                         // in_layer's first weight chunks: fetched behind the encoding
     wpre_load<W3, 6, 0>(pre_in, gW + ((long long)(I::CW_IN + wave * I::KS_IN)) * I::XCH, nullptr, vlo16);
     // ---- encoding (embedding.py:82-91): wave = (tile est, direction half dhalf); owner-lane slots as in step_main_s32 ----
@@ -781,14 +801,13 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     if (wave < 2 && hi == 0) {                                           // heads of tile `wave`: sum of the four waves' partials
         const int pt = 32 * wave + p31;
         if (pt < npts) {
-            const int lray = pt / a.S, smp = pt - lray * a.S, ray = ray0 + lray;
             float v[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c)
                 v[c] = (hp[((0 * 2 + wave) * 32 + p31) * 4 + c] + hp[((1 * 2 + wave) * 32 + p31) * 4 + c]) +
                        (hp[((2 * 2 + wave) * 32 + p31) * 4 + c] + hp[((3 * 2 + wave) * 32 + p31) * 4 + c]);
             float* row = cb + pt * 8;
-            row[6] = a.z[obj * a.z_so + ray * a.z_sr + smp * a.z_ss];
+            row[6] = zv;
             row[0] = sigmoidf_acc((v[0] + SM[I::B_A]) * 10.0f);           // :77 raw*10 ; render_rays.py:6
             row[1] = sigmoidf_acc(v[1] + SM[I::B_OC]);                    // :83
             row[2] = sigmoidf_acc(v[2] + SM[I::B_OC + 1]);
@@ -798,8 +817,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     __syncthreads();
     {
         const StepArgs& al = wv::kernarg_late(ga).s;
-        composite_phase<BWD>(al, cb, loss_cells, obj, ray0, nrays, wave, lane, tid,
-                             load_ray_meta(al, obj, ray0 + min(4 * wave + (lane >> 4), nrays - 1)));
+        composite_phase<BWD>(al, cb, loss_cells, obj, ray0, nrays, wave, lane, tid, rmeta);
     }
     __syncthreads();
     WS_MARK(7);
@@ -998,11 +1016,11 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     if (wave == 0) enc_fetch(I::CT_C + (NB + 0) * JS, 2, 0);
     if (wave == 1) enc_fetch(I::CT_C + (NB + 1) * JS, 2, 1);
     WS_DMARK(1);
-    dw_layer<NB + 2>(dF,
+    dw_layer<NB + 2>(dF, first,
         [&](int kb, const char*& p, int& st) { if (kb < NB) xf_img(kb, p, st); else { p = efx + (3 + kb - NB) * 4096; st = I::EF_ST; } },
-        [&](int kb, const f32x16& v) {
-            if (kb < NB) store_block<0, H + kEmb2>(outW_c + 32 * kb, nullptr, v, 0, 32, p31, hi, first);
-            else store_block<2, H + kEmb2>(outW_c + H, out + L.f[11] + 32 * wave, v, kb - NB, kEmb2, p31, hi, first);
+        [&](int mode, int kb, const f32x16& v, float (&old)[16]) {
+            WS_IO3(mode, kb < NB, (block_io<0, H + kEmb2, M>(outW_c + 32 * kb, nullptr, v, old, 0, 32, p31, hi)),
+                   (block_io<2, H + kEmb2, M>(outW_c + H, out + L.f[11] + 32 * wave, v, old, kb - NB, kEmb2, p31, hi)));
         });
     WS_DMARK(2);
     if (wave == 0) dprop_enc(I::CT_C + (NB + 0) * JS, 2, 0);
@@ -1025,7 +1043,9 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     WS_DMARK(9);
     WS_MARK(10);
     // mid2
-    dw_layer<NB>(dF, xf_img, [&](int kb, const f32x16& v) { store_block<0, H>(outW_m2 + 32 * kb, nullptr, v, 0, 32, p31, hi, first); });
+    dw_layer<NB>(dF, first, xf_img, [&](int mode, int kb, const f32x16& v, float (&old)[16]) {
+        WS_IO3(mode, true, (block_io<0, H, M>(outW_m2 + 32 * kb, nullptr, v, old, 0, 32, p31, hi)), (void)0);
+    });
     WS_DMARK(10);
     db_pair(accw, dF);
     if (p31 == 0) store_rows<1>(out + L.f[7] + 32 * wave, (unsigned)(4 * hi), accw, first);
@@ -1048,11 +1068,11 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     WS_MARK(11);
     WS_DMARK(15);
     // cat_layer
-    dw_layer<NB + 3>(dF,
+    dw_layer<NB + 3>(dF, first,
         [&](int kb, const char*& p, int& st) { if (kb < NB) xf_img(kb, p, st); else { p = efx + (kb - NB) * 4096; st = I::EF_ST; } },
-        [&](int kb, const f32x16& v) {
-            if (kb < NB) store_block<0, H + kEmb1>(outW_cat + 32 * kb, nullptr, v, 0, 32, p31, hi, first);
-            else store_block<1, H + kEmb1>(outW_cat + H, out + L.f[5] + 32 * wave, v, kb - NB, kEmb1, p31, hi, first);
+        [&](int mode, int kb, const f32x16& v, float (&old)[16]) {
+            WS_IO3(mode, kb < NB, (block_io<0, H + kEmb1, M>(outW_cat + 32 * kb, nullptr, v, old, 0, 32, p31, hi)),
+                   (block_io<1, H + kEmb1, M>(outW_cat + H, out + L.f[5] + 32 * wave, v, old, kb - NB, kEmb1, p31, hi)));
         });
     if (wave == 1) dprop_enc(I::CT_CAT + (NB + 0) * JS, 1, 0);
     if (wave == 2) dprop_enc(I::CT_CAT + (NB + 1) * JS, 1, 1);
@@ -1068,7 +1088,9 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     __syncthreads();
     WS_MARK(12);
     // mid1
-    dw_layer<NB>(dF, xf_img, [&](int kb, const f32x16& v) { store_block<0, H>(outW_m1 + 32 * kb, nullptr, v, 0, 32, p31, hi, first); });
+    dw_layer<NB>(dF, first, xf_img, [&](int mode, int kb, const f32x16& v, float (&old)[16]) {
+        WS_IO3(mode, true, (block_io<0, H, M>(outW_m1 + 32 * kb, nullptr, v, old, 0, 32, p31, hi)), (void)0);
+    });
     db_pair(accw, dF);
     if (p31 == 0) store_rows<1>(out + L.f[3] + 32 * wave, (unsigned)(4 * hi), accw, first);
     dprop_hidden(I::CT_M1, false);
@@ -1082,8 +1104,10 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     __syncthreads();
     WS_MARK(13);
     // in_layer
-    dw_layer<3>(dF, [&](int kb, const char*& p, int& st) { p = efx + kb * 4096; st = I::EF_ST; },
-                [&](int kb, const f32x16& v) { store_block<1, kEmb1>(outW_in, out + L.f[1] + 32 * wave, v, kb, kEmb1, p31, hi, first); });
+    dw_layer<3>(dF, first, [&](int kb, const char*& p, int& st) { p = efx + kb * 4096; st = I::EF_ST; },
+                [&](int mode, int kb, const f32x16& v, float (&old)[16]) {
+                    WS_IO3(mode, true, (block_io<1, kEmb1, M>(outW_in, out + L.f[1] + 32 * wave, v, old, kb, kEmb1, p31, hi)), (void)0);
+                });
     if (wave == 0) dprop_enc(I::CT_IN + 0 * JS, 1, 0);
     if (wave == 2) dprop_enc(I::CT_IN + 1 * JS, 1, 1);
     if (wave == 3) dprop_enc(I::CT_IN + 2 * JS, 1, 2);
