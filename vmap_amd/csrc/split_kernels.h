@@ -513,15 +513,20 @@ __device__ __forceinline__ void col_target(int blk, int k, int& col, bool& bias)
     col = c >= 0 ? c : -1;
 }
 // this wave's quarter (rows 8 wave + 4 hi + i) of a reduced block -> the workgroup's partial gradients
+#ifdef VS_EXP_TEMPORAL      // measurement build: partial gradients through the normal L2 write policy
+#define VS_PARTIAL_STORE(v, p) (*(p) = (v))
+#else
+#define VS_PARTIAL_STORE(v, p) __builtin_nontemporal_store((v), (p))
+#endif
 template <int K>
 __device__ __forceinline__ void store_quarter_map(float* out_w, float* out_b, const float (&q)[4], int col, bool bias, int ncols,
                                                   int wave, int hi) {
     if (col >= 0 && col < ncols) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) __builtin_nontemporal_store(q[i], &out_w[(8 * wave + 4 * hi + i) * K + col]);
+        for (int i = 0; i < 4; ++i) VS_PARTIAL_STORE(q[i], &out_w[(8 * wave + 4 * hi + i) * K + col]);
     } else if (bias) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) __builtin_nontemporal_store(q[i], &out_b[8 * wave + 4 * hi + i]);
+        for (int i = 0; i < 4; ++i) VS_PARTIAL_STORE(q[i], &out_b[8 * wave + 4 * hi + i]);
     }
 }
 
