@@ -112,6 +112,32 @@ def test_fwd_bwd_matches_oracle_on_seeded_shapes(n, R, S, seed):
         assert relerr(s[k], o[k]) < 2e-2, k
 
 
+@pytest.mark.parametrize("n,R,S,seed", [(1, 1, 14, 11), (3, 9, 14, 12), (2, 37, 10, 13), (1, 21, 3, 14), (2, 7, 20, 15),
+                                        (1, 5, 40, 16), (1, 3, 64, 17), (5, 300, 14, 18)])
+def test_hidden128_kernel_matches_oracle_on_seeded_shapes(n, R, S, seed):
+    """step_main_ws (hidden 128, the automatic choice) on ragged shapes: single ray, rays that straddle the two tiles of a
+    round (S = 10, 14, 20), one ray per round (S = 40, 64 = the kernel's limit), long rays through the general compositing
+    path (S > 16), several objects, more rounds than workgroups (5 x 75 rounds)."""
+    fc, B, sc = synth.make_params(n, 128, seed=300 + seed)
+    batch = synth.make_batch(n, R, S, seed=400 + seed)
+    c = dict(n=n, R=R, S=S, H=128, fc=fc, B=B, scale=sc, batch=batch)
+    s = _run(c, tuning={"kernel": _lib.KERNEL_AUTO})
+    from oracle import vmap_oracle_torch as vt
+    loss_t, rend_t, grads_t = vt.CpuTrainer(fc, B, sc).step(batch, update=False)
+    assert abs(s["loss"] - float(loss_t)) <= 5e-5 * abs(float(loss_t))
+    for k in RENDER_KEYS:
+        assert relerr(s[k], rend_t[k].detach().numpy()) < 2e-5, k
+    for k, g in zip(GRAD_KEYS, grads_t):
+        assert not np.isnan(s[k]).any(), k
+        assert relerr(s[k], g.numpy()) < 1e-4, k
+    # the exact-fp32 kernel of the same width on the same inputs
+    e = _run(c, tuning={"kernel": _lib.KERNEL_GEN})
+    for k in RENDER_KEYS:
+        assert relerr(s[k], e[k]) < 2e-5, k
+    for k in GRAD_KEYS:
+        assert relerr(s[k], e[k]) < 1e-4, k
+
+
 def test_render_only_equals_fwd_bwd_renders():
     c = cases.build_case("ragged")
     a, b = _run(c), _run(c, fn="render")
