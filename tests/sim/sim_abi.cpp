@@ -47,9 +47,9 @@ extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req, int xcd
     std::vector<int> fl(4, -1);
     const vk::GenLayout GL = vk::gen_layout(H);
     const bool split = g_split && H == 32;
-    const bool ws = g_wide == 3 && H == 128;                 // step_main_ws (split-bf16 matrix pipe, hidden 128)
+    const bool ws = g_wide == 3 && (H == 128 || H == 64);    // step_main_ws (split-bf16 matrix pipe, hidden 128 / 64)
     if (ws && G * S > vk::ImgWs<4>::kPts) return -3;
-    std::vector<float> wimg((size_t)n * (split ? vk::Img32s::BYTES / 4 : ws ? vk::ImgWs<4>::BYTES / 4 : GL.imgp), NAN);
+    std::vector<float> wimg((size_t)n * (split ? vk::Img32s::BYTES / 4 : ws ? (H == 128 ? vk::ImgWs<4>::BYTES : vk::ImgWs<2>::BYTES) / 4 : GL.imgp), NAN);
 
     vk::StepArgs a{};
     a.n_obj = n; a.R = R; a.S = S; a.G = G; a.NG = NG; a.NW = NW; a.PP = PP; a.prep_steps = 1; a.prep_ray_step = 0; a.xcd_affine = (xcd_affine && H == 32) ? 1 : 0; a.hidden = H; a.weights_bf16 = weights_bf16;
@@ -75,12 +75,13 @@ extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req, int xcd
     if (ws) {
         ws_scratch.assign((size_t)n * NW * vk::ImgWs<4>::WG_SCRATCH, (char)0xFF);
         wa.s = a; wa.scratch = ws_scratch.data(); wa.tab_wt = tab_wt.data();
-        sim::launch(1 + n * vk::ws_pack_blocks<4>(), vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep_ws<4>(wa); });
+        if (H == 128) sim::launch(1 + n * vk::ws_pack_blocks<4>(), vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep_ws<4>(wa); });
+        else sim::launch(1 + n * vk::ws_pack_blocks<2>(), vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep_ws<2>(wa); });
     } else if (split) sim::launch(1 + n * vk::kSplitPackBlocks, vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep_s32(a); });
     else sim::launch(1 + n * (vk::gen_layout(H).imgp / 1024), vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep(a); });
     const bool multi = NW < NG;
     const int grid = xcd_affine && H == 32 ? 8 * ((n + 7) / 8) * NW : n * NW;
-    if (ws) {
+    if (ws && H == 128) {
         const int lb = vk::ImgWs<4>::LDS_BYTES;
         if (weights_bf16) {
             if (bwd) sim::launch(n * NW, vk::kWG, lb, [&] { vk::step_main_ws<4, true, false>(wa); });
@@ -88,6 +89,15 @@ extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req, int xcd
         } else {
             if (bwd) sim::launch(n * NW, vk::kWG, lb, [&] { vk::step_main_ws<4, true, true>(wa); });
             else     sim::launch(n * NW, vk::kWG, lb, [&] { vk::step_main_ws<4, false, true>(wa); });
+        }
+    } else if (ws) {
+        const int lb = vk::ImgWs<2>::LDS_BYTES;
+        if (weights_bf16) {
+            if (bwd) sim::launch(n * NW, vk::kWG, lb, [&] { vk::step_main_ws<2, true, false>(wa); });
+            else     sim::launch(n * NW, vk::kWG, lb, [&] { vk::step_main_ws<2, false, false>(wa); });
+        } else {
+            if (bwd) sim::launch(n * NW, vk::kWG, lb, [&] { vk::step_main_ws<2, true, true>(wa); });
+            else     sim::launch(n * NW, vk::kWG, lb, [&] { vk::step_main_ws<2, false, true>(wa); });
         }
     } else if (split) {
         const int lb = vk::Img32s::LDS_BYTES;
@@ -157,7 +167,8 @@ extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req, int xcd
         h.NW = f.NW; h.PP = f.PP; h.weights_bf16 = f.weights_bf16;
         h.decay = f.decay; h.one_minus_beta1 = f.one_minus_beta1; h.beta2 = f.beta2; h.one_minus_beta2 = f.one_minus_beta2;
         h.eps = f.eps; h.step_size = f.step_size; h.bias_corr2_sqrt = f.bias_corr2_sqrt;
-        sim::launch(n * vk::ws_finalize_blocks(PP) + 1, vk::kWG, 4 * vk::kWG * 4, [&] { vk::step_finalize_ws<4>(f, h, tab_wt.data()); });
+        if (H == 128) sim::launch(n * vk::ws_finalize_blocks(PP) + 1, vk::kWG, 4 * vk::kWG * 4, [&] { vk::step_finalize_ws<4>(f, h, tab_wt.data()); });
+        else sim::launch(n * vk::ws_finalize_blocks(PP) + 1, vk::kWG, 4 * vk::kWG * 4, [&] { vk::step_finalize_ws<2>(f, h, tab_wt.data()); });
         return 0;
     }
     if (H == 32 && bwd && do_adam && p_out) {

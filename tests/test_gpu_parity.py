@@ -112,25 +112,33 @@ def test_fwd_bwd_matches_oracle_on_seeded_shapes(n, R, S, seed):
         assert relerr(s[k], o[k]) < 2e-2, k
 
 
+@pytest.mark.parametrize("H", [128, 64])
 @pytest.mark.parametrize("n,R,S,seed", [(1, 1, 14, 11), (3, 9, 14, 12), (2, 37, 10, 13), (1, 21, 3, 14), (2, 7, 20, 15),
                                         (1, 5, 40, 16), (1, 3, 64, 17), (5, 300, 14, 18)])
-def test_hidden128_kernel_matches_oracle_on_seeded_shapes(n, R, S, seed):
-    """step_main_ws (hidden 128, the automatic choice) on ragged shapes: single ray, rays that straddle the two tiles of a
+def test_hidden128_kernel_matches_oracle_on_seeded_shapes(n, R, S, seed, H):
+    """step_main_ws (hidden 128 and 64, the automatic choice) on ragged shapes: single ray, rays that straddle the two tiles of a
     round (S = 10, 14, 20), one ray per round (S = 40, 64 = the kernel's limit), long rays through the general compositing
     path (S > 16), several objects, more rounds than workgroups (5 x 75 rounds)."""
-    fc, B, sc = synth.make_params(n, 128, seed=300 + seed)
+    fc, B, sc = synth.make_params(n, H, seed=300 + seed)
     batch = synth.make_batch(n, R, S, seed=400 + seed)
-    c = dict(n=n, R=R, S=S, H=128, fc=fc, B=B, scale=sc, batch=batch)
+    c = dict(n=n, R=R, S=S, H=H, fc=fc, B=B, scale=sc, batch=batch)
     s = _run(c, tuning={"kernel": _lib.KERNEL_AUTO})
     from oracle import vmap_oracle_torch as vt
     loss_t, rend_t, grads_t = vt.CpuTrainer(fc, B, sc).step(batch, update=False)
     assert abs(s["loss"] - float(loss_t)) <= 5e-5 * abs(float(loss_t))
     for k in RENDER_KEYS:
         assert relerr(s[k], rend_t[k].detach().numpy()) < 2e-5, k
+    # Gradients against the ATen port: 1e-4, except where one hidden unit sits on the other side of a ReLU kink (measured on the
+    # 5 x 300 x 14, hidden 64 case: this kernel and the exact-fp32 kernel agree to 6e-6 and differ from the port by the same
+    # 2.4e-3 in the tensors below mid1 of ONE object) - bounded like the numpy oracle above; the tight comparator is the
+    # exact-fp32 kernel of the same width on the same inputs.
+    loose = 0
     for k, g in zip(GRAD_KEYS, grads_t):
         assert not np.isnan(s[k]).any(), k
-        assert relerr(s[k], g.numpy()) < 1e-4, k
-    # the exact-fp32 kernel of the same width on the same inputs
+        r = relerr(s[k], g.numpy())
+        assert r < 2e-2, k
+        loose += r >= 1e-4
+    assert loose <= 5
     e = _run(c, tuning={"kernel": _lib.KERNEL_GEN})
     for k in RENDER_KEYS:
         assert relerr(s[k], e[k]) < 2e-5, k
@@ -393,7 +401,7 @@ def test_unsupported_hidden_width_fails_loudly():
 @pytest.mark.parametrize("name,kernel", [("h64", "gen"), ("bg_h128_s14", "wide"), ("imap_h256", "wide"),
                                          ("bg_h128_s14", "gen"), ("imap_h256", "gen"), ("bg_h128_s14", "wide_multipass"),
                                          ("bg_h128_s14", "wide2"), ("imap_h256", "wide2"), ("bg_h128_s14", "wide2_multipass"),
-                                         ("bg_h128_s14", "ws"), ("bg_h128_s14", "ws_multipass")])
+                                         ("bg_h128_s14", "ws"), ("bg_h128_s14", "ws_multipass"), ("h64", "ws"), ("h64", "ws_multipass")])
 def test_generic_width_kernel_matches_reference_fixture(name, kernel):
     """hidden = 64 / 128 (background model shapes) / 256 (iMAP, BASELINE configs[0]): step_main_wide (tile per
     workgroup / four tiles per workgroup, also with fewer workgroups than ray groups), step_main_gen, and - hidden 128 -
@@ -696,7 +704,8 @@ def test_frame_trajectory_matches_reference_step_loop(name):
     assert np.quantile(d, 0.99) < q99 and np.median(d) < med, (np.quantile(d, 0.99), np.median(d))
 
 
-@pytest.mark.parametrize("weights,case", [("f32", "scannet_scale"), ("bf16", "scannet_scale"), ("f32", "bg_h128_s14"), ("bf16", "bg_h128_s14")])
+@pytest.mark.parametrize("weights,case", [("f32", "scannet_scale"), ("bf16", "scannet_scale"), ("f32", "bg_h128_s14"), ("bf16", "bg_h128_s14"),
+                                          ("f32", "h64"), ("bf16", "h64")])
 def test_parameter_image_kept_by_finalize_equals_freshly_packed_image(weights, case):
     """The finalize kernel rewrites the packed parameter image (split planes / float32 image) element by element after
     every AdamW update; a new frame call packs it from the parameter tensors.  Two steps in ONE call (step 2 reads the

@@ -149,13 +149,13 @@ def test_sim_wide_kernel_matches_reference(nw):
             assert relerr(s[k], o[k]) < 2e-5, k
 
 
-@pytest.mark.parametrize("nw", [0, 3])
-def test_sim_ws_kernel_matches_reference(nw):
-    """step_main_ws (hidden 128 on the bf16 matrix pipe with split operands: a round of two 32-point tiles per workgroup,
-    wave = output block; nw=3: several rounds per workgroup add into its partial gradients) vs the background-shaped
-    fixture generated by the reference."""
-    c = cases.build_case("bg_h128_s14")
-    g = load_golden("bg_h128_s14")
+@pytest.mark.parametrize("name,nw", [("bg_h128_s14", 0), ("bg_h128_s14", 3), ("h64", 0), ("h64", 2)])
+def test_sim_ws_kernel_matches_reference(name, nw):
+    """step_main_ws (hidden 128 / 64 on the bf16 matrix pipe with split operands: a round of two 32-point tiles per
+    workgroup, wave = output block; nw > 0: several rounds per workgroup add into its partial gradients) vs the fixtures
+    generated by the reference."""
+    c = cases.build_case(name)
+    g = load_golden(name)
     s = simlib.sim_step(c, NW=nw, wide=3)
     assert abs(s["loss"] - float(g["loss"])) <= 2e-5 * abs(float(g["loss"]))
     for k in RENDER_KEYS:

@@ -2,4 +2,4 @@ set -x
 mkdir -p gpurun_out/ws
 export TMPDIR=/tmp
 O=$PWD/gpurun_out/ws
-( timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "hidden128" ) > $O/pytest_ws2.log 2>&1 < /dev/null; echo "pytest rc=$?"; tail -30 $O/pytest_ws2.log
+( timeout 900 python -m pytest tests -m gpu -q ) > $O/pytest_all.log 2>&1 < /dev/null; echo "pytest rc=$?"; tail -12 $O/pytest_all.log

@@ -122,8 +122,8 @@ int make_plan(const vmapstep_shape* sh, int max_steps, Plan& pl, const Layout& L
         if (!pl.wide && force == VMAPSTEP_KERNEL_WIDE2) pl.wide = 2;      // measured: no gain over step_main_gen at 600 tiles (both are
                                                                  // bound by the traffic of the per-tile register images), not automatic
     }
-    // hidden 128: the bf16 matrix pipe with split operands (step_main_ws) unless an exact-fp32 kernel is asked for
-    if (pl.generic && sh->hidden == 128 && force == VMAPSTEP_KERNEL_AUTO && sh->samples <= vk::ImgWs<4>::kPts) pl.wide = 3;
+    // hidden 64 / 128: the bf16 matrix pipe with split operands (step_main_ws) unless an exact-fp32 kernel is asked for
+    if (pl.generic && (sh->hidden == 128 || sh->hidden == 64) && force == VMAPSTEP_KERNEL_AUTO && sh->samples <= vk::ImgWs<4>::kPts) pl.wide = 3;
     pl.G = (pl.wide == 3 ? vk::ImgWs<4>::kPts : pl.wide == 1 ? vk::kWideTile : vk::kMaxPts) / sh->samples;
     if (pl.G > sh->rays) pl.G = sh->rays;
     pl.NG = (sh->rays + pl.G - 1) / pl.G;
@@ -152,7 +152,7 @@ int make_plan(const vmapstep_shape* sh, int max_steps, Plan& pl, const Layout& L
     pl.off_imgtab = o; o += pl.wide == 3 ? 2 * align_up((size_t)L.PP * sizeof(int)) : pl.generic ? 0 : align_up((size_t)L.PP * sizeof(int));
     pl.off_pgrad = o; o += align_up((size_t)sh->n_obj * nw_cap * L.PP * sizeof(float));
     const vk::GenLayout GL = vk::gen_layout(sh->hidden);
-    pl.off_wimg = o; o += align_up(pl.split ? (size_t)sh->n_obj * vk::Img32s::BYTES : pl.wide == 3 ? (size_t)sh->n_obj * vk::ImgWs<4>::BYTES
+    pl.off_wimg = o; o += align_up(pl.split ? (size_t)sh->n_obj * vk::Img32s::BYTES : pl.wide == 3 ? (size_t)sh->n_obj * (sh->hidden == 128 ? vk::ImgWs<4>::BYTES : vk::ImgWs<2>::BYTES)
                                                                                    : (size_t)sh->n_obj * GL.imgp * sizeof(float));
     pl.off_scratch = o;
     if (pl.wide == 3) o += align_up((size_t)sh->n_obj * nw_cap * vk::ImgWs<4>::WG_SCRATCH);
@@ -298,10 +298,10 @@ int launch_split(const vk::StepArgs& a, hipStream_t st) {
     return multi ? launch_split_v<BWD, true, STAMPS, true>(a, st) : launch_split_v<BWD, false, STAMPS, true>(a, st);
 }
 
-template <bool BWD, bool W3, bool STAMPS = false>
+template <int NB, bool BWD, bool W3, bool STAMPS = false>
 int launch_ws_v(const vk::StepArgs& a, hipStream_t st) {
-    using I = vk::ImgWs<4>;
-    auto kern = vk::step_main_ws<4, BWD, W3, STAMPS>;
+    using I = vk::ImgWs<NB>;
+    auto kern = vk::step_main_ws<NB, BWD, W3, STAMPS>;
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), I::LDS_BYTES, "step_main_ws")) return rc;
     vk::WsArgs ga;
     ga.s = a;
@@ -316,7 +316,10 @@ int launch_ws_v(const vk::StepArgs& a, hipStream_t st) {
 template <bool BWD>
 int launch_main(const vk::StepArgs& a, hipStream_t st) {
     if (a.split) return launch_split<BWD>(a, st);
-    if (a.wide == 3) return a.weights_bf16 ? launch_ws_v<BWD, false>(a, st) : launch_ws_v<BWD, true>(a, st);
+    if (a.wide == 3) {
+        if (a.hidden == 128) return a.weights_bf16 ? launch_ws_v<4, BWD, false>(a, st) : launch_ws_v<4, BWD, true>(a, st);
+        return a.weights_bf16 ? launch_ws_v<2, BWD, false>(a, st) : launch_ws_v<2, BWD, true>(a, st);
+    }
     if (a.hidden != 32) return a.wide == 1 ? launch_wide<BWD, 4>(a, st) : a.wide == 2 ? launch_wide<BWD, 2>(a, st) : launch_gen<BWD>(a, st);
     return a.NW < a.NG ? launch_main_v<BWD, true>(a, st) : launch_main_v<BWD, false>(a, st);
 }
@@ -331,7 +334,10 @@ int launch_prep(const vk::StepArgs& a, int n_steps, hipStream_t st) {
         // parameters without a place in the W^T image (biases, heads, B) keep -1 in its table
         hipError_t e = hipMemsetAsync(a.tab_wt, 0xFF, (size_t)a.PP * sizeof(int), st);
         if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "hipMemsetAsync(tab_wt): %s", hipGetErrorString(e));
-        hipLaunchKernelGGL(vk::step_prep_ws<4>, dim3(n_steps + a.n_obj * vk::ws_pack_blocks<4>()), dim3(vk::kWG), 3 * vk::kWG * sizeof(int), st, ga);
+        if (a.hidden == 128)
+            hipLaunchKernelGGL(vk::step_prep_ws<4>, dim3(n_steps + a.n_obj * vk::ws_pack_blocks<4>()), dim3(vk::kWG), 3 * vk::kWG * sizeof(int), st, ga);
+        else
+            hipLaunchKernelGGL(vk::step_prep_ws<2>, dim3(n_steps + a.n_obj * vk::ws_pack_blocks<2>()), dim3(vk::kWG), 3 * vk::kWG * sizeof(int), st, ga);
         e = hipGetLastError();
         if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "step_prep_ws launch: %s", hipGetErrorString(e));
         return VMAPSTEP_OK;
@@ -418,8 +424,12 @@ int launch_finalize(const vk::StepArgs& a, const Layout& L, const vmapstep_param
         }
         vk::CarryHot h;
         fill_carry_hot(h, f, a, L, params, 0u);
-        hipLaunchKernelGGL(vk::step_finalize_ws<4>, dim3(a.n_obj * vk::ws_finalize_blocks(L.PP) + 1), dim3(vk::kWG), 4 * vk::kWG * sizeof(float),
-                           st, f, h, a.tab_wt);
+        if (a.hidden == 128)
+            hipLaunchKernelGGL(vk::step_finalize_ws<4>, dim3(a.n_obj * vk::ws_finalize_blocks(L.PP) + 1), dim3(vk::kWG), 4 * vk::kWG * sizeof(float),
+                               st, f, h, a.tab_wt);
+        else
+            hipLaunchKernelGGL(vk::step_finalize_ws<2>, dim3(a.n_obj * vk::ws_finalize_blocks(L.PP) + 1), dim3(vk::kWG), 4 * vk::kWG * sizeof(float),
+                               st, f, h, a.tab_wt);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "step_finalize_ws launch: %s", hipGetErrorString(e));
         return VMAPSTEP_OK;
@@ -773,7 +783,7 @@ int vmapstep_profile_phases(const vmapstep_shape* shape, const vmapstep_params* 
     a.timing = timing;
     *n_workgroups = a.xcd_affine ? 8 * ((shape->n_obj + 7) / 8) * pl.NW : shape->n_obj * pl.NW;
     if ((rc = launch_prep(a, 1, st))) return rc;
-    if (a.wide == 3) return launch_ws_v<true, true, true>(a, st);
+    if (a.wide == 3) return a.hidden == 128 ? launch_ws_v<4, true, true, true>(a, st) : launch_ws_v<2, true, true, true>(a, st);
     if (a.split) return launch_split<true, true>(a, st);
     return a.NW < a.NG ? launch_main_v<true, true, true>(a, st) : launch_main_v<true, false, true>(a, st);   // the stamped build
 }

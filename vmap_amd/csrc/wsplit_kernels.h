@@ -52,7 +52,8 @@ struct ImgWs {
     static constexpr int DCH = 2048;                                       // ... of a delta image: 2 planes
     static constexpr int ACT = 0, ACT_ST = NB * 2 * XCH, ACT_BYTES = 2 * ACT_ST;      // forward: layer input images [tile][block][step][plane]
     static constexpr int EF = 0, EF_ST = 5 * 4096;                         // backward (over ACT): F-form images of the 5 encoding blocks [tile][5]
-    static constexpr int EIM = ACT_BYTES, E_ST = 9 * XCH, E2_OFF = 6 * XCH;            // forward: encoding images [tile][6 + 3 steps][plane]
+    static constexpr int R0_BYTES = ACT_BYTES > 2 * EF_ST ? ACT_BYTES : 2 * EF_ST;
+    static constexpr int EIM = R0_BYTES, E_ST = 9 * XCH, E2_OFF = 6 * XCH;             // forward: encoding images [tile][6 + 3 steps][plane]
     static constexpr int DLT = EIM, DLT_ST = NB * 2 * DCH;                 // backward (over EIM): delta images [tile][block][step][plane]
     static constexpr int XF = DLT + 2 * DLT_ST, XF_ST = NB * 4096;         // backward: F-form images of the layer input [tile][block]
     static constexpr int R1_BYTES = 2 * E_ST > 2 * DLT_ST + 2 * XF_ST ? 2 * E_ST : 2 * DLT_ST + 2 * XF_ST;
@@ -63,8 +64,7 @@ struct ImgWs {
     static constexpr int LDS_BYTES = LOSS + kWaves * 4 * 4;
     static constexpr int kPts = 64;                                        // sample points per round
 };
-static_assert(ImgWs<4>::LDS_BYTES <= 160 * 1024, "LDS budget");
-static_assert(ImgWs<4>::EF_ST * 2 <= ImgWs<4>::ACT_BYTES, "encoding F images fit the dead layer-input images");
+static_assert(ImgWs<4>::LDS_BYTES <= 160 * 1024 && ImgWs<2>::LDS_BYTES <= 160 * 1024, "LDS budget");
 
 struct WsArgs {
     StepArgs s;
@@ -596,11 +596,12 @@ __device__ __forceinline__ void dw_layer(const unsigned (&dF)[2][16], bool first
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// step_main_ws<NB, BWD, W3>: NB = 4 (hidden 128); W3 = false: bf16 weights (one weight plane)
+// step_main_ws<NB, BWD, W3>: NB = 4 (hidden 128) or 2 (hidden 64: waves 0, 1 own the two output blocks, waves 2, 3 only take
+// part in the encoding and in the d-prop of the encoding blocks); W3 = false: bf16 weights (one weight plane)
 // ---------------------------------------------------------------------------------------------------------
 template <int NB, bool BWD, bool W3, bool STAMPS = false>
 __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
-    static_assert(NB == 4, "one output block per wave");
+    static_assert(NB == 4 || NB == 2, "one output block per wave, at most four");
     using I = ImgWs<NB>;
     constexpr int H = I::H, JS = I::JS;
     const StepArgs& a = ga.s;
@@ -644,6 +645,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     const unsigned tid16 = (unsigned)tid * 16u;
     const int lo16 = lane * 16;
     const unsigned vlo16 = (unsigned)lane * 16u;
+    const bool own = wave < NB;                                          // this wave owns output block `wave` of every layer
     __syncthreads();                                                     // previous round done with LDS
     for (int i = tid; i < I::kPts * 8; i += kWG) cb[i] = 0.0f;
     const int ray0 = grp * a.G;
@@ -658,7 +660,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     }
     const RayMeta rmeta = load_ray_meta(a, obj, ray0 + min(4 * wave + (lane >> 4), nrays - 1));
     WPre pre_in;                                                         // in_layer's first weight chunks: fetched behind the encoding
-    wpre_load<W3, 6, 0>(pre_in, gW + ((long long)(I::CW_IN + wave * I::KS_IN)) * I::XCH, nullptr, vlo16);
+    if (own) wpre_load<W3, 6, 0>(pre_in, gW + ((long long)(I::CW_IN + wave * I::KS_IN)) * I::XCH, nullptr, vlo16);
     // ---- encoding (embedding.py:82-91): wave = (tile est, direction half dhalf); owner-lane slots as in step_main_s32 ----
     {
         const int est = wave & 1, dhalf = wave >> 1;
@@ -766,36 +768,46 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     auto wchunk = [&](int base, int ks, int s) { return gW + ((long long)(base + wave * ks + s)) * I::XCH; };     // wave-uniform
 #endif
     WPre pre;
-    zero_acc(acc[0]); zero_acc(acc[1]);                                  // :59 in_layer (bias rides in the constant-1 column)
-    fwd_run<W3, 6, 0>(acc, pre_in, wchunk(I::CW_IN, I::KS_IN, 0), e1x, I::E_ST, nullptr, nullptr, 0, vlo16);
-    wpre_load<W3, 0, JS>(pre, nullptr, wchunk(I::CW_M1, I::KS_M, 0), vlo16);
-    epilogue(0);
+    if (own) {
+        zero_acc(acc[0]); zero_acc(acc[1]);                              // :59 in_layer (bias rides in the constant-1 column)
+        fwd_run<W3, 6, 0>(acc, pre_in, wchunk(I::CW_IN, I::KS_IN, 0), e1x, I::E_ST, nullptr, nullptr, 0, vlo16);
+        wpre_load<W3, 0, JS>(pre, nullptr, wchunk(I::CW_M1, I::KS_M, 0), vlo16);
+        epilogue(0);
+    }
     __syncthreads();
     WS_MARK(2);
-    load_bias(acc[0], SM + I::B_M1 + 32 * wave, hi); acc[1] = acc[0];    // :60 mid1
-    fwd_run<W3, 0, JS>(acc, pre, nullptr, nullptr, 0, wchunk(I::CW_M1, I::KS_M, 0), actx, I::ACT_ST, vlo16);
-    wpre_load<W3, 6, JS>(pre, wchunk(I::CW_CAT, I::KS_CAT, JS), wchunk(I::CW_CAT, I::KS_CAT, 0), vlo16);
+    if (own) {
+        load_bias(acc[0], SM + I::B_M1 + 32 * wave, hi); acc[1] = acc[0];    // :60 mid1
+        fwd_run<W3, 0, JS>(acc, pre, nullptr, nullptr, 0, wchunk(I::CW_M1, I::KS_M, 0), actx, I::ACT_ST, vlo16);
+        wpre_load<W3, 6, JS>(pre, wchunk(I::CW_CAT, I::KS_CAT, JS), wchunk(I::CW_CAT, I::KS_CAT, 0), vlo16);
+    }
     __syncthreads();                                                     // everybody has read h1
-    epilogue(1);
+    if (own) epilogue(1);
     __syncthreads();
     WS_MARK(3);
-    zero_acc(acc[0]); zero_acc(acc[1]);                                  // :63-64 cat_layer: encoding part, then h2
-    fwd_run<W3, 6, JS>(acc, pre, wchunk(I::CW_CAT, I::KS_CAT, JS), e1x, I::E_ST, wchunk(I::CW_CAT, I::KS_CAT, 0), actx, I::ACT_ST, vlo16);
-    wpre_load<W3, 0, JS>(pre, nullptr, wchunk(I::CW_M2, I::KS_M, 0), vlo16);
+    if (own) {
+        zero_acc(acc[0]); zero_acc(acc[1]);                              // :63-64 cat_layer: encoding part, then h2
+        fwd_run<W3, 6, JS>(acc, pre, wchunk(I::CW_CAT, I::KS_CAT, JS), e1x, I::E_ST, wchunk(I::CW_CAT, I::KS_CAT, 0), actx, I::ACT_ST, vlo16);
+        wpre_load<W3, 0, JS>(pre, nullptr, wchunk(I::CW_M2, I::KS_M, 0), vlo16);
+    }
     __syncthreads();
-    epilogue(2);
+    if (own) epilogue(2);
     __syncthreads();
     WS_MARK(4);
-    load_bias(acc[0], SM + I::B_M2 + 32 * wave, hi); acc[1] = acc[0];    // :67 mid2
-    fwd_run<W3, 0, JS>(acc, pre, nullptr, nullptr, 0, wchunk(I::CW_M2, I::KS_M, 0), actx, I::ACT_ST, vlo16);
-    wpre_load<W3, 3, JS>(pre, wchunk(I::CW_C, I::KS_C, JS), wchunk(I::CW_C, I::KS_C, 0), vlo16);
+    if (own) {
+        load_bias(acc[0], SM + I::B_M2 + 32 * wave, hi); acc[1] = acc[0];    // :67 mid2
+        fwd_run<W3, 0, JS>(acc, pre, nullptr, nullptr, 0, wchunk(I::CW_M2, I::KS_M, 0), actx, I::ACT_ST, vlo16);
+        wpre_load<W3, 3, JS>(pre, wchunk(I::CW_C, I::KS_C, JS), wchunk(I::CW_C, I::KS_C, 0), vlo16);
+    }
     __syncthreads();
-    epilogue(3);
+    if (own) epilogue(3);
     __syncthreads();
     WS_MARK(5);
-    zero_acc(acc[0]); zero_acc(acc[1]);                                  // :81 color_linear: second encoding group, then h4
-    fwd_run<W3, 3, JS>(acc, pre, wchunk(I::CW_C, I::KS_C, JS), e2x, I::E_ST, wchunk(I::CW_C, I::KS_C, 0), actx, I::ACT_ST, vlo16);
-    epilogue(4);
+    if (own) {
+        zero_acc(acc[0]); zero_acc(acc[1]);                              // :81 color_linear: second encoding group, then h4
+        fwd_run<W3, 3, JS>(acc, pre, wchunk(I::CW_C, I::KS_C, JS), e2x, I::E_ST, wchunk(I::CW_C, I::KS_C, 0), actx, I::ACT_ST, vlo16);
+        epilogue(4);
+    }
     __syncthreads();
     WS_MARK(6);
     if (wave < 2 && hi == 0) {                                           // heads of tile `wave`: sum of the four waves' partials
@@ -803,9 +815,10 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
         if (pt < npts) {
             float v[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
-                v[c] = (hp[((0 * 2 + wave) * 32 + p31) * 4 + c] + hp[((1 * 2 + wave) * 32 + p31) * 4 + c]) +
-                       (hp[((2 * 2 + wave) * 32 + p31) * 4 + c] + hp[((3 * 2 + wave) * 32 + p31) * 4 + c]);
+            for (int c = 0; c < 4; ++c) {
+                v[c] = hp[((0 * 2 + wave) * 32 + p31) * 4 + c] + hp[((1 * 2 + wave) * 32 + p31) * 4 + c];
+                if (NB == 4) v[c] += hp[((2 * 2 + wave) * 32 + p31) * 4 + c] + hp[((3 * 2 + wave) * 32 + p31) * 4 + c];
+            }
             float* row = cb + pt * 8;
             row[6] = zv;
             row[0] = sigmoidf_acc((v[0] + SM[I::B_A]) * 10.0f);           // :77 raw*10 ; render_rays.py:6
@@ -829,7 +842,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
         for (int st = 0; st < 2; ++st) { acts_load_plane(ah[st], acts, tid16, layer, st, 0); acts_load_plane(am[st], acts, tid16, layer, st, 1); }
         wv::sched_fence();
     };
-    fetch(3);                                                            // h4: lands during the encoding transposes
+    if (own) fetch(3);                                                   // h4: lands during the encoding transposes
     float d_raw[2], d_c0[2], d_c1[2], d_c2[2];
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
@@ -968,7 +981,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     };
     auto xf_img = [&](int kb, const char*& p, int& st) { p = xfx + kb * 4096; st = I::XF_ST; };
     // -- heads: d W_a = (d raw)^T h4, d W_oc = (d colour)^T hc; rows 0..3 of one block each --
-    {
+    if (own) {
         FImg xi;
         publish_x();                                                     // h4 block: color_linear's weight-gradient operand
         fetch(4);                                                        // hc
@@ -996,118 +1009,130 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
         }
     }
     // -- delta 0 = d hc (through the ReLU; ah = hc's hi plane) --
+    if (own) {
 #pragma unroll
-    for (int st = 0; st < 2; ++st) {
-        f32x16 v;
+        for (int st = 0; st < 2; ++st) {
+            f32x16 v;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int j = 32 * wave + phi(r, hi);
-            v[r] = SM[I::W_OC + j] * d_c0[st] + SM[I::W_OC + H + j] * d_c1[st] + SM[I::W_OC + 2 * H + j] * d_c2[st];
+            for (int r = 0; r < 16; ++r) {
+                const int j = 32 * wave + phi(r, hi);
+                v[r] = SM[I::W_OC + j] * d_c0[st] + SM[I::W_OC + H + j] * d_c1[st] + SM[I::W_OC + 2 * H + j] * d_c2[st];
+            }
+            mask_by(dv[st], v, ah[st]);
         }
-        mask_by(dv[st], v, ah[st]);
+        publish_d();
+        fetch(3);                                                        // h4 again: the mask of delta 1
     }
-    publish_d();
-    fetch(3);                                                            // h4 again: the mask of delta 1
     __syncthreads();
     WS_MARK(9);
     WS_DMARK(0);
     // color_linear: weight gradients (h4 blocks, second-group blocks + bias column), d-prop -> d h4 (+ W_a d raw), d(second group)
-    tpre_load<W3>(tp, hidden_ptr(I::CT_C), vlo16);
-    if (wave == 0) enc_fetch(I::CT_C + (NB + 0) * JS, 2, 0);
-    if (wave == 1) enc_fetch(I::CT_C + (NB + 1) * JS, 2, 1);
+    constexpr int EC0 = NB == 4 ? 0 : 2, EC1 = NB == 4 ? 1 : 3;          // the waves that d-prop color_linear's two encoding blocks
+    if (own) tpre_load<W3>(tp, hidden_ptr(I::CT_C), vlo16);
+    if (wave == EC0) enc_fetch(I::CT_C + (NB + 0) * JS, 2, 0);
+    if (wave == EC1) enc_fetch(I::CT_C + (NB + 1) * JS, 2, 1);
     WS_DMARK(1);
-    dw_layer<NB + 2>(dF, first,
-        [&](int kb, const char*& p, int& st) { if (kb < NB) xf_img(kb, p, st); else { p = efx + (3 + kb - NB) * 4096; st = I::EF_ST; } },
-        [&](int mode, int kb, const f32x16& v, float (&old)[16]) {
-            WS_IO3(mode, kb < NB, (block_io<0, H + kEmb2, M>(outW_c + 32 * kb, nullptr, v, old, 0, 32, p31, hi)),
-                   (block_io<2, H + kEmb2, M>(outW_c + H, out + L.f[11] + 32 * wave, v, old, kb - NB, kEmb2, p31, hi)));
-        });
+    if (own)
+        dw_layer<NB + 2>(dF, first,
+            [&](int kb, const char*& p, int& st) { if (kb < NB) xf_img(kb, p, st); else { p = efx + (3 + kb - NB) * 4096; st = I::EF_ST; } },
+            [&](int mode, int kb, const f32x16& v, float (&old)[16]) {
+                WS_IO3(mode, kb < NB, (block_io<0, H + kEmb2, M>(outW_c + 32 * kb, nullptr, v, old, 0, 32, p31, hi)),
+                       (block_io<2, H + kEmb2, M>(outW_c + H, out + L.f[11] + 32 * wave, v, old, kb - NB, kEmb2, p31, hi)));
+            });
     WS_DMARK(2);
-    if (wave == 0) dprop_enc(I::CT_C + (NB + 0) * JS, 2, 0);
-    if (wave == 1) dprop_enc(I::CT_C + (NB + 1) * JS, 2, 1);
+    if (wave == EC0) dprop_enc(I::CT_C + (NB + 0) * JS, 2, 0);
+    if (wave == EC1) dprop_enc(I::CT_C + (NB + 1) * JS, 2, 1);
     WS_DMARK(3);
-    dprop_hidden(I::CT_C, true);
-    WS_DMARK(4);
+    if (own) {
+        dprop_hidden(I::CT_C, true);
+        WS_DMARK(4);
 #pragma unroll
-    for (int st = 0; st < 2; ++st) mask_by(dv[st], accd[st], ah[st]);  // delta 1 = d h4
-    fetch(2);                                                            // h3: mid2's input and the mask of delta 2
-    tpre_load<W3>(tp, hidden_ptr(I::CT_M2), vlo16);
+        for (int st = 0; st < 2; ++st) mask_by(dv[st], accd[st], ah[st]);  // delta 1 = d h4
+        fetch(2);                                                        // h3: mid2's input and the mask of delta 2
+        tpre_load<W3>(tp, hidden_ptr(I::CT_M2), vlo16);
+    }
     WS_DMARK(5);
     __syncthreads();
     WS_DMARK(6);
-    publish_d();
+    if (own) publish_d();
     WS_DMARK(7);
-    publish_x();
+    if (own) publish_x();
     WS_DMARK(8);
     __syncthreads();
     WS_DMARK(9);
     WS_MARK(10);
     // mid2
-    dw_layer<NB>(dF, first, xf_img, [&](int mode, int kb, const f32x16& v, float (&old)[16]) {
-        WS_IO3(mode, true, (block_io<0, H, M>(outW_m2 + 32 * kb, nullptr, v, old, 0, 32, p31, hi)), (void)0);
-    });
-    WS_DMARK(10);
-    db_pair(accw, dF);
-    if (p31 == 0) store_rows<1>(out + L.f[7] + 32 * wave, (unsigned)(4 * hi), accw, first);
-    WS_DMARK(11);
-    dprop_hidden(I::CT_M2, false);
-    WS_DMARK(12);
+    if (own) {
+        dw_layer<NB>(dF, first, xf_img, [&](int mode, int kb, const f32x16& v, float (&old)[16]) {
+            WS_IO3(mode, true, (block_io<0, H, M>(outW_m2 + 32 * kb, nullptr, v, old, 0, 32, p31, hi)), (void)0);
+        });
+        WS_DMARK(10);
+        db_pair(accw, dF);
+        if (p31 == 0) store_rows<1>(out + L.f[7] + 32 * wave, (unsigned)(4 * hi), accw, first);
+        WS_DMARK(11);
+        dprop_hidden(I::CT_M2, false);
+        WS_DMARK(12);
 #pragma unroll
-    for (int st = 0; st < 2; ++st) mask_by(dv[st], accd[st], ah[st]);  // delta 2 = d h3
-    WS_DMARK(13);
-    fetch(1);                                                            // h2
-    tpre_load<W3>(tp, hidden_ptr(I::CT_CAT), vlo16);
+        for (int st = 0; st < 2; ++st) mask_by(dv[st], accd[st], ah[st]);  // delta 2 = d h3
+        WS_DMARK(13);
+        fetch(1);                                                        // h2
+        tpre_load<W3>(tp, hidden_ptr(I::CT_CAT), vlo16);
+    }
     WS_DMARK(14);
     if (wave == 1) enc_fetch(I::CT_CAT + (NB + 0) * JS, 1, 0);
     if (wave == 2) enc_fetch(I::CT_CAT + (NB + 1) * JS, 1, 1);
     if (wave == 3) enc_fetch(I::CT_CAT + (NB + 2) * JS, 1, 2);
     __syncthreads();
-    publish_d();
-    publish_x();
+    if (own) { publish_d(); publish_x(); }
     __syncthreads();
     WS_MARK(11);
     WS_DMARK(15);
     // cat_layer
-    dw_layer<NB + 3>(dF, first,
-        [&](int kb, const char*& p, int& st) { if (kb < NB) xf_img(kb, p, st); else { p = efx + (kb - NB) * 4096; st = I::EF_ST; } },
-        [&](int mode, int kb, const f32x16& v, float (&old)[16]) {
-            WS_IO3(mode, kb < NB, (block_io<0, H + kEmb1, M>(outW_cat + 32 * kb, nullptr, v, old, 0, 32, p31, hi)),
-                   (block_io<1, H + kEmb1, M>(outW_cat + H, out + L.f[5] + 32 * wave, v, old, kb - NB, kEmb1, p31, hi)));
-        });
+    if (own)
+        dw_layer<NB + 3>(dF, first,
+            [&](int kb, const char*& p, int& st) { if (kb < NB) xf_img(kb, p, st); else { p = efx + (kb - NB) * 4096; st = I::EF_ST; } },
+            [&](int mode, int kb, const f32x16& v, float (&old)[16]) {
+                WS_IO3(mode, kb < NB, (block_io<0, H + kEmb1, M>(outW_cat + 32 * kb, nullptr, v, old, 0, 32, p31, hi)),
+                       (block_io<1, H + kEmb1, M>(outW_cat + H, out + L.f[5] + 32 * wave, v, old, kb - NB, kEmb1, p31, hi)));
+            });
     if (wave == 1) dprop_enc(I::CT_CAT + (NB + 0) * JS, 1, 0);
     if (wave == 2) dprop_enc(I::CT_CAT + (NB + 1) * JS, 1, 1);
     if (wave == 3) dprop_enc(I::CT_CAT + (NB + 2) * JS, 1, 2);
-    dprop_hidden(I::CT_CAT, false);
+    if (own) {
+        dprop_hidden(I::CT_CAT, false);
 #pragma unroll
-    for (int st = 0; st < 2; ++st) mask_by(dv[st], accd[st], ah[st]);  // delta 3 = d h2
-    fetch(0);                                                            // h1
-    tpre_load<W3>(tp, hidden_ptr(I::CT_M1), vlo16);
+        for (int st = 0; st < 2; ++st) mask_by(dv[st], accd[st], ah[st]);  // delta 3 = d h2
+        fetch(0);                                                        // h1
+        tpre_load<W3>(tp, hidden_ptr(I::CT_M1), vlo16);
+    }
     __syncthreads();
-    publish_d();
-    publish_x();
+    if (own) { publish_d(); publish_x(); }
     __syncthreads();
     WS_MARK(12);
     // mid1
-    dw_layer<NB>(dF, first, xf_img, [&](int mode, int kb, const f32x16& v, float (&old)[16]) {
-        WS_IO3(mode, true, (block_io<0, H, M>(outW_m1 + 32 * kb, nullptr, v, old, 0, 32, p31, hi)), (void)0);
-    });
-    db_pair(accw, dF);
-    if (p31 == 0) store_rows<1>(out + L.f[3] + 32 * wave, (unsigned)(4 * hi), accw, first);
-    dprop_hidden(I::CT_M1, false);
+    if (own) {
+        dw_layer<NB>(dF, first, xf_img, [&](int mode, int kb, const f32x16& v, float (&old)[16]) {
+            WS_IO3(mode, true, (block_io<0, H, M>(outW_m1 + 32 * kb, nullptr, v, old, 0, 32, p31, hi)), (void)0);
+        });
+        db_pair(accw, dF);
+        if (p31 == 0) store_rows<1>(out + L.f[3] + 32 * wave, (unsigned)(4 * hi), accw, first);
+        dprop_hidden(I::CT_M1, false);
 #pragma unroll
-    for (int st = 0; st < 2; ++st) mask_by(dv[st], accd[st], ah[st]);  // delta 4 = d h1
+        for (int st = 0; st < 2; ++st) mask_by(dv[st], accd[st], ah[st]);  // delta 4 = d h1
+    }
     if (wave == 0) enc_fetch(I::CT_IN + 0 * JS, 1, 0);
     if (wave == 2) enc_fetch(I::CT_IN + 1 * JS, 1, 1);
     if (wave == 3) enc_fetch(I::CT_IN + 2 * JS, 1, 2);
     __syncthreads();
-    publish_d();
+    if (own) publish_d();
     __syncthreads();
     WS_MARK(13);
     // in_layer
-    dw_layer<3>(dF, first, [&](int kb, const char*& p, int& st) { p = efx + kb * 4096; st = I::EF_ST; },
-                [&](int mode, int kb, const f32x16& v, float (&old)[16]) {
-                    WS_IO3(mode, true, (block_io<1, kEmb1, M>(outW_in, out + L.f[1] + 32 * wave, v, old, kb, kEmb1, p31, hi)), (void)0);
-                });
+    if (own)
+        dw_layer<3>(dF, first, [&](int kb, const char*& p, int& st) { p = efx + kb * 4096; st = I::EF_ST; },
+                    [&](int mode, int kb, const f32x16& v, float (&old)[16]) {
+                        WS_IO3(mode, true, (block_io<1, kEmb1, M>(outW_in, out + L.f[1] + 32 * wave, v, old, kb, kEmb1, p31, hi)), (void)0);
+                    });
     if (wave == 0) dprop_enc(I::CT_IN + 0 * JS, 1, 0);
     if (wave == 2) dprop_enc(I::CT_IN + 1 * JS, 1, 1);
     if (wave == 3) dprop_enc(I::CT_IN + 2 * JS, 1, 2);
