@@ -104,7 +104,7 @@ def main():
     ap.add_argument("--config", default="replica_room0_vmap", choices=list(synth.CONFIGS))
     ap.add_argument("--iters-per-frame", type=int, default=20)       # config: render.iters_per_frame
     ap.add_argument("--weights", default="f32", choices=["f32", "bf16"])   # bf16: BASELINE configs[3]/[4] (fp32 masters + accumulate)
-    ap.add_argument("--kernel", default="auto", choices=["auto", "gen", "wide", "wide2", "f32"])   # measurement: hidden 128 / 256 kernels; f32 = hidden 32
+    ap.add_argument("--kernel", default="auto", choices=["auto", "gen", "wide", "wide2", "f32", "ws1", "wp"])   # measurement: hidden 128 / 256 kernels; f32 = hidden 32
                                                                                                  # on the exact-fp32 matrix instruction (step_main_h32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--slab", action="store_true")                   # the 15 stacked tensors as views of one [n, P] slab (measurement;
@@ -149,7 +149,7 @@ def main():
     tuning = None
     if args.kernel != "auto":
         from vmap_amd import _lib
-        tuning = {"kernel": {"gen": _lib.KERNEL_GEN, "wide": _lib.KERNEL_WIDE4, "wide2": _lib.KERNEL_WIDE2, "f32": _lib.KERNEL_H32_F32}[args.kernel]}
+        tuning = {"kernel": {"gen": _lib.KERNEL_GEN, "wide": _lib.KERNEL_WIDE4, "wide2": _lib.KERNEL_WIDE2, "f32": _lib.KERNEL_H32_F32, "ws1": _lib.KERNEL_WS1, "wp": _lib.KERNEL_WP}[args.kernel]}
     op = step.VmapStep(n, R, S, H, device=dev, max_steps=ipf, weights=args.weights, tuning=tuning)
     opt = step.FusedAdamWState(n, H, dev, lr=1e-3, weight_decay=0.013)
     fargs = (fr["pcs"], fr["z"], fr["gt_depth"], fr["gt_rgb"], fr["sem"], fr["depth_mask"])
@@ -297,10 +297,10 @@ def main():
         # rocprofv3 average; both raw figures are reported next to it.
         k_ms = 0.5 * (k_ms_raw + k_ms_corr)
         split = H == 32 and args.kernel != "f32"
-        ws = H == 128 and args.kernel == "auto" and S <= 64
+        ws = H == 128 and args.kernel in ("auto", "ws1", "wp") and S <= 64
         kernel_name = ("step_main_s32 (bf16 matrix pipe, split operands: 6 products forward, 3 backward)" if split else
                        "step_main_h32 (exact-fp32 matrix instruction)" if H == 32 else
-                       "step_main_ws (hidden 128: bf16 matrix pipe, split operands, two 32-point tiles per workgroup round)" if ws else
+                       ("step_main_wp" if args.kernel == "wp" else "step_main_ws") + " (hidden 128: bf16 matrix pipe, split operands, two 32-point tiles per workgroup round)" if ws else
                        "step_main_gen / step_main_wide (hidden 128, 256: chosen by tile count)")
         flops = layout.step_flops(n, R, S, H)
         abytes = layout.step_bytes(n, R, S, H)

@@ -49,13 +49,16 @@ extern "C" {
  * all-zero = automatic); the library keeps no tuning state of its own, so two operators in one process (two streams,
  * two devices, two threads) cannot influence each other.  The plan - and with it the workspace layout - depends on these
  * values: pass the same tuning to vmapstep_workspace_bytes and to every call that uses that workspace. */
-#define VMAPSTEP_KERNEL_AUTO 0    /* hidden 32: step_main_s32; hidden 128: step_main_ws (both: bf16 matrix pipe, split operands,
+#define VMAPSTEP_KERNEL_AUTO 0    /* hidden 32: step_main_s32; hidden 64: step_main_wp, hidden 128: step_main_ws (all: bf16 matrix pipe, split operands,
                                      float32-equivalent forward); other widths: the exact-fp32 kernels below               */
 #define VMAPSTEP_KERNEL_GEN 1     /* hidden 64..256: step_main_gen (one wave per 32-point tile)                      */
 #define VMAPSTEP_KERNEL_WIDE4 2   /* hidden 128/256: step_main_wide<4> (one tile per workgroup, four waves per tile) */
 #define VMAPSTEP_KERNEL_WIDE2 3   /* hidden 128/256: step_main_wide<2> (four tiles per workgroup, two waves per tile)*/
 #define VMAPSTEP_KERNEL_H32_F32 4 /* hidden 32: step_main_h32 on the exact-fp32 matrix instruction instead of the default
                                      step_main_s32 (bf16 matrix pipe, split operands, float32-equivalent forward)      */
+#define VMAPSTEP_KERNEL_WS1 5     /* hidden 64 / 128: step_main_ws (one wave per output block; the default at hidden 128)            */
+#define VMAPSTEP_KERNEL_WP 6      /* hidden 64 / 128: step_main_wp (two waves per block, partial sums exchanged through LDS; the
+                                     default at hidden 64)                                                               */
 typedef struct vmapstep_tuning {
     int32_t workgroups_per_object; /* 0 = automatic (256 / n_obj, at most one per ray group)                      */
     int32_t kernel;                /* VMAPSTEP_KERNEL_*                                                           */

@@ -7,6 +7,7 @@
 #include "wide_kernels.h"
 #include "split_kernels.h"
 #include "wsplit_kernels.h"
+#include "wpair_kernels.h"
 #include "sample_kernels.h"
 #include "query_kernels.h"
 
@@ -47,7 +48,8 @@ extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req, int xcd
     std::vector<int> fl(4, -1);
     const vk::GenLayout GL = vk::gen_layout(H);
     const bool split = g_split && H == 32;
-    const bool ws = g_wide == 3 && (H == 128 || H == 64);    // step_main_ws (split-bf16 matrix pipe, hidden 128 / 64)
+    const bool wp = g_wide == 4 && (H == 128 || H == 64);    // step_main_wp (two waves per output block)
+    const bool ws = (g_wide == 3 || g_wide == 4) && (H == 128 || H == 64);    // step_main_ws / _wp (split-bf16 matrix pipe, hidden 128 / 64)
     if (ws && G * S > vk::ImgWs<4>::kPts) return -3;
     std::vector<float> wimg((size_t)n * (split ? vk::Img32s::BYTES / 4 : ws ? (H == 128 ? vk::ImgWs<4>::BYTES : vk::ImgWs<2>::BYTES) / 4 : GL.imgp), NAN);
 
@@ -73,7 +75,7 @@ extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req, int xcd
 
     std::vector<char> ws_scratch;
     if (ws) {
-        ws_scratch.assign((size_t)n * NW * vk::ImgWs<4>::WG_SCRATCH, (char)0xFF);
+        ws_scratch.assign((size_t)n * NW * (wp ? vk::LdsWp<4>::WG_SCRATCH : vk::ImgWs<4>::WG_SCRATCH), (char)0xFF);
         wa.s = a; wa.scratch = ws_scratch.data(); wa.tab_wt = tab_wt.data();
         if (H == 128) sim::launch(1 + n * vk::ws_pack_blocks<4>(), vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep_ws<4>(wa); });
         else sim::launch(1 + n * vk::ws_pack_blocks<2>(), vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep_ws<2>(wa); });
@@ -81,7 +83,25 @@ extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req, int xcd
     else sim::launch(1 + n * (vk::gen_layout(H).imgp / 1024), vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep(a); });
     const bool multi = NW < NG;
     const int grid = xcd_affine && H == 32 ? 8 * ((n + 7) / 8) * NW : n * NW;
-    if (ws && H == 128) {
+    if (wp && H == 128) {
+        const int lb = vk::LdsWp<4>::LDS_BYTES;
+        if (weights_bf16) {
+            if (bwd) sim::launch(n * NW, 512, lb, [&] { vk::step_main_wp<4, true, false>(wa); });
+            else     sim::launch(n * NW, 512, lb, [&] { vk::step_main_wp<4, false, false>(wa); });
+        } else {
+            if (bwd) sim::launch(n * NW, 512, lb, [&] { vk::step_main_wp<4, true, true>(wa); });
+            else     sim::launch(n * NW, 512, lb, [&] { vk::step_main_wp<4, false, true>(wa); });
+        }
+    } else if (wp) {
+        const int lb = vk::LdsWp<2>::LDS_BYTES;
+        if (weights_bf16) {
+            if (bwd) sim::launch(n * NW, 256, lb, [&] { vk::step_main_wp<2, true, false>(wa); });
+            else     sim::launch(n * NW, 256, lb, [&] { vk::step_main_wp<2, false, false>(wa); });
+        } else {
+            if (bwd) sim::launch(n * NW, 256, lb, [&] { vk::step_main_wp<2, true, true>(wa); });
+            else     sim::launch(n * NW, 256, lb, [&] { vk::step_main_wp<2, false, true>(wa); });
+        }
+    } else if (ws && H == 128) {
         const int lb = vk::ImgWs<4>::LDS_BYTES;
         if (weights_bf16) {
             if (bwd) sim::launch(n * NW, vk::kWG, lb, [&] { vk::step_main_ws<4, true, false>(wa); });

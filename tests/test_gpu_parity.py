@@ -116,13 +116,13 @@ def test_fwd_bwd_matches_oracle_on_seeded_shapes(n, R, S, seed):
 @pytest.mark.parametrize("n,R,S,seed", [(1, 1, 14, 11), (3, 9, 14, 12), (2, 37, 10, 13), (1, 21, 3, 14), (2, 7, 20, 15),
                                         (1, 5, 40, 16), (1, 3, 64, 17), (5, 300, 14, 18)])
 def test_hidden128_kernel_matches_oracle_on_seeded_shapes(n, R, S, seed, H):
-    """step_main_ws (hidden 128 and 64, the automatic choice) on ragged shapes: single ray, rays that straddle the two tiles of a
+    """step_main_wp (hidden 128 and 64, the automatic choice) and step_main_ws on ragged shapes: single ray, rays that straddle the two tiles of a
     round (S = 10, 14, 20), one ray per round (S = 40, 64 = the kernel's limit), long rays through the general compositing
     path (S > 16), several objects, more rounds than workgroups (5 x 75 rounds)."""
     fc, B, sc = synth.make_params(n, H, seed=300 + seed)
     batch = synth.make_batch(n, R, S, seed=400 + seed)
     c = dict(n=n, R=R, S=S, H=H, fc=fc, B=B, scale=sc, batch=batch)
-    s = _run(c, tuning={"kernel": _lib.KERNEL_AUTO})
+    s = _run(c, tuning={"kernel": _lib.KERNEL_WP})
     from oracle import vmap_oracle_torch as vt
     loss_t, rend_t, grads_t = vt.CpuTrainer(fc, B, sc).step(batch, update=False)
     assert abs(s["loss"] - float(loss_t)) <= 5e-5 * abs(float(loss_t))
@@ -140,10 +140,13 @@ def test_hidden128_kernel_matches_oracle_on_seeded_shapes(n, R, S, seed, H):
         loose += r >= 1e-4
     assert loose <= 5
     e = _run(c, tuning={"kernel": _lib.KERNEL_GEN})
+    w1 = _run(c, tuning={"kernel": _lib.KERNEL_WS1})              # step_main_ws: one wave per output block
     for k in RENDER_KEYS:
         assert relerr(s[k], e[k]) < 2e-5, k
+        assert relerr(w1[k], e[k]) < 2e-5, k
     for k in GRAD_KEYS:
         assert relerr(s[k], e[k]) < 1e-4, k
+        assert relerr(w1[k], e[k]) < 1e-4, k
 
 
 def test_render_only_equals_fwd_bwd_renders():
@@ -401,17 +404,20 @@ def test_unsupported_hidden_width_fails_loudly():
 @pytest.mark.parametrize("name,kernel", [("h64", "gen"), ("bg_h128_s14", "wide"), ("imap_h256", "wide"),
                                          ("bg_h128_s14", "gen"), ("imap_h256", "gen"), ("bg_h128_s14", "wide_multipass"),
                                          ("bg_h128_s14", "wide2"), ("imap_h256", "wide2"), ("bg_h128_s14", "wide2_multipass"),
-                                         ("bg_h128_s14", "ws"), ("bg_h128_s14", "ws_multipass"), ("h64", "ws"), ("h64", "ws_multipass")])
+                                         ("bg_h128_s14", "ws"), ("bg_h128_s14", "ws_multipass"), ("h64", "ws"), ("h64", "ws_multipass"),
+                                         ("bg_h128_s14", "ws1"), ("bg_h128_s14", "ws1_multipass"), ("h64", "ws1"), ("h64", "ws1_multipass")])
 def test_generic_width_kernel_matches_reference_fixture(name, kernel):
     """hidden = 64 / 128 (background model shapes) / 256 (iMAP, BASELINE configs[0]): step_main_wide (tile per
     workgroup / four tiles per workgroup, also with fewer workgroups than ray groups), step_main_gen, and - hidden 128 -
-    step_main_ws (bf16 matrix pipe, split operands: the automatic choice)."""
+    step_main_wp / step_main_ws (bf16 matrix pipe, split operands: two waves / one wave per output block; automatic
+    choice: the first at hidden 64, the second at hidden 128)."""
     c = cases.build_case(name)
     g = load_golden(name)
     tuning = {"kernel": {"gen": _lib.KERNEL_GEN, "wide": _lib.KERNEL_WIDE4, "wide_multipass": _lib.KERNEL_WIDE4,
                          "wide2": _lib.KERNEL_WIDE2, "wide2_multipass": _lib.KERNEL_WIDE2,
-                         "ws": _lib.KERNEL_AUTO, "ws_multipass": _lib.KERNEL_AUTO}[kernel],     # hidden 128, automatic: step_main_ws
-              "workgroups_per_object": {"wide_multipass": 3, "wide2_multipass": 1, "ws_multipass": 3}.get(kernel, 0)}
+                         "ws": _lib.KERNEL_WP, "ws_multipass": _lib.KERNEL_WP,         # step_main_wp (two waves per output block)
+                         "ws1": _lib.KERNEL_WS1, "ws1_multipass": _lib.KERNEL_WS1}[kernel],   # step_main_ws (one wave per block)
+              "workgroups_per_object": {"wide_multipass": 3, "wide2_multipass": 1, "ws_multipass": 3, "ws1_multipass": 3}.get(kernel, 0)}
     s = _run(c, tuning=tuning)
     assert abs(s["loss"] - float(g["loss"])) <= 2e-5 * abs(float(g["loss"]))
     for k in RENDER_KEYS:

@@ -149,14 +149,15 @@ def test_sim_wide_kernel_matches_reference(nw):
             assert relerr(s[k], o[k]) < 2e-5, k
 
 
-@pytest.mark.parametrize("name,nw", [("bg_h128_s14", 0), ("bg_h128_s14", 3), ("h64", 0), ("h64", 2)])
-def test_sim_ws_kernel_matches_reference(name, nw):
-    """step_main_ws (hidden 128 / 64 on the bf16 matrix pipe with split operands: a round of two 32-point tiles per
-    workgroup, wave = output block; nw > 0: several rounds per workgroup add into its partial gradients) vs the fixtures
-    generated by the reference."""
+@pytest.mark.parametrize("name,nw,kernel", [("bg_h128_s14", 0, 3), ("bg_h128_s14", 3, 3), ("h64", 0, 3), ("h64", 2, 3),
+                                            ("bg_h128_s14", 0, 4), ("bg_h128_s14", 3, 4), ("h64", 0, 4), ("h64", 2, 4)])
+def test_sim_ws_kernel_matches_reference(name, nw, kernel):
+    """step_main_ws (kernel 3) / step_main_wp (4): hidden 128 / 64 on the bf16 matrix pipe with split operands, a round of
+    two 32-point tiles per workgroup, one wave / a pair of waves per output block; nw > 0: several rounds per workgroup
+    add into its partial gradients.  Against the fixtures generated by the reference."""
     c = cases.build_case(name)
     g = load_golden(name)
-    s = simlib.sim_step(c, NW=nw, wide=3)
+    s = simlib.sim_step(c, NW=nw, wide=kernel)
     assert abs(s["loss"] - float(g["loss"])) <= 2e-5 * abs(float(g["loss"]))
     for k in RENDER_KEYS:
         assert relerr(s[k], g[k]) < 2e-5, k
@@ -170,7 +171,7 @@ def test_sim_ws_kernel_bf16_weights():
     c = cases.build_case("bg_h128_s14")
     fc_r = [round_bf16(a) for a in c["fc"]]
     B_r = round_bf16(c["B"])
-    s = simlib.sim_step(c, weights_bf16=1, wide=3)
+    s = simlib.sim_step(c, weights_bf16=1, wide=4)
     o = vo.training_step(fc_r, B_r, c["scale"], c["batch"], dtype=np.float32)
     assert abs(s["loss"] - o["loss"]) <= 2e-5 * abs(o["loss"])
     for k in GRAD_KEYS:
@@ -277,7 +278,7 @@ def test_sim_ws_fused_adamw_matches_oracle_update():
     P = flat.shape[1]
     PP = (P + 63) // 64 * 64
     state = dict(p=flat.copy(), m=np.zeros((n, PP), np.float32), v=np.zeros((n, PP), np.float32), step=1)
-    s = simlib.sim_step(c, adam=state, wide=3, NW=5)
+    s = simlib.sim_step(c, adam=state, wide=4, NW=5)
     p_ref, m_ref, v_ref = vo.adamw_update(flat, s["grads_flat"], np.zeros_like(flat), np.zeros_like(flat), 1)
     assert relerr(state["p"], p_ref) < 1e-6
     assert relerr(state["m"][:, :P], m_ref) < 1e-6

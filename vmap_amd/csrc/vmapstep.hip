@@ -18,6 +18,7 @@
 #include "wide_kernels.h"
 #include "split_kernels.h"
 #include "wsplit_kernels.h"
+#include "wpair_kernels.h"
 #include "sample_kernels.h"
 #include "query_kernels.h"
 
@@ -110,7 +111,7 @@ int make_plan(const vmapstep_shape* sh, int max_steps, Plan& pl, const Layout& L
     pl.wide = 0;
     const vmapstep_tuning& tun = tuning_of(sh);
     const int force = tun.kernel;
-    if (force < VMAPSTEP_KERNEL_AUTO || force > VMAPSTEP_KERNEL_H32_F32) return fail(VMAPSTEP_ERR_ARGUMENT, "tuning.kernel=%d", force);
+    if (force < VMAPSTEP_KERNEL_AUTO || force > VMAPSTEP_KERNEL_WP) return fail(VMAPSTEP_ERR_ARGUMENT, "tuning.kernel=%d", force);
     pl.split = !pl.generic && force != VMAPSTEP_KERNEL_H32_F32;
     if (pl.split && tun.carried_finalize) return fail(VMAPSTEP_ERR_UNSUPPORTED, "the carried finalize exists for the exact-fp32 kernel only (tuning.kernel = VMAPSTEP_KERNEL_H32_F32)");
     if (pl.generic && sh->hidden % 128 == 0 && force != VMAPSTEP_KERNEL_GEN) {
@@ -123,14 +124,22 @@ int make_plan(const vmapstep_shape* sh, int max_steps, Plan& pl, const Layout& L
                                                                  // bound by the traffic of the per-tile register images), not automatic
     }
     // hidden 64 / 128: the bf16 matrix pipe with split operands (step_main_ws) unless an exact-fp32 kernel is asked for
-    if (pl.generic && (sh->hidden == 128 || sh->hidden == 64) && force == VMAPSTEP_KERNEL_AUTO && sh->samples <= vk::ImgWs<4>::kPts) pl.wide = 3;
-    pl.G = (pl.wide == 3 ? vk::ImgWs<4>::kPts : pl.wide == 1 ? vk::kWideTile : vk::kMaxPts) / sh->samples;
+    // step_main_ws: one wave per output block; step_main_wp: two (measured: +19 % at hidden 64, where step_main_ws leaves two of its
+    // four waves without a block; within 2-3 % at hidden 128 - the automatic choice follows that)
+    if (pl.generic && (sh->hidden == 128 || sh->hidden == 64) && sh->samples <= vk::ImgWs<4>::kPts) {
+        if (force == VMAPSTEP_KERNEL_AUTO) pl.wide = sh->hidden == 64 ? 4 : 3;
+        else if (force == VMAPSTEP_KERNEL_WS1) pl.wide = 3;
+        else if (force == VMAPSTEP_KERNEL_WP) pl.wide = 4;
+    }
+    if ((force == VMAPSTEP_KERNEL_WS1 || force == VMAPSTEP_KERNEL_WP) && pl.wide < 3)
+        return fail(VMAPSTEP_ERR_UNSUPPORTED, "VMAPSTEP_KERNEL_WS1 / _WP: hidden 64 / 128 with at most 64 samples per ray");
+    pl.G = (pl.wide >= 3 ? vk::ImgWs<4>::kPts : pl.wide == 1 ? vk::kWideTile : vk::kMaxPts) / sh->samples;
     if (pl.G > sh->rays) pl.G = sh->rays;
     pl.NG = (sh->rays + pl.G - 1) / pl.G;
     int nw = tun.workgroups_per_object > 0 ? tun.workgroups_per_object : 256 / sh->n_obj;
     if (nw < 1) nw = 1;
     if (nw > pl.NG) nw = pl.NG;
-    if (pl.wide == 3 && tun.workgroups_per_object <= 0) {
+    if (pl.wide >= 3 && tun.workgroups_per_object <= 0) {
         // one workgroup per CU: with more rounds than workgroup slots the busiest workgroup sets the kernel time, so spread
         // the rounds evenly (300 rounds on 256 CUs: 150 workgroups x 2 rounds) - fewer partial-gradient rows for the finalize
         const int per = (pl.NG + nw - 1) / nw;
@@ -149,13 +158,13 @@ int make_plan(const vmapstep_shape* sh, int max_steps, Plan& pl, const Layout& L
     pl.off_ploss_bytes = align_up((size_t)sh->n_obj * nw_cap * 4 * sizeof(float));
     pl.off_ploss = o; o += 2 * pl.off_ploss_bytes;
     pl.off_cnt = o; o += align_up((size_t)sh->n_obj * 2 * sizeof(unsigned));
-    pl.off_imgtab = o; o += pl.wide == 3 ? 2 * align_up((size_t)L.PP * sizeof(int)) : pl.generic ? 0 : align_up((size_t)L.PP * sizeof(int));
+    pl.off_imgtab = o; o += pl.wide >= 3 ? 2 * align_up((size_t)L.PP * sizeof(int)) : pl.generic ? 0 : align_up((size_t)L.PP * sizeof(int));
     pl.off_pgrad = o; o += align_up((size_t)sh->n_obj * nw_cap * L.PP * sizeof(float));
     const vk::GenLayout GL = vk::gen_layout(sh->hidden);
-    pl.off_wimg = o; o += align_up(pl.split ? (size_t)sh->n_obj * vk::Img32s::BYTES : pl.wide == 3 ? (size_t)sh->n_obj * (sh->hidden == 128 ? vk::ImgWs<4>::BYTES : vk::ImgWs<2>::BYTES)
+    pl.off_wimg = o; o += align_up(pl.split ? (size_t)sh->n_obj * vk::Img32s::BYTES : pl.wide >= 3 ? (size_t)sh->n_obj * (sh->hidden == 128 ? vk::ImgWs<4>::BYTES : vk::ImgWs<2>::BYTES)
                                                                                    : (size_t)sh->n_obj * GL.imgp * sizeof(float));
     pl.off_scratch = o;
-    if (pl.wide == 3) o += align_up((size_t)sh->n_obj * nw_cap * vk::ImgWs<4>::WG_SCRATCH);
+    if (pl.wide >= 3) o += align_up((size_t)sh->n_obj * nw_cap * (pl.wide == 4 ? vk::LdsWp<4>::WG_SCRATCH : vk::ImgWs<4>::WG_SCRATCH));
     else if (pl.generic)   // register-image scratch: per wave (step_main_gen) or per workgroup (step_main_wide)
         o += align_up((size_t)sh->n_obj * nw_cap * (pl.wide == 1 ? 1 : vk::kWaves) * vk::gen_wave_blocks(GL.NB) * vk::kBlk * sizeof(float));
     pl.off_flags = o; o += align_up((size_t)kMaxFrameSteps * 4 * sizeof(int));
@@ -213,8 +222,8 @@ void fill_step_args(vk::StepArgs& a, const vmapstep_shape* sh, const Plan& pl, c
     // hand-off counters exist for the carried finalize only (step_prep skips null pointers); the flat -> image table for hidden 32
     const bool carry = !pl.generic && tuning_of(sh).carried_finalize != 0;
     a.carry_cnt = carry ? reinterpret_cast<unsigned*>(ws + pl.off_cnt) : nullptr;
-    a.img_tab = (!pl.generic || pl.wide == 3) ? reinterpret_cast<int*>(ws + pl.off_imgtab) : nullptr;   // also read by step_finalize_h32
-    a.tab_wt = pl.wide == 3 ? reinterpret_cast<int*>(ws + pl.off_imgtab + align_up((size_t)L.PP * sizeof(int))) : nullptr;
+    a.img_tab = (!pl.generic || pl.wide >= 3) ? reinterpret_cast<int*>(ws + pl.off_imgtab) : nullptr;   // also read by step_finalize_h32
+    a.tab_wt = pl.wide >= 3 ? reinterpret_cast<int*>(ws + pl.off_imgtab + align_up((size_t)L.PP * sizeof(int))) : nullptr;
     a.part_grad = reinterpret_cast<float*>(ws + pl.off_pgrad);
     a.wimg = reinterpret_cast<float*>(ws + pl.off_wimg);
     a.gen_scratch = reinterpret_cast<float*>(ws + pl.off_scratch);
@@ -313,9 +322,28 @@ int launch_ws_v(const vk::StepArgs& a, hipStream_t st) {
     return VMAPSTEP_OK;
 }
 
+template <int NB, bool BWD, bool W3, bool STAMPS = false>
+int launch_wp_v(const vk::StepArgs& a, hipStream_t st) {
+    using LD = vk::LdsWp<NB>;
+    auto kern = vk::step_main_wp<NB, BWD, W3, STAMPS>;
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LD::LDS_BYTES, "step_main_wp")) return rc;
+    vk::WsArgs ga;
+    ga.s = a;
+    ga.scratch = reinterpret_cast<char*>(a.gen_scratch);
+    ga.tab_wt = a.tab_wt;
+    hipLaunchKernelGGL(kern, dim3(a.n_obj * a.NW), dim3(LD::NTH), LD::LDS_BYTES, st, ga);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "step_main_wp launch: %s", hipGetErrorString(e));
+    return VMAPSTEP_OK;
+}
+
 template <bool BWD>
 int launch_main(const vk::StepArgs& a, hipStream_t st) {
     if (a.split) return launch_split<BWD>(a, st);
+    if (a.wide == 4) {
+        if (a.hidden == 128) return a.weights_bf16 ? launch_wp_v<4, BWD, false>(a, st) : launch_wp_v<4, BWD, true>(a, st);
+        return a.weights_bf16 ? launch_wp_v<2, BWD, false>(a, st) : launch_wp_v<2, BWD, true>(a, st);
+    }
     if (a.wide == 3) {
         if (a.hidden == 128) return a.weights_bf16 ? launch_ws_v<4, BWD, false>(a, st) : launch_ws_v<4, BWD, true>(a, st);
         return a.weights_bf16 ? launch_ws_v<2, BWD, false>(a, st) : launch_ws_v<2, BWD, true>(a, st);
@@ -325,7 +353,7 @@ int launch_main(const vk::StepArgs& a, hipStream_t st) {
 }
 
 int launch_prep(const vk::StepArgs& a, int n_steps, hipStream_t st) {
-    if (a.wide == 3) {
+    if (a.wide >= 3) {
         vk::WsArgs ga;
         ga.s = a;
         ga.s.prep_steps = n_steps;
@@ -414,7 +442,7 @@ int launch_finalize(const vk::StepArgs& a, const Layout& L, const vmapstep_param
     const int bpo = (L.PP / 4 + vk::kWG - 1) / vk::kWG;
     // + 1: the loss / flag reduction has a workgroup of its own (it used to ride on block 0 and made it the straggler)
     const int grid = (!have_grad ? 0 : f.xcd_affine ? 8 * ((a.n_obj + 7) / 8) * bpo : a.n_obj * bpo) + 1;
-    if (a.wide == 3 && f.do_adam) {
+    if (a.wide >= 3 && f.do_adam) {
         // step_main_ws: the table-driven finalize is the only writer of the two weight images (see the split case below)
         if (grads) {
             vk::FinalizeArgs fg = f;
@@ -573,8 +601,8 @@ int vmapstep_adamw_apply(const vmapstep_shape* shape, const vmapstep_params* par
     a.part_grad = const_cast<float*>(grad_slab);
     a.wimg = reinterpret_cast<float*>(ws + pl.off_wimg);
     a.wide = pl.wide;
-    a.img_tab = (!pl.generic || pl.wide == 3) ? reinterpret_cast<int*>(ws + pl.off_imgtab) : nullptr;
-    a.tab_wt = pl.wide == 3 ? reinterpret_cast<int*>(ws + pl.off_imgtab + align_up((size_t)L.PP * sizeof(int))) : nullptr;
+    a.img_tab = (!pl.generic || pl.wide >= 3) ? reinterpret_cast<int*>(ws + pl.off_imgtab) : nullptr;
+    a.tab_wt = pl.wide >= 3 ? reinterpret_cast<int*>(ws + pl.off_imgtab + align_up((size_t)L.PP * sizeof(int))) : nullptr;
     return launch_finalize(a, L, params, nullptr, opt, opt->step + 1, true, nullptr, nullptr, static_cast<hipStream_t>(stream),
                            tuning_of(shape).generic_finalize != 0);
 }
@@ -772,7 +800,7 @@ int vmapstep_profile_phases(const vmapstep_shape* shape, const vmapstep_params* 
     if ((rc = check_batch(batch))) return rc;
     if (!pe_scale || !pe_scale->ptr) return fail(VMAPSTEP_ERR_ARGUMENT, "pe_scale is null");
     if (!timing || !n_workgroups) return fail(VMAPSTEP_ERR_ARGUMENT, "timing / n_workgroups is null");
-    if (pl.generic && pl.wide != 3) return fail(VMAPSTEP_ERR_UNSUPPORTED, "phase stamps exist in the hidden=32 kernels and step_main_ws only");
+    if (pl.generic && pl.wide < 3) return fail(VMAPSTEP_ERR_UNSUPPORTED, "phase stamps exist in the hidden=32 kernels and step_main_ws only");
     const size_t need = (size_t)8 * ((shape->n_obj + 7) / 8) * pl.NW * vk::kWaves * vk::kMarks;
     if (timing_elems < need) return fail(VMAPSTEP_ERR_ARGUMENT, "timing buffer %zu < %zu elements", timing_elems, need);
     if ((rc = check_ws(workspace, workspace_bytes, pl))) return rc;
@@ -783,6 +811,7 @@ int vmapstep_profile_phases(const vmapstep_shape* shape, const vmapstep_params* 
     a.timing = timing;
     *n_workgroups = a.xcd_affine ? 8 * ((shape->n_obj + 7) / 8) * pl.NW : shape->n_obj * pl.NW;
     if ((rc = launch_prep(a, 1, st))) return rc;
+    if (a.wide == 4) return a.hidden == 128 ? launch_wp_v<4, true, true, true>(a, st) : launch_wp_v<2, true, true, true>(a, st);
     if (a.wide == 3) return a.hidden == 128 ? launch_ws_v<4, true, true, true>(a, st) : launch_ws_v<2, true, true, true>(a, st);
     if (a.split) return launch_split<true, true>(a, st);
     return a.NW < a.NG ? launch_main_v<true, true, true>(a, st) : launch_main_v<true, false, true>(a, st);   // the stamped build

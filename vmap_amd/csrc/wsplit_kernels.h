@@ -645,7 +645,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     const unsigned tid16 = (unsigned)tid * 16u;
     const int lo16 = lane * 16;
     const unsigned vlo16 = (unsigned)lane * 16u;
-    const bool own = wave < NB;                                          // this wave owns output block `wave` of every layer
+    const bool own = NB == 4 || wave < NB;                               // this wave owns output block `wave` of every layer (NB = 4: all four, known at compile time)
     __syncthreads();                                                     // previous round done with LDS
     for (int i = tid; i < I::kPts * 8; i += kWG) cb[i] = 0.0f;
     const int ray0 = grp * a.G;
