@@ -75,7 +75,7 @@ extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req, int xcd
 
     std::vector<char> ws_scratch;
     if (ws) {
-        ws_scratch.assign((size_t)n * NW * (wp ? vk::LdsWp<4>::WG_SCRATCH : vk::ImgWs<4>::WG_SCRATCH), (char)0xFF);
+        ws_scratch.assign((size_t)n * NW * (wp ? (H == 128 ? vk::LdsWp<4>::WG_SCRATCH : vk::LdsWp<2>::WG_SCRATCH) : vk::ImgWs<4>::WG_SCRATCH), (char)0xFF);
         wa.s = a; wa.scratch = ws_scratch.data(); wa.tab_wt = tab_wt.data();
         if (H == 128) sim::launch(1 + n * vk::ws_pack_blocks<4>(), vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep_ws<4>(wa); });
         else sim::launch(1 + n * vk::ws_pack_blocks<2>(), vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep_ws<2>(wa); });

@@ -136,7 +136,9 @@ int make_plan(const vmapstep_shape* sh, int max_steps, Plan& pl, const Layout& L
     pl.G = (pl.wide >= 3 ? vk::ImgWs<4>::kPts : pl.wide == 1 ? vk::kWideTile : vk::kMaxPts) / sh->samples;
     if (pl.G > sh->rays) pl.G = sh->rays;
     pl.NG = (sh->rays + pl.G - 1) / pl.G;
-    int nw = tun.workgroups_per_object > 0 ? tun.workgroups_per_object : 256 / sh->n_obj;
+    // workgroup slots of the chip: one per CU, two for step_main_wp at hidden 64 (78 KB of LDS per workgroup)
+    const int wg_slots = (pl.wide == 4 && sh->hidden == 64) ? 512 : 256;
+    int nw = tun.workgroups_per_object > 0 ? tun.workgroups_per_object : wg_slots / sh->n_obj;
     if (nw < 1) nw = 1;
     if (nw > pl.NG) nw = pl.NG;
     if (pl.wide >= 3 && tun.workgroups_per_object <= 0) {
@@ -164,7 +166,8 @@ int make_plan(const vmapstep_shape* sh, int max_steps, Plan& pl, const Layout& L
     pl.off_wimg = o; o += align_up(pl.split ? (size_t)sh->n_obj * vk::Img32s::BYTES : pl.wide >= 3 ? (size_t)sh->n_obj * (sh->hidden == 128 ? vk::ImgWs<4>::BYTES : vk::ImgWs<2>::BYTES)
                                                                                    : (size_t)sh->n_obj * GL.imgp * sizeof(float));
     pl.off_scratch = o;
-    if (pl.wide >= 3) o += align_up((size_t)sh->n_obj * nw_cap * (pl.wide == 4 ? vk::LdsWp<4>::WG_SCRATCH : vk::ImgWs<4>::WG_SCRATCH));
+    if (pl.wide >= 3) o += align_up((size_t)sh->n_obj * nw_cap * (pl.wide == 4 ? (sh->hidden == 128 ? vk::LdsWp<4>::WG_SCRATCH : vk::LdsWp<2>::WG_SCRATCH)
+                                                                                 : vk::ImgWs<4>::WG_SCRATCH));
     else if (pl.generic)   // register-image scratch: per wave (step_main_gen) or per workgroup (step_main_wide)
         o += align_up((size_t)sh->n_obj * nw_cap * (pl.wide == 1 ? 1 : vk::kWaves) * vk::gen_wave_blocks(GL.NB) * vk::kBlk * sizeof(float));
     pl.off_flags = o; o += align_up((size_t)kMaxFrameSteps * 4 * sizeof(int));

@@ -21,6 +21,7 @@ template <int NB>
 struct LdsWp {
     using I = ImgWs<NB>;
     static constexpr int NWV = 2 * NB, NTH = 64 * NWV;
+    static constexpr bool EG = NB == 2;      // hidden 64: the encoding's P-form images live in the L2 scratch too - 78 KB of LDS, two workgroups per CU
     static constexpr int ACT = 0, ACT_ST = I::ACT_ST, ACT_BYTES = I::ACT_BYTES;   // forward: layer input images
     static constexpr int XCG = 0, XCG_W = 4096;                                    // backward: partial-sum exchange, one slot per wave
     static constexpr int PX_BYTES = NWV * 2 * 11 * 64 * 4;                         // end of the backward: d(proj) exchange
@@ -29,7 +30,7 @@ struct LdsWp {
     static constexpr int EIM = R0_BYTES, E_ST = I::E_ST, E2_OFF = I::E2_OFF;       // forward: encoding images
     static constexpr int DLT = EIM, DLT_ST = I::DLT_ST;                            // backward: delta images
     static constexpr int XF = DLT + 2 * DLT_ST, XF_ST = I::XF_ST;                  // backward: F-form images of the layer input
-    static constexpr int R1_BYTES = 2 * E_ST > 2 * DLT_ST + 2 * XF_ST ? 2 * E_ST : 2 * DLT_ST + 2 * XF_ST;
+    static constexpr int R1_BYTES = !EG && 2 * E_ST > 2 * DLT_ST + 2 * XF_ST ? 2 * E_ST : 2 * DLT_ST + 2 * XF_ST;
     static constexpr int SCRT = EIM + R1_BYTES;                                    // one transpose tile per wave (forward: the exchange slot)
     static constexpr int HP = SCRT + NWV * Img32s::TILE;                           // head partial sums [block][tile][32 points][4]
     static constexpr int HX = XCG + NWV * XCG_W;                                   // backward (behind the exchange slots): head-gradient partials of the kh = 1 waves [block][8][64]
@@ -41,9 +42,10 @@ struct LdsWp {
     static constexpr int ACTS_OFF = I::ACTS_OFF;
     static constexpr int ACTS_CH = NB * 1024;                                      // one (layer, tile, plane, step) chunk: NB blocks x 64 lanes x 16 B
     static constexpr int EFG_OFF = ACTS_OFF + 5 * 2 * 2 * 2 * ACTS_CH;
-    static constexpr int WG_SCRATCH = EFG_OFF + 2 * 5 * 4096;
+    static constexpr int EIG_OFF = EFG_OFF + 2 * 5 * 4096;                         // (EG) encoding P-form images [tile][9 steps][3 planes][1 KiB]
+    static constexpr int WG_SCRATCH = EIG_OFF + (EG ? 2 * E_ST : 0);
 };
-static_assert(LdsWp<4>::LDS_BYTES <= 160 * 1024 && LdsWp<2>::LDS_BYTES <= 160 * 1024, "LDS budget");
+static_assert(LdsWp<4>::LDS_BYTES <= 160 * 1024 && LdsWp<2>::LDS_BYTES <= 80 * 1024, "LDS budget (hidden 64: two workgroups per CU)");
 static_assert(LdsWp<4>::HX + 4 * 8 * 64 * 4 <= LdsWp<4>::R0_BYTES && LdsWp<2>::HX + 2 * 8 * 64 * 4 <= LdsWp<2>::R0_BYTES, "head partials fit behind the exchange slots");
 
 // partial sum of one tile -> the wave's exchange slot / + the partner's slot
@@ -89,7 +91,7 @@ __device__ __forceinline__ void dw_layer_half(const unsigned (&dF)[2][16], bool 
 }
 
 template <int NB, bool BWD, bool W3, bool STAMPS = false>
-__global__ __launch_bounds__(128 * NB, 1) void step_main_wp(const WsArgs ga) {
+__global__ __launch_bounds__(128 * NB, 2) void step_main_wp(const WsArgs ga) {
     static_assert(NB == 4 || NB == 2, "two waves per output block, at most eight waves");
     using I = ImgWs<NB>;
     using LD = LdsWp<NB>;
@@ -145,7 +147,11 @@ __global__ __launch_bounds__(128 * NB, 1) void step_main_wp(const WsArgs ga) {
     if (wave < kWaves) rmeta = load_ray_meta(a, obj, ray0 + min(4 * wave + (lane >> 4), nrays - 1));
     // ---- forward step lists: a layer = NE encoding steps (weights at chunk JSoff.., inputs from the encoding images) followed by
     //      NH hidden steps; wave kh takes the first / second half of the concatenated list ----
-    const char* e1x = lds + LD::EIM + lo16;
+    constexpr bool EG = LD::EG;
+    // encoding images: LDS (lane offset included) or the workgroup's scratch (wave-uniform base, lane offset = vlo16)
+    char* eimg = EG ? wgs + LD::EIG_OFF : lds + LD::EIM + lo16;
+    const unsigned evo = EG ? vlo16 : 0u;
+    const char* e1x = eimg;
     const char* e2x = e1x + LD::E2_OFF;
     const char* actx = lds + LD::ACT + lo16;
     auto wchunk = [&](int base, int ks, int s) __attribute__((always_inline)) { return gW + ((long long)(base + ob * ks + s)) * I::XCH; };     // wave-uniform
@@ -164,8 +170,8 @@ __global__ __launch_bounds__(128 * NB, 1) void step_main_wp(const WsArgs ga) {
         constexpr int NE = decltype(ne_c)::value, NH = decltype(nh_c)::value;
         WP_SPLIT(NE, NH);
         // acc[0] = this wave's tile (kh), acc[1] = the partner's: the inputs are read in that order (tile stride +- one tile)
-        if (kh == 0) fwd_run<W3, A0, B0>(acc, pre, we, xe, LD::E_ST, wh, xh, LD::ACT_ST, vlo16);
-        else fwd_run<W3, A1, B1>(acc, pre, we + A0 * I::XCH, xe + A0 * I::XCH + LD::E_ST, -LD::E_ST, wh + B0 * I::XCH, xh + B0 * I::XCH + LD::ACT_ST, -LD::ACT_ST, vlo16);
+        if (kh == 0) fwd_run<W3, A0, B0, EG>(acc, pre, we, xe, LD::E_ST, wh, xh, LD::ACT_ST, vlo16);
+        else fwd_run<W3, A1, B1, EG>(acc, pre, we + A0 * I::XCH, xe + A0 * I::XCH + LD::E_ST, -LD::E_ST, wh + B0 * I::XCH, xh + B0 * I::XCH + LD::ACT_ST, -LD::ACT_ST, vlo16);
     };
     using C0 = std::integral_constant<int, 0>;
     using C3 = std::integral_constant<int, 3>;
@@ -195,7 +201,7 @@ __global__ __launch_bounds__(128 * NB, 1) void step_main_wp(const WsArgs ga) {
             amax = fmaxf(amax, fabsf(proj[ii]));
         }
         const bool fast = !wv::wave_any(!(amax * (32.0f * kPi) < kSinCosFastLimit));
-        char* e1img = lds + LD::EIM + est * LD::E_ST + lo16;
+        char* e1img = eimg + est * LD::E_ST + evo;
         char* e2img = e1img + LD::E2_OFF;
         float* cf_out = cfs + est * 66 * 64 + lane;
 #pragma unroll
@@ -369,10 +375,10 @@ __global__ __launch_bounds__(128 * NB, 1) void step_main_wp(const WsArgs ga) {
             const int st = j / 5, eb = j - 5 * st;
             const char* src = eb < 3 ? e1x + st * LD::E_ST + 2 * eb * I::XCH : e2x + st * LD::E_ST + 2 * (eb - 3) * I::XCH;
             unsigned h[8], m[8], f[16];
-            const u32x4 h0 = lds16(src), m0 = lds16(src + 1024);
+            const u32x4 h0 = *reinterpret_cast<const u32x4*>(src + evo), m0 = *reinterpret_cast<const u32x4*>(src + 1024 + evo);
             h[0] = h0[0]; h[1] = h0[1]; h[2] = h0[2]; h[3] = h0[3]; m[0] = m0[0]; m[1] = m0[1]; m[2] = m0[2]; m[3] = m0[3];
             if (eb < 4) {
-                const u32x4 h1 = lds16(src + I::XCH), m1 = lds16(src + I::XCH + 1024);
+                const u32x4 h1 = *reinterpret_cast<const u32x4*>(src + I::XCH + evo), m1 = *reinterpret_cast<const u32x4*>(src + I::XCH + 1024 + evo);
                 h[4] = h1[0]; h[5] = h1[1]; h[6] = h1[2]; h[7] = h1[3]; m[4] = m1[0]; m[5] = m1[1]; m[6] = m1[2]; m[7] = m1[3];
             } else {
                 h[4] = h[5] = h[6] = h[7] = 0u; m[4] = m[5] = m[6] = m[7] = 0u;

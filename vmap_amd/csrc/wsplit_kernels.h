@@ -364,6 +364,13 @@ __device__ __forceinline__ void xop_load(XOp& o, const char* x, int xst) {
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) o.x[st][pl] = lds16(x + st * xst + pl * 1024);
 }
+// the same from images in global memory (ubase wave-uniform, voff = lane * 16)
+__device__ __forceinline__ void xop_load_g(XOp& o, const char* ubase, int xst, unsigned voff) {
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) o.x[st][pl] = ldgu(ubase + st * xst + pl * 1024, voff);
+}
 // six (bf16 weights: three) products per tile, smallest terms first; the two tiles' chains alternate
 template <bool W3>
 __device__ __forceinline__ void fop_mm(f32x16 (&acc)[2], const WOp& w, const XOp& o) {
@@ -392,19 +399,24 @@ __device__ __forceinline__ void wpre_load(WPre& p, const char* wa, const char* w
     wop_load<W3>(p.w[1], NA > 1 ? wa + WS_WSTEP(1) * 3072 : wb + WS_WSTEP(1 - NA) * 3072, voff);
     wv::sched_fence();
 }
-template <bool W3, int NA, int NB2>
+// XAG: the first part's inputs come from global memory (xa = wave-uniform base) instead of LDS
+template <bool W3, int NA, int NB2, bool XAG = false>
 __device__ __forceinline__ void fwd_run(f32x16 (&acc)[2], const WPre& pre, const char* wa, const char* xa, int xsta,
                                         const char* wb, const char* xb, int xstb, unsigned voff) {
     constexpr int NST = NA + NB2;
     WOp w[3];
     XOp xo[2];
     w[0] = pre.w[0]; w[1] = pre.w[1];
-    xop_load(xo[0], NA > 0 ? xa : xb, NA > 0 ? xsta : xstb);
+    if (NA > 0) { if (XAG) xop_load_g(xo[0], xa, xsta, voff); else xop_load(xo[0], xa, xsta); }
+    else xop_load(xo[0], xb, xstb);
     wv::sched_fence();
 #pragma unroll
     for (int s = 0; s < NST; ++s) {
         if (s + 2 < NST) wop_load<W3>(w[(s + 2) % 3], s + 2 < NA ? wa + WS_WSTEP(s + 2) * 3072 : wb + WS_WSTEP(s + 2 - NA) * 3072, voff);
-        if (s + 1 < NST) xop_load(xo[(s + 1) & 1], s + 1 < NA ? xa + (s + 1) * 3072 : xb + (s + 1 - NA) * 3072, s + 1 < NA ? xsta : xstb);
+        if (s + 1 < NST) {
+            if (s + 1 < NA) { if (XAG) xop_load_g(xo[(s + 1) & 1], xa + (s + 1) * 3072, xsta, voff); else xop_load(xo[(s + 1) & 1], xa + (s + 1) * 3072, xsta); }
+            else xop_load(xo[(s + 1) & 1], xb + (s + 1 - NA) * 3072, xstb);
+        }
         wv::sched_fence();
         fop_mm<W3>(acc, w[s % 3], xo[s & 1]);
         wv::sched_fence();
