@@ -445,14 +445,8 @@ int launch_finalize(const vk::StepArgs& a, const Layout& L, const vmapstep_param
     const int bpo = (L.PP / 4 + vk::kWG - 1) / vk::kWG;
     // + 1: the loss / flag reduction has a workgroup of its own (it used to ride on block 0 and made it the straggler)
     const int grid = (!have_grad ? 0 : f.xcd_affine ? 8 * ((a.n_obj + 7) / 8) * bpo : a.n_obj * bpo) + 1;
-    if (a.wide >= 3 && f.do_adam) {
-        // step_main_ws: the table-driven finalize is the only writer of the two weight images (see the split case below)
-        if (grads) {
-            vk::FinalizeArgs fg = f;
-            fg.do_adam = 0;
-            hipLaunchKernelGGL(vk::step_finalize, dim3(grid), dim3(vk::kWG), 2 * vk::kWG * sizeof(float), st, fg);
-            std::memset(f.grad, 0, sizeof(f.grad));
-        }
+    if (a.wide >= 3 && have_grad) {
+        // step_main_ws / _wp: one finalize for gradients to the caller and / or AdamW; it is the only writer of the two weight images
         vk::CarryHot h;
         fill_carry_hot(h, f, a, L, params, 0u);
         if (a.hidden == 128)

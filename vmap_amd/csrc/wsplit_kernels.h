@@ -264,6 +264,7 @@ __device__ __forceinline__ void ws_image_store(char* img, int locw, int locwt, f
 constexpr int kFinGroups = 4, kFinQuads = kWG / kFinGroups;
 __host__ __device__ inline int ws_finalize_blocks(int PP) { return (PP / 4 + kFinQuads - 1) / kFinQuads; }
 
+// Gradients to the caller's tensors (if given), AdamW + image rewrite (if do_adam).
 // The partial gradients are NW rows of PP floats per object (one per workgroup of step_main_ws, up to 256): a quad's four
 // threads sum a quarter of the rows each (loads eight deep), a fixed tree through LDS joins them - same order every run.
 template <int NB>
@@ -301,6 +302,20 @@ __global__ __launch_bounds__(kWG) void step_finalize_ws(const FinalizeArgs a, co
     static_assert(kFinGroups == 4, "the join below is a four-way tree");
     const wv::f32x4 g = (red[ql] + red[kFinQuads + ql]) + (red[2 * kFinQuads + ql] + red[3 * kFinQuads + ql]);
     const long long s = (long long)obj * hh.PP + 4 * q;
+    int ten[4], off[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int i = min(4 * q + e, a.P - 1);
+        int t = 0;
+#pragma unroll
+        for (int k = 1; k <= kNFc; ++k) t += i >= a.offs[k];
+        ten[e] = t; off[e] = i - a.offs[t];
+    }
+    // the caller's gradient tensors (fwd_bwd, the last step of a frame call, the shared background's step)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (4 * q + e < a.P && a.grad[ten[e]].p) a.grad[ten[e]].p[obj * a.grad[ten[e]].stride + off[e]] = g[e];
+    if (!a.do_adam) return;
     wv::f32x4 m4 = *reinterpret_cast<const wv::f32x4*>(hh.m + s);
     wv::f32x4 v4 = *reinterpret_cast<const wv::f32x4*>(hh.v + s);
     const i32x4 iw = *reinterpret_cast<const i32x4*>(hh.img_tab + 4 * q);
@@ -308,11 +323,7 @@ __global__ __launch_bounds__(kWG) void step_finalize_ws(const FinalizeArgs a, co
     float* pp[4]; float pv[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const int i = min(4 * q + e, a.P - 1);
-        int t = 0;
-#pragma unroll
-        for (int k = 1; k <= kNFc; ++k) t += i >= a.offs[k];
-        pp[e] = a.param[t].p + obj * a.param[t].stride + (i - a.offs[t]);
+        pp[e] = a.param[ten[e]].p + obj * a.param[ten[e]].stride + off[e];
         pv[e] = *pp[e];
     }
     char* image = reinterpret_cast<char*>(hh.wimg) + (long long)obj * ImgWs<NB>::BYTES;
