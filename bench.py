@@ -308,12 +308,18 @@ def main():
         # HBM-side bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE, see
         # profiles/*_pmc_counters.json); counters cannot be sampled from inside this process
         traffic = None
-        pmcs = []
+        pmc_file = None
         try:
-            pmcs = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_counters.json"))
-            if pmcs and args.config == "replica_room0_vmap":
-                with open(os.path.join(ROOT, "profiles", pmcs[-1])) as fh:
-                    traffic = json.load(fh)["_notes"]["hbm_traffic_bytes_per_launch_step_main"]
+            # the committed counter file of the kernel this run used
+            if args.config == "replica_room0_vmap" and split:
+                pmc_file, key = "r02d_pmc_counters_step_main_s32_first.json", "hbm_traffic_bytes_per_launch_step_main"
+            elif args.config == "replica_room0_vmap":
+                pmc_file, key = "r01m_pmc_counters.json", "hbm_traffic_bytes_per_launch_step_main"
+            elif args.config == "background" and args.kernel == "auto":
+                pmc_file, key = "r02j_pmc_counters_background_ws.json", "hbm_traffic_bytes_per_launch_step_main_ws"
+            if pmc_file:
+                with open(os.path.join(ROOT, "profiles", pmc_file)) as fh:
+                    traffic = json.load(fh)["_notes"][key]
         except Exception:
             traffic = None
         # forward+backward only (no optimiser), same loop structure
@@ -337,7 +343,7 @@ def main():
             "roofline": {"bound": "mfma", "kernel": kernel_name, "achieved": achieved,
                          "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
                          "traffic": traffic,
-                         "traffic_source": ("copied from the committed rocprofv3 --pmc passes of this kernel (profiles/" + pmcs[-1] +
+                         "traffic_source": ("copied from the committed rocprofv3 --pmc passes of this kernel (profiles/" + pmc_file +
                                             "), not observed in this run") if traffic is not None else None,
                          "kernel_ms": k_ms, "kernel_ms_event_pair_raw": k_ms_raw, "kernel_ms_minus_empty_event_pair": k_ms_corr,
                          "kernel_ms_note": "kernel_ms = midpoint of the raw event-pair time and the pair-minus-empty-pair time (= the rocprofv3 per-dispatch average of the same command within ~1 %, profiles/)", "kernel_ms_back_to_back": k_ms_alone, "algorithmic_flops_per_launch": flops,
