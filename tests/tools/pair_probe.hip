@@ -15,7 +15,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
-enum Role { NONE = 0, M16 = 1, M32 = 2, SPL = 3, FMA = 4, MIX16 = 5, MIX32 = 6 };
+enum Role { NONE = 0, M16 = 1, M32 = 2, SPL = 3, FMA = 4, MIX16 = 5, MIX32 = 6, M32N = 7, M32S = 8 };
 constexpr int ITERS = 64;
 
 __device__ __forceinline__ unsigned pk(float a, float b) { f32x2 v = {a, b}; return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2)); }
@@ -61,6 +61,21 @@ __device__ __forceinline__ float run(float seed, int lane) {
                     acc_u ^= ph ^ pm ^ pk(ra - __uint_as_float(pm << 16), rb - __uint_as_float(pm & 0xffff0000u));
                     x[k] += 1.0f;
                 }
+            }
+        }
+        out = c0[0] + c0[7];
+    } else if constexpr (ROLE == M32N || ROLE == M32S) {
+        // the same dependent chain, but the wave does not present the next matrix instruction to the issue stage while the
+        // previous one occupies the pipe: M32N pads with s_nop (scalar class), M32S with s_sleep
+        f32x16 c0 = {};
+        for (int i = 0; i < ITERS; ++i) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c0, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (ROLE == M32N) asm volatile("s_nop 15\n\ts_nop 9" ::: "memory");
+                else asm volatile("s_sleep 0" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         out = c0[0] + c0[7];
@@ -130,6 +145,13 @@ int main() {
     go<FMA, NONE>("one wave/SIMD: 176 v_fma", d_clk, d_sink);
     go<MIX32, NONE>("one wave/SIMD: 16 x (mfma 32x32x16 + pair-split)", d_clk, d_sink);
     go<MIX16, NONE>("one wave/SIMD: 16 x (2 mfma 16x16x32 + pair-split)", d_clk, d_sink);
+    go<M32N, NONE>("one wave/SIMD: 16 x (mfma 32x32x16 + s_nop 26)", d_clk, d_sink);
+    go<M32S, NONE>("one wave/SIMD: 16 x (mfma 32x32x16 + s_sleep 0)", d_clk, d_sink);
+    go<M32N, SPL>("two waves/SIMD: A = mfma 32x32x16 chain padded with s_nop, B = pair-splits", d_clk, d_sink);
+    go<M32S, SPL>("two waves/SIMD: A = mfma 32x32x16 chain padded with s_sleep, B = pair-splits", d_clk, d_sink);
+    go<SPL, M32>("two waves/SIMD: A = pair-splits, B = mfma 32x32x16 chain", d_clk, d_sink);
+    go<M32N, FMA>("two waves/SIMD: A = mfma chain padded with s_nop, B = v_fma", d_clk, d_sink);
+    go<M32, FMA>("two waves/SIMD: A = mfma chain, B = v_fma", d_clk, d_sink);
     go<M32, SPL>("two waves/SIMD: A = mfma 32x32x16 chain, B = pair-splits", d_clk, d_sink);
     go<M16, SPL>("two waves/SIMD: A = mfma 16x16x32 chain, B = pair-splits", d_clk, d_sink);
     go<SPL, SPL>("two waves/SIMD: both pair-splits", d_clk, d_sink);
