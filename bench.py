@@ -264,6 +264,11 @@ def main():
             td.barrier()
             td.destroy_process_group()
         if rank == 0:
+            try:
+                import ctypes
+                ctypes.CDLL(None).fflush(None)
+            except Exception:
+                pass
             print(json.dumps({"value": value, "ms_per_step": ms_per_step, "steps": args.steps, "warmup": args.warmup,
                               "preheat_ms": args.preheat_ms, "timed_only": True}), flush=True)
         return
@@ -376,6 +381,12 @@ def main():
         td.barrier()                     # rank 0 measured the kernel / the baselines; everybody leaves together
         td.destroy_process_group()       # (RCCL prints its version banner on stdout: the JSON line comes after it, last)
     if rank == 0:
+        # RCCL writes its banner through C stdio (buffered when stdout is a file): push it out first, the JSON line stays last
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         sys.stdout.flush()
         print(json.dumps(out), flush=True)
 
