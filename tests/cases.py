@@ -62,6 +62,7 @@ FRAME_CASES = {
     "cfg2_frame20":   (20, 120, 10, 32, 2.0, 20, 121, 20, None),            # BASELINE configs[1], the frame bench.py times
     "scannet50_frame": (50, 120, 10, 32, 3.0, 90, 191, 4, (0, 7, 23, 49)),  # configs[3]: 50 objects -> multi-pass step_main at real n
     "h64_r256_frame": (32, 256, 10, 64, 2.0, 92, 193, 3, (0, 13, 31)),      # configs[4] per-GPU shape (256 objects / 8 GPUs)
+    "bg128_frame":    (1, 240, 14, 128, 5.0, 94, 195, 4, None),             # the background model (train.py:308-316): hidden 128, 14 samples; 60 rounds per step
 }
 
 
