@@ -79,3 +79,29 @@ def test_step_operator_refuses_cpu():
     from vmap_amd import step
     with pytest.raises(_lib.VmapStepError):
         step.VmapStep(2, 12, 10, 32, device="cpu")
+
+
+def test_kernel_choice_per_width_shows_in_the_workspace_plan():
+    """hidden 64 / 128 with at most 64 samples per ray run on the split-bf16 kernels (step_main_wp / step_main_ws): their
+    workspace carries the W / W^T images and per-workgroup scratch, the exact-fp32 kernels' does not; VMAPSTEP_KERNEL_WS1 /
+    _WP are refused where those kernels do not exist (hidden 32, 256, long rays)."""
+    lib = _lib.load()
+
+    def need(shape, kernel=None):
+        n = ctypes.c_size_t()
+        if kernel is not None:
+            t = _lib.Tuning(kernel=kernel)
+            shape.tuning = ctypes.pointer(t)
+        rc = lib.vmapstep_workspace_bytes(ctypes.byref(shape), 20, ctypes.byref(n))
+        return rc, n.value
+
+    for H in (64, 128):
+        rc_a, auto = need(_lib.Shape(1, 1200, 14, H, 0))
+        rc_g, gen = need(_lib.Shape(1, 1200, 14, H, 0), _lib.KERNEL_GEN)
+        rc_1, ws1 = need(_lib.Shape(1, 1200, 14, H, 0), _lib.KERNEL_WS1)
+        rc_p, wp = need(_lib.Shape(1, 1200, 14, H, 0), _lib.KERNEL_WP)
+        assert (rc_a, rc_g, rc_1, rc_p) == (0, 0, 0, 0)
+        assert auto in (ws1, wp) and auto != gen
+    for sh in (_lib.Shape(4, 120, 10, 32, 0), _lib.Shape(1, 100, 14, 256, 0), _lib.Shape(1, 8, 100, 128, 0)):
+        assert need(sh, _lib.KERNEL_WS1)[0] != 0
+        assert b"WS1" in lib.vmapstep_last_error()
