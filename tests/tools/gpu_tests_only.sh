@@ -1,3 +1,5 @@
-mkdir -p gpurun_out; export TMPDIR=/tmp
-( time timeout 900 python -m pytest tests -m gpu -q ) > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"
-tail -30 gpurun_out/pytest_gpu.log
+set -x
+mkdir -p gpurun_out/final
+export TMPDIR=/tmp
+O=$PWD/gpurun_out/final
+( time timeout 900 python -m pytest tests -m gpu -q ) > $O/pytest_gpu.log 2>&1 < /dev/null; echo "pytest rc=$?"; grep -n "passed\|failed" $O/pytest_gpu.log | tail -2
