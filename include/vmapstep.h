@@ -59,6 +59,8 @@ extern "C" {
 #define VMAPSTEP_KERNEL_WS1 5     /* hidden 64 / 128: step_main_ws (one wave per output block; the default at hidden 128)            */
 #define VMAPSTEP_KERNEL_WP 6      /* hidden 64 / 128: step_main_wp (two waves per block, partial sums exchanged through LDS; the
                                      default at hidden 64)                                                               */
+#define VMAPSTEP_KERNEL_S16_FWD 7 /* hidden 32, vmapstep_render only: forward on 16-point tiles, eight waves per workgroup
+                                     (measurement prototype of the two-tiles-per-SIMD design; training calls refuse it)      */
 typedef struct vmapstep_tuning {
     int32_t workgroups_per_object; /* 0 = automatic (256 / n_obj, at most one per ray group)                      */
     int32_t kernel;                /* VMAPSTEP_KERNEL_*                                                           */

@@ -8,6 +8,7 @@
 #include "split_kernels.h"
 #include "wsplit_kernels.h"
 #include "wpair_kernels.h"
+#include "split16_kernels.h"
 #include "sample_kernels.h"
 #include "query_kernels.h"
 
@@ -48,6 +49,8 @@ extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req, int xcd
     std::vector<int> fl(4, -1);
     const vk::GenLayout GL = vk::gen_layout(H);
     const bool split = g_split && H == 32;
+    const bool s16 = g_split == 2 && H == 32;                // step_main_s16_fwd (forward-only prototype)
+    if (s16 && bwd) return -4;
     const bool wp = g_wide == 4 && (H == 128 || H == 64);    // step_main_wp (two waves per output block)
     const bool ws = (g_wide == 3 || g_wide == 4) && (H == 128 || H == 64);    // step_main_ws / _wp (split-bf16 matrix pipe, hidden 128 / 64)
     if (ws && G * S > vk::ImgWs<4>::kPts) return -3;
@@ -79,7 +82,8 @@ extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req, int xcd
         wa.s = a; wa.scratch = ws_scratch.data(); wa.tab_wt = tab_wt.data();
         if (H == 128) sim::launch(1 + n * vk::ws_pack_blocks<4>(), vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep_ws<4>(wa); });
         else sim::launch(1 + n * vk::ws_pack_blocks<2>(), vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep_ws<2>(wa); });
-    } else if (split) sim::launch(1 + n * vk::kSplitPackBlocks, vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep_s32(a); });
+    } else if (s16) sim::launch(1 + n * vk::kPack16Blocks, vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep_s16(a); });
+    else if (split) sim::launch(1 + n * vk::kSplitPackBlocks, vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep_s32(a); });
     else sim::launch(1 + n * (vk::gen_layout(H).imgp / 1024), vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep(a); });
     const bool multi = NW < NG;
     const int grid = xcd_affine && H == 32 ? 8 * ((n + 7) / 8) * NW : n * NW;
@@ -119,6 +123,10 @@ extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req, int xcd
             if (bwd) sim::launch(n * NW, vk::kWG, lb, [&] { vk::step_main_ws<2, true, true>(wa); });
             else     sim::launch(n * NW, vk::kWG, lb, [&] { vk::step_main_ws<2, false, true>(wa); });
         }
+    } else if (s16) {
+        const int lb = vk::Img16::LDS_BYTES;
+        if (weights_bf16) sim::launch(n * NW, vk::kWG16, lb, [&] { vk::step_main_s16_fwd<false>(a); });
+        else sim::launch(n * NW, vk::kWG16, lb, [&] { vk::step_main_s16_fwd<true>(a); });
     } else if (split) {
         const int lb = vk::Img32s::LDS_BYTES;
         if (weights_bf16) {

@@ -69,6 +69,30 @@ inline f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
     return d;
 }
 
+// v_mfma_f32_16x16x32_bf16 (same model as mfma_bf16)
+typedef float f32x4m __attribute__((ext_vector_type(4)));
+inline f32x4m mfma16_bf16(u32x4 a, u32x4 b, f32x4m c) {
+    const int w = sim::wave_id(), l = sim::lane_id();
+    sim::Block* B = sim::g_block;
+    for (int i = 0; i < 4; ++i) { B->xa4[w][l][i] = a[i]; B->xb4[w][l][i] = b[i]; }
+    sim::wave_barrier();
+    const int n = l & 15, g = l >> 4;
+    f32x4m d = c;
+    for (int r = 0; r < 4; ++r) {
+        const int m = 4 * g + r;
+        double acc = c[r];
+        for (int kg = 0; kg < 4; ++kg)
+            for (int t = 0; t < 8; ++t) {
+                const unsigned ua = B->xa4[w][16 * kg + m][t >> 1], ub = B->xb4[w][16 * kg + n][t >> 1];
+                const float fa = bf16_to_f32((t & 1) ? ua >> 16 : ua), fb = bf16_to_f32((t & 1) ? ub >> 16 : ub);
+                acc += (double)fa * (double)fb;
+            }
+        d[r] = (float)acc;
+    }
+    sim::wave_barrier();
+    return d;
+}
+
 // ds_read_b64_tr_b16 (see the device header): lane c of a 16-lane group gets element (c & 3) of the 4 words at lane 4j + (c >> 2)'s address
 inline u32x2 lds_tr16(const void* p) {
     const int w = sim::wave_id(), l = sim::lane_id();

@@ -737,3 +737,17 @@ def test_parameter_image_kept_by_finalize_equals_freshly_packed_image(weights, c
     assert torch.equal(outs[0][0], outs[1][0])
     for x, y in zip(outs[0][1], outs[1][1]):
         assert torch.equal(x, y)
+
+
+def test_s16_forward_prototype_renders_like_the_default_kernel_and_refuses_training():
+    """VMAPSTEP_KERNEL_S16_FWD (16-point tiles, forward only: a measurement prototype): render parity
+    with the fixture; a training call with it is refused loudly."""
+    c = cases.build_case("cfg2")
+    g = load_golden("cfg2")
+    op = step.VmapStep(c["n"], c["R"], c["S"], c["H"], device=DEV, tuning={"kernel": _lib.KERNEL_S16_FWD})
+    s = _run(c, fn="render", op=op)
+    assert abs(s["loss"] - float(g["loss"])) <= 2e-5 * abs(float(g["loss"]))
+    for k in RENDER_KEYS:
+        assert relerr(s[k], g[k]) < 2e-5, k
+    with pytest.raises(_lib.VmapStepError, match="forward-only"):
+        _run(c, op=op)

@@ -283,3 +283,15 @@ def test_sim_ws_fused_adamw_matches_oracle_update():
     assert relerr(state["p"], p_ref) < 1e-6
     assert relerr(state["m"][:, :P], m_ref) < 1e-6
     assert relerr(state["v"][:, :P], v_ref) < 1e-6
+
+
+@pytest.mark.parametrize("name", ["tiny", "ragged"])
+def test_sim_s16_forward_prototype_matches_reference(name):
+    """step_main_s16_fwd (measurement prototype: hidden 32 on 16-point tiles, v_mfma_f32_16x16x32_bf16, forward only) renders
+    like the reference."""
+    c = cases.build_case(name)
+    g = load_golden(name)
+    s = simlib.sim_step(c, split=2, bwd=False)
+    assert abs(s["loss"] - float(g["loss"])) <= 2e-5 * abs(float(g["loss"]))
+    for k in RENDER_KEYS:
+        assert relerr(s[k], g[k]) < 2e-5, k

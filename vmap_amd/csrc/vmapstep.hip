@@ -19,6 +19,7 @@
 #include "split_kernels.h"
 #include "wsplit_kernels.h"
 #include "wpair_kernels.h"
+#include "split16_kernels.h"
 #include "sample_kernels.h"
 #include "query_kernels.h"
 
@@ -59,6 +60,7 @@ struct Plan {
     size_t off_stats, off_flags, off_ploss, off_ploss_bytes, off_cnt, off_imgtab, off_pgrad, off_wimg, off_scratch, total;
     bool generic;      // hidden != 32: step_main_gen (global-memory activations) instead of step_main_h32
     bool split;        // hidden 32 on the bf16 matrix pipe with split operands (step_main_s32; the default at hidden 32)
+    bool s16;          // ... on 16-point tiles, forward / render calls only (prototype: VMAPSTEP_KERNEL_S16_FWD)
     int wide;          // hidden 128 / 256: 0 = step_main_gen, 1 = step_main_wide<4> (one tile per workgroup, four waves
                        // per tile), 2 = step_main_wide<2> (four tiles per 512-thread workgroup, two waves per tile)
 };
@@ -111,8 +113,10 @@ int make_plan(const vmapstep_shape* sh, int max_steps, Plan& pl, const Layout& L
     pl.wide = 0;
     const vmapstep_tuning& tun = tuning_of(sh);
     const int force = tun.kernel;
-    if (force < VMAPSTEP_KERNEL_AUTO || force > VMAPSTEP_KERNEL_WP) return fail(VMAPSTEP_ERR_ARGUMENT, "tuning.kernel=%d", force);
+    if (force < VMAPSTEP_KERNEL_AUTO || force > VMAPSTEP_KERNEL_S16_FWD) return fail(VMAPSTEP_ERR_ARGUMENT, "tuning.kernel=%d", force);
     pl.split = !pl.generic && force != VMAPSTEP_KERNEL_H32_F32;
+    pl.s16 = force == VMAPSTEP_KERNEL_S16_FWD;
+    if (pl.s16 && pl.generic) return fail(VMAPSTEP_ERR_UNSUPPORTED, "VMAPSTEP_KERNEL_S16_FWD: hidden 32 only");
     if (pl.split && tun.carried_finalize) return fail(VMAPSTEP_ERR_UNSUPPORTED, "the carried finalize exists for the exact-fp32 kernel only (tuning.kernel = VMAPSTEP_KERNEL_H32_F32)");
     if (pl.generic && sh->hidden % 128 == 0 && force != VMAPSTEP_KERNEL_GEN) {
         if (sh->samples <= vk::kWideTile) {
@@ -218,7 +222,7 @@ void fill_step_args(vk::StepArgs& a, const vmapstep_shape* sh, const Plan& pl, c
     a.hidden = sh->hidden;
     a.weights_bf16 = sh->weight_dtype == VMAPSTEP_WEIGHTS_BF16 ? 1 : 0;
     a.wide = pl.wide;
-    a.split = pl.split ? 1 : 0;
+    a.split = pl.s16 ? 2 : pl.split ? 1 : 0;
     a.stats = reinterpret_cast<float*>(ws + pl.off_stats);
     a.flags = reinterpret_cast<int*>(ws + pl.off_flags);
     a.part_loss = reinterpret_cast<float*>(ws + pl.off_ploss);      // half 0; the step loop of a frame alternates (ploss_half)
@@ -340,8 +344,23 @@ int launch_wp_v(const vk::StepArgs& a, hipStream_t st) {
     return VMAPSTEP_OK;
 }
 
+// prototype: hidden 32 on 16-point tiles, forward only (tuning.kernel = VMAPSTEP_KERNEL_S16_FWD)
+int launch_s16_fwd(const vk::StepArgs& a, hipStream_t st) {
+    using I = vk::Img16;
+    auto kern = a.weights_bf16 ? vk::step_main_s16_fwd<false> : vk::step_main_s16_fwd<true>;
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), I::LDS_BYTES, "step_main_s16_fwd")) return rc;
+    hipLaunchKernelGGL(kern, dim3(a.n_obj * a.NW), dim3(vk::kWG16), I::LDS_BYTES, st, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "step_main_s16_fwd launch: %s", hipGetErrorString(e));
+    return VMAPSTEP_OK;
+}
+
 template <bool BWD>
 int launch_main(const vk::StepArgs& a, hipStream_t st) {
+    if (a.split == 2) {
+        if (BWD) return fail(VMAPSTEP_ERR_UNSUPPORTED, "VMAPSTEP_KERNEL_S16_FWD is a forward-only prototype (vmapstep_render)");
+        return launch_s16_fwd(a, st);
+    }
     if (a.split) return launch_split<BWD>(a, st);
     if (a.wide == 4) {
         if (a.hidden == 128) return a.weights_bf16 ? launch_wp_v<4, BWD, false>(a, st) : launch_wp_v<4, BWD, true>(a, st);
@@ -371,6 +390,12 @@ int launch_prep(const vk::StepArgs& a, int n_steps, hipStream_t st) {
             hipLaunchKernelGGL(vk::step_prep_ws<2>, dim3(n_steps + a.n_obj * vk::ws_pack_blocks<2>()), dim3(vk::kWG), 3 * vk::kWG * sizeof(int), st, ga);
         e = hipGetLastError();
         if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "step_prep_ws launch: %s", hipGetErrorString(e));
+        return VMAPSTEP_OK;
+    }
+    if (a.split == 2) {
+        hipLaunchKernelGGL(vk::step_prep_s16, dim3(n_steps + a.n_obj * vk::kPack16Blocks), dim3(vk::kWG), 3 * vk::kWG * sizeof(int), st, a);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "step_prep_s16 launch: %s", hipGetErrorString(e));
         return VMAPSTEP_OK;
     }
     if (a.split) {

@@ -41,6 +41,13 @@ typedef short s16x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
+// D = A(16x32) * B(32x16) + C on v_mfma_f32_16x16x32_bf16 (16 cycles): a: lane l supplies A[l & 15][8 (l >> 4) + t]; b: lane l
+// supplies B[8 (l >> 4) + t][l & 15]; c / d: lane l, register r <-> D[4 (l >> 4) + r][l & 15]  (checked against a host product:
+// tests/tools/mfma16_probe.hip)
+typedef float f32x4m __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4m mfma16_bf16(u32x4 a, u32x4 b, f32x4m c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
 // two floats -> one dword of two bfloat16 (round to nearest even), lo in the low half: one v_cvt_pk_bf16_f32
 __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
     const f32x2 v = {lo, hi};
