@@ -825,6 +825,12 @@ __device__ __forceinline__ void step_main_s32_body(const StepArgs& a) {
     split_planes<24, 3>(e2, e2h, e2m, e2l);
     VS_MARK(2);
     __syncthreads();        // parameter image landed (the barrier drains the LDS-DMA), composite buffer zeroed
+#ifndef VS_NO_RAY_PREFETCH
+    // ground truth of the ray this lane composites: its six vector loads fly during the MLP forward (at the compositing they
+    // cost a full memory round trip of an otherwise idle workgroup)
+    const RayMeta rays_meta = load_ray_meta_rays(a, obj, ray0 + min(4 * wave + (lane >> 4), nrays - 1));
+    wv::sched_fence();
+#endif
 
     // ---- field MLP forward (model.py:59-83) ----
     unsigned h1h[8], h1m[8], h2h[8], h2m[8], h3h[8], h3m[8], h4h[8], h4m[8];
@@ -891,7 +897,11 @@ __device__ __forceinline__ void step_main_s32_body(const StepArgs& a) {
     {
         const StepArgs& al = wv::kernarg_late(a);
         composite_phase<BWD>(al, cb, loss_cells, obj, ray0, nrays, wave, lane, tid,
+#ifndef VS_NO_RAY_PREFETCH
+                             finish_ray_meta(al, obj, rays_meta));
+#else
                              load_ray_meta(al, obj, ray0 + min(4 * wave + (lane >> 4), nrays - 1)));
+#endif
     }
     __syncthreads();
     VS_MARK(6);

@@ -632,6 +632,24 @@ struct RayMeta {
     float gtd, q0, q1, q2;
     float inv_dd, inv_o, inv_s;
 };
+// the same in two halves: the per-ray vector loads (issued early, e.g. in front of the MLP forward) ...
+__device__ __forceinline__ RayMeta load_ray_meta_rays(const StepArgs& a, int obj, int rr) {
+    RayMeta m;
+    m.sem = a.sem[obj * a.sem_so + rr * a.sem_sr];
+    m.dm = a.dmask[obj * a.dm_so + rr * a.dm_sr];
+    m.gtd = a.gt_depth[obj * a.gd_so + rr * a.gd_sr];
+    const float* rgb = a.gt_rgb + obj * a.rgb_so + rr * a.rgb_sr;
+    m.q0 = rgb[0]; m.q1 = rgb[a.rgb_sc]; m.q2 = rgb[2 * a.rgb_sc];
+    m.inv_dd = m.inv_o = m.inv_s = 0.0f;
+    return m;
+}
+// ... and the per-object scalar part (switches and normalisers), where the compositing starts
+__device__ __forceinline__ RayMeta finish_ray_meta(const StepArgs& a, int obj, RayMeta m) {
+    m.inv_dd = a.flags[0] ? 0.0f : 1.0f / (a.stats[obj * 4 + 0] + 1e-10f);            // render_rays.py:68-73,87
+    m.inv_o = a.flags[1] ? 0.0f : 1.0f / (a.stats[obj * 4 + 1] + 1e-10f);
+    m.inv_s = a.flags[2] ? 0.0f : 1.0f / (a.stats[obj * 4 + 2] + 1e-10f);
+    return m;
+}
 __device__ __forceinline__ RayMeta load_ray_meta(const StepArgs& a, int obj, int rr) {
     RayMeta m;
     m.sem = a.sem[obj * a.sem_so + rr * a.sem_sr];
