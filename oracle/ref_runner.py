@@ -154,11 +154,17 @@ def reference_step(fc_np, B_np, scale_np, batch, H, dtype=torch.float32, strateg
 
 
 def reference_frame(fc_np, B_np, scale_np, frame, H, rays_per_step, n_steps, dtype=torch.float32,
-                    lr=1e-3, weight_decay=0.013):
+                    lr=1e-3, weight_decay=0.013, weights_bf16=False):
     """The reference's OWN step loop over one frame (train.py:270-326, vmap strategy): the per-frame sample tensors
     ``[n, n_steps * rays_per_step, ...]`` are sliced with ``data_idx = slice(i * R, (i + 1) * R)`` on dimension 1 (strided
     views, exactly like train.py:271-277), every step is vmap(pe) -> vmap(fc) -> loss.step_batch_loss -> backward ->
     ``AdamW.step()`` -> ``zero_grad(set_to_none=True)`` on an optimiser built like train.py:67 + utils.py:33.
+
+    ``weights_bf16`` (BASELINE configs[3]/[4] "bf16 weights + fp32 accumulate"; the reference itself has no reduced
+    precision, train.py:64-66): the stacked tensors the optimiser owns stay full-precision MASTERS; every step evaluates
+    the unmodified reference modules on a copy of the masters rounded to bfloat16 (round-to-nearest-even, all 15
+    tensors), and the gradients of that copy become the masters' ``.grad`` before ``AdamW.step()`` - the semantics of
+    ``vmapstep_shape::weight_dtype = VMAPSTEP_WEIGHTS_BF16`` (include/vmapstep.h).
 
     Returns the per-step losses (float64 array), the final parameters and the gradients of the FIRST step."""
     mods = _import_reference()
@@ -190,14 +196,22 @@ def reference_frame(fc_np, B_np, scale_np, frame, H, rays_per_step, n_steps, dty
         pcs, z = N_pcs[:, data_idx, ...], N_z[:, data_idx, ...]
         gt_depth, gt_rgb = N_gt_depth[:, data_idx, ...], N_gt_rgb[:, data_idx, ...]
         sem, dmask = N_sem[:, data_idx, ...], N_dmask[:, data_idx, ...]
+        if weights_bf16:
+            run_fc = tuple(p.detach().to(torch.bfloat16).to(dtype).requires_grad_() for p in fc_param)
+            run_pe = tuple(p.detach().to(torch.bfloat16).to(dtype).requires_grad_() for p in pe_param)
+        else:
+            run_fc, run_pe = fc_param, pe_param
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            emb = vmap(pe_model)(pe_param, pe_buffer, pcs)                       # train.py:293
-            alpha, color = vmap(fc_model)(fc_param, fc_buffer, emb)              # train.py:294
+            emb = vmap(pe_model)(run_pe, pe_buffer, pcs)                         # train.py:293
+            alpha, color = vmap(fc_model)(run_fc, fc_buffer, emb)                # train.py:294
         l, _ = loss_mod.step_batch_loss(alpha, color, gt_depth.detach(), gt_rgb.detach(), sem.detach(), dmask.detach(),
                                         z.detach())                             # train.py:303-306
         if l.requires_grad:
             l.backward()                                                         # train.py:324
+        if weights_bf16:
+            for m_, r_ in zip(list(fc_param) + list(pe_param), list(run_fc) + list(run_pe)):
+                m_.grad = r_.grad
         if it == 0:
             first_grads = [(p.grad if p.grad is not None else torch.zeros_like(p)).detach().numpy().copy()
                            for p in list(fc_param) + list(pe_param)]

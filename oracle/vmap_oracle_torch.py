@@ -63,7 +63,11 @@ def forward_loss(fc, B, scale, pcs, z, gt_depth, gt_rgb, sem, depth_mask, color_
 class CpuTrainer:
     """fwd + loss + backward + AdamW on CPU tensors (train.py:293-326 without the data plumbing)."""
 
-    def __init__(self, fc_np, B_np, scale_np, lr=1e-3, weight_decay=0.013, device="cpu"):
+    def __init__(self, fc_np, B_np, scale_np, lr=1e-3, weight_decay=0.013, device="cpu", weights_bf16=False):
+        """``weights_bf16``: "bf16 weights + fp32 accumulate" (BASELINE configs[3]/[4]): the tensors the optimiser owns are fp32
+        masters; every step is evaluated on a copy rounded to bfloat16 whose gradients become the masters' gradients
+        (same semantics as oracle.ref_runner.reference_frame(weights_bf16=True))."""
+        self.weights_bf16 = weights_bf16
         self.device = torch.device(device)
         self.fc = [torch.from_numpy(a.copy()).to(self.device).requires_grad_() for a in fc_np]
         self.B = torch.from_numpy(B_np.copy()).to(self.device).requires_grad_()
@@ -73,9 +77,15 @@ class CpuTrainer:
     def step(self, batch, update=True):
         args = [batch[k] if torch.is_tensor(batch[k]) else torch.from_numpy(batch[k]).to(self.device)
                 for k in ("pcs", "z", "gt_depth", "gt_rgb", "sem", "depth_mask")]
-        loss, rend = forward_loss(self.fc, self.B, self.scale, *args)
+        run = self.fc + [self.B]
+        if self.weights_bf16:
+            run = [p.detach().to(torch.bfloat16).to(p.dtype).requires_grad_() for p in run]
+        loss, rend = forward_loss(run[:14], run[14], self.scale, *args)
         if loss.requires_grad:
             loss.backward()
+            if self.weights_bf16:
+                for m, r in zip(self.fc + [self.B], run):
+                    m.grad = r.grad
         grads = [(p.grad.clone() if p.grad is not None else torch.zeros_like(p)) for p in self.fc + [self.B]]
         if update:
             self.opt.step()

@@ -29,6 +29,10 @@ CASES = {
 }
 
 
+# step fixtures that also exist on bfloat16-rounded parameters (<name>_bf16.npz): BASELINE configs[3] / [4] weight mode
+BF16_CASES = ("scannet_scale", "h64", "bg_h128_s14")
+
+
 def build_case(name):
     n, R, S, H, scale, ps, bs, gain, edit = CASES[name]
     fc, B, pe_scale = synth.make_params(n, H, scale=scale, seed=ps, gain=gain)
@@ -64,6 +68,11 @@ FRAME_CASES = {
     "h64_r256_frame": (32, 256, 10, 64, 2.0, 92, 193, 3, (0, 13, 31)),      # configs[4] per-GPU shape (256 objects / 8 GPUs)
     "bg128_frame":    (1, 240, 14, 128, 5.0, 94, 195, 4, None),             # the background model (train.py:308-316): hidden 128, 14 samples; 60 rounds per step
 }
+
+
+# The same frames with "bf16 weights + fp32 accumulate" (BASELINE configs[3] / [4]): fp32 masters, every step computed from
+# the masters rounded to bfloat16 (oracle/ref_runner.reference_frame(weights_bf16=True)); fixture <name>_bf16.npz.
+BF16_FRAME_CASES = ("scannet50_frame", "h64_r256_frame", "bg128_frame")
 
 
 def build_frame_case(name):

@@ -47,3 +47,35 @@ def round_bf16(a):
     u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32).astype(np.uint64)
     u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
     return u.astype(np.uint32).view(np.float32).reshape(np.shape(a))
+
+
+def kink_aware(got, ref, n_obj):
+    """ReLU-kink accounting (oracle.vmap_oracle.kink_deltas): ``ref`` = an oracle result computed with ``kinks=True``, ``got`` = another
+    float32 implementation's result.  Per object, the derivative bit of every kink-adjacent hidden unit is solved for by least
+    squares (one unknown per ambiguous entry against the object's ~10^4..10^5 gradient elements), REQUIRED to round to 0 or 1,
+    and the rounded combination is added to the oracle's gradients.  Returns ({key: corrected oracle gradient}, flipped bits,
+    ambiguous entries, worst effect of rounding a beta, in units of the affected tensor's max)."""
+    shapes = [np.shape(ref[k]) for k in GRAD_KEYS]
+    flat = lambda d, k: np.concatenate([np.asarray(d[key], np.float64)[k].ravel() for key in GRAD_KEYS])
+    # per-element scale of an object's flat gradient vector: the max of the tensor the element belongs to (the tolerance is per tensor)
+    corr = {key: np.array(ref[key], dtype=np.float64) for key in GRAD_KEYS}
+    flipped, worst = 0, 0.0
+    for k in range(n_obj):
+        scale = np.concatenate([np.full(int(np.prod(shp[1:])), np.abs(np.asarray(ref[key])[k]).max() + 1e-30)
+                                for key, shp in zip(GRAD_KEYS, shapes)])
+        # an entry whose flip moves no tensor by 1e-7 of its max (dead downstream path, masked ray) is not ambiguous in effect
+        D = [d for (ko, d) in ref["kink_deltas"] if ko == k and np.abs(d / scale).max() > 1e-7]
+        if not D:
+            continue
+        A = np.stack(D, axis=1)
+        beta, *_ = np.linalg.lstsq(A / scale[:, None], (flat(got, k) - flat(ref, k)) / scale, rcond=None)
+        rb = np.clip(np.round(beta), 0, 1)
+        worst = max(worst, float((np.abs(beta - rb) * np.abs(A / scale[:, None]).max(axis=0)).max()))
+        flipped += int(rb.sum())
+        add = A @ rb
+        o = 0
+        for key, shp in zip(GRAD_KEYS, shapes):
+            sz = int(np.prod(shp[1:]))
+            corr[key][k] += add[o:o + sz].reshape(shp[1:])
+            o += sz
+    return corr, flipped, len(ref["kink_deltas"]), worst

@@ -9,6 +9,8 @@ slices of the frame tensors, functorch vmap, loss.step_batch_loss, backward, Ada
 float32 and stores the per-step losses, the gradients of the first step and the final parameters of the kept objects
 (all objects for the headline frame), plus per-object / per-tensor L2 norms of the final parameters of every object; the
 float64 twin contributes its losses (the tie-breaker for how fast the two precisions drift apart).
+``<name>_bf16``: the same frame with bfloat16-rounded run-time weights over full-precision masters
+(``reference_frame(weights_bf16=True)``), for the cases listed in ``cases.BF16_FRAME_CASES``.
 """
 from __future__ import annotations
 
@@ -30,11 +32,15 @@ import cases  # noqa: E402
 def main(names=None):
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    for name in (names or cases.FRAME_CASES):
-        c = cases.build_frame_case(name)
+    todo = names or (list(cases.FRAME_CASES) + [f"{n}_bf16" for n in cases.BF16_FRAME_CASES])
+    for name in todo:
+        bf16 = name.endswith("_bf16")
+        c = cases.build_frame_case(name[:-5] if bf16 else name)
         keep = list(c["keep"])
-        r32 = ref_runner.reference_frame(c["fc"], c["B"], c["scale"], c["frame"], c["H"], c["R"], c["n_steps"], torch.float32)
-        r64 = ref_runner.reference_frame(c["fc"], c["B"], c["scale"], c["frame"], c["H"], c["R"], c["n_steps"], torch.float64)
+        r32 = ref_runner.reference_frame(c["fc"], c["B"], c["scale"], c["frame"], c["H"], c["R"], c["n_steps"], torch.float32,
+                                         weights_bf16=bf16)
+        r64 = ref_runner.reference_frame(c["fc"], c["B"], c["scale"], c["frame"], c["H"], c["R"], c["n_steps"], torch.float64,
+                                         weights_bf16=bf16)
         out = {"losses": r32["losses"], "f64_losses": r64["losses"], "keep": np.array(keep)}
         for t in list(range(14)) + ["B"]:
             k = f"fc{t}" if t != "B" else "B"

@@ -9,6 +9,8 @@ model.py / embedding.py / render_rays.py / loss.py driven through functorch exac
 utils.py:30-34 + train.py:293-326) in float32, and again in float64 (the tie-breaker), and stores
 loss, rendered depth/colour/opacity/variance and all 15 gradient tensors.  Inputs are not stored:
 they are re-derived from the seeds, and ``input_sha256`` guards against generator drift.
+``<name>_bf16`` (``cases.BF16_CASES``): the same case with every parameter tensor rounded to bfloat16 first
+(the weight_dtype = bf16 mode of the library computes from exactly those values).
 """
 from __future__ import annotations
 
@@ -30,8 +32,12 @@ import cases  # noqa: E402
 def main(names=None):
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    for name in (names or cases.CASES):
-        c = cases.build_case(name)
+    for name in (names or (list(cases.CASES) + [f"{n}_bf16" for n in cases.BF16_CASES])):
+        bf16 = name.endswith("_bf16")
+        c = cases.build_case(name[:-5] if bf16 else name)
+        if bf16:      # "bf16 weights + fp32 accumulate": the unmodified reference evaluated on bfloat16-rounded parameters
+            rnd = lambda a: torch.from_numpy(a).to(torch.bfloat16).to(torch.float32).numpy()
+            c = dict(c, fc=[rnd(a) for a in c["fc"]], B=rnd(c["B"]))
         out = {}
         r32 = ref_runner.reference_step(c["fc"], c["B"], c["scale"], c["batch"], c["H"], torch.float32)
         r64 = ref_runner.reference_step(c["fc"], c["B"], c["scale"], c["batch"], c["H"], torch.float64)

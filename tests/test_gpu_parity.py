@@ -9,7 +9,7 @@ import pytest
 import torch
 
 import cases
-from conftest import tensor_err_q, GRAD_KEYS, RENDER_KEYS, load_golden, relerr
+from conftest import tensor_err_q, kink_aware, GRAD_KEYS, RENDER_KEYS, load_golden, relerr
 from oracle import vmap_oracle as vo
 from vmap_amd import _lib, layout, step, synth
 
@@ -50,6 +50,13 @@ def _run(c, fn="fwd_bwd", op=None, tuning=None, **kw):
 H32_CASES = [n for n, v in cases.CASES.items() if v[3] == 32]
 
 
+def _var_tol(g, base=2e-5):
+    """Rendered variance (loss.py:28-29; an output of the boundary) against the reference fixture: 2e-5 of its
+    max like the other renders, widened only where the reference's OWN float32 and float64 runs drift further apart (the
+    saturated case: occupancy == 1.0f makes var a difference of rounding errors, 8e-4 between the two precisions)."""
+    return max(base, 3.0 * relerr(g["var"], g["f64_var"]))
+
+
 @pytest.fixture(autouse=True, params=["split", "f32"])
 def h32_kernel(request):
     """Every test of this module runs twice: hidden 32 on the default split-bf16 kernel (step_main_s32) and on the
@@ -76,6 +83,7 @@ def test_fwd_bwd_matches_reference_fixture(name):
     assert abs(s["loss"] - float(g["loss"])) <= 2e-5 * abs(float(g["loss"]))
     for k in RENDER_KEYS:
         assert relerr(s[k], g[k]) < rt, k
+    assert relerr(s["var"], g["var"]) < _var_tol(g, rt)
     for k in GRAD_KEYS:
         assert not np.isnan(s[k]).any(), k
         assert relerr(s[k], g[k]) < gt, k
@@ -105,11 +113,23 @@ def test_fwd_bwd_matches_oracle_on_seeded_shapes(n, R, S, seed):
         assert relerr(s[k], rend_t[k].detach().numpy()) < 2e-5, k
     for k, g in zip(GRAD_KEYS, grads_t):
         assert relerr(s[k], g.numpy()) < 1e-4, k
-    o = vo.training_step(fc, B, sc, batch, dtype=np.float32)
-    for k in RENDER_KEYS:
+    o = vo.training_step(fc, B, sc, batch, dtype=np.float32, kinks=True)
+    for k in RENDER_KEYS + ["var"]:
         assert relerr(s[k], o[k]) < 2e-5, k
+    _assert_grads_match_oracle_up_to_kinks(s, o, n)
+
+
+def _assert_grads_match_oracle_up_to_kinks(s, o, n_obj, tol=1e-4):
+    """Gradients against the numpy oracle at north_star's 1e-4, with the ReLU kinks ACCOUNTED FOR instead of tolerated: the
+    oracle lists every hidden unit whose pre-activation lies inside float32 forward rounding of 0 and the exact gradient change
+    of flipping its derivative bit; the kernel's gradients must equal the oracle's plus a 0/1 combination of those changes
+    (conftest.kink_aware: measured on the 5 x 300 x 14 hidden-128 case 3 flipped bits of 276 candidates take the raw
+    difference from 3.5e-2 to 4e-6)."""
+    corr, flipped, cand, worst = kink_aware(s, o, n_obj)
+    assert worst < 1e-5, (worst, flipped, cand)                 # every solved bit is 0 or 1
     for k in GRAD_KEYS:
-        assert relerr(s[k], o[k]) < 2e-2, k
+        assert not np.isnan(s[k]).any(), k
+        assert relerr(s[k], corr[k]) < tol, (k, flipped, cand)
 
 
 @pytest.mark.parametrize("H", [128, 64])
@@ -128,17 +148,12 @@ def test_hidden128_kernel_matches_oracle_on_seeded_shapes(n, R, S, seed, H):
     assert abs(s["loss"] - float(loss_t)) <= 5e-5 * abs(float(loss_t))
     for k in RENDER_KEYS:
         assert relerr(s[k], rend_t[k].detach().numpy()) < 2e-5, k
-    # Gradients against the ATen port: 1e-4, except where one hidden unit sits on the other side of a ReLU kink (measured on the
-    # 5 x 300 x 14, hidden 64 case: this kernel and the exact-fp32 kernel agree to 6e-6 and differ from the port by the same
-    # 2.4e-3 in the tensors below mid1 of ONE object) - bounded like the numpy oracle above; the tight comparator is the
-    # exact-fp32 kernel of the same width on the same inputs.
-    loose = 0
-    for k, g in zip(GRAD_KEYS, grads_t):
-        assert not np.isnan(s[k]).any(), k
-        r = relerr(s[k], g.numpy())
-        assert r < 2e-2, k
-        loose += r >= 1e-4
-    assert loose <= 5
+    # gradients: the numpy oracle with its kink-adjacent hidden units accounted for bit by bit, at 1e-4 (this replaces the
+    # former "up to 5 of 15 tensors may sit at 2e-2 of the ATen port" rule)
+    o = vo.training_step(fc, B, sc, batch, dtype=np.float32, kinks=True)
+    for k in RENDER_KEYS + ["var"]:
+        assert relerr(s[k], o[k]) < 2e-5, k
+    _assert_grads_match_oracle_up_to_kinks(s, o, n)
     e = _run(c, tuning={"kernel": _lib.KERNEL_GEN})
     w1 = _run(c, tuning={"kernel": _lib.KERNEL_WS1})              # step_main_ws: one wave per output block
     for k in RENDER_KEYS:
@@ -211,13 +226,19 @@ def test_slab_views_as_parameters():
     assert relerr(gviews[14].cpu().numpy(), g["g_B"]) < 1e-4
 
 
+@pytest.mark.parametrize("weights", ["f32", "bf16"])
 @pytest.mark.parametrize("nw", [1, 2, 3, 10])
-def test_workgroups_per_object_does_not_change_results(nw):
+def test_workgroups_per_object_does_not_change_results(nw, weights):
+    """1, 2, 3 workgroups per object = the multi-pass instantiation (4, 5, 10 passes), 10 = single pass; bf16: the W3 = false
+    instantiations against the reference evaluated on bfloat16-rounded parameters (fixture scannet_scale_bf16)."""
     c = cases.build_case("scannet_scale")      # R=120 -> 10 ray groups per object
-    g = load_golden("scannet_scale")
-    s = _run(c, tuning={"workgroups_per_object": nw})
+    g = load_golden("scannet_scale" if weights == "f32" else "scannet_scale_bf16")
+    op = step.VmapStep(c["n"], c["R"], c["S"], c["H"], device=DEV, weights=weights, tuning={"workgroups_per_object": nw})
+    s = _run(c, op=op)
+    assert abs(s["loss"] - float(g["loss"])) <= 2e-5 * abs(float(g["loss"]))
     for k in RENDER_KEYS + GRAD_KEYS:
         assert relerr(s[k], g[k]) < 1e-4, k
+    assert relerr(s["var"], g["var"]) < _var_tol(g)
 
 
 def test_far_point_cold_path():
@@ -422,6 +443,7 @@ def test_generic_width_kernel_matches_reference_fixture(name, kernel):
     assert abs(s["loss"] - float(g["loss"])) <= 2e-5 * abs(float(g["loss"]))
     for k in RENDER_KEYS:
         assert relerr(s[k], g[k]) < 2e-5, k
+    assert relerr(s["var"], g["var"]) < _var_tol(g)
     for k in GRAD_KEYS:
         assert not np.isnan(s[k]).any(), k
         assert relerr(s[k], g[k]) < 1e-4, k
@@ -552,22 +574,31 @@ def test_headless_driver_object_list_semantics():
     assert torch.isfinite(res2.loss).all()
 
 
-@pytest.mark.parametrize("name", ["scannet_scale", "h64"])
-def test_bf16_weight_mode_equals_oracle_on_rounded_weights(name):
-    """BASELINE configs[3]/[4] 'bf16 weights + fp32 accumulate': masters fp32, image rounded to bfloat16."""
+@pytest.mark.parametrize("name,kernel", [("scannet_scale", 0), ("h64", 0), ("h64", _lib.KERNEL_WS1), ("bg_h128_s14", 0),
+                                         ("bg_h128_s14", _lib.KERNEL_WP)])
+def test_bf16_weight_mode_equals_reference_on_rounded_weights(name, kernel):
+    """BASELINE configs[3]/[4] 'bf16 weights + fp32 accumulate': masters fp32, image rounded to bfloat16.  Comparators: the
+    UNMODIFIED reference evaluated on the rounded parameters (fixture <name>_bf16.npz) and the ATen port of the oracle."""
     from conftest import tensor_err_q, round_bf16
     from oracle import vmap_oracle_torch as vt
     c = cases.build_case(name)
+    g = load_golden(name + "_bf16")
     fc_r = [round_bf16(a) for a in c["fc"]]
     B_r = round_bf16(c["B"])
     loss_t, rend_t, grads_t = vt.CpuTrainer(fc_r, B_r, c["scale"]).step(c["batch"], update=False)
-    op = step.VmapStep(c["n"], c["R"], c["S"], c["H"], device=DEV, weights="bf16")
+    op = step.VmapStep(c["n"], c["R"], c["S"], c["H"], device=DEV, weights="bf16", tuning={"kernel": kernel} if kernel else None)
     s = _run(c, op=op)
+    assert abs(s["loss"] - float(g["loss"])) <= 2e-5 * abs(float(g["loss"]))
+    for k in RENDER_KEYS:
+        assert relerr(s[k], g[k]) < 2e-5, k
+    assert relerr(s["var"], g["var"]) < _var_tol(g)
+    for k in GRAD_KEYS:
+        assert relerr(s[k], g[k]) < 1e-4, k
     assert abs(s["loss"] - float(loss_t)) <= 5e-5 * abs(float(loss_t))
     for k in RENDER_KEYS:
         assert relerr(s[k], rend_t[k].detach().numpy()) < 2e-5, k
-    for k, g in zip(GRAD_KEYS, grads_t):
-        assert relerr(s[k], g.numpy()) < 1e-4, k
+    for k, gt_ in zip(GRAD_KEYS, grads_t):
+        assert relerr(s[k], gt_.numpy()) < 1e-4, k
     # masters stay fp32: one fused AdamW step moves them by ~lr although that is far below bf16 resolution
     fc, B, sc, b = _to_dev(c)
     st = step.FusedAdamWState(c["n"], c["H"], DEV)
@@ -664,21 +695,24 @@ FRAME_TOL = {   # (relative loss tolerance for steps < 5, for later steps, q99 /
 }
 
 
-@pytest.mark.parametrize("name", list(cases.FRAME_CASES))
+@pytest.mark.parametrize("name", list(cases.FRAME_CASES) + [f"{n}_bf16" for n in cases.BF16_FRAME_CASES])
 def test_frame_trajectory_matches_reference_step_loop(name):
     """vmapstep_train_steps over a whole frame - distinct strided ray slices per step, fused AdamW - against the
     reference's OWN loop (train.py:270-326: functorch vmap + loss.step_batch_loss + torch.optim.AdamW), fixture
     tests/golden/<name>.npz.  cfg2_frame20 is the frame bench.py times; scannet50_frame runs the multi-pass kernel at a
     real object count; h64_r256_frame is the per-GPU shape of BASELINE configs[4]; bg128_frame the background model's
-    (hidden 128, 14 samples: step_main_ws, several rounds per workgroup)."""
-    c = cases.build_frame_case(name)
+    (hidden 128, 14 samples: step_main_ws, several rounds per workgroup).  <name>_bf16: weight_dtype = bf16 at the SAME shapes
+    (50 objects: step_main_s32<BWD, MULTI, ., W3 = false>; 32 x 256 rays at hidden 64: multi-round step_main_wp<2, ., W3 = false>)
+    against the reference loop run with bfloat16-rounded run-time weights over full-precision masters."""
+    bf16 = name.endswith("_bf16")
+    c = cases.build_frame_case(name[:-5] if bf16 else name)
     g = load_golden(name)
     n, R, S, H, steps = c["n"], c["R"], c["S"], c["H"], c["n_steps"]
     fc = [torch.from_numpy(a).to(DEV) for a in c["fc"]]
     B = torch.from_numpy(c["B"]).to(DEV)
     sc = torch.from_numpy(c["scale"]).to(DEV)
     fr = {k: torch.from_numpy(v).to(DEV) for k, v in c["frame"].items()}
-    op = step.VmapStep(n, R, S, H, device=DEV, max_steps=steps)
+    op = step.VmapStep(n, R, S, H, device=DEV, max_steps=steps, weights="bf16" if bf16 else "f32")
     st = step.FusedAdamWState(n, H, DEV)
     # first-step gradients (same state): fixture parity of the strided slice [0, R)
     gfc = [torch.zeros_like(t) for t in fc]
@@ -696,6 +730,7 @@ def test_frame_trajectory_matches_reference_step_loop(name):
     assert int(res.flags[:, 3].max()) == 0
     early, late, q99, med = FRAME_TOL[name]
     rel = np.abs(losses - g["losses"]) / np.abs(g["losses"])
+    assert rel[0] <= 2e-5 or not bf16, rel
     assert rel[:5].max() <= early, rel
     assert rel.max() <= late, rel
     diffs = []

@@ -295,3 +295,32 @@ def test_sim_s16_forward_prototype_matches_reference(name):
     assert abs(s["loss"] - float(g["loss"])) <= 2e-5 * abs(float(g["loss"]))
     for k in RENDER_KEYS:
         assert relerr(s[k], g[k]) < 2e-5, k
+
+
+@pytest.mark.parametrize("name,kw", [("ragged", dict(split=True, NW=2, G=5)), ("ragged", dict(split=True, NW=1)),
+                                     ("h64", dict(wide=4, NW=2)), ("h64", dict(wide=3, NW=2)), ("bg_h128_s14", dict(wide=3, NW=3))])
+def test_sim_bf16_weights_in_the_multi_pass_and_multi_round_forms(name, kw):
+    """weight_dtype = bf16 in the instantiations BASELINE configs[3] / [4] actually run: step_main_s32<., MULTI, ., W3 = false>
+    (several passes per workgroup: the staging tiles overlay the planes the one-plane form does not have), step_main_wp<2> /
+    step_main_ws with several rounds per workgroup.  Comparators: the reference evaluated on bfloat16-rounded parameters
+    (fixture <name>_bf16.npz) where it exists, else the ATen port on the rounded weights."""
+    from conftest import round_bf16
+    from oracle import vmap_oracle_torch as vt
+    c = cases.build_case(name)
+    fc_r, B_r = [round_bf16(a) for a in c["fc"]], round_bf16(c["B"])
+    s = simlib.sim_step(c, weights_bf16=1, **kw)
+    if name in cases.BF16_CASES:
+        g = load_golden(name + "_bf16")
+        ref = {k: g[k] for k in RENDER_KEYS + GRAD_KEYS}
+        loss = float(g["loss"])
+    else:
+        loss_t, rend_t, grads_t = vt.CpuTrainer(fc_r, B_r, c["scale"]).step(c["batch"], update=False)
+        ref = {k: rend_t[k].detach().numpy() for k in RENDER_KEYS}
+        ref.update({k: gr.numpy() for k, gr in zip(GRAD_KEYS, grads_t)})
+        loss = float(loss_t)
+    assert abs(s["loss"] - loss) <= 2e-5 * abs(loss)
+    for k in RENDER_KEYS:
+        assert relerr(s[k], ref[k]) < 2e-5, k
+    for k in GRAD_KEYS:
+        assert not np.isnan(s[k]).any(), k
+        assert relerr(s[k], ref[k]) < 1e-4, k
