@@ -10,8 +10,13 @@ plumbing).  Workload at N=1: BASELINE configs[1] (20 objects x 4-layer/32-hidden
 samples/ray, fp32).  N>1: weak scaling - every rank owns its own 20 objects (objects are independent units,
 no data-path collective); value = rays of all ranks / max-over-ranks time.
 
+N>1 also trains the SHARED background model (train.py:308-316) ray-sharded over the ranks next to the objects - the path's
+one real collective (ONE all-reduce of [gradients | loss terms] per step over RCCL) - and reports it under `with_background`;
+`value` stays the objects-only rate (the metric).
+
 Rank 0 prints ONE JSON line with the contract fields plus
-  roofline     - the dominant kernel (step_main_h32) against the fp32 MFMA peak, timed live with events
+  roofline     - the dominant kernel against the matrix peaks (fp32-equivalent and the executed bf16 pipe), timed live with the
+                 dispatch's own begin / end events
   cpu_baseline - the PyTorch-CPU port of the oracle timed on this host's cores (reported, not a target)
 """
 from __future__ import annotations
@@ -104,7 +109,7 @@ def main():
     ap.add_argument("--config", default="replica_room0_vmap", choices=list(synth.CONFIGS))
     ap.add_argument("--iters-per-frame", type=int, default=20)       # config: render.iters_per_frame
     ap.add_argument("--weights", default="f32", choices=["f32", "bf16"])   # bf16: BASELINE configs[3]/[4] (fp32 masters + accumulate)
-    ap.add_argument("--kernel", default="auto", choices=["auto", "gen", "wide", "wide2", "f32", "ws1", "wp"])   # measurement: hidden 128 / 256 kernels; f32 = hidden 32
+    ap.add_argument("--kernel", default="auto", choices=["auto", "gen", "wide", "f32", "ws1", "wp"])   # measurement: hidden 128 / 256 kernels; f32 = hidden 32
                                                                                                  # on the exact-fp32 matrix instruction (step_main_h32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--slab", action="store_true")                   # the 15 stacked tensors as views of one [n, P] slab (measurement;
@@ -114,7 +119,9 @@ def main():
     ap.add_argument("--no-gpu-baseline", action="store_true")
     ap.add_argument("--with-background", action="store_true")      # also train the SHARED background model (train.py:308-316; hidden 128,
                                                                      # 1200 rays / step split over the ranks, ONE gradient all-reduce per
-                                                                     # step) next to the objects, on a second stream; reported separately
+                                                                     # step) next to the objects, on a second stream; reported separately.
+                                                                     # ON by default whenever WORLD_SIZE > 1 (the scaling run exercises RCCL)
+    ap.add_argument("--no-background", action="store_true")
     ap.add_argument("--timed-only", action="store_true")            # skip the roofline / baseline legs (for kernel traces of the timed region)
     ap.add_argument("--unbound", action="store_true")               # marshal the arguments on every frame call (VmapStep.train_steps)
     args = ap.parse_args()
@@ -149,7 +156,7 @@ def main():
     tuning = None
     if args.kernel != "auto":
         from vmap_amd import _lib
-        tuning = {"kernel": {"gen": _lib.KERNEL_GEN, "wide": _lib.KERNEL_WIDE4, "wide2": _lib.KERNEL_WIDE2, "f32": _lib.KERNEL_H32_F32, "ws1": _lib.KERNEL_WS1, "wp": _lib.KERNEL_WP}[args.kernel]}
+        tuning = {"kernel": {"gen": _lib.KERNEL_GEN, "wide": _lib.KERNEL_WIDE4, "f32": _lib.KERNEL_H32_F32, "ws1": _lib.KERNEL_WS1, "wp": _lib.KERNEL_WP}[args.kernel]}
     op = step.VmapStep(n, R, S, H, device=dev, max_steps=ipf, weights=args.weights, tuning=tuning)
     opt = step.FusedAdamWState(n, H, dev, lr=1e-3, weight_decay=0.013)
     fargs = (fr["pcs"], fr["z"], fr["gt_depth"], fr["gt_rgb"], fr["sem"], fr["depth_mask"])
@@ -181,7 +188,7 @@ def main():
 
     # ---- the shared background model (the north star's one collective): replicas + ray sharding ----
     bg = None
-    if args.with_background:
+    if (args.with_background or world > 1) and not args.no_background:
         from vmap_amd import fields, parallel
         bcfg = synth.CONFIGS["background"]
         torch.manual_seed(7)                                          # the same replica on every rank
@@ -197,7 +204,8 @@ def main():
             bg = parallel.SharedBackgroundHip(bfc, bpe, bR, bcfg["S"], dev, max_steps=ipf)
         bg_info = {"hidden": bcfg["H"], "rays_per_step_all_ranks": bR * world, "rays_per_step_this_rank": bR, "samples_per_ray": bcfg["S"],
                    "collectives": "per frame: one all_reduce(SUM) of the [steps, 4] mask counts; per step: ONE all_reduce(SUM) of "
-                                  f"[gradient slab | loss] = {bg.buf.numel() * 4} bytes between two launches"}
+                                  f"[gradient slab | loss terms] = {bg.buf.numel() * 4} bytes between two launches "
+                                  "(forward/backward; AdamW + image rewrite + global loss/flags)"}
 
     def run_with_bg(n_steps):
         """objects on the current stream, the background frame on its own stream, joined per frame call"""
@@ -294,19 +302,24 @@ def main():
         k_ms_alone = op.profile_main_kernel(tfc, tB, tsc, *b0, reps=args.profile_reps)
         reps = max(1, args.profile_reps // ipf)
         pairs = [op.profile_train_steps(tfc, tB, tsc, *fargs, opt=opt, n_steps=ipf) for _ in range(reps)]
-        k_ms_raw = sum(p[0] for p in pairs) / reps           # raw event-pair time around every launch
-        k_ms_corr = sum(p[1] for p in pairs) / reps          # minus the cost of an empty event pair
-        # An event pair around a launch reads ~2.5 us MORE than rocprofv3's per-dispatch duration of the same command and the
-        # pair-minus-empty-pair form ~2.6 us LESS (profiles/r02b_rocprofv3_kernel_stats.csv: 23.5 us; events: 26.0 / 20.9):
-        # half of an empty pair's cost is inherent to one recorded event.  The roofline uses the midpoint, which tracks the
-        # rocprofv3 average; both raw figures are reported next to it.
-        k_ms = 0.5 * (k_ms_raw + k_ms_corr)
+        k_ms = sum(p[0] for p in pairs) / reps               # the dispatch's own begin -> end timestamps (hipExtLaunchKernel events):
+                                                             # the quantity a rocprofv3 --kernel-trace reports per dispatch (profiles/)
+        k_ms_pair = sum(p[1] for p in pairs) / reps          # a pair of stream events around the launch (includes the events' own cost)
         split = H == 32 and args.kernel != "f32"
-        ws = H == 128 and args.kernel in ("auto", "ws1", "wp") and S <= 64
-        kernel_name = ("step_main_s32 (bf16 matrix pipe, split operands: 6 products forward, 3 backward)" if split else
-                       "step_main_h32 (exact-fp32 matrix instruction)" if H == 32 else
-                       ("step_main_wp" if args.kernel == "wp" else "step_main_ws") + " (hidden 128: bf16 matrix pipe, split operands, two 32-point tiles per workgroup round)" if ws else
-                       "step_main_gen / step_main_wide (hidden 128, 256: chosen by tile count)")
+        wsk = H in (64, 128) and args.kernel in ("auto", "ws1", "wp") and S <= 64
+        wp = wsk and (args.kernel == "wp" or (args.kernel == "auto" and H == 64))
+        kernel_name = ("step_main_s32 (hidden 32: bf16 matrix pipe, split operands: 6 products forward, 3 backward)" if split else
+                       "step_main_h32 (hidden 32: exact-fp32 matrix instruction)" if H == 32 else
+                       (("step_main_wp" if wp else "step_main_ws") + f" (hidden {H}: bf16 matrix pipe, split operands, two 32-point tiles per "
+                        "workgroup round, " + ("two waves" if wp else "one wave") + " per output block)") if wsk else
+                       ("step_main_wide<4>" if (args.kernel == "wide" or (args.kernel == "auto" and H % 128 == 0 and n * ((R + 32 // S - 1) // (32 // S)) <= 256))
+                        else "step_main_gen") + f" (hidden {H}: exact-fp32 matrix instruction)")
+        on_bf16_pipe = split or wsk
+        dtype_label = ("f32 I/O, masters, accumulation" + ("" if args.weights == "f32" else " on bf16-rounded run-time weights") +
+                       ("; matrix operands split into bf16 planes: forward 6 products (~2^-24, float32-equivalent), backward 3 (~2^-16)"
+                        if on_bf16_pipe and args.weights == "f32" else
+                        "; bf16 matrix pipe: one weight plane x three activation planes forward, 2 + 3 products backward" if on_bf16_pipe
+                        else "; exact-fp32 matrix instruction"))
         flops = layout.step_flops(n, R, S, H)
         abytes = layout.step_bytes(n, R, S, H)
         achieved = flops / (k_ms * 1e-3) / 1e12
@@ -327,6 +340,23 @@ def main():
                     traffic = json.load(fh)["_notes"][key]
         except Exception:
             traffic = None
+        # what the matrix pipe actually executes (bf16 kernels): instructions per 32-point tile / 64-point round x tiles x 32x32x16 x 2 FLOP
+        executed_tflops, mm_per_launch = None, None
+        if split:
+            per_tile = 288 if args.weights == "f32" else 195
+            mm_per_launch = n * ((R + (128 // S) - 1) // (128 // S)) * 4 * per_tile
+        elif wsk and H == 128:
+            mm_per_launch = n * ((R + (64 // S) - 1) // (64 // S)) * 4 * (1185 if args.weights == "f32" else 807)
+        if mm_per_launch:
+            executed_tflops = mm_per_launch * 32768 / (k_ms * 1e-3) / 1e12
+        # Floor of THIS formulation at hidden 32 (one 32-point tile per wave, one wave per SIMD): a SIMD's time is the SUM of its matrix
+        # and its vector instructions (measured: profiles/r02o_pair_probe.jsonl - neither a second wave nor interleaving overlaps
+        # them): 296 matrix instructions x 32 clocks + 3838 vector instructions x 4.8 clocks = 27.9 k clocks at 2.4 GHz.
+        floor_us, floor_note = None, None
+        if split and args.weights == "f32":
+            floor_us = (296 * 32 + 3838 * 4.8) / 2400.0
+            floor_note = ("sum of one tile's matrix (296 x 32 clk) and vector (3838 x 4.8 clk) issue time on its SIMD at 2.4 GHz: the part of "
+                          "kernel_ms no schedule of this tiling can remove; kernel_ms - floor_us = waits, barriers, issue stalls, launch ramp")
         # forward+backward only (no optimiser), same loop structure
         gfc = [torch.zeros_like(t) for t in tfc]
         gB = torch.zeros_like(tB)
@@ -336,34 +366,58 @@ def main():
             op.fwd_bwd(tfc, tB, tsc, *b0, grads_fc=gfc, grad_B=gB)
         torch.cuda.synchronize()
         fb_ms = (time.perf_counter() - t1) / 100 * 1e3
+        # the same workload on the exact-fp32 matrix instruction (step_main_h32: every product an fp32 FMA; the A/B reference of the
+        # default kernel's split-bf16 operands), timed like `value`: the number to quote if the backward's ~2^-16 operands are not wanted
+        exact = None
+        if split and world == 1:
+            from vmap_amd import _lib as _l
+            op_x = step.VmapStep(n, R, S, H, device=dev, max_steps=ipf, weights=args.weights, tuning={"kernel": _l.KERNEL_H32_F32})
+            opt_x = step.FusedAdamWState(n, H, dev, lr=1e-3, weight_decay=0.013)
+            xfc, xB = [t.clone() for t in tfc], tB.clone()
+            bx = op_x.bind(xfc, xB, tsc, *fargs, opt=opt_x)
+            for _ in range(max(1, args.warmup // ipf)):
+                bx.train_steps(ipf)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            done = 0
+            while done < args.steps:
+                k = min(ipf, args.steps - done)
+                bx.train_steps(k)
+                done += k
+            torch.cuda.synchronize()
+            x_ms = (time.perf_counter() - t1) / args.steps * 1e3
+            exact = {"value": n * R / (x_ms * 1e-3), "ms_per_step": x_ms, "kernel": "step_main_h32 (v_mfma_f32_32x32x2_f32)"}
         out = {
             "metric": "training rays/sec (all objects) per step", "value": value, "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.weights == "f32" else "f32 compute on bf16-rounded weights", "data": "synthetic",
+            "dtype": dtype_label, "data": "synthetic",
             "config": {"workload": f"{args.config}: {n} objects/GPU x 4-layer/{H}-hidden MLP, {R} rays/object, "
                                    f"{S} samples/ray, fwd+loss+bwd+fused AdamW, {ipf} steps per frame call",
                        "objects_per_gpu": n, "rays_per_object": R, "samples_per_ray": S, "hidden": H,
                        "parallelism": f"objects sharded over {world} GPU(s); no per-step collective, one 4x{ipf}-int32 flag all-reduce per frame"},
             "roofline": {"bound": "mfma", "kernel": kernel_name, "achieved": achieved,
                          "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
+                         "frac_is": "fp32-EQUIVALENT: algorithmic float32 FLOPs (n R S 6 H (4H + 220)) per launch / launch duration / the float32 "
+                                    "matrix = vector peak (157.3 TFLOP/s) - the rate of the path's arithmetic type; comparable across rounds",
+                         "frac_of_executed_pipe": (executed_tflops / BF16_MFMA_PEAK_TFLOPS) if executed_tflops else achieved / FP32_MFMA_PEAK_TFLOPS,
+                         "executed_pipe": ({"instruction": "v_mfma_f32_32x32x16_bf16", "peak_tflops": BF16_MFMA_PEAK_TFLOPS,
+                                            "executed_tflops": executed_tflops, "matrix_instructions_per_launch": mm_per_launch}
+                                           if executed_tflops else {"instruction": "v_mfma_f32_32x32x2_f32", "peak_tflops": FP32_MFMA_PEAK_TFLOPS}),
+                         "floor_us": floor_us, "floor_note": floor_note,
                          "traffic": traffic,
                          "traffic_source": ("copied from the committed rocprofv3 --pmc passes of this kernel (profiles/" + pmc_file +
                                             "), not observed in this run") if traffic is not None else None,
-                         "kernel_ms": k_ms, "kernel_ms_event_pair_raw": k_ms_raw, "kernel_ms_minus_empty_event_pair": k_ms_corr,
-                         "kernel_ms_note": "kernel_ms = midpoint of the raw event-pair time and the pair-minus-empty-pair time (= the rocprofv3 per-dispatch average of the same command within ~1 %, profiles/)", "kernel_ms_back_to_back": k_ms_alone, "algorithmic_flops_per_launch": flops,
+                         "kernel_ms": k_ms, "kernel_ms_stream_event_pair": k_ms_pair,
+                         "kernel_ms_note": "kernel_ms = average of the dispatches' own begin -> end timestamps (events attached to the launch, "
+                                           "hipExtLaunchKernel) over the real prep / main / finalize sequence = what rocprofv3 --kernel-trace reports "
+                                           "(profiles/); kernel_ms_stream_event_pair = events recorded on the stream around the launch",
+                         "kernel_ms_back_to_back": k_ms_alone, "algorithmic_flops_per_launch": flops,
                          "algorithmic_bytes_per_launch": abytes,
                          "hbm_achieved_GBs": abytes / (k_ms * 1e-3) / 1e9,
-                         "hbm_frac": abytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "peak_note": "peak = the float32 matrix / vector rate (157.3 TFLOP/s), the rate of the path's own arithmetic type; "
-                                      "achieved = ALGORITHMIC float32 FLOPs (n R S 6 H (4H + 220)) per launch / launch duration"},
+                         "hbm_frac": abytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "value_exact_fp32_kernel": exact,
             "fwd_bwd_only": {"ms_per_step_host_launched": fb_ms, "rays_per_s": n * R / (fb_ms * 1e-3)},
-            "matrix_pipe": ({"instruction": "v_mfma_f32_32x32x16_bf16", "instructions_per_32_point_tile": 288 if args.weights == "f32" else 195,
-                             "executed_tflops": (n * ((R + (128 // S) - 1) // (128 // S)) * 4 * (288 if args.weights == "f32" else 195) * 32768) / (k_ms * 1e-3) / 1e12,
-                             "peak_tflops": BF16_MFMA_PEAK_TFLOPS} if split else
-                            {"instruction": "v_mfma_f32_32x32x16_bf16", "instructions_per_64_point_round": 4 * (1185 if args.weights == "f32" else 807),
-                             "executed_tflops": (n * ((R + (64 // S) - 1) // (64 // S)) * 4 * (1185 if args.weights == "f32" else 807) * 32768) / (k_ms * 1e-3) / 1e12,
-                             "peak_tflops": BF16_MFMA_PEAK_TFLOPS} if ws else None),
             "preheat": {"ms": args.preheat_ms, "steps": preheat_steps, "timed": False},
             "with_background": with_bg,
             "world": {"world_size": world, "devices": devices, "rccl": rccl_version},

@@ -13,7 +13,8 @@
  * Conventions
  *   - every pointer is a DEVICE pointer owned by the caller (PyTorch tensors in the Python host code);
  *     the library never allocates, frees or synchronises: it only enqueues kernels on `stream`
- *     (a hipStream_t passed as void*; NULL = the default stream);
+ *     (a hipStream_t passed as void*; NULL = the default stream of the CURRENT device).  A call runs on the device
+ *     that owns `stream`, whatever device is current on the calling thread (which is restored on return);
  *   - strides are in ELEMENTS; tensors may be the non-contiguous slices train.py:271-277 produces;
  *   - return value 0 = ok, negative = error; vmapstep_last_error() describes the last failure of the
  *     calling thread; no C++ exception crosses the ABI;
@@ -30,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VMAPSTEP_ABI_VERSION 4
+#define VMAPSTEP_ABI_VERSION 5
 #define VMAPSTEP_NUM_FC 14 /* field-MLP tensors per object, nn.Module.parameters() order (model.py:28-49) */
 
 #define VMAPSTEP_OK 0
@@ -53,21 +54,17 @@ extern "C" {
                                      float32-equivalent forward); other widths: the exact-fp32 kernels below               */
 #define VMAPSTEP_KERNEL_GEN 1     /* hidden 64..256: step_main_gen (one wave per 32-point tile)                      */
 #define VMAPSTEP_KERNEL_WIDE4 2   /* hidden 128/256: step_main_wide<4> (one tile per workgroup, four waves per tile) */
-#define VMAPSTEP_KERNEL_WIDE2 3   /* hidden 128/256: step_main_wide<2> (four tiles per workgroup, two waves per tile)*/
 #define VMAPSTEP_KERNEL_H32_F32 4 /* hidden 32: step_main_h32 on the exact-fp32 matrix instruction instead of the default
                                      step_main_s32 (bf16 matrix pipe, split operands, float32-equivalent forward)      */
 #define VMAPSTEP_KERNEL_WS1 5     /* hidden 64 / 128: step_main_ws (one wave per output block; the default at hidden 128)            */
 #define VMAPSTEP_KERNEL_WP 6      /* hidden 64 / 128: step_main_wp (two waves per block, partial sums exchanged through LDS; the
                                      default at hidden 64)                                                               */
-#define VMAPSTEP_KERNEL_S16_FWD 7 /* hidden 32, vmapstep_render only: forward on 16-point tiles, eight waves per workgroup
-                                     (measurement prototype of the two-tiles-per-SIMD design; training calls refuse it)      */
+/* (3 and 7 were measurement prototypes of earlier versions - step_main_wide<2>, 16-point forward tiles - and are refused.) */
 typedef struct vmapstep_tuning {
     int32_t workgroups_per_object; /* 0 = automatic (256 / n_obj, at most one per ray group)                      */
     int32_t kernel;                /* VMAPSTEP_KERNEL_*                                                           */
     int32_t generic_finalize;      /* 1: step_finalize instead of the table-driven step_finalize_h32 (A/B parity) */
-    int32_t carried_finalize;      /* 1: hidden 32, all workgroups resident: step i's launch finishes step i-1
-                                      (bit-identical, measured slower: DESIGN.md 6b); default off                 */
-    uint32_t* carry_stamps;        /* diagnostics: device buffer [workgroups][8] for the carried prologue, or NULL */
+    int32_t reserved;              /* 0                                                                           */
 } vmapstep_tuning;
 
 typedef struct vmapstep_shape {
@@ -117,6 +114,10 @@ typedef struct vmapstep_outputs {
     float* render_color;  /* [n,R,3]  optional: loss.py:30                                        */
     float* opacity;       /* [n,R]    optional: loss.py:31                                        */
     float* var;           /* [n,R]    optional: loss.py:28-29                                     */
+    float* loss_terms;    /* [n,4]    optional, last step only: per object the depth, colour and opacity terms BEFORE their
+                             weights (render_rays.py:87's three reductions) and l_batch = depth + colour_scaling * colour +
+                             opacity_scaling * opacity (loss.py:59).  A ray-sharded caller sums them over ranks together
+                             with the gradients and hands the sums to vmapstep_adamw_apply.                              */
 } vmapstep_outputs;
 
 /* torch.optim.AdamW hyper-parameters + state for the fused update (train.py:67, :325). */
@@ -184,10 +185,18 @@ int vmapstep_fwd_bwd_prepared(const vmapstep_shape* shape, const vmapstep_params
 /* torch.optim.AdamW's update of `params` from EXTERNALLY provided gradients (train.py:325 for a model whose gradients
  * were summed over ranks by the caller: the shared background model, train.py:308-316): `grad_slab` holds, per object,
  * the gradients in flat parameter order (the 14 field tensors then B_layer.weight), one row of grad_stride =
- * padded_params floats (vmapstep_param_layout) per object, 16-byte aligned.  Also rewrites the packed parameter image in `workspace`, so that the next
- * vmapstep_fwd_bwd_prepared of the frame reads the updated weights.  opt->step = updates already applied. */
+ * padded_params floats (vmapstep_param_layout) per object, 16-byte aligned.  Also rewrites the packed parameter image in
+ * `workspace`, so that the next vmapstep_fwd_bwd_prepared of the frame reads the updated weights.  opt->step = updates
+ * already applied.
+ * `loss_terms` (optional, [n][4] as written by vmapstep_outputs::loss_terms and summed over ranks): the same launch then
+ * also produces the step's GLOBAL result - out->loss[0] = sum of l_batch over objects (loss.py:60) and out->flags[0..3] =
+ * the (already reduced) empty-mask switches of step `step_index` of the prepared frame + the "loss explode" test of
+ * render_rays.py:88-90 on the summed terms - so a ray-sharded step needs no launch besides forward/backward, the
+ * collective and this one. */
 int vmapstep_adamw_apply(const vmapstep_shape* shape, const vmapstep_params* params, const float* grad_slab,
-                         int64_t grad_stride, const vmapstep_adamw* opt, void* workspace, size_t workspace_bytes, void* stream);
+                         int64_t grad_stride, const vmapstep_adamw* opt, const float* loss_terms, int32_t step_index,
+                         float color_scaling, float opacity_scaling, const vmapstep_outputs* out,
+                         void* workspace, size_t workspace_bytes, void* stream);
 int vmapstep_train_steps_prepared(const vmapstep_shape* shape, const vmapstep_params* params,
                                   const vmapstep_tensor* pe_scale, const vmapstep_batch* frame, int64_t ray_step,
                                   int32_t n_steps, float color_scaling, float opacity_scaling,
@@ -249,10 +258,11 @@ int vmapstep_query_points(int32_t hidden, const vmapstep_params* params, const v
                           const float* points, int64_t n_points, const int64_t points_stride[2],
                           float* occupancy, float* color, void* workspace, size_t workspace_bytes, void* stream);
 
-/* Measurement hook: vmapstep_train_steps with a pair of events around every launch of the dominant kernel, in the real
- * step sequence (prep, then main / finalize alternating); waits for the device and returns the average durations in
- * milliseconds: main_kernel_ms[0] = the raw event-pair time (what a rocprofv3 kernel trace of the same run reports,
- * and what bench.py's roofline uses), main_kernel_ms[1] = the same minus the cost of an empty event pair. */
+/* Measurement hook: vmapstep_train_steps with every launch of the dominant kernel timed in the real step sequence (prep,
+ * then main / finalize alternating); waits for the device and returns average durations in milliseconds:
+ * main_kernel_ms[0] = the dispatch's own begin -> end timestamps (events attached to the launch with hipExtLaunchKernel:
+ * what a rocprofv3 kernel trace of the same run reports per dispatch, and what bench.py's roofline uses),
+ * main_kernel_ms[1] = a pair of stream events recorded around the launch (includes the cost of the events themselves). */
 int vmapstep_profile_train_steps(const vmapstep_shape* shape, const vmapstep_params* params, const vmapstep_tensor* pe_scale,
                                  const vmapstep_batch* frame, int64_t ray_step, int32_t n_steps,
                                  float color_scaling, float opacity_scaling, const vmapstep_adamw* opt,

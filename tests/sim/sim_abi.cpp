@@ -8,7 +8,6 @@
 #include "split_kernels.h"
 #include "wsplit_kernels.h"
 #include "wpair_kernels.h"
-#include "split16_kernels.h"
 #include "sample_kernels.h"
 #include "query_kernels.h"
 
@@ -23,7 +22,7 @@ extern "C" int vmsim_lds_bytes() { return vk::Lds32::BYTES; }
 static int g_wide = 0;
 extern "C" void vmsim_set_wide(int w) { g_wide = w; }
 static int g_split = 0;
-extern "C" void vmsim_set_split(int on) { g_split = on; }   // hidden 32: 1 = step_main_s32 (split-bf16 matrix pipe) instead of step_main_h32   // hidden 128 / 256: 1 = step_main_wide<4> (G * S <= 32), 2 = step_main_wide<2>
+extern "C" void vmsim_set_split(int on) { g_split = on; }   // hidden 32: 1 = step_main_s32 (split-bf16 matrix pipe) instead of step_main_h32   
 
 // fc[t]: [n][size_t] contiguous; grads: flat slab [n][P] in natural order (14 field tensors then B).
 extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req, int xcd_affine, int weights_bf16,
@@ -49,8 +48,6 @@ extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req, int xcd
     std::vector<int> fl(4, -1);
     const vk::GenLayout GL = vk::gen_layout(H);
     const bool split = g_split && H == 32;
-    const bool s16 = g_split == 2 && H == 32;                // step_main_s16_fwd (forward-only prototype)
-    if (s16 && bwd) return -4;
     const bool wp = g_wide == 4 && (H == 128 || H == 64);    // step_main_wp (two waves per output block)
     const bool ws = (g_wide == 3 || g_wide == 4) && (H == 128 || H == 64);    // step_main_ws / _wp (split-bf16 matrix pipe, hidden 128 / 64)
     if (ws && G * S > vk::ImgWs<4>::kPts) return -3;
@@ -82,8 +79,7 @@ extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req, int xcd
         wa.s = a; wa.scratch = ws_scratch.data(); wa.tab_wt = tab_wt.data();
         if (H == 128) sim::launch(1 + n * vk::ws_pack_blocks<4>(), vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep_ws<4>(wa); });
         else sim::launch(1 + n * vk::ws_pack_blocks<2>(), vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep_ws<2>(wa); });
-    } else if (s16) sim::launch(1 + n * vk::kPack16Blocks, vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep_s16(a); });
-    else if (split) sim::launch(1 + n * vk::kSplitPackBlocks, vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep_s32(a); });
+    } else if (split) sim::launch(1 + n * vk::kSplitPackBlocks, vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep_s32(a); });
     else sim::launch(1 + n * (vk::gen_layout(H).imgp / 1024), vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep(a); });
     const bool multi = NW < NG;
     const int grid = xcd_affine && H == 32 ? 8 * ((n + 7) / 8) * NW : n * NW;
@@ -123,10 +119,6 @@ extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req, int xcd
             if (bwd) sim::launch(n * NW, vk::kWG, lb, [&] { vk::step_main_ws<2, true, true>(wa); });
             else     sim::launch(n * NW, vk::kWG, lb, [&] { vk::step_main_ws<2, false, true>(wa); });
         }
-    } else if (s16) {
-        const int lb = vk::Img16::LDS_BYTES;
-        if (weights_bf16) sim::launch(n * NW, vk::kWG16, lb, [&] { vk::step_main_s16_fwd<false>(a); });
-        else sim::launch(n * NW, vk::kWG16, lb, [&] { vk::step_main_s16_fwd<true>(a); });
     } else if (split) {
         const int lb = vk::Img32s::LDS_BYTES;
         if (weights_bf16) {
@@ -154,12 +146,6 @@ extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req, int xcd
             const int lb = vk::LdsWide<4>::bytes(GL.small_n);
             if (bwd) sim::launch(n * NW, 256, lb, [&] { vk::step_main_wide<true, 4>(ga); });
             else     sim::launch(n * NW, 256, lb, [&] { vk::step_main_wide<false, 4>(ga); });
-        } else if (g_wide == 2) {
-            if (H % 128 != 0) return -3;
-            ga.s.wide = 2;
-            const int lb = vk::LdsWide<2>::bytes(GL.small_n);
-            if (bwd) sim::launch(n * NW, 512, lb, [&] { vk::step_main_wide<true, 2>(ga); });
-            else     sim::launch(n * NW, 512, lb, [&] { vk::step_main_wide<false, 2>(ga); });
         } else if (bwd) sim::launch(n * NW, vk::kWG, vk::LdsGen::bytes(GL.small_n), [&] { vk::step_main_gen<true>(ga); });
         else     sim::launch(n * NW, vk::kWG, vk::LdsGen::bytes(GL.small_n), [&] { vk::step_main_gen<false>(ga); });
     }
@@ -185,7 +171,7 @@ extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req, int xcd
     const int bpo = (PP / 4 + vk::kWG - 1) / vk::kWG;
     if (ws && bwd) {
         // one finalize for the gradients the tests look at and / or the AdamW update (as the library launches it)
-        vk::CarryHot h{};
+        vk::FinalizeHot h{};
         h.m = f.m; h.v = f.v; h.part_grad = f.part_grad; h.wimg = f.wimg; h.img_tab = img_tab.data();
         h.NW = f.NW; h.PP = f.PP; h.weights_bf16 = f.weights_bf16;
         h.decay = f.decay; h.one_minus_beta1 = f.one_minus_beta1; h.beta2 = f.beta2; h.one_minus_beta2 = f.one_minus_beta2;
@@ -204,7 +190,7 @@ extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req, int xcd
             sim::launch(n * bpo + 1, vk::kWG, 2 * vk::kWG * 4, [&] { vk::step_finalize(fg); });
             for (int t = 0; t < 15; ++t) f.grad[t] = {nullptr, P};
         }
-        vk::CarryHot h{};
+        vk::FinalizeHot h{};
         h.m = f.m; h.v = f.v; h.part_grad = f.part_grad; h.wimg = f.wimg; h.img_tab = img_tab.data();
         h.slab = p_out; h.slab_stride = P;
         h.NW = f.NW; h.PP = f.PP; h.weights_bf16 = f.weights_bf16;

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in _declared_functions():
         assert hasattr(lib, name), name
-    assert lib.vmapstep_abi_version() == 4
+    assert lib.vmapstep_abi_version() == 5
 
 
 @pytest.mark.parametrize("H", [32, 64, 128, 256])
@@ -55,7 +55,7 @@ def test_workspace_and_error_reporting():
 
 
 def test_tuning_is_per_call_state_not_library_state():
-    """ABI v4: the plan overrides travel in vmapstep_shape::tuning; the library holds no tuning state, so sizing the
+    """The plan overrides travel in vmapstep_shape::tuning (since ABI v4); the library holds no tuning state, so sizing the
     workspace for one operator cannot change the plan of another."""
     lib = _lib.load()
     auto, tuned = ctypes.c_size_t(), ctypes.c_size_t()
@@ -69,9 +69,10 @@ def test_tuning_is_per_call_state_not_library_state():
     again = ctypes.c_size_t()
     assert lib.vmapstep_workspace_bytes(ctypes.byref(sh), 20, ctypes.byref(again)) == 0
     assert again.value == auto.value                             # ... and nothing of it stuck to the library
-    bad = _lib.Tuning(kernel=17)
-    sh2.tuning = ctypes.pointer(bad)
-    assert lib.vmapstep_workspace_bytes(ctypes.byref(sh2), 20, ctypes.byref(tuned)) == -1
+    for k in (17, 7):                  # 7: a measurement prototype of ABI v4 (16-point forward tiles), no longer in the library
+        bad = _lib.Tuning(kernel=k)
+        sh2.tuning = ctypes.pointer(bad)
+        assert lib.vmapstep_workspace_bytes(ctypes.byref(sh2), 20, ctypes.byref(tuned)) == -1
     assert not hasattr(lib, "vmapstep_set_workgroups_per_object")
 
 
@@ -105,3 +106,14 @@ def test_kernel_choice_per_width_shows_in_the_workspace_plan():
     for sh in (_lib.Shape(4, 120, 10, 32, 0), _lib.Shape(1, 100, 14, 256, 0), _lib.Shape(1, 8, 100, 128, 0)):
         assert need(sh, _lib.KERNEL_WS1)[0] != 0
         assert b"WS1" in lib.vmapstep_last_error()
+
+
+def test_adamw_apply_checks_its_arguments_without_a_device():
+    """vmapstep_adamw_apply (ABI v5: + reduced loss terms, step index, outputs): null / inconsistent arguments are refused
+    before anything is enqueued."""
+    lib = _lib.load()
+    sh = _lib.Shape(1, 150, 14, 128, 0)
+    assert lib.vmapstep_adamw_apply(ctypes.byref(sh), None, None, 0, None, None, 0, 5.0, 10.0, None, None, 0, None) == -1
+    assert b"params" in lib.vmapstep_last_error()
+    assert lib.vmapstep_adamw_apply(ctypes.byref(sh), None, None, 0, None, None, -1, 5.0, 10.0, None, None, 0, None) == -1
+    assert b"step_index" in lib.vmapstep_last_error()

@@ -12,17 +12,17 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VMAPSTEP_LIBRARY", os.path.join(_HERE, "libvmapstep.so"))   # override: measurement builds only
 
 NUM_FC = 14
-ABI_VERSION = 4
+ABI_VERSION = 5
 WEIGHTS_F32, WEIGHTS_BF16 = 0, 1
 
 
-KERNEL_AUTO, KERNEL_GEN, KERNEL_WIDE4, KERNEL_WIDE2, KERNEL_H32_F32, KERNEL_WS1, KERNEL_WP, KERNEL_S16_FWD = 0, 1, 2, 3, 4, 5, 6, 7
+KERNEL_AUTO, KERNEL_GEN, KERNEL_WIDE4, KERNEL_H32_F32, KERNEL_WS1, KERNEL_WP = 0, 1, 2, 4, 5, 6
 
 
 class Tuning(ctypes.Structure):
     """vmapstep_tuning: measurement / test overrides of the automatic launch plan, passed per call through Shape.tuning."""
     _fields_ = [("workgroups_per_object", ctypes.c_int32), ("kernel", ctypes.c_int32), ("generic_finalize", ctypes.c_int32),
-                ("carried_finalize", ctypes.c_int32), ("carry_stamps", ctypes.c_void_p)]
+                ("reserved", ctypes.c_int32)]
 
 
 class Shape(ctypes.Structure):
@@ -52,7 +52,8 @@ class Batch(ctypes.Structure):
 
 class Outputs(ctypes.Structure):
     _fields_ = [("loss", ctypes.c_void_p), ("flags", ctypes.c_void_p), ("render_depth", ctypes.c_void_p),
-                ("render_color", ctypes.c_void_p), ("opacity", ctypes.c_void_p), ("var", ctypes.c_void_p)]
+                ("render_color", ctypes.c_void_p), ("opacity", ctypes.c_void_p), ("var", ctypes.c_void_p),
+                ("loss_terms", ctypes.c_void_p)]
 
 
 class AdamW(ctypes.Structure):
@@ -128,7 +129,8 @@ def load():
                                               ctypes.POINTER(Batch), ctypes.c_int32, ctypes.c_float, ctypes.c_float, ctypes.POINTER(Params),
                                               ctypes.POINTER(Outputs), ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
     lib.vmapstep_adamw_apply.argtypes = [ctypes.POINTER(Shape), ctypes.POINTER(Params), ctypes.c_void_p, ctypes.c_int64,
-                                         ctypes.POINTER(AdamW), ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+                                         ctypes.POINTER(AdamW), ctypes.c_void_p, ctypes.c_int32, ctypes.c_float, ctypes.c_float,
+                                         ctypes.POINTER(Outputs), ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
     lib.vmapstep_workspace_counts_offset.argtypes = [ctypes.POINTER(Shape), ctypes.c_int32, ctypes.POINTER(ctypes.c_size_t)]
     lib.vmapstep_sample_frame.argtypes = [ctypes.POINTER(SampleCfg), ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,

@@ -1,0 +1,58 @@
+// k_ws.hip - hidden 64 / 128 on the bf16 matrix pipe, one wave per output block (wsplit_kernels.h): step_prep_ws,
+// step_main_ws, step_finalize_ws (the last two also serve step_main_wp).  The background model's path.  gfx950 only.
+#include "launch.h"
+#include "wsplit_kernels.h"
+
+namespace vl {
+
+namespace {
+template <int NB, bool BWD, bool W3, bool STAMPS>
+int main_v(const vk::StepArgs& a, hipStream_t st) {
+    using I = vk::ImgWs<NB>;
+    auto kern = vk::step_main_ws<NB, BWD, W3, STAMPS>;
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), I::LDS_BYTES, "step_main_ws")) return rc;
+    vk::WsArgs ga;
+    ga.s = a;
+    ga.scratch = reinterpret_cast<char*>(a.gen_scratch);
+    ga.tab_wt = a.tab_wt;
+    VL_LAUNCH_MAIN(kern, dim3(a.n_obj * a.NW), dim3(vk::kWG), I::LDS_BYTES, st, ga);
+    return launched("step_main_ws");
+}
+template <int NB>
+int main_nb(const vk::StepArgs& a, bool bwd, bool stamps, hipStream_t st) {
+    if (stamps) return main_v<NB, true, true, true>(a, st);
+    if (a.weights_bf16) return bwd ? main_v<NB, true, false, false>(a, st) : main_v<NB, false, false, false>(a, st);
+    return bwd ? main_v<NB, true, true, false>(a, st) : main_v<NB, false, true, false>(a, st);
+}
+}  // namespace
+
+int main_ws(const vk::StepArgs& a, bool bwd, bool stamps, hipStream_t st) {
+    return a.hidden == 128 ? main_nb<4>(a, bwd, stamps, st) : main_nb<2>(a, bwd, stamps, st);
+}
+
+int prep_ws(const vk::StepArgs& a, int n_steps, hipStream_t st) {
+    vk::WsArgs ga;
+    ga.s = a;
+    ga.s.prep_steps = n_steps;
+    ga.scratch = reinterpret_cast<char*>(a.gen_scratch);
+    ga.tab_wt = a.tab_wt;
+    // parameters without a place in the W^T image (biases, heads, B) keep -1 in its table
+    hipError_t e = hipMemsetAsync(a.tab_wt, 0xFF, (size_t)a.PP * sizeof(int), st);
+    if (e != hipSuccess) return fail(-4, "hipMemsetAsync(tab_wt): %s", hipGetErrorString(e));
+    if (a.hidden == 128)
+        hipLaunchKernelGGL(vk::step_prep_ws<4>, dim3(n_steps + a.n_obj * vk::ws_pack_blocks<4>()), dim3(vk::kWG), 3 * vk::kWG * sizeof(int), st, ga);
+    else
+        hipLaunchKernelGGL(vk::step_prep_ws<2>, dim3(n_steps + a.n_obj * vk::ws_pack_blocks<2>()), dim3(vk::kWG), 3 * vk::kWG * sizeof(int), st, ga);
+    return launched("step_prep_ws");
+}
+
+int finalize_ws(const vk::FinalizeArgs& f, const vk::FinalizeHot& h, const int* tab_wt, hipStream_t st) {
+    const int grid = f.n_obj * vk::ws_finalize_blocks(f.PP) + 1;
+    if (f.hidden == 128)
+        hipLaunchKernelGGL(vk::step_finalize_ws<4>, dim3(grid), dim3(vk::kWG), 4 * vk::kWG * sizeof(float), st, f, h, tab_wt);
+    else
+        hipLaunchKernelGGL(vk::step_finalize_ws<2>, dim3(grid), dim3(vk::kWG), 4 * vk::kWG * sizeof(float), st, f, h, tab_wt);
+    return launched("step_finalize_ws");
+}
+
+}  // namespace vl

@@ -32,13 +32,7 @@
 #pragma once
 #include "step_kernels.h"
 
-// Measurement builds only (tests/tools/build_exp.sh; results are WRONG with any of these defined):
-//   VS_EXP_NOBARRIER  the backward's workgroup barriers removed    VS_EXP_NOFIN  no staging / finishing of weight-gradient blocks
-#if defined(VS_EXP_NOBARRIER)
-#define VS_BWD_BARRIER() do {} while (0)
-#else
 #define VS_BWD_BARRIER() __syncthreads()
-#endif
 
 namespace vk {
 
@@ -181,6 +175,7 @@ __device__ __forceinline__ void split_image_store(char* img, int loc, float p, i
 constexpr int kSplitPackBlocks = (Img32s::ELEMS / 4 + kWG - 1) / kWG;       // 13
 static_assert(kSplitPackBlocks * kWG - Img32s::ELEMS / 4 >= 64, "room for the small-vector threads");
 
+template <int = 0>
 __global__ __launch_bounds__(kWG) void step_prep_s32(const StepArgs a) {
     using I = Img32s;
     const int tid = threadIdx.x;
@@ -234,7 +229,7 @@ __global__ __launch_bounds__(kWG) void step_prep_s32(const StepArgs a) {
 // step_finalize_s32: step_finalize_h32 (same sums in the same order, same adamw_elem) writing the split image
 // ---------------------------------------------------------------------------------------------------------
 template <bool SLAB>
-__device__ __forceinline__ void finalize_quad_s32(const FinalizeArgs& f, const CarryHot& a, int obj, int q) {
+__device__ __forceinline__ void finalize_quad_s32(const FinalizeArgs& f, const FinalizeHot& a, int obj, int q) {
     typedef int i32x4 __attribute__((ext_vector_type(4)));
     const long long s = (long long)obj * a.PP + 4 * q;
     const wv::f32x4* pg = reinterpret_cast<const wv::f32x4*>(a.part_grad + (long long)obj * a.NW * a.PP + 4 * q);
@@ -286,7 +281,8 @@ __device__ __forceinline__ void finalize_quad_s32(const FinalizeArgs& f, const C
     *reinterpret_cast<wv::f32x4*>(a.v + s) = v4;
 }
 
-__global__ __launch_bounds__(kWG) void step_finalize_s32(const FinalizeArgs a, const CarryHot hh) {
+template <int = 0>
+__global__ __launch_bounds__(kWG) void step_finalize_s32(const FinalizeArgs a, const FinalizeHot hh) {
     const int quads = a.PP / 4;
     const int blocks_per_obj = (quads + kWG - 1) / kWG;
     if (blockIdx.x == gridDim.x - 1) {
@@ -513,11 +509,7 @@ __device__ __forceinline__ void col_target(int blk, int k, int& col, bool& bias)
     col = c >= 0 ? c : -1;
 }
 // this wave's quarter (rows 8 wave + 4 hi + i) of a reduced block -> the workgroup's partial gradients
-#ifdef VS_EXP_TEMPORAL      // measurement build: partial gradients through the normal L2 write policy
-#define VS_PARTIAL_STORE(v, p) (*(p) = (v))
-#else
 #define VS_PARTIAL_STORE(v, p) __builtin_nontemporal_store((v), (p))
-#endif
 template <int K>
 __device__ __forceinline__ void store_quarter_map(float* out_w, float* out_b, const float (&q)[4], int col, bool bias, int ncols,
                                                   int wave, int hi) {
@@ -825,12 +817,10 @@ __device__ __forceinline__ void step_main_s32_body(const StepArgs& a) {
     split_planes<24, 3>(e2, e2h, e2m, e2l);
     VS_MARK(2);
     __syncthreads();        // parameter image landed (the barrier drains the LDS-DMA), composite buffer zeroed
-#ifndef VS_NO_RAY_PREFETCH
     // ground truth of the ray this lane composites: its six vector loads fly during the MLP forward (at the compositing they
     // cost a full memory round trip of an otherwise idle workgroup)
     const RayMeta rays_meta = load_ray_meta_rays(a, obj, ray0 + min(4 * wave + (lane >> 4), nrays - 1));
     wv::sched_fence();
-#endif
 
     // ---- field MLP forward (model.py:59-83) ----
     unsigned h1h[8], h1m[8], h2h[8], h2m[8], h3h[8], h3m[8], h4h[8], h4m[8];
@@ -897,11 +887,7 @@ __device__ __forceinline__ void step_main_s32_body(const StepArgs& a) {
     {
         const StepArgs& al = wv::kernarg_late(a);
         composite_phase<BWD>(al, cb, loss_cells, obj, ray0, nrays, wave, lane, tid,
-#ifndef VS_NO_RAY_PREFETCH
                              finish_ray_meta(al, obj, rays_meta));
-#else
-                             load_ray_meta(al, obj, ray0 + min(4 * wave + (lane >> 4), nrays - 1)));
-#endif
     }
     __syncthreads();
     VS_MARK(6);
@@ -968,15 +954,11 @@ __device__ __forceinline__ void step_main_s32_body(const StepArgs& a) {
     unsigned d3h[8], d3m[8], d2h[8], d2m[8], d1h[8], d1m[8], dF3[16], dF1[16];
     constexpr int NA = kDpropMM(W3);
     const auto nothing = [](int) {};
-#if defined(VS_EXP_NOFIN)
-#define VS_FIN(KIND, K, QI, STG, OW, OB, BLK, NC) [&](int) {}
-#else
 #define VS_FIN(KIND, K, QI, STG, OW, OB, BLK, NC)                                                                             \
     [&](int i) {                                                                                                              \
         if (i == 0) fin_chunk<KIND, K, MULTI>(0, fs, qacc[QI], STG, OW, OB, BLK, NC, wave, p31, hi);                          \
         if (i == NA - 3) fin_chunk<KIND, K, MULTI>(1, fs, qacc[QI], STG, OW, OB, BLK, NC, wave, p31, hi);                     \
     }
-#endif
     tile_put<4>(scrD, dch, dcm, p31, hi);
     tile_put<4>(scrX, h4h, h4m, p31, hi);
     wt_get<I::PIT_C, W3>(wA, W + I::O_C, 0, TL);

@@ -73,7 +73,6 @@ struct StepArgs {
     int hidden;                        // H (step_prep packs with gen_layout(hidden); step_main_h32 requires 32)
     int weights_bf16;                  // 1: the parameter image holds the masters rounded to bfloat16 (RNE)
     int wide;                          // 1: step_main_wide (tile per workgroup, G*S <= 32) instead of step_main_gen; 3: step_main_ws (wsplit_kernels.h)
-    unsigned* carry_cnt;               // step_prep: [n_obj][2] hand-off counters of the carried finalize, zeroed per frame
     int* img_tab;                      // step_prep: [PP] flat parameter -> image position table (or null)
     int split;                         // 1: hidden 32 on the split-bf16 kernels (split_kernels.h); wimg is then the byte image of Img32s
     float* gen_scratch;                // step_main_gen / step_main_wide: per-wave (per-workgroup) register-image scratch (workspace)
@@ -126,8 +125,7 @@ struct Lds32 {
     static constexpr int VEC = STG + 2 * kWaves * STG_TILE;   // per-wave private small-vector gradient accumulators
     static constexpr int CB = VEC + kWaves * SMALL_N;         // composite buffer [kMaxPts][8]
     static constexpr int LOSS = CB + kMaxPts * 8;             // per-wave loss partials [kWaves][4]
-    static constexpr int BS = LOSS + kWaves * 4;              // B_layer.weight of the current step (carried finalize only)
-    static constexpr int TOTAL = BS + 64;
+    static constexpr int TOTAL = LOSS + kWaves * 4;
     static constexpr int BYTES = TOTAL * 4;
 };
 static_assert(Lds32::BYTES <= 160 * 1024, "LDS budget");
@@ -834,8 +832,6 @@ __device__ __forceinline__ void prep_stats(const StepArgs& a, int step, int tabl
     float* lds = wv::lds_base();
     int* dropw = reinterpret_cast<int*>(lds);          // [kWaves]
     const int lane = tid & 63, wave = tid >> 6;
-    if (step == 0 && a.carry_cnt)
-        for (int i = tid; i < 2 * a.n_obj; i += kWG) a.carry_cnt[i] = 0u;
     if (step == 0 && a.img_tab) {                      // padding entries; the real ones are written by the pack blocks of object 0
         for (int i = table_len_P + tid; i < table_len_PP; i += kWG) a.img_tab[i] = 0;
     }
@@ -876,6 +872,7 @@ __device__ __forceinline__ void prep_stats(const StepArgs& a, int step, int tabl
     }
 }
 
+template <int = 0>
 __global__ __launch_bounds__(kWG) void step_prep(const StepArgs a) {
     const int tid = threadIdx.x;
     if ((int)blockIdx.x >= a.prep_steps) {
@@ -910,9 +907,7 @@ __global__ __launch_bounds__(kWG) void step_prep(const StepArgs a) {
 // written to the parameter tensor AND to the packed image the next step's step_main stages from), the scalar
 // loss (loss.py:59-60) and the "loss explode" flag (render_rays.py:88-90).
 // The two halves are device functions (finalize_quad: four consecutive flat parameters of one object;
-// finalize_loss: the loss / flag reduction of one workgroup) because they run in two places: the stand-alone
-// step_finalize kernel, and the prologue of step_main_h32_carry, where every workgroup of step i first finishes its
-// share of step i-1 ("carried finalize", see there).
+// finalize_loss: the loss / flag reduction of one workgroup) shared by the finalize kernels of all widths.
 // ---------------------------------------------------------------------------------------------------------
 struct FinalizeArgs {
     int n_obj, NW, PP, P;              // NW partials per object; P = real parameter count per object (flat order: 14 field tensors, then B)
@@ -926,6 +921,7 @@ struct FinalizeArgs {
     const float* part_grad; const float* part_loss;
     const int* flags_in; int* flags_out;
     float* loss_out;                   // [1]
+    float* terms_out;                  // optional [n_obj][4]: per-object depth / colour / opacity terms (unweighted) and l_batch (loss.py:59)
     float color_w, opac_w;
     int do_adam;
     int have_grad;                     // 0: forward-only call, skip the gradient/optimiser part
@@ -935,7 +931,7 @@ struct FinalizeArgs {
 };
 
 // torch.optim.AdamW, single-tensor form, one element
-template <class Consts>      // FinalizeArgs or CarryHot: same field names
+template <class Consts>      // FinalizeArgs or FinalizeHot: same field names
 __device__ __forceinline__ void adamw_elem(const Consts& a, float ge, float& p, float& m, float& v) {
     // every operation rounded on its own, like the eager tensor ops it restates - and so that the two places this is
     // inlined into (step_finalize, the carried finalize) cannot end up with different fused forms
@@ -1032,7 +1028,9 @@ __device__ __forceinline__ void finalize_loss(const FinalizeArgs& a) {
             ld += pl[0]; lc += pl[1]; lo += pl[2];
         }
         explode |= (ld > 100000.0f) || (lc > 100000.0f) || (lo > 100000.0f);   // render_rays.py:88
-        loss += ld + lc * a.color_w + lo * a.opac_w;                            // loss.py:59
+        const float lb = ld + lc * a.color_w + lo * a.opac_w;                   // loss.py:59
+        loss += lb;
+        if (a.terms_out) { a.terms_out[4 * k] = ld; a.terms_out[4 * k + 1] = lc; a.terms_out[4 * k + 2] = lo; a.terms_out[4 * k + 3] = lb; }
     }
     red[threadIdx.x] = loss;
     redi[threadIdx.x] = explode;
@@ -1052,39 +1050,16 @@ __device__ __forceinline__ void finalize_loss(const FinalizeArgs& a) {
     }
 }
 
-// Everything the carried pass of a workgroup reads in the common case (slab parameters), side by side in the kernel
-// argument segment: fetched with two wide scalar loads at the top of the kernel (the by-field accesses of FinalizeArgs
-// cost a dozen dependent scalar round trips, ~2 k cycles in front of the first vector load).
-struct CarryHot {
+// The fields the table-driven finalize kernels read per quad, side by side in the kernel argument segment (the by-field
+// accesses of FinalizeArgs cost a dozen dependent scalar round trips in front of the first vector load).
+struct FinalizeHot {
     float* m; float* v; const float* part_grad; float* wimg;
     const int* img_tab;                // [PP] image position of every flat parameter (step_prep)
     float* slab; long long slab_stride;   // non-null: the 15 parameter tensors are views of one [n, >= P] slab in flat order
                                        // (flat parameter i of object k at slab[k * slab_stride + i]): no per-element lookup
-    unsigned* cnt;                     // [n_obj][2], zeroed by step_prep; [1] += 1 per workgroup of the object whose slice is updated
     int NW, PP, weights_bf16;
-    unsigned epoch;                    // number of carrying launches since step_prep, this one included
     float decay, one_minus_beta1, beta2, one_minus_beta2, eps, step_size, bias_corr2_sqrt;
-    int pad;
 };
-__device__ __forceinline__ CarryHot load_hot(const CarryHot& src) {
-    // all fields are read HERE, in one basic block (adjacent scalar loads merge into wide ones; one wait)
-    static_assert(sizeof(CarryHot) % 16 == 0, "whole 16-byte words");
-    union { CarryHot h; unsigned w[sizeof(CarryHot) / 4]; } u;
-    u.h = src;
-#pragma unroll
-    for (int i = 0; i < (int)(sizeof(CarryHot) / 4); i += 4)
-        wv::touch_scalar4(u.w[i], u.w[i + 1], u.w[i + 2], u.w[i + 3]);
-    return u.h;
-}
-
-// what step_main_h32_carry needs on top of StepArgs: the finalize of the PREVIOUS step and the hand-off counters
-struct CarryArgs {
-    CarryHot h;
-    FinalizeArgs f;
-    unsigned* stamps;                  // diagnostics: [workgroups][8] shader-clock stamps of the prologue, or null
-};
-constexpr int kCarryMaxPolls = 1 << 18;   // ~0.3 s: a bound, not a tuning knob (see wv::wait_ge)
-
 // tensor index and offset inside it of flat parameter i (hidden 32, compile-time offsets)
 __device__ __forceinline__ void flat32_tensor_of(int i, int& t, int& o) {
     using F = Flat32;
@@ -1101,96 +1076,20 @@ __device__ __forceinline__ void flat32_tensor_of(int i, int& t, int& o) {
     o = i - base;
 }
 
-// One quad (flat parameters 4q .. 4q+3 of object obj) of the carried finalize: partial sums in step_finalize's order
-// (workgroup 0 .. NW-1), the update is adamw_elem.  Written for SIZE: this code runs once per launch with a cold
-// instruction cache (measured: ~14 cycles per instruction of straight-line code), so the caller keeps it in a rolled loop
-// and only the partial loads are batched.  store = false (the quads of B_layer.weight, which every workgroup of the
-// object recomputes from the old state for its own encoding): nothing is written, the caller gets (p4, m4, v4).
-template <bool SLAB>
-__device__ __forceinline__ void carry_quad(const CarryHot& a, const FinalizeArgs& f, int obj, int q, bool store,
-                                           wv::f32x4& p4, wv::f32x4& m4, wv::f32x4& v4, unsigned* stamp = nullptr) {
-    using L = Lds32;
-    typedef int i32x4 __attribute__((ext_vector_type(4)));
-    constexpr int NB = 6;              // partials in flight per batch
-    const long long s = (long long)obj * a.PP + 4 * q;
-    m4 = *reinterpret_cast<const wv::f32x4*>(a.m + s);
-    v4 = *reinterpret_cast<const wv::f32x4*>(a.v + s);
-    const i32x4 img = *reinterpret_cast<const i32x4*>(a.img_tab + 4 * q);
-    float* pp[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int i = min(4 * q + e, Flat32::P - 1);          // the one padding lane (index P) re-reads the last parameter
-        if (SLAB) {
-            pp[e] = a.slab + obj * a.slab_stride + i;
-        } else {
-            int t, o;
-            flat32_tensor_of(i, t, o);
-            pp[e] = f.param[t].p + obj * f.param[t].stride + o;
-        }
-        p4[e] = *pp[e];
-    }
-    if (stamp) stamp[1] = wv::clock32();
-    wv::f32x4 g = {0.0f, 0.0f, 0.0f, 0.0f};
-    const wv::f32x4* pg = reinterpret_cast<const wv::f32x4*>(a.part_grad + (long long)obj * a.NW * a.PP + 4 * q);
-    const long long qs = a.PP / 4;
-#pragma unroll 1
-    for (int q0 = 0; q0 < a.NW; q0 += NB) {
-        wv::f32x4 t[NB];
-#pragma unroll
-        for (int u = 0; u < NB; ++u) t[u] = pg[min(q0 + u, a.NW - 1) * qs];
-#pragma unroll
-        for (int u = 0; u < NB; ++u)
-            if (q0 + u < a.NW) g += t[u];
-    }
-    if (stamp) stamp[2] = wv::clock32();
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        float p = p4[e], m = m4[e], v = v4[e];
-        adamw_elem(a, g[e], p, m, v);
-        if (4 * q + e >= Flat32::P) { p = 0.0f; m = 0.0f; v = 0.0f; }     // padding lane of the PP-pitched slabs stays zero
-        p4[e] = p; m4[e] = m; v4[e] = v;
-        if (store) {
-            *pp[e] = p;
-            wv::store_wt(a.wimg + (long long)obj * L::IMGP + img[e], a.weights_bf16 ? round_bf16(p) : p);
-        }
-    }
-    if (store) {
-        *reinterpret_cast<wv::f32x4*>(a.m + s) = m4;
-        *reinterpret_cast<wv::f32x4*>(a.v + s) = v4;
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // step_main_h32
 // MULTI = a workgroup covers several ray groups (NW < NG): reduced gradient quarters persist in registers over
 // the passes and are stored once at the end; otherwise (one pass per workgroup) each quarter is stored as soon
 // as it is reduced and no accumulator registers are held.
 // ---------------------------------------------------------------------------------------------------------
-//
-// CARRY ("carried finalize", step_main_h32_carry): the launch of step i also finishes step i-1.  Every workgroup of
-// an object first sums its 1/NW share of the object's gradient partials of step i-1, applies AdamW and writes the
-// parameter tensors, the moments and (write-through) its slice of the parameter image, then signals a per-object
-// counter; it computes its encoding while the other workgroups of the object do the same, waits until all NW slices
-// are signalled and only then copies the image into LDS (L1-bypassing LDS-DMA).  Workgroup 0 of the object updates
-// B_layer.weight first (the encoding needs it) and signals it separately.  The stand-alone step_finalize launch and
-// one of the two kernel boundaries of a step disappear; arithmetic and summation order are those of step_finalize
-// (finalize_quad is the same code), so the result is bit-identical.  Requires every workgroup of the launch to be
-// resident at once (n_obj * NW <= CUs, one workgroup per CU) - the host falls back to the two-kernel form otherwise -
-// and the waits are bounded: a timeout raises flags[3] of the step instead of hanging the device.
-template <bool BWD, bool MULTI, bool STAMPS, bool CARRY>
-__device__ __forceinline__ void step_main_body(const StepArgs& a, const CarryArgs* cptr) {
+template <bool BWD, bool MULTI, bool STAMPS>
+__device__ __forceinline__ void step_main_body(const StepArgs& a) {
     using L = Lds32;
     using F = Flat32;
     constexpr int H = 32;
     float* lds = wv::lds_base();
     float* W = lds + L::WGT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p31 = lane & 31, hi = lane >> 5;
-    if constexpr (CARRY) {
-        if (blockIdx.x == gridDim.x - 1) {      // one extra workgroup: loss / flags of the previous step
-            finalize_loss(cptr->f);
-            return;
-        }
-    }
     float* Gv = lds + L::VEC + wave * L::SMALL_N - L::SMALL0;   // this wave's private small-vector gradients
     // Block -> (object, workgroup-of-object).  The dispatcher places block b on XCD b % 8 (measured: tests/tools/xcd_probe.hip,
     // profiles/r01m_xcd_probe.jsonl); with the
@@ -1210,55 +1109,6 @@ __device__ __forceinline__ void step_main_body(const StepArgs& a, const CarryArg
     unsigned* tmark = STAMPS && a.timing ? a.timing + ((long long)blockIdx.x * kWaves + wave) * kMarks : nullptr;
 #define VK_MARK(i) do { if constexpr (STAMPS) { if (tmark && lane == 0) tmark[i] = wv::clock32(); } } while (0)
     VK_MARK(0);
-    float* Bs = lds + L::BS;            // CARRY: B_layer.weight of this step (every workgroup updates it for itself)
-    wv::f32x4 carry_pB, carry_mB, carry_vB;
-    if constexpr (CARRY) {
-        static_assert(F::PE_B % 4 == 0, "the field tensors end on a 16-byte boundary of the flat order");
-        const CarryArgs& c = *cptr;
-        const CarryHot h = load_hot(c.h);
-        const GenLayout GL = gen_layout(H);
-        constexpr int QFC = F::PE_B / 4, QALL = (F::P + 3) / 4;      // quads of the 14 field tensors / of everything
-        const int Q = (QFC + a.NW - 1) / a.NW;
-        const int q_hi = min((wgo + 1) * Q, QFC);
-        unsigned* cnt = h.cnt + 2 * obj;
-        unsigned* stamp = c.stamps && tid == 0 ? c.stamps + 8 * blockIdx.x : nullptr;
-#define VK_CST(i) do { if (stamp) stamp[i] = wv::clock32(); } while (0)
-        VK_CST(0);
-        // items of this thread, one per trip of a ROLLED loop: field-tensor quads wgo*Q + tid + 256 r (r = 0, 1, ...),
-        // then - threads 240..255 only - one quad of B_layer.weight (every workgroup recomputes B for its own encoding;
-        // workgroup 0 stores it later).  A wave skips the trips none of its lanes takes part in.
-        wv::f32x4 pB = {0.0f, 0.0f, 0.0f, 0.0f}, mB = pB, vB = pB;
-        const bool b_thread = tid >= kWG - (QALL - QFC);
-        const int fc_trips = (q_hi - wgo * Q + kWG - 1) / kWG;
-#pragma unroll 1
-        for (int trip = 0; trip <= fc_trips; ++trip) {
-            const bool isB = trip == fc_trips;
-            const int q = isB ? QFC + tid - (kWG - (QALL - QFC)) : wgo * Q + trip * kWG + tid;
-            const bool on = isB ? b_thread : q < q_hi;
-            if (!wv::wave_any(on)) continue;
-            if (on) {
-                wv::f32x4 p4, m4, v4;
-                unsigned* st = trip == 0 ? stamp : nullptr;
-                if (h.slab) carry_quad<true>(h, c.f, obj, q, !isB, p4, m4, v4, st);
-                else carry_quad<false>(h, c.f, obj, q, !isB, p4, m4, v4, st);
-                if (isB) { pB = p4; mB = m4; vB = v4; }
-            }
-            if (stamp && trip < 2) stamp[3 + trip] = wv::clock32();
-        }
-        if (b_thread) {                                               // the new B for this step's encoding; its state for later
-            const int j = 4 * (tid - (kWG - (QALL - QFC)));
-#pragma unroll
-            for (int e = 0; e < 4; ++e) Bs[j + e] = h.weights_bf16 ? round_bf16(pB[e]) : pB[e];     // what the image will hold
-        }
-        wv::drain_vm();
-        __syncthreads();                                              // also: Bs visible to the workgroup
-        VK_CST(5);
-        if (tid == 0) wv::signal_add(cnt + 1);
-        // workgroup 0 of the object stores B's parameter, moments and image slots once nobody reads the old ones any more
-        // (after the wait below); until then they sit in registers of 16 lanes
-        carry_pB = pB; carry_mB = mB; carry_vB = vB;
-    }
-
     if (BWD) {
         for (int i = tid; i < kWaves * L::SMALL_N; i += kWG) lds[L::VEC + i] = 0.0f;
     }
@@ -1306,38 +1156,13 @@ __device__ __forceinline__ void step_main_body(const StepArgs& a, const CarryArg
     float proj[kDirs];
 #pragma unroll
     for (int d = 0; d < kDirs; ++d)        // embedding.py:84 B_layer(tensor); B straight from the global image (wave-uniform)
-        proj[d] = CARRY ? fmaf(t[2], Bs[3 * d + 2], fmaf(t[1], Bs[3 * d + 1], t[0] * Bs[3 * d]))
-                        : fmaf(t[2], Bg[3 * d + 2], fmaf(t[1], Bg[3 * d + 1], t[0] * Bg[3 * d]));
+        proj[d] = fmaf(t[2], Bg[3 * d + 2], fmaf(t[1], Bg[3 * d + 1], t[0] * Bg[3 * d]));
 
     // ---- first pass: start the asynchronous copy of the parameter image into LDS (lands during the encoding) ----
     if (grp == wgo) {
         const float* src = a.wimg + (long long)obj * L::IMGP + wave * 256 + lane * 4;
-        if constexpr (CARRY) {
-            // every slice of this object's image has been rewritten for this step once all NW workgroups have signalled
-            if (cptr->stamps && tid == 0) cptr->stamps[8 * blockIdx.x + 6] = wv::clock32();
-            if (tid == 0 && !wv::wait_ge(cptr->h.cnt + 2 * obj + 1, cptr->h.epoch * (unsigned)a.NW, kCarryMaxPolls)) a.flags[3] = 1;
-            __syncthreads();
-            if (cptr->stamps && tid == 0) cptr->stamps[8 * blockIdx.x + 7] = wv::clock32();
-            if (wgo == 0 && tid >= kWG - ((F::P + 3) / 4 - F::PE_B / 4)) {
-                const FinalizeArgs& f = cptr->f;
-                const int j = 4 * (tid - (kWG - ((F::P + 3) / 4 - F::PE_B / 4)));
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (j + e < 63) {
-                        f.param[kNFc].p[obj * f.param[kNFc].stride + j + e] = carry_pB[e];
-                        f.wimg[(long long)obj * L::IMGP + L::PE_B + j + e] = f.weights_bf16 ? round_bf16(carry_pB[e]) : carry_pB[e];
-                    }
-                }
-                const long long s = (long long)obj * f.PP + F::PE_B + j;
-                *reinterpret_cast<wv::f32x4*>(f.m + s) = carry_mB;
-                *reinterpret_cast<wv::f32x4*>(f.v + s) = carry_vB;
-            }
-#pragma unroll
-            for (int c = 0; c < L::DMA_ROUNDS; ++c) wv::glds16_wt(src + c * 1024, W + c * 1024 + wave * 256);
-        } else {
-#pragma unroll
-            for (int c = 0; c < L::DMA_ROUNDS; ++c) wv::glds16(src + c * 1024, W + c * 1024 + wave * 256);
-        }
+        for (int c = 0; c < L::DMA_ROUNDS; ++c) wv::glds16(src + c * 1024, W + c * 1024 + wave * 256);
     }
     VK_MARK(1);
 
@@ -1710,21 +1535,15 @@ __device__ __forceinline__ void step_main_body(const StepArgs& a, const CarryArg
 
 template <bool BWD, bool MULTI, bool STAMPS = false>      // STAMPS: the phase-clock instantiation (vmapstep_profile_phases)
 __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
-    step_main_body<BWD, MULTI, STAMPS, false>(a, nullptr);
+    step_main_body<BWD, MULTI, STAMPS>(a);
 }
-// training step i >= 1 of a frame with the finalize of step i-1 carried in its prologue (grid = step_main_h32's + 1)
-template <bool MULTI>
-__global__ __launch_bounds__(kWG, 1) void step_main_h32_carry(const StepArgs a, const CarryArgs c) {
-    step_main_body<true, MULTI, false, true>(a, &c);
-}
-
 // finalize_quad for hidden 32 in the common case (AdamW on, no gradient output): the image position of a flat parameter
 // comes from the table step_prep wrote (img_tab) and the parameter address from compile-time offsets - or from one slab
 // base - instead of fifteen runtime comparisons and the integer divisions of gen_image_index per element.  Same sums in
 // the same order, same adamw_elem: bit-identical to finalize_quad (measured: step_finalize spent its 6.4 us issuing
 // ~1000 instructions per thread on 3.5 waves per SIMD, not waiting for memory).
 template <bool SLAB>
-__device__ __forceinline__ void finalize_quad_h32(const FinalizeArgs& f, const CarryHot& a, int obj, int q) {
+__device__ __forceinline__ void finalize_quad_h32(const FinalizeArgs& f, const FinalizeHot& a, int obj, int q) {
     using L = Lds32;
     typedef int i32x4 __attribute__((ext_vector_type(4)));
     const long long s = (long long)obj * a.PP + 4 * q;
@@ -1778,7 +1597,8 @@ __device__ __forceinline__ void finalize_quad_h32(const FinalizeArgs& f, const C
 
 // step_finalize for hidden 32, AdamW on, gradients not wanted by the caller (every training step but the last of a call
 // that asks for them): same grid, same block -> object map, same loss workgroup
-__global__ __launch_bounds__(kWG) void step_finalize_h32(const FinalizeArgs a, const CarryHot hh) {
+template <int = 0>
+__global__ __launch_bounds__(kWG) void step_finalize_h32(const FinalizeArgs a, const FinalizeHot hh) {
     const int quads = a.PP / 4;
     const int blocks_per_obj = (quads + kWG - 1) / kWG;
     if (blockIdx.x == gridDim.x - 1) {
@@ -1802,6 +1622,7 @@ __global__ __launch_bounds__(kWG) void step_finalize_h32(const FinalizeArgs a, c
     }
 }
 
+template <int = 0>
 __global__ __launch_bounds__(kWG) void step_finalize(const FinalizeArgs a) {
     const GenLayout GL = gen_layout(a.hidden);
     // one thread per 4 consecutive flat parameters

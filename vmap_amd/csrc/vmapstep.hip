@@ -15,21 +15,17 @@
 #include <vector>
 
 #include "../../include/vmapstep.h"
+#include "launch.h"
+// layouts only (image sizes, LDS / scratch budgets of the plan): no kernel of these headers is instantiated in this unit
 #include "wide_kernels.h"
-#include "split_kernels.h"
-#include "wsplit_kernels.h"
 #include "wpair_kernels.h"
-#include "split16_kernels.h"
-#include "sample_kernels.h"
-#include "query_kernels.h"
 
 namespace {
-
 thread_local char g_err[512] = "";
-// No tuning state lives in the library (ABI v4): overrides of the automatic plan arrive per call in vmapstep_shape::tuning.
-const vmapstep_tuning kAutoTuning = {0, VMAPSTEP_KERNEL_AUTO, 0, 0, nullptr};
-const vmapstep_tuning& tuning_of(const vmapstep_shape* sh) { return (sh && sh->tuning) ? *sh->tuning : kAutoTuning; }
+}
 
+namespace vl {
+thread_local const DispatchEvents* g_dispatch_events = nullptr;
 int fail(int code, const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -37,6 +33,39 @@ int fail(int code, const char* fmt, ...) {
     va_end(ap);
     return code;
 }
+int launched(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "%s launch: %s", what, hipGetErrorString(e));
+    return VMAPSTEP_OK;
+}
+}  // namespace vl
+
+namespace {
+using vl::fail;
+// No tuning state lives in the library: overrides of the automatic plan arrive per call in vmapstep_shape::tuning.
+const vmapstep_tuning kAutoTuning = {0, VMAPSTEP_KERNEL_AUTO, 0, 0};
+const vmapstep_tuning& tuning_of(const vmapstep_shape* sh) { return (sh && sh->tuning) ? *sh->tuning : kAutoTuning; }
+
+// Every entry point runs on the device that OWNS the caller's stream, whatever device is current on the calling thread (one
+// process may drive several GPUs): kernel attributes, CU counts and the launches themselves are per device.  With the NULL
+// stream the current device is used as it is.
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(void* stream) {
+        if (!stream) return;
+        int dev = -1, cur = -1;
+        if (hipStreamGetDevice(static_cast<hipStream_t>(stream), &dev) != hipSuccess || hipGetDevice(&cur) != hipSuccess) { ok = false; return; }
+        if (dev != cur) {
+            if (hipSetDevice(dev) != hipSuccess) { ok = false; return; }
+            prev = cur;
+        }
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+#define VMAPSTEP_ON_STREAM_DEVICE(stream)                                                                   \
+    DeviceGuard device_guard_(stream);                                                                      \
+    if (!device_guard_.ok) return fail(VMAPSTEP_ERR_DEVICE, "cannot switch to the device of the stream")
 
 constexpr size_t kAlign = 256;
 constexpr int kMaxFrameSteps = 256;      // optimisation steps per API call (the flag array has this fixed capacity)
@@ -57,12 +86,11 @@ void make_layout(int H, Layout& L) {
 
 struct Plan {
     int G, NG, NW;
-    size_t off_stats, off_flags, off_ploss, off_ploss_bytes, off_cnt, off_imgtab, off_pgrad, off_wimg, off_scratch, total;
+    size_t off_stats, off_flags, off_ploss, off_imgtab, off_pgrad, off_wimg, off_scratch, total;
     bool generic;      // hidden != 32: step_main_gen (global-memory activations) instead of step_main_h32
     bool split;        // hidden 32 on the bf16 matrix pipe with split operands (step_main_s32; the default at hidden 32)
-    bool s16;          // ... on 16-point tiles, forward / render calls only (prototype: VMAPSTEP_KERNEL_S16_FWD)
-    int wide;          // hidden 128 / 256: 0 = step_main_gen, 1 = step_main_wide<4> (one tile per workgroup, four waves
-                       // per tile), 2 = step_main_wide<2> (four tiles per 512-thread workgroup, two waves per tile)
+    int wide;          // 0 = step_main_gen, 1 = step_main_wide<4> (hidden 128 / 256: one tile per workgroup, four waves per
+                       // tile), 3 = step_main_ws, 4 = step_main_wp (hidden 64 / 128, bf16 matrix pipe)
 };
 
 // Per-device facts and one-time per-device function attributes.  A process may drive several GPUs (one
@@ -82,8 +110,9 @@ int cu_count() {
     if (!cus[dev] && hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus[dev] = -1;
     return cus[dev];
 }
+}  // namespace
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (device, kernel)
-int ensure_dynamic_lds(const void* kernel, size_t bytes, const char* what) {
+int vl::ensure_dynamic_lds(const void* kernel, size_t bytes, const char* what) {
     static std::vector<const void*> done[kMaxDevices];
     const int dev = current_device();
     if (dev < 0 || dev >= kMaxDevices) return fail(VMAPSTEP_ERR_DEVICE, "hipGetDevice failed");
@@ -94,6 +123,7 @@ int ensure_dynamic_lds(const void* kernel, size_t bytes, const char* what) {
     done[dev].push_back(kernel);
     return VMAPSTEP_OK;
 }
+namespace {
 
 int make_plan(const vmapstep_shape* sh, int max_steps, Plan& pl, const Layout& L) {
     if (!sh) return fail(VMAPSTEP_ERR_ARGUMENT, "shape is null");
@@ -108,24 +138,18 @@ int make_plan(const vmapstep_shape* sh, int max_steps, Plan& pl, const Layout& L
         return fail(VMAPSTEP_ERR_UNSUPPORTED, "samples=%d > %d", sh->samples, vk::kMaxPts);
     // Wide fields (hidden 128 / 256).  step_main_wide<4>: one 32-point tile per workgroup, four waves split its output
     // blocks - for latency-bound batches where every tile gets its own workgroup (it pays the whole parameter set in
-    // partial-gradient traffic per 32 points).  step_main_wide<2>: four tiles per 512-thread workgroup, two waves per tile
-    // (twice step_main_gen's waves for the same tiles and partial traffic).  step_main_gen: one wave per tile.
+    // partial-gradient traffic per 32 points).  step_main_gen: one wave per tile.
     pl.wide = 0;
     const vmapstep_tuning& tun = tuning_of(sh);
     const int force = tun.kernel;
-    if (force < VMAPSTEP_KERNEL_AUTO || force > VMAPSTEP_KERNEL_S16_FWD) return fail(VMAPSTEP_ERR_ARGUMENT, "tuning.kernel=%d", force);
+    if (force < VMAPSTEP_KERNEL_AUTO || force > VMAPSTEP_KERNEL_WP) return fail(VMAPSTEP_ERR_ARGUMENT, "tuning.kernel=%d", force);
     pl.split = !pl.generic && force != VMAPSTEP_KERNEL_H32_F32;
-    pl.s16 = force == VMAPSTEP_KERNEL_S16_FWD;
-    if (pl.s16 && pl.generic) return fail(VMAPSTEP_ERR_UNSUPPORTED, "VMAPSTEP_KERNEL_S16_FWD: hidden 32 only");
-    if (pl.split && tun.carried_finalize) return fail(VMAPSTEP_ERR_UNSUPPORTED, "the carried finalize exists for the exact-fp32 kernel only (tuning.kernel = VMAPSTEP_KERNEL_H32_F32)");
     if (pl.generic && sh->hidden % 128 == 0 && force != VMAPSTEP_KERNEL_GEN) {
         if (sh->samples <= vk::kWideTile) {
             const int gw = std::min(vk::kWideTile / sh->samples, sh->rays);
             const long long tiles = (long long)sh->n_obj * ((sh->rays + gw - 1) / gw);
             if (force == VMAPSTEP_KERNEL_WIDE4 || (force == VMAPSTEP_KERNEL_AUTO && tiles <= 256)) pl.wide = 1;
         }
-        if (!pl.wide && force == VMAPSTEP_KERNEL_WIDE2) pl.wide = 2;      // measured: no gain over step_main_gen at 600 tiles (both are
-                                                                 // bound by the traffic of the per-tile register images), not automatic
     }
     // hidden 64 / 128: the bf16 matrix pipe with split operands (step_main_ws) unless an exact-fp32 kernel is asked for
     // step_main_ws: one wave per output block; step_main_wp: two (measured: +19 % at hidden 64, where step_main_ws leaves two of its
@@ -159,11 +183,7 @@ int make_plan(const vmapstep_shape* sh, int max_steps, Plan& pl, const Layout& L
     // prepared step of it and the optimiser-only call address the same buffers.  The per-step arrays come last.
     if (max_steps > kMaxFrameSteps) return fail(VMAPSTEP_ERR_UNSUPPORTED, "steps per call %d > %d", max_steps, kMaxFrameSteps);
     size_t o = 0;
-    // loss partials: two halves used alternately by consecutive steps (the carried finalize of step i-1 reads its half
-    // while the workgroups of step i write theirs)
-    pl.off_ploss_bytes = align_up((size_t)sh->n_obj * nw_cap * 4 * sizeof(float));
-    pl.off_ploss = o; o += 2 * pl.off_ploss_bytes;
-    pl.off_cnt = o; o += align_up((size_t)sh->n_obj * 2 * sizeof(unsigned));
+    pl.off_ploss = o; o += align_up((size_t)sh->n_obj * nw_cap * 4 * sizeof(float));
     pl.off_imgtab = o; o += pl.wide >= 3 ? 2 * align_up((size_t)L.PP * sizeof(int)) : pl.generic ? 0 : align_up((size_t)L.PP * sizeof(int));
     pl.off_pgrad = o; o += align_up((size_t)sh->n_obj * nw_cap * L.PP * sizeof(float));
     const vk::GenLayout GL = vk::gen_layout(sh->hidden);
@@ -222,13 +242,10 @@ void fill_step_args(vk::StepArgs& a, const vmapstep_shape* sh, const Plan& pl, c
     a.hidden = sh->hidden;
     a.weights_bf16 = sh->weight_dtype == VMAPSTEP_WEIGHTS_BF16 ? 1 : 0;
     a.wide = pl.wide;
-    a.split = pl.s16 ? 2 : pl.split ? 1 : 0;
+    a.split = pl.split ? 1 : 0;
     a.stats = reinterpret_cast<float*>(ws + pl.off_stats);
     a.flags = reinterpret_cast<int*>(ws + pl.off_flags);
-    a.part_loss = reinterpret_cast<float*>(ws + pl.off_ploss);      // half 0; the step loop of a frame alternates (ploss_half)
-    // hand-off counters exist for the carried finalize only (step_prep skips null pointers); the flat -> image table for hidden 32
-    const bool carry = !pl.generic && tuning_of(sh).carried_finalize != 0;
-    a.carry_cnt = carry ? reinterpret_cast<unsigned*>(ws + pl.off_cnt) : nullptr;
+    a.part_loss = reinterpret_cast<float*>(ws + pl.off_ploss);
     a.img_tab = (!pl.generic || pl.wide >= 3) ? reinterpret_cast<int*>(ws + pl.off_imgtab) : nullptr;   // also read by step_finalize_h32
     a.tab_wt = pl.wide >= 3 ? reinterpret_cast<int*>(ws + pl.off_imgtab + align_up((size_t)L.PP * sizeof(int))) : nullptr;
     a.part_grad = reinterpret_cast<float*>(ws + pl.off_pgrad);
@@ -236,184 +253,23 @@ void fill_step_args(vk::StepArgs& a, const vmapstep_shape* sh, const Plan& pl, c
     a.gen_scratch = reinterpret_cast<float*>(ws + pl.off_scratch);
 }
 
-template <bool BWD, bool MULTI, bool STAMPS = false>
-int launch_main_v(const vk::StepArgs& a, hipStream_t st) {
-    auto kern = vk::step_main_h32<BWD, MULTI, STAMPS>;
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), vk::Lds32::BYTES, "step_main_h32")) return rc;
-    const int grid = a.xcd_affine ? 8 * ((a.n_obj + 7) / 8) * a.NW : a.n_obj * a.NW;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(vk::kWG), vk::Lds32::BYTES, st, a);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "step_main launch: %s", hipGetErrorString(e));
-    return VMAPSTEP_OK;
-}
-
-// step i >= 1 of a frame with the finalize of step i-1 carried in its prologue
-template <bool MULTI>
-int launch_main_carry(const vk::StepArgs& a, const vk::CarryArgs& c, hipStream_t st) {
-    auto kern = vk::step_main_h32_carry<MULTI>;
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), vk::Lds32::BYTES, "step_main_h32_carry")) return rc;
-    const int grid = (a.xcd_affine ? 8 * ((a.n_obj + 7) / 8) * a.NW : a.n_obj * a.NW) + 1;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(vk::kWG), vk::Lds32::BYTES, st, a, c);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "step_main_h32_carry launch: %s", hipGetErrorString(e));
-    return VMAPSTEP_OK;
-}
-
-// The carried finalize needs every workgroup of the launch resident at once (they wait for each other): one workgroup
-// per CU (132 KB of LDS each), so n_obj * NW real workgroups must not exceed the CU count.
-bool carry_eligible(const vmapstep_shape* sh, const Plan& pl) {
-    if (!tuning_of(sh).carried_finalize || pl.generic) return false;
-    return cu_count() > 0 && (long long)sh->n_obj * pl.NW <= cu_count();
-}
-
-template <bool BWD>
-int launch_gen(const vk::StepArgs& a, hipStream_t st) {
-    auto kern = vk::step_main_gen<BWD>;
-    const vk::GenLayout GL = vk::gen_layout(a.hidden);
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), vk::LdsGen::bytes(vk::gen_layout(256).small_n), "step_main_gen")) return rc;
-    vk::GenArgs ga;
-    ga.s = a;
-    ga.scratch = a.gen_scratch;
-    ga.wave_blocks = vk::gen_wave_blocks(GL.NB);
-    hipLaunchKernelGGL(kern, dim3(a.n_obj * a.NW), dim3(vk::kWG), vk::LdsGen::bytes(GL.small_n), st, ga);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "step_main_gen launch: %s", hipGetErrorString(e));
-    return VMAPSTEP_OK;
-}
-
-template <bool BWD, int SPLIT>
-int launch_wide(const vk::StepArgs& a, hipStream_t st) {
-    using LW = vk::LdsWide<SPLIT>;
-    auto kern = vk::step_main_wide<BWD, SPLIT>;
-    const vk::GenLayout GL = vk::gen_layout(a.hidden);
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LW::bytes(vk::gen_layout(256).small_n), "step_main_wide")) return rc;
-    vk::GenArgs ga;
-    ga.s = a;
-    ga.scratch = a.gen_scratch;
-    ga.wave_blocks = vk::gen_wave_blocks(GL.NB);
-    hipLaunchKernelGGL(kern, dim3(a.n_obj * a.NW), dim3(64 * LW::NWAVES), LW::bytes(GL.small_n), st, ga);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "step_main_wide launch: %s", hipGetErrorString(e));
-    return VMAPSTEP_OK;
-}
-
-template <bool BWD, bool MULTI, bool STAMPS, bool W3>
-int launch_split_v(const vk::StepArgs& a, hipStream_t st) {
-    auto kern = vk::step_main_s32<BWD, MULTI, STAMPS, W3>;
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), vk::Img32s::LDS_BYTES, "step_main_s32")) return rc;
-    const int grid = a.xcd_affine ? 8 * ((a.n_obj + 7) / 8) * a.NW : a.n_obj * a.NW;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(vk::kWG), vk::Img32s::LDS_BYTES, st, a);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "step_main_s32 launch: %s", hipGetErrorString(e));
-    return VMAPSTEP_OK;
-}
-template <bool BWD, bool STAMPS = false>
-int launch_split(const vk::StepArgs& a, hipStream_t st) {
-    const bool multi = a.NW < a.NG;
-    if (a.weights_bf16) return multi ? launch_split_v<BWD, true, STAMPS, false>(a, st) : launch_split_v<BWD, false, STAMPS, false>(a, st);
-    return multi ? launch_split_v<BWD, true, STAMPS, true>(a, st) : launch_split_v<BWD, false, STAMPS, true>(a, st);
-}
-
-template <int NB, bool BWD, bool W3, bool STAMPS = false>
-int launch_ws_v(const vk::StepArgs& a, hipStream_t st) {
-    using I = vk::ImgWs<NB>;
-    auto kern = vk::step_main_ws<NB, BWD, W3, STAMPS>;
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), I::LDS_BYTES, "step_main_ws")) return rc;
-    vk::WsArgs ga;
-    ga.s = a;
-    ga.scratch = reinterpret_cast<char*>(a.gen_scratch);
-    ga.tab_wt = a.tab_wt;
-    hipLaunchKernelGGL(kern, dim3(a.n_obj * a.NW), dim3(vk::kWG), I::LDS_BYTES, st, ga);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "step_main_ws launch: %s", hipGetErrorString(e));
-    return VMAPSTEP_OK;
-}
-
-template <int NB, bool BWD, bool W3, bool STAMPS = false>
-int launch_wp_v(const vk::StepArgs& a, hipStream_t st) {
-    using LD = vk::LdsWp<NB>;
-    auto kern = vk::step_main_wp<NB, BWD, W3, STAMPS>;
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LD::LDS_BYTES, "step_main_wp")) return rc;
-    vk::WsArgs ga;
-    ga.s = a;
-    ga.scratch = reinterpret_cast<char*>(a.gen_scratch);
-    ga.tab_wt = a.tab_wt;
-    hipLaunchKernelGGL(kern, dim3(a.n_obj * a.NW), dim3(LD::NTH), LD::LDS_BYTES, st, ga);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "step_main_wp launch: %s", hipGetErrorString(e));
-    return VMAPSTEP_OK;
-}
-
-// prototype: hidden 32 on 16-point tiles, forward only (tuning.kernel = VMAPSTEP_KERNEL_S16_FWD)
-int launch_s16_fwd(const vk::StepArgs& a, hipStream_t st) {
-    using I = vk::Img16;
-    auto kern = a.weights_bf16 ? vk::step_main_s16_fwd<false> : vk::step_main_s16_fwd<true>;
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), I::LDS_BYTES, "step_main_s16_fwd")) return rc;
-    hipLaunchKernelGGL(kern, dim3(a.n_obj * a.NW), dim3(vk::kWG16), I::LDS_BYTES, st, a);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "step_main_s16_fwd launch: %s", hipGetErrorString(e));
-    return VMAPSTEP_OK;
-}
-
-template <bool BWD>
-int launch_main(const vk::StepArgs& a, hipStream_t st) {
-    if (a.split == 2) {
-        if (BWD) return fail(VMAPSTEP_ERR_UNSUPPORTED, "VMAPSTEP_KERNEL_S16_FWD is a forward-only prototype (vmapstep_render)");
-        return launch_s16_fwd(a, st);
-    }
-    if (a.split) return launch_split<BWD>(a, st);
-    if (a.wide == 4) {
-        if (a.hidden == 128) return a.weights_bf16 ? launch_wp_v<4, BWD, false>(a, st) : launch_wp_v<4, BWD, true>(a, st);
-        return a.weights_bf16 ? launch_wp_v<2, BWD, false>(a, st) : launch_wp_v<2, BWD, true>(a, st);
-    }
-    if (a.wide == 3) {
-        if (a.hidden == 128) return a.weights_bf16 ? launch_ws_v<4, BWD, false>(a, st) : launch_ws_v<4, BWD, true>(a, st);
-        return a.weights_bf16 ? launch_ws_v<2, BWD, false>(a, st) : launch_ws_v<2, BWD, true>(a, st);
-    }
-    if (a.hidden != 32) return a.wide == 1 ? launch_wide<BWD, 4>(a, st) : a.wide == 2 ? launch_wide<BWD, 2>(a, st) : launch_gen<BWD>(a, st);
-    return a.NW < a.NG ? launch_main_v<BWD, true>(a, st) : launch_main_v<BWD, false>(a, st);
+// the dominant kernel of the plan (bwd = false: the forward-only instantiation of vmapstep_render; stamps: vmapstep_profile_phases)
+int launch_main(const vk::StepArgs& a, bool bwd, bool stamps, hipStream_t st) {
+    if (a.split) return vl::main_s32(a, bwd, stamps, st);
+    if (a.wide == 4) return vl::main_wp(a, bwd, stamps, st);
+    if (a.wide == 3) return vl::main_ws(a, bwd, stamps, st);
+    return vl::main_f32(a, bwd, stamps, st);
 }
 
 int launch_prep(const vk::StepArgs& a, int n_steps, hipStream_t st) {
-    if (a.wide >= 3) {
-        vk::WsArgs ga;
-        ga.s = a;
-        ga.s.prep_steps = n_steps;
-        ga.scratch = reinterpret_cast<char*>(a.gen_scratch);
-        ga.tab_wt = a.tab_wt;
-        // parameters without a place in the W^T image (biases, heads, B) keep -1 in its table
-        hipError_t e = hipMemsetAsync(a.tab_wt, 0xFF, (size_t)a.PP * sizeof(int), st);
-        if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "hipMemsetAsync(tab_wt): %s", hipGetErrorString(e));
-        if (a.hidden == 128)
-            hipLaunchKernelGGL(vk::step_prep_ws<4>, dim3(n_steps + a.n_obj * vk::ws_pack_blocks<4>()), dim3(vk::kWG), 3 * vk::kWG * sizeof(int), st, ga);
-        else
-            hipLaunchKernelGGL(vk::step_prep_ws<2>, dim3(n_steps + a.n_obj * vk::ws_pack_blocks<2>()), dim3(vk::kWG), 3 * vk::kWG * sizeof(int), st, ga);
-        e = hipGetLastError();
-        if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "step_prep_ws launch: %s", hipGetErrorString(e));
-        return VMAPSTEP_OK;
-    }
-    if (a.split == 2) {
-        hipLaunchKernelGGL(vk::step_prep_s16, dim3(n_steps + a.n_obj * vk::kPack16Blocks), dim3(vk::kWG), 3 * vk::kWG * sizeof(int), st, a);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "step_prep_s16 launch: %s", hipGetErrorString(e));
-        return VMAPSTEP_OK;
-    }
-    if (a.split) {
-        hipLaunchKernelGGL(vk::step_prep_s32, dim3(n_steps + a.n_obj * vk::kSplitPackBlocks), dim3(vk::kWG), 3 * vk::kWG * sizeof(int), st, a);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "step_prep_s32 launch: %s", hipGetErrorString(e));
-        return VMAPSTEP_OK;
-    }
-    const int pack_blocks = a.n_obj * (vk::gen_layout(a.hidden).imgp / 1024);
-    hipLaunchKernelGGL(vk::step_prep, dim3(n_steps + pack_blocks), dim3(vk::kWG), 3 * vk::kWG * sizeof(int), st, a);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "step_prep launch: %s", hipGetErrorString(e));
-    return VMAPSTEP_OK;
+    if (a.wide >= 3) return vl::prep_ws(a, n_steps, st);
+    if (a.split) return vl::prep_s32(a, n_steps, st);
+    return vl::prep_f32(a, n_steps + a.n_obj * (vk::gen_layout(a.hidden).imgp / 1024), st);
 }
 
 void fill_finalize_args(vk::FinalizeArgs& f, const vk::StepArgs& a, const Layout& L, const vmapstep_params* params,
                         const vmapstep_params* grads, const vmapstep_adamw* opt, int step_after, bool have_grad,
-                        float* loss_out, int* flags_out) {
+                        float* loss_out, int* flags_out, float* terms_out) {
     std::memset(&f, 0, sizeof(f));
     f.n_obj = a.n_obj; f.NW = a.NW; f.PP = L.PP; f.P = L.P; f.hidden = a.hidden; f.weights_bf16 = a.weights_bf16;
     for (int t = 0; t < 16; ++t) f.offs[t] = L.offs[t];
@@ -426,7 +282,7 @@ void fill_finalize_args(vk::FinalizeArgs& f, const vk::StepArgs& a, const Layout
         }
     }
     f.part_grad = a.part_grad; f.part_loss = a.part_loss; f.wimg = a.wimg;
-    f.flags_in = a.flags; f.flags_out = flags_out; f.loss_out = loss_out;
+    f.flags_in = a.flags; f.flags_out = flags_out; f.loss_out = loss_out; f.terms_out = terms_out;
     f.color_w = a.color_w; f.opac_w = a.opac_w;
     f.have_grad = have_grad ? 1 : 0;
     f.do_adam = (opt && have_grad) ? 1 : 0;
@@ -444,12 +300,10 @@ void fill_finalize_args(vk::FinalizeArgs& f, const vk::StepArgs& a, const Layout
     f.xcd_affine = (a.xcd_affine && have_grad) ? 1 : 0;
 }
 
-// the hot fields of a finalize (vk::CarryHot) from its FinalizeArgs
-void fill_carry_hot(vk::CarryHot& h, const vk::FinalizeArgs& f, const vk::StepArgs& a, const Layout& L, const vmapstep_params* params,
-                    unsigned epoch) {
+// the per-quad fields of a finalize (vk::FinalizeHot) from its FinalizeArgs
+void fill_hot(vk::FinalizeHot& h, const vk::FinalizeArgs& f, const vk::StepArgs& a, const Layout& L, const vmapstep_params* params) {
     std::memset(&h, 0, sizeof(h));
     h.m = f.m; h.v = f.v; h.part_grad = f.part_grad; h.wimg = f.wimg; h.img_tab = a.img_tab;
-    h.cnt = a.carry_cnt; h.epoch = epoch;
     h.NW = f.NW; h.PP = f.PP; h.weights_bf16 = f.weights_bf16;
     h.decay = f.decay; h.one_minus_beta1 = f.one_minus_beta1; h.beta2 = f.beta2; h.one_minus_beta2 = f.one_minus_beta2;
     h.eps = f.eps; h.step_size = f.step_size; h.bias_corr2_sqrt = f.bias_corr2_sqrt;
@@ -464,25 +318,17 @@ void fill_carry_hot(vk::CarryHot& h, const vk::FinalizeArgs& f, const vk::StepAr
 
 int launch_finalize(const vk::StepArgs& a, const Layout& L, const vmapstep_params* params, const vmapstep_params* grads,
                     const vmapstep_adamw* opt, int step_after, bool have_grad, float* loss_out, int* flags_out,
-                    hipStream_t st, bool generic_finalize) {
+                    float* terms_out, hipStream_t st, bool generic_finalize) {
     vk::FinalizeArgs f;
-    fill_finalize_args(f, a, L, params, grads, opt, step_after, have_grad, loss_out, flags_out);
+    fill_finalize_args(f, a, L, params, grads, opt, step_after, have_grad, loss_out, flags_out, terms_out);
     const int bpo = (L.PP / 4 + vk::kWG - 1) / vk::kWG;
     // + 1: the loss / flag reduction has a workgroup of its own (it used to ride on block 0 and made it the straggler)
     const int grid = (!have_grad ? 0 : f.xcd_affine ? 8 * ((a.n_obj + 7) / 8) * bpo : a.n_obj * bpo) + 1;
+    vk::FinalizeHot h;
     if (a.wide >= 3 && have_grad) {
         // step_main_ws / _wp: one finalize for gradients to the caller and / or AdamW; it is the only writer of the two weight images
-        vk::CarryHot h;
-        fill_carry_hot(h, f, a, L, params, 0u);
-        if (a.hidden == 128)
-            hipLaunchKernelGGL(vk::step_finalize_ws<4>, dim3(a.n_obj * vk::ws_finalize_blocks(L.PP) + 1), dim3(vk::kWG), 4 * vk::kWG * sizeof(float),
-                               st, f, h, a.tab_wt);
-        else
-            hipLaunchKernelGGL(vk::step_finalize_ws<2>, dim3(a.n_obj * vk::ws_finalize_blocks(L.PP) + 1), dim3(vk::kWG), 4 * vk::kWG * sizeof(float),
-                               st, f, h, a.tab_wt);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "step_finalize_ws launch: %s", hipGetErrorString(e));
-        return VMAPSTEP_OK;
+        fill_hot(h, f, a, L, params);
+        return vl::finalize_ws(f, h, a.tab_wt, st);
     }
     if (a.split && f.do_adam) {
         // split image: the table-driven finalize is the only writer of the planes.  A caller that also wants the gradients of
@@ -490,29 +336,19 @@ int launch_finalize(const vk::StepArgs& a, const Layout& L, const vmapstep_param
         if (grads) {
             vk::FinalizeArgs fg = f;
             fg.do_adam = 0;
-            hipLaunchKernelGGL(vk::step_finalize, dim3(grid), dim3(vk::kWG), 2 * vk::kWG * sizeof(float), st, fg);
+            fg.loss_out = nullptr;             // the loss / flag workgroup runs once, in the second launch
+            if (int rc = vl::finalize_generic(fg, grid, st)) return rc;
             std::memset(f.grad, 0, sizeof(f.grad));
         }
-        vk::CarryHot h;
-        fill_carry_hot(h, f, a, L, params, 0u);
-        hipLaunchKernelGGL(vk::step_finalize_s32, dim3(grid), dim3(vk::kWG), 2 * vk::kWG * sizeof(float), st, f, h);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "step_finalize_s32 launch: %s", hipGetErrorString(e));
-        return VMAPSTEP_OK;
+        fill_hot(h, f, a, L, params);
+        return vl::finalize_s32(f, h, grid, st);
     }
     if (!generic_finalize && a.hidden == 32 && a.img_tab && f.do_adam && !grads) {
         // the common training step at hidden 32: table-driven form (same sums, same update, a third of the instructions)
-        vk::CarryHot h;
-        fill_carry_hot(h, f, a, L, params, 0u);
-        hipLaunchKernelGGL(vk::step_finalize_h32, dim3(grid), dim3(vk::kWG), 2 * vk::kWG * sizeof(float), st, f, h);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "step_finalize_h32 launch: %s", hipGetErrorString(e));
-        return VMAPSTEP_OK;
+        fill_hot(h, f, a, L, params);
+        return vl::finalize_h32(f, h, grid, st);
     }
-    hipLaunchKernelGGL(vk::step_finalize, dim3(grid), dim3(vk::kWG), 2 * vk::kWG * sizeof(float), st, f);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "step_finalize launch: %s", hipGetErrorString(e));
-    return VMAPSTEP_OK;
+    return vl::finalize_generic(f, grid, st);
 }
 
 int check_ws(void* ws, size_t bytes, const Plan& pl) {
@@ -557,6 +393,7 @@ static int fwd_bwd_impl(const vmapstep_shape* shape, const vmapstep_params* para
                         void* workspace, size_t workspace_bytes, void* stream, bool do_prep, int step_index = 0) {
     int rc;
     if (!shape) return fail(VMAPSTEP_ERR_ARGUMENT, "shape is null");
+    VMAPSTEP_ON_STREAM_DEVICE(stream);
     Layout L;
     make_layout(shape->hidden, L);
     Plan pl;
@@ -577,8 +414,9 @@ static int fwd_bwd_impl(const vmapstep_shape* shape, const vmapstep_params* para
     a.flags += (size_t)step_index * 4;
     a.dbg_depth = out->render_depth; a.dbg_rgb = out->render_color; a.dbg_opacity = out->opacity; a.dbg_var = out->var;
     if (do_prep && (rc = launch_prep(a, 1, st))) return rc;
-    if ((rc = launch_main<true>(a, st))) return rc;
-    return launch_finalize(a, L, params, grads, nullptr, 0, true, out->loss, out->flags, st, tuning_of(shape).generic_finalize != 0);
+    if ((rc = launch_main(a, true, false, st))) return rc;
+    return launch_finalize(a, L, params, grads, nullptr, 0, true, out->loss, out->flags, out->loss_terms, st,
+                           tuning_of(shape).generic_finalize != 0);
 }
 
 int vmapstep_fwd_bwd(const vmapstep_shape* shape, const vmapstep_params* params, const vmapstep_tensor* pe_scale,
@@ -598,21 +436,27 @@ int vmapstep_fwd_bwd_prepared(const vmapstep_shape* shape, const vmapstep_params
 }
 
 int vmapstep_adamw_apply(const vmapstep_shape* shape, const vmapstep_params* params, const float* grad_slab,
-                         int64_t grad_stride, const vmapstep_adamw* opt, void* workspace, size_t workspace_bytes, void* stream) {
+                         int64_t grad_stride, const vmapstep_adamw* opt, const float* loss_terms, int32_t step_index,
+                         float color_scaling, float opacity_scaling, const vmapstep_outputs* out,
+                         void* workspace, size_t workspace_bytes, void* stream) {
     int rc;
     if (!shape) return fail(VMAPSTEP_ERR_ARGUMENT, "shape is null");
+    VMAPSTEP_ON_STREAM_DEVICE(stream);
     Layout L;
     make_layout(shape->hidden, L);
     Plan pl;
-    if ((rc = make_plan(shape, 1, pl, L))) return rc;
+    if (step_index < 0) return fail(VMAPSTEP_ERR_ARGUMENT, "step_index=%d", step_index);
+    if ((rc = make_plan(shape, step_index + 1, pl, L))) return rc;
     if ((rc = check_params(params, "params", false))) return rc;
     if (!grad_slab || grad_stride != L.PP || reinterpret_cast<uintptr_t>(grad_slab) % 16)
         return fail(VMAPSTEP_ERR_ARGUMENT, "grad_slab: need 16-byte aligned rows of padded_params = %d floats (vmapstep_param_layout)", L.PP);
     if (!opt || !opt->exp_avg || !opt->exp_avg_sq) return fail(VMAPSTEP_ERR_ARGUMENT, "optimiser state is required");
+    if (loss_terms && (!out || !out->loss || !out->flags)) return fail(VMAPSTEP_ERR_ARGUMENT, "loss_terms given: outputs.loss / outputs.flags are required");
     if (!workspace || reinterpret_cast<uintptr_t>(workspace) % kAlign || workspace_bytes < pl.total)
         return fail(VMAPSTEP_ERR_WORKSPACE, "workspace too small / misaligned for this shape's parameter image");
     // the gradient slab plays the role of ONE row of partial gradients per object (NW = 1, row pitch = grad_stride): the
-    // finalize kernels' ordered sum degenerates to a copy, their AdamW update and image rewrite are what is wanted
+    // finalize kernels' ordered sum degenerates to a copy, their AdamW update and image rewrite are what is wanted; the
+    // reduced loss terms play the role of the one row of loss partials per object
     vk::StepArgs a;
     std::memset(&a, 0, sizeof(a));
     char* ws = static_cast<char*>(workspace);
@@ -621,11 +465,15 @@ int vmapstep_adamw_apply(const vmapstep_shape* shape, const vmapstep_params* par
     a.split = pl.split ? 1 : 0;
     a.xcd_affine = 0;
     a.part_grad = const_cast<float*>(grad_slab);
+    a.part_loss = const_cast<float*>(loss_terms);
+    a.flags = reinterpret_cast<int*>(ws + pl.off_flags) + (size_t)step_index * 4;
+    a.color_w = color_scaling; a.opac_w = opacity_scaling;
     a.wimg = reinterpret_cast<float*>(ws + pl.off_wimg);
     a.wide = pl.wide;
     a.img_tab = (!pl.generic || pl.wide >= 3) ? reinterpret_cast<int*>(ws + pl.off_imgtab) : nullptr;
     a.tab_wt = pl.wide >= 3 ? reinterpret_cast<int*>(ws + pl.off_imgtab + align_up((size_t)L.PP * sizeof(int))) : nullptr;
-    return launch_finalize(a, L, params, nullptr, opt, opt->step + 1, true, nullptr, nullptr, static_cast<hipStream_t>(stream),
+    return launch_finalize(a, L, params, nullptr, opt, opt->step + 1, true, loss_terms ? out->loss : nullptr,
+                           loss_terms ? out->flags : nullptr, nullptr, static_cast<hipStream_t>(stream),
                            tuning_of(shape).generic_finalize != 0);
 }
 
@@ -645,6 +493,7 @@ int vmapstep_render(const vmapstep_shape* shape, const vmapstep_params* params, 
                     const vmapstep_outputs* out, void* workspace, size_t workspace_bytes, void* stream) {
     int rc;
     if (!shape) return fail(VMAPSTEP_ERR_ARGUMENT, "shape is null");
+    VMAPSTEP_ON_STREAM_DEVICE(stream);
     Layout L;
     make_layout(shape->hidden, L);
     Plan pl;
@@ -660,8 +509,9 @@ int vmapstep_render(const vmapstep_shape* shape, const vmapstep_params* params, 
     a.prep_steps = 1; a.prep_ray_step = 0;
     a.dbg_depth = out->render_depth; a.dbg_rgb = out->render_color; a.dbg_opacity = out->opacity; a.dbg_var = out->var;
     if ((rc = launch_prep(a, 1, st))) return rc;
-    if ((rc = launch_main<false>(a, st))) return rc;
-    return launch_finalize(a, L, params, nullptr, nullptr, 0, false, out->loss, out->flags, st, tuning_of(shape).generic_finalize != 0);
+    if ((rc = launch_main(a, false, false, st))) return rc;
+    return launch_finalize(a, L, params, nullptr, nullptr, 0, false, out->loss, out->flags, out->loss_terms, st,
+                           tuning_of(shape).generic_finalize != 0);
 }
 
 static int train_steps_impl(const vmapstep_shape* shape, const vmapstep_params* params, const vmapstep_tensor* pe_scale,
@@ -672,6 +522,7 @@ static int train_steps_impl(const vmapstep_shape* shape, const vmapstep_params* 
                             size_t* flags_offset, float* time_main_ms = nullptr) {
     int rc;
     if (!shape) return fail(VMAPSTEP_ERR_ARGUMENT, "shape is null");
+    VMAPSTEP_ON_STREAM_DEVICE(stream);
     if (n_steps < 1) return fail(VMAPSTEP_ERR_ARGUMENT, "n_steps=%d", n_steps);
     Layout L;
     make_layout(shape->hidden, L);
@@ -698,53 +549,41 @@ static int train_steps_impl(const vmapstep_shape* shape, const vmapstep_params* 
     if (!out || !out->loss || !out->flags) return fail(VMAPSTEP_ERR_ARGUMENT, "outputs.loss / outputs.flags are required");
     std::vector<hipEvent_t> ev;
     if (time_main_ms) {
-        ev.resize(3 * (size_t)n_steps);      // per step: before main, after main, and one more right behind it (the cost of
-                                             // an event pair with nothing in between is subtracted)
+        ev.resize(4 * (size_t)n_steps);      // per step: stream events in front of / behind the launch, and the launch's own
+                                             // dispatch begin / end events (hipExtLaunchKernel)
         for (auto& e : ev)
             if (hipEventCreate(&e) != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "hipEventCreate failed");
     }
-    // Two forms of the loop.  Plain: main(i), finalize(i) per step.  Carried (hidden 32, all workgroups resident at once):
-    // main(0), then main(i) with finalize(i-1) in its prologue for i >= 1, then finalize(n-1) - one launch per step.
-    const bool carry = carry_eligible(shape, pl);
-    vk::StepArgs prev;
     for (int i = 0; i < n_steps; ++i) {
         fill_step_args(a, shape, pl, L, params, pe_scale, frame, (int64_t)i * ray_step, color_scaling, opacity_scaling, ws);
         a.stats += (size_t)i * shape->n_obj * 4;
         a.flags += (size_t)i * 4;
-        a.part_loss = reinterpret_cast<float*>(ws + pl.off_ploss + (size_t)(i & 1) * pl.off_ploss_bytes);
         const bool last = i == n_steps - 1;
         if (last) { a.dbg_depth = out->render_depth; a.dbg_rgb = out->render_color; a.dbg_opacity = out->opacity; a.dbg_var = out->var; }
-        if (!ev.empty() && hipEventRecord(ev[3 * i], st) != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "hipEventRecord failed");
-        if (carry && i > 0) {
-            vk::CarryArgs c;
-            fill_finalize_args(c.f, prev, L, params, nullptr, opt, opt->step + i, true, out->loss + (i - 1), out->flags + 4 * (i - 1));
-            c.stamps = tuning_of(shape).carry_stamps;
-            fill_carry_hot(c.h, c.f, a, L, params, (unsigned)i);
-            rc = a.NW < a.NG ? launch_main_carry<true>(a, c, st) : launch_main_carry<false>(a, c, st);
-            if (rc) return rc;
-        } else if ((rc = launch_main<true>(a, st))) return rc;
-        if (!ev.empty() && (hipEventRecord(ev[3 * i + 1], st) != hipSuccess || hipEventRecord(ev[3 * i + 2], st) != hipSuccess))
-            return fail(VMAPSTEP_ERR_DEVICE, "hipEventRecord failed");
-        if (!carry || last) {
-            if ((rc = launch_finalize(a, L, params, last ? grads : nullptr, opt, opt->step + i + 1, true,
-                                      out->loss + i, out->flags + 4 * i, st, tuning_of(shape).generic_finalize != 0))) return rc;
-        }
-        prev = a;
+        if (!ev.empty() && hipEventRecord(ev[4 * i], st) != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "hipEventRecord failed");
+        vl::DispatchEvents de = {nullptr, nullptr};
+        if (!ev.empty()) { de = {ev[4 * i + 2], ev[4 * i + 3]}; vl::g_dispatch_events = &de; }
+        rc = launch_main(a, true, false, st);
+        vl::g_dispatch_events = nullptr;
+        if (rc) return rc;
+        if (!ev.empty() && hipEventRecord(ev[4 * i + 1], st) != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "hipEventRecord failed");
+        if ((rc = launch_finalize(a, L, params, last ? grads : nullptr, opt, opt->step + i + 1, true, out->loss + i, out->flags + 4 * i,
+                                  last ? out->loss_terms : nullptr, st, tuning_of(shape).generic_finalize != 0))) return rc;
     }
     if (!ev.empty()) {                       // measurement only: the one place this library waits for the device
-        bool ok = hipEventSynchronize(ev.back()) == hipSuccess;
-        double sum_raw = 0.0, sum_empty = 0.0;
+        bool ok = hipStreamSynchronize(st) == hipSuccess;
+        double sum_dispatch = 0.0, sum_pair = 0.0;
         for (int i = 0; i < n_steps && ok; ++i) {
-            float ms = 0.0f, empty = 0.0f;
-            ok = hipEventElapsedTime(&ms, ev[3 * i], ev[3 * i + 1]) == hipSuccess &&
-                 hipEventElapsedTime(&empty, ev[3 * i + 1], ev[3 * i + 2]) == hipSuccess;
-            sum_raw += ms;
-            sum_empty += empty;
+            float ms = 0.0f, pair = 0.0f;
+            ok = hipEventElapsedTime(&ms, ev[4 * i + 2], ev[4 * i + 3]) == hipSuccess &&
+                 hipEventElapsedTime(&pair, ev[4 * i], ev[4 * i + 1]) == hipSuccess;
+            sum_dispatch += ms;
+            sum_pair += pair;
         }
         for (auto& e : ev) ok = (hipEventDestroy(e) == hipSuccess) && ok;
         if (!ok) return fail(VMAPSTEP_ERR_DEVICE, "event timing of the step loop failed");
-        time_main_ms[0] = (float)(sum_raw / n_steps);                  // raw event-pair time around the launch
-        time_main_ms[1] = (float)((sum_raw - sum_empty) / n_steps);    // minus what an empty event pair costs
+        time_main_ms[0] = (float)(sum_dispatch / n_steps);             // the dispatch's own begin -> end (= a kernel trace's duration)
+        time_main_ms[1] = (float)(sum_pair / n_steps);                 // stream events recorded around the launch (includes their own cost)
     }
     return VMAPSTEP_OK;
 }
@@ -790,6 +629,7 @@ int vmapstep_profile_main_kernel(const vmapstep_shape* shape, const vmapstep_par
                                  void* workspace, size_t workspace_bytes, void* stream) {
     int rc;
     if (!shape) return fail(VMAPSTEP_ERR_ARGUMENT, "shape is null");
+    VMAPSTEP_ON_STREAM_DEVICE(stream);
     Layout L;
     make_layout(shape->hidden, L);
     Plan pl;
@@ -804,7 +644,7 @@ int vmapstep_profile_main_kernel(const vmapstep_shape* shape, const vmapstep_par
     a.prep_steps = 1; a.prep_ray_step = 0;
     if ((rc = launch_prep(a, 1, st))) return rc;
     for (int i = 0; i < reps; ++i)
-        if ((rc = launch_main<true>(a, st))) return rc;
+        if ((rc = launch_main(a, true, false, st))) return rc;
     return VMAPSTEP_OK;
 }
 
@@ -814,6 +654,7 @@ int vmapstep_profile_phases(const vmapstep_shape* shape, const vmapstep_params* 
                             void* workspace, size_t workspace_bytes, void* stream) {
     int rc;
     if (!shape) return fail(VMAPSTEP_ERR_ARGUMENT, "shape is null");
+    VMAPSTEP_ON_STREAM_DEVICE(stream);
     Layout L;
     make_layout(shape->hidden, L);
     Plan pl;
@@ -833,10 +674,7 @@ int vmapstep_profile_phases(const vmapstep_shape* shape, const vmapstep_params* 
     a.timing = timing;
     *n_workgroups = a.xcd_affine ? 8 * ((shape->n_obj + 7) / 8) * pl.NW : shape->n_obj * pl.NW;
     if ((rc = launch_prep(a, 1, st))) return rc;
-    if (a.wide == 4) return a.hidden == 128 ? launch_wp_v<4, true, true, true>(a, st) : launch_wp_v<2, true, true, true>(a, st);
-    if (a.wide == 3) return a.hidden == 128 ? launch_ws_v<4, true, true, true>(a, st) : launch_ws_v<2, true, true, true>(a, st);
-    if (a.split) return launch_split<true, true>(a, st);
-    return a.NW < a.NG ? launch_main_v<true, true, true>(a, st) : launch_main_v<true, false, true>(a, st);   // the stamped build
+    return launch_main(a, true, true, st);   // the stamped instantiation
 }
 
 int vmapstep_query_workspace_bytes(int32_t hidden, size_t* bytes) {
@@ -859,47 +697,20 @@ int vmapstep_query_points(int32_t hidden, const vmapstep_params* params, const v
     if (!workspace || reinterpret_cast<uintptr_t>(workspace) % kAlign || workspace_bytes < need)
         return fail(VMAPSTEP_ERR_WORKSPACE, "workspace must be 256-byte aligned and >= %zu bytes", need);
     if (n_points == 0) return VMAPSTEP_OK;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    // pack this object's image (step_prep's pack role, zero mask-statistics blocks)
+    VMAPSTEP_ON_STREAM_DEVICE(stream);
+    // pack this object's image (step_prep's pack role, zero mask-statistics blocks), then the query kernel
     vk::StepArgs a;
     std::memset(&a, 0, sizeof(a));
     a.n_obj = 1; a.hidden = hidden; a.prep_steps = 0;
     for (int t = 0; t < VMAPSTEP_NUM_FC; ++t) a.fc[t] = {params->fc[t].ptr + (long long)obj_index * params->fc[t].obj_stride, 0};
     a.pe_B = {params->pe_B.ptr + (long long)obj_index * params->pe_B.obj_stride, 0};
     a.wimg = static_cast<float*>(workspace);
-    hipLaunchKernelGGL(vk::step_prep, dim3(vk::gen_layout(hidden).imgp / 1024), dim3(vk::kWG), 3 * vk::kWG * sizeof(int), st, a);
     vk::QueryArgs q;
     q.wimg = a.wimg;
     q.scale = pe_scale->ptr + (long long)obj_index * pe_scale->obj_stride;
     q.pts = points; q.pts_sn = points_stride[0]; q.pts_sc = points_stride[1];
     q.n_pts = n_points; q.occ = occupancy; q.rgb = color;
-    const long long chunks = (n_points + vk::kMaxPts - 1) / vk::kMaxPts;
-    if (hidden == 32) {
-        if ((rc = ensure_dynamic_lds(reinterpret_cast<const void*>(vk::field_query_h32<2>), vk::Lds32::IMGP * sizeof(float), "field_query_h32"))) return rc;
-        const int grid = (int)(chunks < 512 ? chunks : 512);          // two resident workgroups per CU (236 registers each)
-        hipLaunchKernelGGL(vk::field_query_h32<2>, dim3(grid), dim3(vk::kWG), vk::Lds32::IMGP * sizeof(float), st, q);
-    } else {
-        const int grid = (int)(chunks < 256 ? chunks : 256);
-        const int nb = hidden / 32;
-        const size_t lds = nb > 4 ? (size_t)nb * 1024 * vk::kWaves * sizeof(float) : 0;   // second activation set (NB > 4)
-        if (nb > 4) {
-            const void* big[4] = {reinterpret_cast<const void*>(vk::field_query_gen<5>), reinterpret_cast<const void*>(vk::field_query_gen<6>),
-                                  reinterpret_cast<const void*>(vk::field_query_gen<7>), reinterpret_cast<const void*>(vk::field_query_gen<8>)};
-            if ((rc = ensure_dynamic_lds(big[nb - 5], lds, "field_query_gen"))) return rc;
-        }
-        switch (nb) {
-            case 2: hipLaunchKernelGGL(vk::field_query_gen<2>, dim3(grid), dim3(vk::kWG), lds, st, q); break;
-            case 3: hipLaunchKernelGGL(vk::field_query_gen<3>, dim3(grid), dim3(vk::kWG), lds, st, q); break;
-            case 4: hipLaunchKernelGGL(vk::field_query_gen<4>, dim3(grid), dim3(vk::kWG), lds, st, q); break;
-            case 5: hipLaunchKernelGGL(vk::field_query_gen<5>, dim3(grid), dim3(vk::kWG), lds, st, q); break;
-            case 6: hipLaunchKernelGGL(vk::field_query_gen<6>, dim3(grid), dim3(vk::kWG), lds, st, q); break;
-            case 7: hipLaunchKernelGGL(vk::field_query_gen<7>, dim3(grid), dim3(vk::kWG), lds, st, q); break;
-            default: hipLaunchKernelGGL(vk::field_query_gen<8>, dim3(grid), dim3(vk::kWG), lds, st, q); break;
-        }
-    }
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "field_query launch: %s", hipGetErrorString(e));
-    return VMAPSTEP_OK;
+    return vl::query_points(hidden, a, q, n_points, static_cast<hipStream_t>(stream));
 }
 
 static_assert(sizeof(vmapstep_sample_object) == sizeof(vs::SampleObject), "sample object table layout");
@@ -929,17 +740,8 @@ int vmapstep_sample_frame(const vmapstep_sample_cfg* cfg, const vmapstep_sample_
         a.rnd.u_z = test_randoms->u_z; a.rnd.g_z = test_randoms->g_z;
     }
     a.pcs = pcs; a.z = z; a.gt_depth = gt_depth; a.gt_rgb = gt_rgb; a.sem = sem; a.depth_mask = depth_mask;
-    if (FP <= vs::kMaxStagedRays) {
-        const size_t lds = (3 * (size_t)FP + vs::kWG) * sizeof(float);
-        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(vs::frame_sample<true>), 160 * 1024, "frame_sample")) return rc;
-        hipLaunchKernelGGL(vs::frame_sample<true>, dim3(n_obj), dim3(vs::kWG), lds, static_cast<hipStream_t>(stream), a);
-    } else {
-        // more rays per object than the staging area holds (the background model's frame): phase A is evaluated twice
-        hipLaunchKernelGGL(vs::frame_sample<false>, dim3(n_obj), dim3(vs::kWG), vs::kWG * sizeof(float), static_cast<hipStream_t>(stream), a);
-    }
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "frame_sample launch: %s", hipGetErrorString(e));
-    return VMAPSTEP_OK;
+    VMAPSTEP_ON_STREAM_DEVICE(stream);
+    return vl::sample_frame(a, n_obj, FP, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

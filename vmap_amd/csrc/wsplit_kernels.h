@@ -268,7 +268,7 @@ __host__ __device__ inline int ws_finalize_blocks(int PP) { return (PP / 4 + kFi
 // The partial gradients are NW rows of PP floats per object (one per workgroup of step_main_ws, up to 256): a quad's four
 // threads sum a quarter of the rows each (loads eight deep), a fixed tree through LDS joins them - same order every run.
 template <int NB>
-__global__ __launch_bounds__(kWG) void step_finalize_ws(const FinalizeArgs a, const CarryHot hh, const int* tab_wt) {
+__global__ __launch_bounds__(kWG) void step_finalize_ws(const FinalizeArgs a, const FinalizeHot hh, const int* tab_wt) {
     typedef int i32x4 __attribute__((ext_vector_type(4)));
     const int quads = a.PP / 4;
     const int blocks_per_obj = ws_finalize_blocks(a.PP);
@@ -341,11 +341,7 @@ __global__ __launch_bounds__(kWG) void step_finalize_ws(const FinalizeArgs a, co
 }
 
 // ---- device helpers of step_main_ws -----------------------------------------------------------------------------------
-#ifdef WS_EXP_HOTW       // measurement build: every weight load hits the same two chunks (no L2 / HBM misses on the weight streams)
-#define WS_WSTEP(s) ((s) & 1)
-#else
 #define WS_WSTEP(s) (s)
-#endif
 // block_io of a layer for a runtime (wave-uniform) mode; A / B: the hidden-block / encoding-block form, M = the mode
 #define WS_IO3(mode, is_a, A, B)                                                              \
     do {                                                                                       \
@@ -558,9 +554,6 @@ __device__ __forceinline__ void db_pair(f32x16& acc, const unsigned (&dF)[2][16]
 // MODE 0: store (a workgroup's first round); 1: read the values of the earlier rounds into old; 2: store old + acc.
 template <int K, int MODE>
 __device__ __forceinline__ void rows_io(float* ubase, unsigned voff, const f32x16& acc, float (&old)[16]) {
-#ifdef WS_EXP_NOSTORE       // measurement build: the partial-gradient stores never execute
-    if (acc[0] != 12345.678f) return;
-#endif
     float* q = ubase + voff;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -643,13 +636,8 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     const float* Bg = SM + I::PE_B;
     char* wgs_k = ga.scratch + (long long)blockIdx.x * I::WG_SCRATCH;
     unsigned* tmark = STAMPS && a.timing ? a.timing + ((long long)blockIdx.x * kWaves + (tid_k >> 6)) * kMarks : nullptr;
-#ifdef WS_EXP_DETAIL     // measurement build: the 16 stamps sit inside the backward pass of color_linear and mid2
-#define WS_MARK(i) do { } while (0)
-#define WS_DMARK(i) do { if constexpr (STAMPS) { if (tmark && first && (tid_k & 63) == 0) tmark[i] = wv::clock32(); } } while (0)
-#else
 #define WS_MARK(i) do { if constexpr (STAMPS) { if (tmark && first && (tid_k & 63) == 0) tmark[i] = wv::clock32(); } } while (0)
 #define WS_DMARK(i) do { } while (0)
-#endif
 
     for (int grp = wgo; grp < a.NG; grp += a.NW) {
     const bool first = grp == wgo;
@@ -785,11 +773,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
             if (BWD) acts_store(acts, tid16, layer, st, ph, pm);
         }
     };
-#ifdef WS_EXP_HOTW
-    auto wchunk = [&](int, int, int) { return gW + (long long)wave * 2 * I::XCH; };
-#else
     auto wchunk = [&](int base, int ks, int s) { return gW + ((long long)(base + wave * ks + s)) * I::XCH; };     // wave-uniform
-#endif
     WPre pre;
     if (own) {
         zero_acc(acc[0]); zero_acc(acc[1]);                              // :59 in_layer (bias rides in the constant-1 column)
@@ -945,11 +929,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     // d-prop into the wave's own hidden block of layer ct (both tiles); the first W^T chunks (tp) were fetched at the phase start
     TPre tp, tpe;
     auto hidden_ptr = [&](int ct_base) {
-#ifdef WS_EXP_HOTW
-        return gWT + ((long long)(0 * ct_base + wave * 2)) * I::DCH;
-#else
         return gWT + ((long long)(ct_base + wave * JS)) * I::DCH;
-#endif
     };
     auto dprop_hidden = [&](int ct_base, bool add_alpha) {
 #pragma unroll
@@ -964,11 +944,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     // d-prop into an encoding block -> d(proj) through the cos factors (cfr: fetched at the phase start, with tpe)
     float cfr[2][16];
     auto enc_ptr = [&](int ct_chunk) {
-#ifdef WS_EXP_HOTW
-        return gWT + (long long)(0 * ct_chunk + wave * 2) * I::DCH;
-#else
         return gWT + (long long)ct_chunk * I::DCH;
-#endif
     };
     auto enc_fetch = [&](int ct_chunk, int group, int blk) {
         tpre_load<W3>(tpe, enc_ptr(ct_chunk), vlo16);
@@ -979,11 +955,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
             for (int r = 0; r < 16; ++r) {
                 const int R = 16 * blk + r;
                 const int idx = group == 1 ? (R < 44 ? 6 * (R >> 2) + (R & 3) : -1) : (R < 22 ? 6 * (R >> 1) + 4 + (R & 1) : -1);
-#ifdef WS_EXP_NOCF
-                cfr[st][r] = 0.5f;
-#else
                 cfr[st][r] = idx >= 0 ? *reinterpret_cast<const float*>(cfu + idx * 256 + (unsigned)lane * 4u) : 0.0f;
-#endif
             }
         }
         wv::sched_fence();

@@ -55,9 +55,9 @@ class SharedBackgroundHip:
     Every rank holds a replica whose 15 tensors are views of ONE ``[1, P]`` slab.  Per FRAME: ``vmapstep_prepare`` (parameter
     image + this rank's mask counts of every step) and ONE ``all_reduce(SUM)`` of the ``[n_steps, 4]`` counts, from which the
     empty-mask switches of all steps are rewritten.  Per STEP: launch (forward / loss / backward on this rank's rays with
-    the GLOBAL normalisers: ``vmapstep_fwd_bwd_prepared``) -> ONE ``all_reduce(SUM)`` of ``[gradient slab | loss]`` (378 KB
+    the GLOBAL normalisers: ``vmapstep_fwd_bwd_prepared``) -> ONE ``all_reduce(SUM)`` of ``[gradient slab | loss terms]`` (378 KB
     at hidden 128: latency-bound on xGMI, hence a single message) -> launch (``vmapstep_adamw_apply``: identical fused AdamW
-    on every rank + rewrite of the parameter image).  Everything is enqueued on the caller's current stream; nothing
+    on every rank + rewrite of the parameter image + global loss and "loss explode" flag from the summed terms).  Everything is enqueued on the caller's current stream; nothing
     synchronises the host.
     """
 
@@ -74,8 +74,12 @@ class SharedBackgroundHip:
         self.opt = step.FusedAdamWState(1, H, dev, lr=lr, weight_decay=weight_decay)
         PP = self.opt.padded
         self.slab = torch.zeros(1, P, dtype=torch.float32, device=dev)
-        self.buf = torch.zeros(PP + 4, dtype=torch.float32, device=dev)           # [gradient row (padded) | loss, pad]
+        # ONE message per step: [gradient row (padded) | depth, colour, opacity terms, l_batch] - the kernels write both parts in place
+        self.buf = torch.zeros(PP + 4, dtype=torch.float32, device=dev)
         self.gslab = self.buf[:PP].view(1, PP)
+        self.terms = self.buf[PP:].view(1, 4)
+        self.losses = torch.zeros(max_steps, dtype=torch.float32, device=dev)      # global loss per step of the current frame
+        self.flags = torch.zeros(max_steps, 4, dtype=torch.int32, device=dev)      # global flags per step (empty masks, explode)
         offs = layout.flat_offsets(H)
         shapes = list(layout.fc_shapes(H)) + [layout.PE_B_SHAPE]
         src = list(fc_occ_map.parameters()) + [pe.B_layer.weight]
@@ -108,21 +112,36 @@ class SharedBackgroundHip:
 
     @torch.no_grad()
     def step_prepared(self, i: int) -> torch.Tensor:
-        """Step i of the prepared frame: launch, ONE all_reduce, launch.  Returns the global loss (0-dim device tensor)."""
+        """Step i of the prepared frame: launch, ONE all_reduce, launch.  Returns the global loss (0-dim view of ``self.losses``).
+
+        The forward/backward launch leaves this rank's gradients AND its three loss terms in ``self.buf``; after the all-reduce
+        ``vmapstep_adamw_apply`` updates the replica and, in the same launch, evaluates the step's global loss and the
+        "loss explode" test (render_rays.py:88-90) on the SUMMED terms - no launch besides the two and the collective."""
         R = self.rays_local
         batch = tuple(x[:, i * R:(i + 1) * R] for x in self._frame)
-        res = self.op.fwd_bwd(self.views[:14], self.views[14], self.scale, *batch, grads_fc=self.gviews[:14], grad_B=self.gviews[14],
-                              prepared_step=i)
-        self.buf[-4] = res.loss[0]
+        self.op.fwd_bwd(self.views[:14], self.views[14], self.scale, *batch, grads_fc=self.gviews[:14], grad_B=self.gviews[14],
+                        prepared_step=i, loss_terms=self.terms)
         if self.world_size > 1:
-            dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=self.group)      # ONE message: gradients + loss
-        self.op.adamw_apply(self.views[:14], self.views[14], self.gslab, self.opt)
-        return self.buf[-4]
+            dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=self.group)      # ONE message: gradients + loss terms
+        self.op.adamw_apply(self.views[:14], self.views[14], self.gslab, self.opt, loss_terms=self.terms, step_index=i,
+                            loss_out=self.losses[i:i + 1], flags_out=self.flags[i])
+        return self.losses[i]
 
     def train_frame(self, pcs, z, gt_depth, gt_rgb, sem, depth_mask, n_steps: int) -> torch.Tensor:
-        """The background part of train.py:270-326 for one frame; returns the per-step global losses [n_steps]."""
+        """The background part of train.py:270-326 for one frame; returns the per-step global losses [n_steps]
+        (``self.flags[:n_steps]`` holds the per-step flags; ``check_flags`` turns an explode into an exception)."""
         self.prepare_frame(pcs, z, gt_depth, gt_rgb, sem, depth_mask, n_steps)
-        return torch.stack([self.step_prepared(i).clone() for i in range(n_steps)])
+        for i in range(n_steps):
+            self.step_prepared(i)
+        return self.losses[:n_steps].clone()
+
+    def check_flags(self, n_steps: Optional[int] = None):
+        """Host-side check of the explode flags of the last frame (synchronises): the reference calls exit(-1) at
+        render_rays.py:88-90; here the decision travels as a device flag and the caller decides when to look."""
+        fl = self.flags[:self._n_steps if n_steps is None else n_steps, 3]
+        if bool((fl != 0).any()):
+            raise RuntimeError("background model: loss explode (render_rays.py:88-90) in step(s) "
+                               f"{torch.nonzero(fl).flatten().tolist()}")
 
     def step(self, pcs, z, gt_depth, gt_rgb, sem, depth_mask) -> torch.Tensor:
         """One optimisation step on a one-step frame ([R_local, ...] inputs); returns the global loss."""

@@ -57,8 +57,9 @@ class VmapStep:
     def __init__(self, n_obj: int, rays: int, samples: int, hidden: int, device="cuda:0", max_steps: int = 32,
                  color_scaling: float = 5.0, opacity_scaling: float = 10.0, weights: str = "f32", tuning: Optional[dict] = None):
         """``tuning``: optional overrides of the automatic launch plan for measurements / A-B tests (fields of
-        ``vmapstep_tuning``: workgroups_per_object, kernel, generic_finalize, carried_finalize, carry_stamps).  They belong
-        to THIS operator (the C library keeps no tuning state)."""
+        ``vmapstep_tuning``: workgroups_per_object, kernel, generic_finalize).  They belong to THIS operator (the C library
+        keeps no tuning state).  The operator may live on any GPU of the process: every C call runs on the device that owns
+        the stream it is given (``torch.cuda.current_stream(self.device)``), whatever device is current on the thread."""
         self.lib = _lib.load()
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -130,7 +131,7 @@ class VmapStep:
         loss = torch.empty(n_steps, dtype=torch.float32, device=dev)
         flags = torch.empty(n_steps, 4, dtype=torch.int32, device=dev)
         res = StepResult(loss, flags)
-        o = _lib.Outputs(loss.data_ptr(), flags.data_ptr(), None, None, None, None)
+        o = _lib.Outputs(loss.data_ptr(), flags.data_ptr(), None, None, None, None, None)
         if render:
             n, R = self.n_obj, self.rays
             res.render_depth = torch.empty(n, R, dtype=torch.float32, device=dev)
@@ -151,12 +152,14 @@ class VmapStep:
         return self.workspace[start:start + nbytes]
 
     def fwd_bwd(self, fc, B, pe_scale, pcs, z, gt_depth, gt_rgb, sem, depth_mask, grads_fc=None, grad_B=None,
-                render: bool = False, prepared_step: Optional[int] = None) -> StepResult:
+                render: bool = False, prepared_step: Optional[int] = None, loss_terms: Optional[torch.Tensor] = None) -> StepResult:
         """Loss + gradients of all 15 stacked tensors (train.py:293-306 + :324). Gradients are written to
         ``grads_fc``/``grad_B`` if given, else into freshly allocated ``p.grad`` of the parameters.
 
         ``prepared_step``: run step i of a frame prepared with ``prepare_frame`` (mask counts / switches possibly reduced
-        over ranks by the caller, parameter image kept current by ``adamw_apply``); the batch tensors are that step's slice."""
+        over ranks by the caller, parameter image kept current by ``adamw_apply``); the batch tensors are that step's slice.
+        ``loss_terms``: optional float32 [n, 4] device tensor receiving, per object, the depth / colour / opacity terms before their
+        weights and l_batch (loss.py:59) - what a ray-sharded caller sums over ranks next to the gradients."""
         if grads_fc is None:
             grads_fc = []
             for p in list(fc) + [B]:
@@ -169,6 +172,11 @@ class VmapStep:
         sc = _lib.Tensor(pe_scale.data_ptr(), pe_scale.stride(0) if pe_scale.dim() else 0)
         bt = self._batch(pcs, z, gt_depth, gt_rgb, sem, depth_mask)
         res, out = self._outputs(1, render)
+        if loss_terms is not None:
+            if tuple(loss_terms.shape) != (self.n_obj, 4) or loss_terms.dtype != torch.float32 or not loss_terms.is_contiguous() \
+                    or loss_terms.device != self.device:
+                raise ValueError(f"loss_terms: need contiguous float32 {(self.n_obj, 4)} on {self.device}")
+            out.loss_terms = loss_terms.data_ptr()
         if prepared_step is not None:
             _lib.check(self.lib.vmapstep_fwd_bwd_prepared(ctypes.byref(self.shape), ctypes.byref(pp), ctypes.byref(sc), ctypes.byref(bt),
                                                           int(prepared_step), self.color_scaling, self.opacity_scaling,
@@ -197,15 +205,28 @@ class VmapStep:
         flags = self._ws_view(foff.value, n_steps * 16).view(torch.int32).view(n_steps, 4)
         return counts, flags
 
-    def adamw_apply(self, fc, B, grad_slab: torch.Tensor, opt: "FusedAdamWState"):
+    def adamw_apply(self, fc, B, grad_slab: torch.Tensor, opt: "FusedAdamWState", loss_terms: Optional[torch.Tensor] = None,
+                    step_index: int = 0, loss_out: Optional[torch.Tensor] = None, flags_out: Optional[torch.Tensor] = None):
         """torch.optim.AdamW's update from an externally reduced gradient slab ([n, padded_params] float32, flat parameter
-        order) + rewrite of the packed parameter image (vmapstep_adamw_apply); ``opt.step`` is advanced."""
+        order) + rewrite of the packed parameter image (vmapstep_adamw_apply); ``opt.step`` is advanced.
+
+        ``loss_terms`` (float32 [n, 4], the rank-summed ``fwd_bwd(..., loss_terms=)`` rows): the SAME launch also writes the
+        step's global loss to ``loss_out[0]`` and its flags to ``flags_out[0:4]`` (the reduced empty-mask switches of prepared
+        step ``step_index`` + render_rays.py:88-90's explode test on the summed terms)."""
         if tuple(grad_slab.shape) != (self.n_obj, opt.padded) or grad_slab.dtype != torch.float32 or not grad_slab.is_contiguous():
             raise ValueError(f"grad_slab: need contiguous float32 {(self.n_obj, opt.padded)}")
         pp = self._params(fc, B)
         oc = opt.c_struct()
+        out, lt = None, None
+        if loss_terms is not None:
+            if loss_out is None or flags_out is None or loss_out.dtype != torch.float32 or flags_out.dtype != torch.int32 \
+                    or flags_out.numel() < 4 or not flags_out.is_contiguous():
+                raise ValueError("loss_terms given: loss_out (float32 [>=1]) and flags_out (contiguous int32 [>=4]) are required")
+            out = ctypes.byref(_lib.Outputs(loss_out.data_ptr(), flags_out.data_ptr(), None, None, None, None, None))
+            lt = loss_terms.data_ptr()
         _lib.check(self.lib.vmapstep_adamw_apply(ctypes.byref(self.shape), ctypes.byref(pp), grad_slab.data_ptr(), opt.padded,
-                                                 ctypes.byref(oc), self._ws_ptr, self._ws_bytes, self._stream()))
+                                                 ctypes.byref(oc), lt, int(step_index), self.color_scaling, self.opacity_scaling, out,
+                                                 self._ws_ptr, self._ws_bytes, self._stream()))
         opt.step += 1
 
     def render(self, fc, B, pe_scale, pcs, z, gt_depth, gt_rgb, sem, depth_mask) -> StepResult:
@@ -240,7 +261,7 @@ class VmapStep:
         pp = self._params(fc, B)
         sc = _lib.Tensor(pe_scale.data_ptr(), pe_scale.stride(0) if pe_scale.dim() else 0)
         bt = self._batch(pcs, z, gt_depth, gt_rgb, sem, depth_mask)
-        cap = 8 * ((self.n_obj + 7) // 8) * 256 * 4 * 16      # up to 256 workgroups per object
+        cap = 8 * ((self.n_obj + 7) // 8) * 512 * 4 * 16      # up to 512 workgroups per object (step_main_wp at hidden 64: two per CU)
         buf = torch.zeros(cap, dtype=torch.int32, device=self.device)
         nwg = ctypes.c_int32(0)
         _lib.check(self.lib.vmapstep_profile_phases(ctypes.byref(self.shape), ctypes.byref(pp), ctypes.byref(sc),
@@ -340,9 +361,9 @@ VmapStep.bind = _bind
 
 
 def _profile_train_steps(self, fc, B, pe_scale, pcs, z, gt_depth, gt_rgb, sem, depth_mask, opt: "FusedAdamWState", n_steps: int) -> float:
-    """Average duration (ms) of the dominant kernel over ``n_steps`` real training steps (events around every launch,
-    in the prep / main / finalize sequence of ``train_steps``); waits for the device.  Returns (raw event-pair time,
-    the same minus the cost of an empty event pair)."""
+    """Average duration (ms) of the dominant kernel over ``n_steps`` real training steps, in the prep / main / finalize sequence
+    of ``train_steps``; waits for the device.  Returns (the dispatch's own begin -> end time - what a kernel trace reports -,
+    a pair of stream events around the launch)."""
     pp = self._params(fc, B)
     sc = _lib.Tensor(pe_scale.data_ptr(), pe_scale.stride(0) if pe_scale.dim() else 0)
     bt = self._batch(pcs, z, gt_depth, gt_rgb, sem, depth_mask, rays_total=pcs.shape[1])
