@@ -49,12 +49,16 @@ def round_bf16(a):
     return u.astype(np.uint32).view(np.float32).reshape(np.shape(a))
 
 
-def kink_aware(got, ref, n_obj):
+def kink_aware(got, ref, n_obj, signed=False):
     """ReLU-kink accounting (oracle.vmap_oracle.kink_deltas): ``ref`` = an oracle result computed with ``kinks=True``, ``got`` = another
     float32 implementation's result.  Per object, the derivative bit of every kink-adjacent hidden unit is solved for by least
     squares (one unknown per ambiguous entry against the object's ~10^4..10^5 gradient elements), REQUIRED to round to 0 or 1,
     and the rounded combination is added to the oracle's gradients.  Returns ({key: corrected oracle gradient}, flipped bits,
-    ambiguous entries, worst effect of rounding a beta, in units of the affected tensor's max)."""
+    ambiguous entries, worst effect of rounding a beta, in units of the affected tensor's max).
+
+    ``signed``: ``ref``'s gradients come from a THIRD implementation (a reference fixture) while its ``kink_deltas`` are the
+    oracle's: a bit may then differ from the oracle's state in ``ref``, in ``got`` or in both, so each coefficient is the
+    difference of two bits, in {-1, 0, +1}."""
     shapes = [np.shape(ref[k]) for k in GRAD_KEYS]
     flat = lambda d, k: np.concatenate([np.asarray(d[key], np.float64)[k].ravel() for key in GRAD_KEYS])
     # per-element scale of an object's flat gradient vector: the max of the tensor the element belongs to (the tolerance is per tensor)
@@ -69,9 +73,9 @@ def kink_aware(got, ref, n_obj):
             continue
         A = np.stack(D, axis=1)
         beta, *_ = np.linalg.lstsq(A / scale[:, None], (flat(got, k) - flat(ref, k)) / scale, rcond=None)
-        rb = np.clip(np.round(beta), 0, 1)
+        rb = np.clip(np.round(beta), -1 if signed else 0, 1)
         worst = max(worst, float((np.abs(beta - rb) * np.abs(A / scale[:, None]).max(axis=0)).max()))
-        flipped += int(rb.sum())
+        flipped += int(np.abs(rb).sum())
         add = A @ rb
         o = 0
         for key, shp in zip(GRAD_KEYS, shapes):
