@@ -4,12 +4,9 @@
 #include <cstring>
 #include <vector>
 
-#include "wide_kernels.h"
-#include "split_kernels.h"
-#include "wsplit_kernels.h"
-#include "wpair_kernels.h"
-#include "sample_kernels.h"
-#include "query_kernels.h"
+#include <cmath>
+
+#include "sim_launch.h"
 
 namespace {
 void fc_sizes(int H, int* sz) {
@@ -77,78 +74,13 @@ extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req, int xcd
     if (ws) {
         ws_scratch.assign((size_t)n * NW * (wp ? (H == 128 ? vk::LdsWp<4>::WG_SCRATCH : vk::LdsWp<2>::WG_SCRATCH) : vk::ImgWs<4>::WG_SCRATCH), (char)0xFF);
         wa.s = a; wa.scratch = ws_scratch.data(); wa.tab_wt = tab_wt.data();
-        if (H == 128) sim::launch(1 + n * vk::ws_pack_blocks<4>(), vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep_ws<4>(wa); });
-        else sim::launch(1 + n * vk::ws_pack_blocks<2>(), vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep_ws<2>(wa); });
-    } else if (split) sim::launch(1 + n * vk::kSplitPackBlocks, vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep_s32(a); });
-    else sim::launch(1 + n * (vk::gen_layout(H).imgp / 1024), vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep(a); });
-    const bool multi = NW < NG;
-    const int grid = xcd_affine && H == 32 ? 8 * ((n + 7) / 8) * NW : n * NW;
-    if (wp && H == 128) {
-        const int lb = vk::LdsWp<4>::LDS_BYTES;
-        if (weights_bf16) {
-            if (bwd) sim::launch(n * NW, 512, lb, [&] { vk::step_main_wp<4, true, false>(wa); });
-            else     sim::launch(n * NW, 512, lb, [&] { vk::step_main_wp<4, false, false>(wa); });
-        } else {
-            if (bwd) sim::launch(n * NW, 512, lb, [&] { vk::step_main_wp<4, true, true>(wa); });
-            else     sim::launch(n * NW, 512, lb, [&] { vk::step_main_wp<4, false, true>(wa); });
-        }
-    } else if (wp) {
-        const int lb = vk::LdsWp<2>::LDS_BYTES;
-        if (weights_bf16) {
-            if (bwd) sim::launch(n * NW, 256, lb, [&] { vk::step_main_wp<2, true, false>(wa); });
-            else     sim::launch(n * NW, 256, lb, [&] { vk::step_main_wp<2, false, false>(wa); });
-        } else {
-            if (bwd) sim::launch(n * NW, 256, lb, [&] { vk::step_main_wp<2, true, true>(wa); });
-            else     sim::launch(n * NW, 256, lb, [&] { vk::step_main_wp<2, false, true>(wa); });
-        }
-    } else if (ws && H == 128) {
-        const int lb = vk::ImgWs<4>::LDS_BYTES;
-        if (weights_bf16) {
-            if (bwd) sim::launch(n * NW, vk::kWG, lb, [&] { vk::step_main_ws<4, true, false>(wa); });
-            else     sim::launch(n * NW, vk::kWG, lb, [&] { vk::step_main_ws<4, false, false>(wa); });
-        } else {
-            if (bwd) sim::launch(n * NW, vk::kWG, lb, [&] { vk::step_main_ws<4, true, true>(wa); });
-            else     sim::launch(n * NW, vk::kWG, lb, [&] { vk::step_main_ws<4, false, true>(wa); });
-        }
-    } else if (ws) {
-        const int lb = vk::ImgWs<2>::LDS_BYTES;
-        if (weights_bf16) {
-            if (bwd) sim::launch(n * NW, vk::kWG, lb, [&] { vk::step_main_ws<2, true, false>(wa); });
-            else     sim::launch(n * NW, vk::kWG, lb, [&] { vk::step_main_ws<2, false, false>(wa); });
-        } else {
-            if (bwd) sim::launch(n * NW, vk::kWG, lb, [&] { vk::step_main_ws<2, true, true>(wa); });
-            else     sim::launch(n * NW, vk::kWG, lb, [&] { vk::step_main_ws<2, false, true>(wa); });
-        }
-    } else if (split) {
-        const int lb = vk::Img32s::LDS_BYTES;
-        if (weights_bf16) {
-            if (bwd && multi)  sim::launch(grid, vk::kWG, lb, [&] { vk::step_main_s32<true, true, false, false>(a); });
-            if (bwd && !multi) sim::launch(grid, vk::kWG, lb, [&] { vk::step_main_s32<true, false, false, false>(a); });
-            if (!bwd)          sim::launch(grid, vk::kWG, lb, [&] { vk::step_main_s32<false, false, false, false>(a); });
-        } else {
-            if (bwd && multi)  sim::launch(grid, vk::kWG, lb, [&] { vk::step_main_s32<true, true, false, true>(a); });
-            if (bwd && !multi) sim::launch(grid, vk::kWG, lb, [&] { vk::step_main_s32<true, false, false, true>(a); });
-            if (!bwd)          sim::launch(grid, vk::kWG, lb, [&] { vk::step_main_s32<false, false, false, true>(a); });
-        }
-    } else if (H == 32) {
-        if (bwd && multi)  sim::launch(grid, vk::kWG, vk::Lds32::BYTES, [&] { vk::step_main_h32<true, true>(a); });
-        if (bwd && !multi) sim::launch(grid, vk::kWG, vk::Lds32::BYTES, [&] { vk::step_main_h32<true, false>(a); });
-        if (!bwd)          sim::launch(grid, vk::kWG, vk::Lds32::BYTES, [&] { vk::step_main_h32<false, false>(a); });
-    } else {
-        vk::GenArgs ga;
-        ga.s = a;
-        ga.wave_blocks = vk::gen_wave_blocks(GL.NB);
-        std::vector<float> scratch((size_t)n * NW * vk::kWaves * ga.wave_blocks * vk::kBlk, NAN);
-        ga.scratch = scratch.data();
-        if (g_wide == 1) {
-            if (H % 128 != 0 || G * S > vk::kWideTile) return -3;
-            ga.s.wide = 1;
-            const int lb = vk::LdsWide<4>::bytes(GL.small_n);
-            if (bwd) sim::launch(n * NW, 256, lb, [&] { vk::step_main_wide<true, 4>(ga); });
-            else     sim::launch(n * NW, 256, lb, [&] { vk::step_main_wide<false, 4>(ga); });
-        } else if (bwd) sim::launch(n * NW, vk::kWG, vk::LdsGen::bytes(GL.small_n), [&] { vk::step_main_gen<true>(ga); });
-        else     sim::launch(n * NW, vk::kWG, vk::LdsGen::bytes(GL.small_n), [&] { vk::step_main_gen<false>(ga); });
-    }
+        sl::prep_ws(wa);
+    } else if (split) sl::prep_s32(a);
+    else sl::prep_f32(a, 1 + n * (vk::gen_layout(H).imgp / 1024));
+    if (wp) sl::main_wp(wa, bwd);
+    else if (ws) sl::main_ws(wa, bwd);
+    else if (split) sl::main_s32(a, bwd);
+    else if (int rc = sl::main_f32(a, g_wide, bwd, G)) return rc;
 
     vk::FinalizeArgs f{};
     f.n_obj = n; f.NW = NW; f.PP = PP; f.P = P; f.hidden = H; f.weights_bf16 = weights_bf16;
@@ -177,8 +109,7 @@ extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req, int xcd
         h.decay = f.decay; h.one_minus_beta1 = f.one_minus_beta1; h.beta2 = f.beta2; h.one_minus_beta2 = f.one_minus_beta2;
         h.eps = f.eps; h.step_size = f.step_size; h.bias_corr2_sqrt = f.bias_corr2_sqrt;
         f.do_adam = do_adam && p_out;
-        if (H == 128) sim::launch(n * vk::ws_finalize_blocks(PP) + 1, vk::kWG, 4 * vk::kWG * 4, [&] { vk::step_finalize_ws<4>(f, h, tab_wt.data()); });
-        else sim::launch(n * vk::ws_finalize_blocks(PP) + 1, vk::kWG, 4 * vk::kWG * 4, [&] { vk::step_finalize_ws<2>(f, h, tab_wt.data()); });
+        sl::finalize_ws(f, h, tab_wt.data());
         return 0;
     }
     if (H == 32 && bwd && do_adam && p_out) {
@@ -187,7 +118,7 @@ extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req, int xcd
         if (grads) {
             vk::FinalizeArgs fg = f;
             fg.do_adam = 0;
-            sim::launch(n * bpo + 1, vk::kWG, 2 * vk::kWG * 4, [&] { vk::step_finalize(fg); });
+            sl::finalize_generic(fg, n * bpo + 1);
             for (int t = 0; t < 15; ++t) f.grad[t] = {nullptr, P};
         }
         vk::FinalizeHot h{};
@@ -196,11 +127,11 @@ extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req, int xcd
         h.NW = f.NW; h.PP = f.PP; h.weights_bf16 = f.weights_bf16;
         h.decay = f.decay; h.one_minus_beta1 = f.one_minus_beta1; h.beta2 = f.beta2; h.one_minus_beta2 = f.one_minus_beta2;
         h.eps = f.eps; h.step_size = f.step_size; h.bias_corr2_sqrt = f.bias_corr2_sqrt;
-        if (split) sim::launch(n * bpo + 1, vk::kWG, 2 * vk::kWG * 4, [&] { vk::step_finalize_s32(f, h); });
-        else sim::launch(n * bpo + 1, vk::kWG, 2 * vk::kWG * 4, [&] { vk::step_finalize_h32(f, h); });
+        if (split) sl::finalize_s32(f, h, n * bpo + 1);
+        else sl::finalize_h32(f, h, n * bpo + 1);
         return 0;
     }
-    sim::launch(n * bpo + 1, vk::kWG, 2 * vk::kWG * 4, [&] { vk::step_finalize(f); });
+    sl::finalize_generic(f, n * bpo + 1);
     return 0;
 }
 
@@ -216,8 +147,7 @@ extern "C" int vmsim_sample(const vs::SampleObject* objs, int n_obj, int W, int 
     a.seed_lo = (unsigned)seed; a.seed_hi = (unsigned)(seed >> 32); a.frame_counter = frame_counter;
     a.rnd.kf_ids = kf_ids; a.rnd.u_w = u_w; a.rnd.u_h = u_h; a.rnd.u_z = u_z; a.rnd.g_z = g_z;
     a.pcs = pcs; a.z = z; a.gt_depth = gt_depth; a.gt_rgb = gt_rgb; a.sem = sem; a.depth_mask = dmask;
-    if ((long long)F * P <= vs::kMaxStagedRays) sim::launch(n_obj, vs::kWG, (3 * (size_t)F * P + vs::kWG) * 4, [&] { vs::frame_sample<true>(a); });
-    else sim::launch(n_obj, vs::kWG, vs::kWG * 4, [&] { vs::frame_sample<false>(a); });
+    sl::sample(a, n_obj, (long long)F * P);
     return 0;
 }
 extern "C" int vmsim_sample_object_size() { return (int)sizeof(vs::SampleObject); }
@@ -232,15 +162,7 @@ extern "C" int vmsim_query(const float* const* fc, const float* B, const float* 
     for (int t = 0; t < 14; ++t) a.fc[t] = {const_cast<float*>(fc[t]), 0};
     a.pe_B = {const_cast<float*>(B), 0};
     a.wimg = img.data();
-    sim::launch(GL.imgp / 1024, vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep(a); });
     vk::QueryArgs q{};
     q.wimg = img.data(); q.scale = scale; q.pts = pts; q.pts_sn = 3; q.pts_sc = 1; q.n_pts = n_pts; q.occ = occ; q.rgb = rgb;
-    switch (H / 32) {
-        case 1: sim::launch(grid, vk::kWG, vk::Lds32::IMGP * 4, [&] { vk::field_query_h32<2>(q); }); break;
-        case 2: sim::launch(grid, vk::kWG, 64, [&] { vk::field_query_gen<2>(q); }); break;
-        case 4: sim::launch(grid, vk::kWG, 64, [&] { vk::field_query_gen<4>(q); }); break;
-        case 8: sim::launch(grid, vk::kWG, 8 * 1024 * vk::kWaves * 4, [&] { vk::field_query_gen<8>(q); }); break;
-        default: return -2;
-    }
-    return 0;
+    return sl::query(H, a, q, grid);
 }

@@ -1,0 +1,20 @@
+// TEST INFRASTRUCTURE: simulator launchers of the frame sampler and the inference query (see sim_launch.h)
+#include "sim_launch.h"
+
+namespace sl {
+void sample(const vs::SampleArgs& a, int n_obj, long long rays) {
+    if (rays <= vs::kMaxStagedRays) sim::launch(n_obj, vs::kWG, (3 * (size_t)rays + vs::kWG) * 4, [&] { vs::frame_sample<true>(a); });
+    else sim::launch(n_obj, vs::kWG, vs::kWG * 4, [&] { vs::frame_sample<false>(a); });
+}
+int query(int H, const vk::StepArgs& pack, const vk::QueryArgs& q, int grid) {
+    sim::launch(vk::gen_layout(H).imgp / 1024, vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep(pack); });
+    switch (H / 32) {
+        case 1: sim::launch(grid, vk::kWG, vk::Lds32::IMGP * 4, [&] { vk::field_query_h32<2>(q); }); break;
+        case 2: sim::launch(grid, vk::kWG, 64, [&] { vk::field_query_gen<2>(q); }); break;
+        case 4: sim::launch(grid, vk::kWG, 64, [&] { vk::field_query_gen<4>(q); }); break;
+        case 8: sim::launch(grid, vk::kWG, 8 * 1024 * vk::kWaves * 4, [&] { vk::field_query_gen<8>(q); }); break;
+        default: return -2;
+    }
+    return 0;
+}
+}  // namespace sl

@@ -14,27 +14,49 @@ OUT = os.path.join(SIM, "_build", "libvmsim.so")
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 
 
+UNITS = ("sim_abi", "sim_runtime", "sim_k_f32", "sim_k_s32", "sim_k_ws", "sim_k_wp", "sim_k_misc")
+
+
+def _deps(src, pool):
+    """The files of `pool` a source includes, transitively (by base name)."""
+    import re
+    by_name = {os.path.basename(h): h for h in pool}
+    seen, todo = set(), [src]
+    while todo:
+        with open(todo.pop()) as fh:
+            for inc in re.findall(r'#include\s+[<"]([^">]+)[">]', fh.read()):
+                h = by_name.get(os.path.basename(inc))
+                if h and h not in seen:
+                    seen.add(h)
+                    todo.append(h)
+    return sorted(seen)
+
+
 def build(force=False):
-    srcs = [os.path.join(SIM, "sim_abi.cpp"), os.path.join(SIM, "sim_runtime.cpp")]
-    deps = srcs + [os.path.join(SIM, "sim_runtime.h"), os.path.join(SIM, "wave_ops.h"),
-                   os.path.join(SIM, "include", "hip", "hip_runtime.h"),
-                   os.path.join(ROOT, "vmap_amd", "csrc", "step_kernels.h"),
-                   os.path.join(ROOT, "vmap_amd", "csrc", "gen_kernels.h"),
-                   os.path.join(ROOT, "vmap_amd", "csrc", "sample_kernels.h"),
-                   os.path.join(ROOT, "vmap_amd", "csrc", "query_kernels.h"),
-                   os.path.join(ROOT, "vmap_amd", "csrc", "wide_kernels.h"),
-                   os.path.join(ROOT, "vmap_amd", "csrc", "split_kernels.h"),
-                   os.path.join(ROOT, "vmap_amd", "csrc", "wsplit_kernels.h"),
-                   os.path.join(ROOT, "vmap_amd", "csrc", "wpair_kernels.h")]
-    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
-        return OUT
+    """One object per kernel family (like the device build), compiled side by side by the host compiler, linked into
+    tests/sim/_build/libvmsim.so; a unit is rebuilt only when one of the headers it includes changed."""
+    csrc = os.path.join(ROOT, "vmap_amd", "csrc")
+    pool = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".h")] + \
+           [os.path.join(SIM, f) for f in os.listdir(SIM) if f.endswith(".h")] + [os.path.join(SIM, "include", "hip", "hip_runtime.h")]
+    # the sim's wave_ops.h and fake <hip/hip_runtime.h> shadow the device ones (include order below)
+    pool = [h for h in pool if h != os.path.join(csrc, "wave_ops.h")]
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     cxx = CLANG if os.path.exists(CLANG) else "clang++"
-    # include order: the sim's wave_ops.h and fake <hip/hip_runtime.h> shadow the device ones
-    cmd = [cxx, "-std=c++17", "-O2", "-mfma", "-ffp-contract=fast", "-fPIC", "-shared",
-           "-I", SIM, "-I", os.path.join(SIM, "include"), "-I", os.path.join(ROOT, "vmap_amd", "csrc"),
-           "-Wno-unused-value", "-Wno-psabi", "-Wno-pass-failed", "-o", OUT] + srcs
-    subprocess.run(cmd, check=True)
+    flags = [cxx, "-std=c++17", "-O2", "-mfma", "-ffp-contract=fast", "-fPIC", "-I", SIM, "-I", os.path.join(SIM, "include"),
+             "-I", csrc, "-Wno-unused-value", "-Wno-psabi", "-Wno-pass-failed"]
+    procs, objs = [], []
+    for u in UNITS:
+        src, obj = os.path.join(SIM, u + ".cpp"), os.path.join(os.path.dirname(OUT), u + ".o")
+        objs.append(obj)
+        deps = [src, os.path.abspath(__file__)] + _deps(src, pool)
+        if force or not os.path.exists(obj) or any(os.path.getmtime(obj) < os.path.getmtime(d) for d in deps):
+            procs.append((u, subprocess.Popen(flags + ["-c", src, "-o", obj])))
+    failed = [u for u, p in procs if p.wait() != 0]
+    if failed:
+        raise subprocess.CalledProcessError(1, f"simulator build: {failed}")
+    if force or procs or not os.path.exists(OUT) or any(os.path.getmtime(OUT) < os.path.getmtime(o) for o in objs):
+        subprocess.run([cxx, "-shared", "-fPIC", "-o", OUT + ".tmp"] + objs, check=True)
+        os.replace(OUT + ".tmp", OUT)
     return OUT
 
 
