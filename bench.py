@@ -124,6 +124,7 @@ def main():
     ap.add_argument("--no-background", action="store_true")
     ap.add_argument("--timed-only", action="store_true")            # skip the roofline / baseline legs (for kernel traces of the timed region)
     ap.add_argument("--unbound", action="store_true")               # marshal the arguments on every frame call (VmapStep.train_steps)
+    ap.add_argument("--graph", action="store_true")                 # measurement: the bound frame call replayed as a hipGraph (bit-identical; no gain: profiles/r03i)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -169,7 +170,7 @@ def main():
 
     # the frame tensors and the stacked parameters do not move between frame calls: marshal them once (BoundFrame), as
     # driver.HipMapper does for its slab and its sampler's frame buffers
-    bound = None if args.unbound else op.bind(tfc, tB, tsc, *fargs, opt=opt, flag_reduce=flag_reduce)
+    bound = None if args.unbound else op.bind(tfc, tB, tsc, *fargs, opt=opt, flag_reduce=flag_reduce, graph=args.graph)
 
     def run(n_steps):
         done = 0
@@ -421,7 +422,9 @@ def main():
             "preheat": {"ms": args.preheat_ms, "steps": preheat_steps, "timed": False},
             "with_background": with_bg,
             "world": {"world_size": world, "devices": devices, "rccl": rccl_version},
-            "frame_call": "bound (arguments marshalled once)" if bound is not None else "marshalled per call",
+            "frame_call": ("marshalled per call" if bound is None else
+                           "bound (arguments marshalled once), replayed as a hipGraph per frame (device-resident optimiser step count)" if bound.graph
+                           else "bound (arguments marshalled once), launched kernel by kernel"),
         }
     if dist:
         td.barrier()

@@ -126,6 +126,15 @@ typedef struct vmapstep_adamw {
     int32_t step;        /* number of updates already applied to this stack (0 for a fresh update_vmap) */
     float* exp_avg;      /* [n][padded_params] first moments  (see vmapstep_param_layout)               */
     float* exp_avg_sq;   /* [n][padded_params] second moments                                           */
+    /* Optional, for callers that REPLAY a captured frame call (hipGraph: kernel arguments are frozen, so the step count
+     * cannot come from `step`): a device table bias_table[t] = { lr / (1 - beta1^(t+1)), sqrt(1 - beta2^(t+1)) } for
+     * t = 0 .. table_len - 1 (later steps use the last entry: build it until both factors stop changing in float32) and a
+     * device int32 step_counter[2] = { updates applied before the call, steps of the previous call not yet folded in }.
+     * vmapstep_train_steps then takes the step count from the device (its first launch folds [1] into [0] and sets [1] =
+     * n_steps) and ignores `step`.  NULL = the host-side count above.  Not accepted by the prepared / apply entry points. */
+    const float* bias_table;
+    int32_t table_len;
+    int32_t* step_counter;
 } vmapstep_adamw;
 
 const char* vmapstep_last_error(void);

@@ -746,3 +746,64 @@ def test_parameter_image_kept_by_finalize_equals_freshly_packed_image(weights, c
     assert torch.equal(outs[0][0], outs[1][0])
     for x, y in zip(outs[0][1], outs[1][1]):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("name,steps", [("cfg2", 20), ("bg_h128_s14", 6), ("h64", 5)])
+def test_graph_replay_of_a_bound_frame_is_bit_identical_to_eager_calls(name, steps):
+    """step.BoundFrame(graph=True): the frame call (1 + 2 n launches) captured once per step count as a hipGraph and replayed,
+    with the optimiser's step count on the device (FusedAdamWState.enable_device_steps: bias corrections from a host-built
+    table, the count advanced by the call's first launch) - against the same frames through the eager path with the
+    host-side count.  Five frames, the third with a different step count (its own capture): losses, parameters and both
+    moments bit for bit; the device count equals the host count."""
+    c = cases.build_case(name)
+    outs = []
+    for graph in (False, True):
+        fc, B, sc, b = _to_dev(c)
+        op = step.VmapStep(c["n"], c["R"], c["S"], c["H"], device=DEV, max_steps=steps)
+        st = step.FusedAdamWState(c["n"], c["H"], DEV)
+        frame = {k: torch.cat([v.roll(i, dims=1) for i in range(steps)], dim=1).contiguous() for k, v in b.items()}
+        bound = op.bind(fc, B, sc, frame["pcs"], frame["z"], frame["gt_depth"], frame["gt_rgb"], frame["sem"], frame["depth_mask"], opt=st,
+                        graph=graph)
+        assert bound.graph == graph
+        losses = []
+        for n in (steps, steps, 3, steps, steps, 3, 3):
+            res = bound.train_steps(n)
+            losses.append(res.loss[:n].clone())
+        torch.cuda.synchronize()
+        assert st.step == 4 * steps + 9
+        if graph:
+            assert sorted(bound._graphs) == [3, steps]
+            assert int(st.step_counter.sum()) == st.step          # [0] + the last call's not-yet-folded steps
+        outs.append(dict(p=[t.clone() for t in fc + [B]], m=st.exp_avg.clone(), v=st.exp_avg_sq.clone(), losses=torch.cat(losses)))
+    a, g = outs
+    assert bool(torch.isfinite(a["losses"]).all())
+    assert torch.equal(a["losses"], g["losses"])
+    for x, y in zip(a["p"], g["p"]):
+        assert torch.equal(x, y)
+    assert torch.equal(a["m"], g["m"]) and torch.equal(a["v"], g["v"])
+
+
+def test_device_step_count_survives_mixed_host_and_device_calls():
+    """A state with the device-resident step count used by calls that take the count from the host in between (the prepared
+    path of a multi-rank caller: flag_reduce): both counts stay in step and the trajectory equals the all-host one."""
+    c = cases.build_case("tiny")
+    outs = []
+    for device_steps in (False, True):
+        fc, B, sc, b = _to_dev(c)
+        op = step.VmapStep(c["n"], c["R"], c["S"], c["H"], device=DEV, max_steps=4)
+        st = step.FusedAdamWState(c["n"], c["H"], DEV)
+        if device_steps:
+            st.enable_device_steps()
+        frame = {k: torch.cat([v.roll(i, dims=1) for i in range(4)], dim=1).contiguous() for k, v in b.items()}
+        args = (frame["pcs"], frame["z"], frame["gt_depth"], frame["gt_rgb"], frame["sem"], frame["depth_mask"])
+        losses = []
+        for i in range(6):
+            kw = dict(flag_reduce=(lambda f: f)) if i % 3 == 1 else {}        # every third frame through prepare / train_steps_prepared
+            losses.append(op.train_steps(fc, B, sc, *args, opt=st, n_steps=4 - (i % 2), **kw).loss.clone())
+        torch.cuda.synchronize()
+        if device_steps:
+            assert int(st.step_counter.sum()) == st.step == 21
+        outs.append((torch.cat(losses), [t.clone() for t in fc + [B]]))
+    assert torch.equal(outs[0][0], outs[1][0])
+    for x, y in zip(outs[0][1], outs[1][1]):
+        assert torch.equal(x, y)

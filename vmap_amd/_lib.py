@@ -59,7 +59,8 @@ class Outputs(ctypes.Structure):
 class AdamW(ctypes.Structure):
     _fields_ = [("lr", ctypes.c_float), ("beta1", ctypes.c_float), ("beta2", ctypes.c_float),
                 ("eps", ctypes.c_float), ("weight_decay", ctypes.c_float), ("step", ctypes.c_int32),
-                ("exp_avg", ctypes.c_void_p), ("exp_avg_sq", ctypes.c_void_p)]
+                ("exp_avg", ctypes.c_void_p), ("exp_avg_sq", ctypes.c_void_p),
+                ("bias_table", ctypes.c_void_p), ("table_len", ctypes.c_int32), ("step_counter", ctypes.c_void_p)]
 
 
 class SampleObject(ctypes.Structure):

@@ -230,6 +230,8 @@ __global__ __launch_bounds__(kWG) void step_prep_s32(const StepArgs a) {
 // ---------------------------------------------------------------------------------------------------------
 template <bool SLAB>
 __device__ __forceinline__ void finalize_quad_s32(const FinalizeArgs& f, const FinalizeHot& a, int obj, int q) {
+    float ss, bc;
+    adam_step_consts(f, a, ss, bc);
     typedef int i32x4 __attribute__((ext_vector_type(4)));
     const long long s = (long long)obj * a.PP + 4 * q;
     const wv::f32x4* pg = reinterpret_cast<const wv::f32x4*>(a.part_grad + (long long)obj * a.NW * a.PP + 4 * q);
@@ -272,7 +274,7 @@ __device__ __forceinline__ void finalize_quad_s32(const FinalizeArgs& f, const F
     for (int e = 0; e < 4; ++e) {
         if (4 * q + e < Flat32::P) {
             float p = pv[e], m = m4[e], v = v4[e];
-            adamw_elem(a, g[e], p, m, v);
+            adamw_elem(a, ss, bc, g[e], p, m, v);
             *pp[e] = p; m4[e] = m; v4[e] = v;
             split_image_store(image, img[e], p, a.weights_bf16);
         }

@@ -78,6 +78,8 @@ struct StepArgs {
     float* gen_scratch;                // step_main_gen / step_main_wide: per-wave (per-workgroup) register-image scratch (workspace)
                                        // step_main_ws (wide == 3): per-workgroup cos factors of the encoding
     int* tab_wt;                       // step_prep_ws / step_finalize_ws: [PP] flat parameter -> element of the W^T image planes (or -1)
+    int* adam_counter;                 // device-resident optimiser step count (vmapstep_adamw::step_counter) or null: the first prep
+                                       // block of a training call advances it by the previous call's steps (see prep_stats)
 };
 
 __device__ __forceinline__ constexpr int phi(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
@@ -832,6 +834,11 @@ __device__ __forceinline__ void prep_stats(const StepArgs& a, int step, int tabl
     float* lds = wv::lds_base();
     int* dropw = reinterpret_cast<int*>(lds);          // [kWaves]
     const int lane = tid & 63, wave = tid >> 6;
+    // Device-resident step count of the fused AdamW (a frame call replayed as a graph has frozen arguments, so the bias
+    // corrections of its steps cannot come from the host): [0] = updates applied before THIS call, [1] = steps of this call,
+    // folded into [0] by the next call's first launch.  Single writer, stream-ordered against every reader (the finalize
+    // kernels of this call read [0] only).
+    if (step == 0 && tid == 0 && a.adam_counter) { a.adam_counter[0] += a.adam_counter[1]; a.adam_counter[1] = a.prep_steps; }
     if (step == 0 && a.img_tab) {                      // padding entries; the real ones are written by the pack blocks of object 0
         for (int i = table_len_P + tid; i < table_len_PP; i += kWG) a.img_tab[i] = 0;
     }
@@ -928,19 +935,31 @@ struct FinalizeArgs {
     int xcd_affine;                    // block -> object map that keeps an object on the XCD step_main used for it
     // AdamW constants, evaluated by the host in double and rounded once (as torch's Python-side scalars are)
     float decay, one_minus_beta1, beta2, one_minus_beta2, eps, step_size, bias_corr2_sqrt;
+    // ... or, for graph replay, the two step-dependent ones from a host-built table indexed by the device-resident step count:
+    // adam_tab[2 t] = lr / (1 - beta1^(t+1)), adam_tab[2 t + 1] = sqrt(1 - beta2^(t+1)), t = adam_cnt[0] + adam_i (clamped)
+    const float* adam_tab; const int* adam_cnt; int adam_i, adam_len;
 };
+// the two step-dependent AdamW constants of this launch (wave-uniform scalar loads in table mode)
+template <class Consts>
+__device__ __forceinline__ void adam_step_consts(const FinalizeArgs& f, const Consts& c, float& step_size, float& bias_corr2_sqrt) {
+    step_size = c.step_size; bias_corr2_sqrt = c.bias_corr2_sqrt;
+    if (f.adam_tab) {
+        const int t = min(f.adam_cnt[0] + f.adam_i, f.adam_len - 1);
+        step_size = f.adam_tab[2 * t]; bias_corr2_sqrt = f.adam_tab[2 * t + 1];
+    }
+}
 
 // torch.optim.AdamW, single-tensor form, one element
 template <class Consts>      // FinalizeArgs or FinalizeHot: same field names
-__device__ __forceinline__ void adamw_elem(const Consts& a, float ge, float& p, float& m, float& v) {
+__device__ __forceinline__ void adamw_elem(const Consts& a, float step_size, float bias_corr2_sqrt, float ge, float& p, float& m, float& v) {
     // every operation rounded on its own, like the eager tensor ops it restates - and so that the two places this is
     // inlined into (step_finalize, the carried finalize) cannot end up with different fused forms
 #pragma clang fp contract(off)
     p = p * a.decay;                                          // param.mul_(1 - lr * wd)
     m = m + (ge - m) * a.one_minus_beta1;                     // exp_avg.lerp_(grad, 1 - beta1)
     v = v * a.beta2 + (ge * ge) * a.one_minus_beta2;          // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
-    const float denom = sqrtf(v) / a.bias_corr2_sqrt + a.eps;
-    p = p - a.step_size * (m / denom);                        // param.addcdiv_(exp_avg, denom, -lr / bc1)
+    const float denom = sqrtf(v) / bias_corr2_sqrt + a.eps;
+    p = p - step_size * (m / denom);                        // param.addcdiv_(exp_avg, denom, -lr / bc1)
 }
 
 // flat parameters 4*q4 .. 4*q4+3 of object obj.  The partial rows and the moment slabs are PP-pitched (PP % 64 == 0,
@@ -985,6 +1004,8 @@ __device__ __forceinline__ void finalize_quad(const FinalizeArgs& a, const GenLa
         for (int u = 0; u < 8; ++u)
             if (q + u < a.NW) g += t[u];
     }
+    float ss, bc;
+    adam_step_consts(a, a, ss, bc);
     const long long s = (long long)obj * a.PP + i0;
     wv::f32x4 m4 = {0.0f, 0.0f, 0.0f, 0.0f}, v4 = m4;
     if (a.do_adam) {
@@ -999,7 +1020,7 @@ __device__ __forceinline__ void finalize_quad(const FinalizeArgs& a, const GenLa
             if (gp[e]) *gp[e] = ge;
             if (a.do_adam) {
                 float p = pv[e], m = m4[e], v = v4[e];
-                adamw_elem(a, ge, p, m, v);
+                adamw_elem(a, ss, bc, ge, p, m, v);
                 *pp[e] = p; m4[e] = m; v4[e] = v;
                 float* ip = a.wimg + (long long)obj * GL.imgp + img[e];
                 const float pw = a.weights_bf16 ? round_bf16(p) : p;
@@ -1544,6 +1565,8 @@ __global__ __launch_bounds__(kWG, 1) void step_main_h32(const StepArgs a) {
 // ~1000 instructions per thread on 3.5 waves per SIMD, not waiting for memory).
 template <bool SLAB>
 __device__ __forceinline__ void finalize_quad_h32(const FinalizeArgs& f, const FinalizeHot& a, int obj, int q) {
+    float ss, bc;
+    adam_step_consts(f, a, ss, bc);
     using L = Lds32;
     typedef int i32x4 __attribute__((ext_vector_type(4)));
     const long long s = (long long)obj * a.PP + 4 * q;
@@ -1586,7 +1609,7 @@ __device__ __forceinline__ void finalize_quad_h32(const FinalizeArgs& f, const F
     for (int e = 0; e < 4; ++e) {
         if (4 * q + e < Flat32::P) {
             float p = pv[e], m = m4[e], v = v4[e];
-            adamw_elem(a, g[e], p, m, v);
+            adamw_elem(a, ss, bc, g[e], p, m, v);
             *pp[e] = p; m4[e] = m; v4[e] = v;
             a.wimg[(long long)obj * L::IMGP + img[e]] = a.weights_bf16 ? round_bf16(p) : p;
         }

@@ -269,7 +269,7 @@ int launch_prep(const vk::StepArgs& a, int n_steps, hipStream_t st) {
 
 void fill_finalize_args(vk::FinalizeArgs& f, const vk::StepArgs& a, const Layout& L, const vmapstep_params* params,
                         const vmapstep_params* grads, const vmapstep_adamw* opt, int step_after, bool have_grad,
-                        float* loss_out, int* flags_out, float* terms_out) {
+                        float* loss_out, int* flags_out, float* terms_out, int step_in_call) {
     std::memset(&f, 0, sizeof(f));
     f.n_obj = a.n_obj; f.NW = a.NW; f.PP = L.PP; f.P = L.P; f.hidden = a.hidden; f.weights_bf16 = a.weights_bf16;
     for (int t = 0; t < 16; ++t) f.offs[t] = L.offs[t];
@@ -296,6 +296,9 @@ void fill_finalize_args(vk::FinalizeArgs& f, const vk::StepArgs& a, const Layout
         f.eps = opt->eps;
         f.step_size = (float)(lr / (1.0 - std::pow(b1, (double)step_after)));
         f.bias_corr2_sqrt = (float)std::sqrt(1.0 - std::pow(b2, (double)step_after));
+        if (opt->bias_table) {           // device-resident step count (graph replay): the two factors above come from the table
+            f.adam_tab = opt->bias_table; f.adam_cnt = opt->step_counter; f.adam_i = step_in_call; f.adam_len = opt->table_len;
+        }
     }
     f.xcd_affine = (a.xcd_affine && have_grad) ? 1 : 0;
 }
@@ -318,9 +321,9 @@ void fill_hot(vk::FinalizeHot& h, const vk::FinalizeArgs& f, const vk::StepArgs&
 
 int launch_finalize(const vk::StepArgs& a, const Layout& L, const vmapstep_params* params, const vmapstep_params* grads,
                     const vmapstep_adamw* opt, int step_after, bool have_grad, float* loss_out, int* flags_out,
-                    float* terms_out, hipStream_t st, bool generic_finalize) {
+                    float* terms_out, hipStream_t st, bool generic_finalize, int step_in_call = 0) {
     vk::FinalizeArgs f;
-    fill_finalize_args(f, a, L, params, grads, opt, step_after, have_grad, loss_out, flags_out, terms_out);
+    fill_finalize_args(f, a, L, params, grads, opt, step_after, have_grad, loss_out, flags_out, terms_out, step_in_call);
     const int bpo = (L.PP / 4 + vk::kWG - 1) / vk::kWG;
     // + 1: the loss / flag reduction has a workgroup of its own (it used to ride on block 0 and made it the straggler)
     const int grid = (!have_grad ? 0 : f.xcd_affine ? 8 * ((a.n_obj + 7) / 8) * bpo : a.n_obj * bpo) + 1;
@@ -451,6 +454,7 @@ int vmapstep_adamw_apply(const vmapstep_shape* shape, const vmapstep_params* par
     if (!grad_slab || grad_stride != L.PP || reinterpret_cast<uintptr_t>(grad_slab) % 16)
         return fail(VMAPSTEP_ERR_ARGUMENT, "grad_slab: need 16-byte aligned rows of padded_params = %d floats (vmapstep_param_layout)", L.PP);
     if (!opt || !opt->exp_avg || !opt->exp_avg_sq) return fail(VMAPSTEP_ERR_ARGUMENT, "optimiser state is required");
+    if (opt->bias_table) return fail(VMAPSTEP_ERR_UNSUPPORTED, "vmapstep_adamw_apply takes the step count from opt->step (bias_table must be NULL)");
     if (loss_terms && (!out || !out->loss || !out->flags)) return fail(VMAPSTEP_ERR_ARGUMENT, "loss_terms given: outputs.loss / outputs.flags are required");
     if (!workspace || reinterpret_cast<uintptr_t>(workspace) % kAlign || workspace_bytes < pl.total)
         return fail(VMAPSTEP_ERR_WORKSPACE, "workspace too small / misaligned for this shape's parameter image");
@@ -538,9 +542,13 @@ static int train_steps_impl(const vmapstep_shape* shape, const vmapstep_params* 
     vmapstep_tensor dummy_scale = {params->fc[0].ptr, 0};
     const vmapstep_tensor* sc = pe_scale ? pe_scale : &dummy_scale;
     vk::StepArgs a;
+    const bool device_steps = do_steps && opt && opt->bias_table;
+    if (device_steps && (!opt->step_counter || opt->table_len < 1)) return fail(VMAPSTEP_ERR_ARGUMENT, "bias_table given: step_counter and table_len are required");
+    if (device_steps && !do_prep) return fail(VMAPSTEP_ERR_UNSUPPORTED, "the device-resident step count is advanced by vmapstep_train_steps' own first launch: not available on the prepared path");
     if (do_prep) {
         fill_step_args(a, shape, pl, L, params, sc, frame, 0, color_scaling, opacity_scaling, ws);
         a.prep_steps = n_steps; a.prep_ray_step = ray_step;
+        a.adam_counter = device_steps ? opt->step_counter : nullptr;
         if ((rc = launch_prep(a, n_steps, st))) return rc;
     }
     if (!do_steps) return VMAPSTEP_OK;
@@ -568,7 +576,7 @@ static int train_steps_impl(const vmapstep_shape* shape, const vmapstep_params* 
         if (rc) return rc;
         if (!ev.empty() && hipEventRecord(ev[4 * i + 1], st) != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "hipEventRecord failed");
         if ((rc = launch_finalize(a, L, params, last ? grads : nullptr, opt, opt->step + i + 1, true, out->loss + i, out->flags + 4 * i,
-                                  last ? out->loss_terms : nullptr, st, tuning_of(shape).generic_finalize != 0))) return rc;
+                                  last ? out->loss_terms : nullptr, st, tuning_of(shape).generic_finalize != 0, i))) return rc;
     }
     if (!ev.empty()) {                       // measurement only: the one place this library waits for the device
         bool ok = hipStreamSynchronize(st) == hipSuccess;

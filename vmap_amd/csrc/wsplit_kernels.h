@@ -316,6 +316,8 @@ __global__ __launch_bounds__(kWG) void step_finalize_ws(const FinalizeArgs a, co
     for (int e = 0; e < 4; ++e)
         if (4 * q + e < a.P && a.grad[ten[e]].p) a.grad[ten[e]].p[obj * a.grad[ten[e]].stride + off[e]] = g[e];
     if (!a.do_adam) return;
+    float ss, bc;
+    adam_step_consts(a, hh, ss, bc);
     wv::f32x4 m4 = *reinterpret_cast<const wv::f32x4*>(hh.m + s);
     wv::f32x4 v4 = *reinterpret_cast<const wv::f32x4*>(hh.v + s);
     const i32x4 iw = *reinterpret_cast<const i32x4*>(hh.img_tab + 4 * q);
@@ -331,7 +333,7 @@ __global__ __launch_bounds__(kWG) void step_finalize_ws(const FinalizeArgs a, co
     for (int e = 0; e < 4; ++e) {
         if (4 * q + e < a.P) {
             float p = pv[e], m = m4[e], v = v4[e];
-            adamw_elem(hh, g[e], p, m, v);
+            adamw_elem(hh, ss, bc, g[e], p, m, v);
             *pp[e] = p; m4[e] = m; v4[e] = v;
             ws_image_store<NB>(image, iw[e], it[e], p, hh.weights_bf16);
         }

@@ -42,9 +42,46 @@ class FusedAdamWState:
         self.step = 0
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
 
-    def c_struct(self) -> _lib.AdamW:
+    def c_struct(self, device_steps: bool = False) -> _lib.AdamW:
+        if device_steps:
+            return _lib.AdamW(self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step,
+                              self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.bias_table.data_ptr(),
+                              self.bias_table.shape[0], self.step_counter.data_ptr())
         return _lib.AdamW(self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step,
-                          self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr())
+                          self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), None, 0, None)
+
+    # ---- device-resident step count (for frame calls replayed as a graph: their kernel arguments are frozen) ----------
+    bias_table: Optional[torch.Tensor] = None
+    step_counter: Optional[torch.Tensor] = None
+
+    def enable_device_steps(self, max_len: int = 1 << 16):
+        """Build the table the kernels index with the device-side step count: for t = 1, 2, ... the two step-dependent AdamW
+        scalars exactly as the host path forms them (double arithmetic, rounded once to float32: lr / (1 - beta1^t) and
+        sqrt(1 - beta2^t)), until both stop changing in float32 (beta 0.9 / 0.999: 16 610 entries) - later steps use the
+        last entry.  The counter starts at the host count; from here on ``vmapstep_train_steps`` advances it on the device."""
+        import math
+        if self.bias_table is not None:
+            return
+        import numpy as np
+        rows = []
+        # the C side forms them from the float32 members of vmapstep_adamw widened to double: do the same, bit for bit
+        lr, b1, b2 = (float(np.float32(x)) for x in (self.lr, self.betas[0], self.betas[1]))
+        last = None
+        for t in range(1, max_len + 1):
+            cur = (np.float32(lr / (1.0 - math.pow(b1, float(t)))), np.float32(math.sqrt(1.0 - math.pow(b2, float(t)))))
+            rows.append(cur)
+            if cur == (np.float32(lr), np.float32(1.0)) and cur == last:          # saturated at the exact limits
+                break
+            last = cur
+        dev = self.exp_avg.device
+        self.bias_table = torch.tensor(np.asarray(rows, dtype=np.float32), device=dev).contiguous()
+        self.step_counter = torch.tensor([self.step, 0], dtype=torch.int32, device=dev)
+
+    def note_host_steps(self, n: int):
+        """A call that took the step count from the host (prepared / apply paths) advanced the optimiser by n steps: keep the
+        device-side count in step (a tiny stream-ordered add; only when both kinds of calls are mixed on one state)."""
+        if self.step_counter is not None:
+            self.step_counter[1] += n
 
 
 class VmapStep:
@@ -228,6 +265,7 @@ class VmapStep:
                                                  ctypes.byref(oc), lt, int(step_index), self.color_scaling, self.opacity_scaling, out,
                                                  self._ws_ptr, self._ws_bytes, self._stream()))
         opt.step += 1
+        opt.note_host_steps(1)
 
     def render(self, fc, B, pe_scale, pcs, z, gt_depth, gt_rgb, sem, depth_mask) -> StepResult:
         """Forward + loss only: rendered depth / colour / opacity / variance (loss.py:24-31)."""
@@ -293,7 +331,8 @@ class VmapStep:
         sc = _lib.Tensor(pe_scale.data_ptr(), pe_scale.stride(0) if pe_scale.dim() else 0)
         bt = self._batch(pcs, z, gt_depth, gt_rgb, sem, depth_mask, rays_total=rays_total)
         res, out = self._outputs(n_steps, render)
-        oc = opt.c_struct()
+        on_device = opt.bias_table is not None and flag_reduce is None
+        oc = opt.c_struct(device_steps=on_device)
         fn = self.lib.vmapstep_train_steps
         if flag_reduce is not None:
             off = ctypes.c_size_t(0)
@@ -308,6 +347,8 @@ class VmapStep:
                       ctypes.byref(gp) if gp is not None else None, ctypes.byref(out),
                       self._ws_ptr, self._ws_bytes, self._stream()))
         opt.step += n_steps
+        if not on_device:
+            opt.note_host_steps(n_steps)
         return res
 
 
@@ -317,10 +358,17 @@ class BoundFrame:
     one C call.  For callers whose buffers do not move between frames (the slab of ``driver.HipMapper``, a sampler that
     writes into fixed frame tensors, ``bench.py``): per-call Python shrinks from ~0.1 ms of shape checks and struct
     filling - a tenth of a 20-step frame - to the call itself.  Outputs (loss [max_steps], flags [max_steps, 4]) are
-    reused by every call: read or copy them before the next one."""
+    reused by every call: read or copy them before the next one.
+
+    ``graph=True`` (opt-in; single-rank callers only): the frame call - 1 + 2 n launches - is captured ONCE per step count as
+    a hipGraph and replayed; the optimiser's step count then lives on the device (``FusedAdamWState.enable_device_steps``),
+    because a replayed launch cannot take a new scalar from the host.  Same kernels, same arguments, bit-identical results
+    (tests/test_gpu_parity.py).  Off by default because it buys nothing on this stack: 29.58 / 29.76 us per step replayed
+    against 29.44 / 29.61 launched kernel by kernel at the headline shape (profiles/r03i_graph_replay.json; round 1 had
+    measured +2 % on a slower step) - what separates consecutive kernels is the dispatch boundary on the device, not the host."""
 
     def __init__(self, op: "VmapStep", fc, B, pe_scale, pcs, z, gt_depth, gt_rgb, sem, depth_mask, opt: "FusedAdamWState",
-                 ray_step: Optional[int] = None, render: bool = False, flag_reduce=None):
+                 ray_step: Optional[int] = None, render: bool = False, flag_reduce=None, graph: bool = False):
         self.op, self.opt, self.flag_reduce = op, opt, flag_reduce
         self.ray_step = op.rays if ray_step is None else int(ray_step)
         self.rays_total = pcs.shape[1]
@@ -330,31 +378,58 @@ class BoundFrame:
         self._bt = op._batch(pcs, z, gt_depth, gt_rgb, sem, depth_mask, rays_total=self.rays_total)
         self.result, self._out = op._outputs(op.max_steps, render)
         self._stream = op._stream()
+        self.graph = bool(graph) and flag_reduce is None
+        self._graphs, self._warm = {}, set()
+        if self.graph:
+            opt.enable_device_steps()
 
-    def train_steps(self, n_steps: int) -> StepResult:
+    def _call(self, n_steps: int, stream: int):
         op, opt = self.op, self.opt
-        if n_steps > op.max_steps or (n_steps - 1) * self.ray_step + op.rays > self.rays_total:
-            raise ValueError(f"n_steps={n_steps}: the bound frame holds {self.rays_total} rays, max_steps={op.max_steps}")
-        oc = opt.c_struct()
         lib, sh = op.lib, ctypes.byref(op.shape)
         fn = lib.vmapstep_train_steps
         if self.flag_reduce is not None:
             off = ctypes.c_size_t(0)
             _lib.check(lib.vmapstep_prepare(sh, ctypes.byref(self._pp), ctypes.byref(self._bt), self.ray_step, n_steps,
-                                            op._ws_ptr, op._ws_bytes, ctypes.byref(off), self._stream))
+                                            op._ws_ptr, op._ws_bytes, ctypes.byref(off), stream))
             self.flag_reduce(op._ws_view(off.value, n_steps * 16).view(torch.int32).view(n_steps, 4))
             fn = lib.vmapstep_train_steps_prepared
+        on_device = opt.bias_table is not None and self.flag_reduce is None
+        oc = opt.c_struct(device_steps=on_device)
         _lib.check(fn(sh, ctypes.byref(self._pp), ctypes.byref(self._sc), ctypes.byref(self._bt), self.ray_step, n_steps,
                       op.color_scaling, op.opacity_scaling, ctypes.byref(oc), None, ctypes.byref(self._out),
-                      op._ws_ptr, op._ws_bytes, self._stream))
+                      op._ws_ptr, op._ws_bytes, stream))
+        return on_device
+
+    def train_steps(self, n_steps: int) -> StepResult:
+        op, opt = self.op, self.opt
+        if n_steps > op.max_steps or (n_steps - 1) * self.ray_step + op.rays > self.rays_total:
+            raise ValueError(f"n_steps={n_steps}: the bound frame holds {self.rays_total} rays, max_steps={op.max_steps}")
+        g = self._graphs.get(n_steps) if self.graph else None
+        if g is not None:
+            g.replay()                                   # on the current stream of the device
+            opt.step += n_steps
+            return self.result
+        if self.graph and n_steps in self._warm:
+            # second call with this step count: capture it (nothing runs during capture), then replay the capture as this call
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._call(n_steps, torch.cuda.current_stream(op.device).cuda_stream)
+            self._graphs[n_steps] = g
+            g.replay()
+            opt.step += n_steps
+            return self.result
+        on_device = self._call(n_steps, self._stream)    # first call: eager (sets the kernels' per-device attributes once)
+        self._warm.add(n_steps)
         opt.step += n_steps
+        if not on_device:
+            opt.note_host_steps(n_steps)
         return self.result
 
 
 def _bind(self, fc, B, pe_scale, pcs, z, gt_depth, gt_rgb, sem, depth_mask, opt: "FusedAdamWState", ray_step=None,
-          render: bool = False, flag_reduce=None) -> BoundFrame:
+          render: bool = False, flag_reduce=None, graph: bool = False) -> BoundFrame:
     """Marshal once, call many times: see ``BoundFrame``.  Bound to the CURRENT stream of the operator's device."""
-    return BoundFrame(self, fc, B, pe_scale, pcs, z, gt_depth, gt_rgb, sem, depth_mask, opt, ray_step, render, flag_reduce)
+    return BoundFrame(self, fc, B, pe_scale, pcs, z, gt_depth, gt_rgb, sem, depth_mask, opt, ray_step, render, flag_reduce, graph)
 
 
 VmapStep.bind = _bind
@@ -374,6 +449,7 @@ def _profile_train_steps(self, fc, B, pe_scale, pcs, z, gt_depth, gt_rgb, sem, d
                                                      self.rays, n_steps, self.color_scaling, self.opacity_scaling, ctypes.byref(oc),
                                                      ctypes.byref(out), self._ws_ptr, self._ws_bytes, self._stream(), ms))
     opt.step += n_steps
+    opt.note_host_steps(n_steps)
     return float(ms[0]), float(ms[1])
 
 
