@@ -111,6 +111,7 @@ def main():
     ap.add_argument("--weights", default="f32", choices=["f32", "bf16"])   # bf16: BASELINE configs[3]/[4] (fp32 masters + accumulate)
     ap.add_argument("--kernel", default="auto", choices=["auto", "gen", "wide", "f32", "ws1", "wp"])   # measurement: hidden 128 / 256 kernels; f32 = hidden 32
                                                                                                  # on the exact-fp32 matrix instruction (step_main_h32)
+    ap.add_argument("--ws-two-tile", action="store_true")           # measurement: step_main_ws never uses single-tile rounds (tuning.ws_flags = 1; A/B)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--slab", action="store_true")                   # the 15 stacked tensors as views of one [n, P] slab (measurement;
                                                                      # default: separately allocated, utils.update_vmap's own layout)
@@ -158,6 +159,8 @@ def main():
     if args.kernel != "auto":
         from vmap_amd import _lib
         tuning = {"kernel": {"gen": _lib.KERNEL_GEN, "wide": _lib.KERNEL_WIDE4, "f32": _lib.KERNEL_H32_F32, "ws1": _lib.KERNEL_WS1, "wp": _lib.KERNEL_WP}[args.kernel]}
+    if args.ws_two_tile:
+        tuning = dict(tuning or {}, ws_flags=1)
     op = step.VmapStep(n, R, S, H, device=dev, max_steps=ipf, weights=args.weights, tuning=tuning)
     opt = step.FusedAdamWState(n, H, dev, lr=1e-3, weight_decay=0.013)
     fargs = (fr["pcs"], fr["z"], fr["gt_depth"], fr["gt_rgb"], fr["sem"], fr["depth_mask"])

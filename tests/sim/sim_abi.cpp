@@ -51,6 +51,7 @@ extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req, int xcd
     std::vector<float> wimg((size_t)n * (split ? vk::Img32s::BYTES / 4 : ws ? (H == 128 ? vk::ImgWs<4>::BYTES : vk::ImgWs<2>::BYTES) / 4 : GL.imgp), NAN);
 
     vk::StepArgs a{};
+    a.tiles = (g_wide == 3 && G * S <= 32) ? 1 : 2;           // step_main_ws: single-tile rounds when the caller's ray groups fit one tile
     a.n_obj = n; a.R = R; a.S = S; a.G = G; a.NG = NG; a.NW = NW; a.PP = PP; a.prep_steps = 1; a.prep_ray_step = 0; a.xcd_affine = (xcd_affine && H == 32) ? 1 : 0; a.hidden = H; a.weights_bf16 = weights_bf16;
     for (int t = 0; t < 14; ++t) a.fc[t] = {const_cast<float*>(fc[t]), sz[t]};
     a.pe_B = {const_cast<float*>(B), 63};

@@ -7,28 +7,38 @@ void prep_ws(const vk::WsArgs& wa) {
     if (wa.s.hidden == 128) sim::launch(wa.s.prep_steps + n * vk::ws_pack_blocks<4>(), vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep_ws<4>(wa); });
     else sim::launch(wa.s.prep_steps + n * vk::ws_pack_blocks<2>(), vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep_ws<2>(wa); });
 }
+namespace {
+template <int NT>
+void main_ws_t(const vk::WsArgs& wa, bool bwd);
+}
 void main_ws(const vk::WsArgs& wa, bool bwd) {
+    if (wa.s.tiles == 1) main_ws_t<1>(wa, bwd); else main_ws_t<2>(wa, bwd);
+}
+namespace {
+template <int NT>
+void main_ws_t(const vk::WsArgs& wa, bool bwd) {
     const int grid = wa.s.n_obj * wa.s.NW;
     if (wa.s.hidden == 128) {
         const int lb = vk::ImgWs<4>::LDS_BYTES;
         if (wa.s.weights_bf16) {
-            if (bwd) sim::launch(grid, vk::kWG, lb, [&] { vk::step_main_ws<4, true, false>(wa); });
-            else     sim::launch(grid, vk::kWG, lb, [&] { vk::step_main_ws<4, false, false>(wa); });
+            if (bwd) sim::launch(grid, vk::kWG, lb, [&] { vk::step_main_ws<4, true, false, false, NT>(wa); });
+            else     sim::launch(grid, vk::kWG, lb, [&] { vk::step_main_ws<4, false, false, false, NT>(wa); });
         } else {
-            if (bwd) sim::launch(grid, vk::kWG, lb, [&] { vk::step_main_ws<4, true, true>(wa); });
-            else     sim::launch(grid, vk::kWG, lb, [&] { vk::step_main_ws<4, false, true>(wa); });
+            if (bwd) sim::launch(grid, vk::kWG, lb, [&] { vk::step_main_ws<4, true, true, false, NT>(wa); });
+            else     sim::launch(grid, vk::kWG, lb, [&] { vk::step_main_ws<4, false, true, false, NT>(wa); });
         }
     } else {
         const int lb = vk::ImgWs<2>::LDS_BYTES;
         if (wa.s.weights_bf16) {
-            if (bwd) sim::launch(grid, vk::kWG, lb, [&] { vk::step_main_ws<2, true, false>(wa); });
-            else     sim::launch(grid, vk::kWG, lb, [&] { vk::step_main_ws<2, false, false>(wa); });
+            if (bwd) sim::launch(grid, vk::kWG, lb, [&] { vk::step_main_ws<2, true, false, false, NT>(wa); });
+            else     sim::launch(grid, vk::kWG, lb, [&] { vk::step_main_ws<2, false, false, false, NT>(wa); });
         } else {
-            if (bwd) sim::launch(grid, vk::kWG, lb, [&] { vk::step_main_ws<2, true, true>(wa); });
-            else     sim::launch(grid, vk::kWG, lb, [&] { vk::step_main_ws<2, false, true>(wa); });
+            if (bwd) sim::launch(grid, vk::kWG, lb, [&] { vk::step_main_ws<2, true, true, false, NT>(wa); });
+            else     sim::launch(grid, vk::kWG, lb, [&] { vk::step_main_ws<2, false, true, false, NT>(wa); });
         }
     }
 }
+}  // namespace
 void finalize_ws(const vk::FinalizeArgs& f, const vk::FinalizeHot& h, const int* tab_wt) {
     const int grid = f.n_obj * vk::ws_finalize_blocks(f.PP) + 1;
     if (f.hidden == 128) sim::launch(grid, vk::kWG, 4 * vk::kWG * 4, [&] { vk::step_finalize_ws<4>(f, h, tab_wt); });

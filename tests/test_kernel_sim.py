@@ -298,3 +298,19 @@ def test_sim_bf16_weights_in_the_multi_pass_and_multi_round_forms(name, kw):
     for k in GRAD_KEYS:
         assert not np.isnan(s[k]).any(), k
         assert relerr(s[k], ref[k]) < 1e-4, k
+
+
+@pytest.mark.parametrize("name,G,nw,bf16", [("bg_h128_s14", 2, 0, 0), ("bg_h128_s14", 2, 5, 0), ("bg_h128_s14", 1, 0, 1), ("h64", 3, 0, 0), ("h64", 2, 4, 0)])
+def test_sim_ws_single_tile_rounds_match_reference(name, G, nw, bf16):
+    """step_main_ws<., ., ., ., NT = 1>: rounds of ONE 32-point tile (ray groups of G rays with G S <= 32: 2 x 14, 3 x 10 points;
+    fewer rays than fit; several rounds per workgroup adding into its row) - the form the launch plan picks when every tile
+    gets a compute unit of its own.  Same fixtures as the two-tile form (bf16: the reference on the rounded weights)."""
+    c = cases.build_case(name)
+    g = load_golden(name + ("_bf16" if bf16 else ""))
+    s = simlib.sim_step(c, wide=3, G=G, NW=nw, weights_bf16=bf16)
+    assert abs(s["loss"] - float(g["loss"])) <= 2e-5 * abs(float(g["loss"]))
+    for k in RENDER_KEYS:
+        assert relerr(s[k], g[k]) < 2e-5, k
+    for k in GRAD_KEYS:
+        assert not np.isnan(s[k]).any(), k
+        assert relerr(s[k], g[k]) < 1e-4, k

@@ -22,7 +22,7 @@ KERNEL_AUTO, KERNEL_GEN, KERNEL_WIDE4, KERNEL_H32_F32, KERNEL_WS1, KERNEL_WP = 0
 class Tuning(ctypes.Structure):
     """vmapstep_tuning: measurement / test overrides of the automatic launch plan, passed per call through Shape.tuning."""
     _fields_ = [("workgroups_per_object", ctypes.c_int32), ("kernel", ctypes.c_int32), ("generic_finalize", ctypes.c_int32),
-                ("reserved", ctypes.c_int32)]
+                ("ws_flags", ctypes.c_int32)]
 
 
 class Shape(ctypes.Structure):

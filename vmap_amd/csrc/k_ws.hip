@@ -6,10 +6,10 @@
 namespace vl {
 
 namespace {
-template <int NB, bool BWD, bool W3, bool STAMPS>
-int main_v(const vk::StepArgs& a, hipStream_t st) {
+template <int NB, bool BWD, bool W3, bool STAMPS, int NT>
+int main_t(const vk::StepArgs& a, hipStream_t st) {
     using I = vk::ImgWs<NB>;
-    auto kern = vk::step_main_ws<NB, BWD, W3, STAMPS>;
+    auto kern = vk::step_main_ws<NB, BWD, W3, STAMPS, NT>;
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), I::LDS_BYTES, "step_main_ws")) return rc;
     vk::WsArgs ga;
     ga.s = a;
@@ -17,6 +17,10 @@ int main_v(const vk::StepArgs& a, hipStream_t st) {
     ga.tab_wt = a.tab_wt;
     VL_LAUNCH_MAIN(kern, dim3(a.n_obj * a.NW), dim3(vk::kWG), I::LDS_BYTES, st, ga);
     return launched("step_main_ws");
+}
+template <int NB, bool BWD, bool W3, bool STAMPS>
+int main_v(const vk::StepArgs& a, hipStream_t st) {
+    return a.tiles == 1 ? main_t<NB, BWD, W3, STAMPS, 1>(a, st) : main_t<NB, BWD, W3, STAMPS, 2>(a, st);
 }
 template <int NB>
 int main_nb(const vk::StepArgs& a, bool bwd, bool stamps, hipStream_t st) {

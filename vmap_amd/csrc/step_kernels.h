@@ -78,6 +78,7 @@ struct StepArgs {
     float* gen_scratch;                // step_main_gen / step_main_wide: per-wave (per-workgroup) register-image scratch (workspace)
                                        // step_main_ws (wide == 3): per-workgroup cos factors of the encoding
     int* tab_wt;                       // step_prep_ws / step_finalize_ws: [PP] flat parameter -> element of the W^T image planes (or -1)
+    int tiles;                         // step_main_ws: 32-point tiles per round, 2 (default, also when 0) or 1 (single-tile rounds: launch plan)
     int* adam_counter;                 // device-resident optimiser step count (vmapstep_adamw::step_counter) or null: the first prep
                                        // block of a training call advances it by the previous call's steps (see prep_stats)
 };

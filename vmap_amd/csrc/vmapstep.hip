@@ -86,6 +86,7 @@ void make_layout(int H, Layout& L) {
 
 struct Plan {
     int G, NG, NW;
+    int tiles;         // step_main_ws: 32-point tiles per round (2, or 1 = single-tile rounds when every tile gets a compute unit of its own)
     size_t off_stats, off_flags, off_ploss, off_imgtab, off_pgrad, off_wimg, off_scratch, total;
     bool generic;      // hidden != 32: step_main_gen (global-memory activations) instead of step_main_h32
     bool split;        // hidden 32 on the bf16 matrix pipe with split operands (step_main_s32; the default at hidden 32)
@@ -162,6 +163,14 @@ int make_plan(const vmapstep_shape* sh, int max_steps, Plan& pl, const Layout& L
     if ((force == VMAPSTEP_KERNEL_WS1 || force == VMAPSTEP_KERNEL_WP) && pl.wide < 3)
         return fail(VMAPSTEP_ERR_UNSUPPORTED, "VMAPSTEP_KERNEL_WS1 / _WP: hidden 64 / 128 with at most 64 samples per ray");
     pl.G = (pl.wide >= 3 ? vk::ImgWs<4>::kPts : pl.wide == 1 ? vk::kWideTile : vk::kMaxPts) / sh->samples;
+    pl.tiles = 2;
+    if (pl.wide == 3 && tun.workgroups_per_object <= 0 && !(tun.ws_flags & 1)) {
+        // step_main_ws on a mostly idle chip (the ray-sharded background model of a multi-GPU run: 150 rays per rank at 8 ranks): if
+        // every 32-point tile can have a compute unit of its own, single-tile rounds (about 0.65 of a two-tile round's time) halve
+        // the points per workgroup; the extra partial-gradient rows cost the finalize ~0.1 us each (profiles/r03j_*)
+        const int g1 = 32 / sh->samples;
+        if (g1 >= 1 && (long long)sh->n_obj * ((sh->rays + g1 - 1) / g1) <= 256) { pl.G = g1; pl.tiles = 1; }
+    }
     if (pl.G > sh->rays) pl.G = sh->rays;
     pl.NG = (sh->rays + pl.G - 1) / pl.G;
     // workgroup slots of the chip: one per CU, two for step_main_wp at hidden 64 (78 KB of LDS per workgroup)
@@ -220,7 +229,7 @@ void fill_step_args(vk::StepArgs& a, const vmapstep_shape* sh, const Plan& pl, c
                     int64_t ray0, float cw, float ow, char* ws) {
     std::memset(&a, 0, sizeof(a));
     a.n_obj = sh->n_obj; a.R = sh->rays; a.S = sh->samples;
-    a.G = pl.G; a.NG = pl.NG; a.NW = pl.NW; a.PP = L.PP;
+    a.G = pl.G; a.NG = pl.NG; a.NW = pl.NW; a.PP = L.PP; a.tiles = pl.tiles;
     // XCD-affine block map only while every XCD's share still fits its 32 CUs in one round
     a.xcd_affine = (!pl.generic && ((sh->n_obj + 7) / 8) * pl.NW <= 32) ? 1 : 0;
     for (int t = 0; t < VMAPSTEP_NUM_FC; ++t) a.fc[t] = {params->fc[t].ptr, params->fc[t].obj_stride};

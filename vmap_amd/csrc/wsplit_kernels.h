@@ -367,38 +367,40 @@ __device__ __forceinline__ void wop_load(WOp& o, const char* ubase, unsigned vof
     o.p[0] = ldgu(ubase, voff);
     if (W3) { o.p[1] = ldgu(ubase + 1024, voff); o.p[2] = ldgu(ubase + 2048, voff); }
 }
+template <int NT = 2>
 __device__ __forceinline__ void xop_load(XOp& o, const char* x, int xst) {
 #pragma unroll
-    for (int st = 0; st < 2; ++st)
+    for (int st = 0; st < NT; ++st)
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) o.x[st][pl] = lds16(x + st * xst + pl * 1024);
 }
 // the same from images in global memory (ubase wave-uniform, voff = lane * 16)
+template <int NT = 2>
 __device__ __forceinline__ void xop_load_g(XOp& o, const char* ubase, int xst, unsigned voff) {
 #pragma unroll
-    for (int st = 0; st < 2; ++st)
+    for (int st = 0; st < NT; ++st)
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) o.x[st][pl] = ldgu(ubase + st * xst + pl * 1024, voff);
 }
 // six (bf16 weights: three) products per tile, smallest terms first; the two tiles' chains alternate
-template <bool W3>
+template <bool W3, int NT = 2>
 __device__ __forceinline__ void fop_mm(f32x16 (&acc)[2], const WOp& w, const XOp& o) {
 #pragma unroll
-    for (int st = 0; st < 2; ++st) acc[st] = wv::mfma_bf16(w.p[0], o.x[st][2], acc[st]);
+    for (int st = 0; st < NT; ++st) acc[st] = wv::mfma_bf16(w.p[0], o.x[st][2], acc[st]);
     if (W3) {
 #pragma unroll
-        for (int st = 0; st < 2; ++st) acc[st] = wv::mfma_bf16(w.p[2], o.x[st][0], acc[st]);
+        for (int st = 0; st < NT; ++st) acc[st] = wv::mfma_bf16(w.p[2], o.x[st][0], acc[st]);
 #pragma unroll
-        for (int st = 0; st < 2; ++st) acc[st] = wv::mfma_bf16(w.p[1], o.x[st][1], acc[st]);
+        for (int st = 0; st < NT; ++st) acc[st] = wv::mfma_bf16(w.p[1], o.x[st][1], acc[st]);
     }
 #pragma unroll
-    for (int st = 0; st < 2; ++st) acc[st] = wv::mfma_bf16(w.p[0], o.x[st][1], acc[st]);
+    for (int st = 0; st < NT; ++st) acc[st] = wv::mfma_bf16(w.p[0], o.x[st][1], acc[st]);
     if (W3) {
 #pragma unroll
-        for (int st = 0; st < 2; ++st) acc[st] = wv::mfma_bf16(w.p[1], o.x[st][0], acc[st]);
+        for (int st = 0; st < NT; ++st) acc[st] = wv::mfma_bf16(w.p[1], o.x[st][0], acc[st]);
     }
 #pragma unroll
-    for (int st = 0; st < 2; ++st) acc[st] = wv::mfma_bf16(w.p[0], o.x[st][0], acc[st]);
+    for (int st = 0; st < NT; ++st) acc[st] = wv::mfma_bf16(w.p[0], o.x[st][0], acc[st]);
 }
 // A run of NA + NB2 steps: the first NA steps read weight chunks at wa + s * 3072 and inputs at xa + s * 3072 (tile 1:
 // + xsta), the following NB2 steps at wb / xb (cat_layer and color_linear: encoding part, then hidden part)
@@ -409,25 +411,25 @@ __device__ __forceinline__ void wpre_load(WPre& p, const char* wa, const char* w
     wv::sched_fence();
 }
 // XAG: the first part's inputs come from global memory (xa = wave-uniform base) instead of LDS
-template <bool W3, int NA, int NB2, bool XAG = false>
+template <bool W3, int NA, int NB2, bool XAG = false, int NT = 2>
 __device__ __forceinline__ void fwd_run(f32x16 (&acc)[2], const WPre& pre, const char* wa, const char* xa, int xsta,
                                         const char* wb, const char* xb, int xstb, unsigned voff) {
     constexpr int NST = NA + NB2;
     WOp w[3];
     XOp xo[2];
     w[0] = pre.w[0]; w[1] = pre.w[1];
-    if (NA > 0) { if (XAG) xop_load_g(xo[0], xa, xsta, voff); else xop_load(xo[0], xa, xsta); }
-    else xop_load(xo[0], xb, xstb);
+    if (NA > 0) { if (XAG) xop_load_g<NT>(xo[0], xa, xsta, voff); else xop_load<NT>(xo[0], xa, xsta); }
+    else xop_load<NT>(xo[0], xb, xstb);
     wv::sched_fence();
 #pragma unroll
     for (int s = 0; s < NST; ++s) {
         if (s + 2 < NST) wop_load<W3>(w[(s + 2) % 3], s + 2 < NA ? wa + WS_WSTEP(s + 2) * 3072 : wb + WS_WSTEP(s + 2 - NA) * 3072, voff);
         if (s + 1 < NST) {
-            if (s + 1 < NA) { if (XAG) xop_load_g(xo[(s + 1) & 1], xa + (s + 1) * 3072, xsta, voff); else xop_load(xo[(s + 1) & 1], xa + (s + 1) * 3072, xsta); }
-            else xop_load(xo[(s + 1) & 1], xb + (s + 1 - NA) * 3072, xstb);
+            if (s + 1 < NA) { if (XAG) xop_load_g<NT>(xo[(s + 1) & 1], xa + (s + 1) * 3072, xsta, voff); else xop_load<NT>(xo[(s + 1) & 1], xa + (s + 1) * 3072, xsta); }
+            else xop_load<NT>(xo[(s + 1) & 1], xb + (s + 1 - NA) * 3072, xstb);
         }
         wv::sched_fence();
-        fop_mm<W3>(acc, w[s % 3], xo[s & 1]);
+        fop_mm<W3, NT>(acc, w[s % 3], xo[s & 1]);
         wv::sched_fence();
     }
 }
@@ -448,34 +450,35 @@ __device__ __forceinline__ void tpre_load(TPre& p, const char* gwt, unsigned vof
     top_load<W3>(p.w[2], gwt + WS_WSTEP(2) * 2048, voff);
     wv::sched_fence();
 }
+template <int NT = 2>
 __device__ __forceinline__ void dop_load(DOp& o, const char* d, int dst) {
 #pragma unroll
-    for (int st = 0; st < 2; ++st) { o.d[st][0] = lds16(d + st * dst); o.d[st][1] = lds16(d + st * dst + 1024); }
+    for (int st = 0; st < NT; ++st) { o.d[st][0] = lds16(d + st * dst); o.d[st][1] = lds16(d + st * dst + 1024); }
 }
-template <bool W3>
+template <bool W3, int NT = 2>
 __device__ __forceinline__ void bop_mm(f32x16 (&acc)[2], const TOp& w, const DOp& o) {
 #pragma unroll
-    for (int st = 0; st < 2; ++st) acc[st] = wv::mfma_bf16(w.p[0], o.d[st][1], acc[st]);
+    for (int st = 0; st < NT; ++st) acc[st] = wv::mfma_bf16(w.p[0], o.d[st][1], acc[st]);
     if (W3) {
 #pragma unroll
-        for (int st = 0; st < 2; ++st) acc[st] = wv::mfma_bf16(w.p[1], o.d[st][0], acc[st]);
+        for (int st = 0; st < NT; ++st) acc[st] = wv::mfma_bf16(w.p[1], o.d[st][0], acc[st]);
     }
 #pragma unroll
-    for (int st = 0; st < 2; ++st) acc[st] = wv::mfma_bf16(w.p[0], o.d[st][0], acc[st]);
+    for (int st = 0; st < NT; ++st) acc[st] = wv::mfma_bf16(w.p[0], o.d[st][0], acc[st]);
 }
-template <bool W3, int NST>
+template <bool W3, int NST, int NT = 2>
 __device__ __forceinline__ void bwd_run(f32x16 (&acc)[2], const TPre& pre, const char* gwt, unsigned voff, const char* d, int dst) {
     TOp w[4];
     DOp dd[2];
     w[0] = pre.w[0]; w[1] = pre.w[1]; w[2] = pre.w[2];
-    dop_load(dd[0], d, dst);
+    dop_load<NT>(dd[0], d, dst);
     wv::sched_fence();
 #pragma unroll
     for (int s = 0; s < NST; ++s) {
         if (s + 3 < NST) top_load<W3>(w[(s + 3) & 3], gwt + WS_WSTEP(s + 3) * 2048, voff);
-        if (s + 1 < NST) dop_load(dd[(s + 1) & 1], d + (s + 1) * 2048, dst);
+        if (s + 1 < NST) dop_load<NT>(dd[(s + 1) & 1], d + (s + 1) * 2048, dst);
         wv::sched_fence();
-        bop_mm<W3>(acc, w[s & 3], dd[s & 1]);
+        bop_mm<W3, NT>(acc, w[s & 3], dd[s & 1]);
         wv::sched_fence();
     }
 }
@@ -519,17 +522,19 @@ __device__ __forceinline__ void put_F(char* img, const unsigned (&f)[16]) {
     for (int c = 0; c < 4; ++c) *reinterpret_cast<u32x4*>(img + c * 1024) = u32x4{f[4 * c], f[4 * c + 1], f[4 * c + 2], f[4 * c + 3]};
 }
 struct FImg { u32x4 c[2][4]; };                                          // the two tiles' F-form images of one block
+template <int NT = 2>
 __device__ __forceinline__ void fimg_load(FImg& o, const char* img, int xst) {
 #pragma unroll
-    for (int st = 0; st < 2; ++st)
+    for (int st = 0; st < NT; ++st)
 #pragma unroll
         for (int c = 0; c < 4; ++c) o.c[st][c] = lds16(img + st * xst + c * 1024);
 }
 // one weight-gradient block over the round's two tiles: acc = sum_tiles dY^T X (F-form: c[0..1] hi plane steps, c[2..3] mid)
+template <int NT = 2>
 __device__ __forceinline__ void dw_mm_pair(f32x16& acc, const unsigned (&dF)[2][16], const FImg& x) {
     zero_acc(acc);
 #pragma unroll
-    for (int st = 0; st < 2; ++st)
+    for (int st = 0; st < NT; ++st)
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const u32x4 ah = u32x4{dF[st][4 * s], dF[st][4 * s + 1], dF[st][4 * s + 2], dF[st][4 * s + 3]};
@@ -540,11 +545,12 @@ __device__ __forceinline__ void dw_mm_pair(f32x16& acc, const unsigned (&dF)[2][
         }
 }
 // bias gradient of a layer without constant-1 input column: dY^T . ones
+template <int NT = 2>
 __device__ __forceinline__ void db_pair(f32x16& acc, const unsigned (&dF)[2][16]) {
     const u32x4 ones = u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
     zero_acc(acc);
 #pragma unroll
-    for (int st = 0; st < 2; ++st)
+    for (int st = 0; st < NT; ++st)
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             acc = wv::mfma_bf16(u32x4{dF[st][8 + 4 * s], dF[st][8 + 4 * s + 1], dF[st][8 + 4 * s + 2], dF[st][8 + 4 * s + 3]}, ones, acc);
@@ -595,18 +601,18 @@ __device__ __forceinline__ void mask_by(float (&d)[16], const f32x16& v, const u
 // weight-gradient blocks of one layer: N input blocks (images at ximg(kb), tile 1: + xst(kb)).  Stage kb: LDS reads of block
 // kb + 1 and (later rounds) the global reads of block kb's earlier sums go out, the matrix instructions of block kb run, the
 // stores of block kb - 1 retire.  io(mode, kb, acc, old): block_io of the layer.
-template <int N, class XI, class IO>
+template <int N, int NT = 2, class XI, class IO>
 __device__ __forceinline__ void dw_layer(const unsigned (&dF)[2][16], bool first, XI&& ximg, IO&& io) {
     FImg x[2];
     f32x16 acc[2];
     float old[2][16];
-    { const char* p; int st; ximg(0, p, st); fimg_load(x[0], p, st); }
+    { const char* p; int st; ximg(0, p, st); fimg_load<NT>(x[0], p, st); }
 #pragma unroll
     for (int kb = 0; kb < N; ++kb) {
-        if (kb + 1 < N) { const char* p; int st; ximg(kb + 1, p, st); fimg_load(x[(kb + 1) & 1], p, st); }
+        if (kb + 1 < N) { const char* p; int st; ximg(kb + 1, p, st); fimg_load<NT>(x[(kb + 1) & 1], p, st); }
         if (!first) io(1, kb, acc[kb & 1], old[kb & 1]);
         wv::sched_fence();
-        dw_mm_pair(acc[kb & 1], dF, x[kb & 1]);
+        dw_mm_pair<NT>(acc[kb & 1], dF, x[kb & 1]);
         if (kb > 0) io(first ? 0 : 2, kb - 1, acc[(kb - 1) & 1], old[(kb - 1) & 1]);
         wv::sched_fence();
     }
@@ -617,9 +623,15 @@ __device__ __forceinline__ void dw_layer(const unsigned (&dF)[2][16], bool first
 // step_main_ws<NB, BWD, W3>: NB = 4 (hidden 128) or 2 (hidden 64: waves 0, 1 own the two output blocks, waves 2, 3 only take
 // part in the encoding and in the d-prop of the encoding blocks); W3 = false: bf16 weights (one weight plane)
 // ---------------------------------------------------------------------------------------------------------
-template <int NB, bool BWD, bool W3, bool STAMPS = false>
+// NT = tiles per round.  2: the throughput form (one weight operand feeds two accumulators).  1: SINGLE-TILE rounds - half the
+// per-tile work of a round with the weight streams unchanged, about 0.65 of its time (measured: profiles/r03j_*) - chosen by the
+// launch plan when every tile of the batch gets a workgroup of its own on an otherwise idle chip: the ray-sharded background
+// model of a multi-GPU run (150 rays per rank at 8 ranks = 38 two-tile rounds on 38 of 256 compute units, or 75 single-tile
+// rounds on 75), where the step is one round's LATENCY.
+template <int NB, bool BWD, bool W3, bool STAMPS = false, int NT = 2>
 __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     static_assert(NB == 4 || NB == 2, "one output block per wave, at most four");
+    static_assert(NT == 1 || NT == 2, "one or two 32-point tiles per round");
     using I = ImgWs<NB>;
     constexpr int H = I::H, JS = I::JS;
     const StepArgs& a = ga.s;
@@ -663,11 +675,11 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     for (int i = tid; i < I::kPts * 8; i += kWG) cb[i] = 0.0f;
     const int ray0 = grp * a.G;
     const int nrays = min(a.G, a.R - ray0);
-    const int npts = nrays * a.S;                                        // <= 64
+    const int npts = nrays * a.S;                                        // <= 32 NT
     // compositing inputs (depth of this lane's sample, ground truth of the ray this lane composites): fetched at the top of the
     // round, where the encoding covers them (their scalar loads would otherwise serialise with the LDS operand reads)
     float zv = 0.0f;
-    if (wave < 2 && hi == 0 && 32 * wave + p31 < npts) {
+    if (wave < NT && hi == 0 && 32 * wave + p31 < npts) {
         const int pt = 32 * wave + p31, lray = pt / a.S, smp = pt - lray * a.S;
         zv = a.z[obj * a.z_so + (ray0 + lray) * a.z_sr + smp * a.z_ss];
     }
@@ -675,7 +687,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     WPre pre_in;                                                         // in_layer's first weight chunks: fetched behind the encoding
     if (own) wpre_load<W3, 6, 0>(pre_in, gW + ((long long)(I::CW_IN + wave * I::KS_IN)) * I::XCH, nullptr, vlo16);
     // ---- encoding (embedding.py:82-91): wave = (tile est, direction half dhalf); owner-lane slots as in step_main_s32 ----
-    {
+    if (NT == 2 || (wave & 1) == 0) {                                    // single-tile rounds: the waves of tile 1 have no encoding to do
         const int est = wave & 1, dhalf = wave >> 1;
         const int pt = 32 * est + p31;
         const bool valid = pt < npts;
@@ -746,7 +758,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     // included) and, hi / mid, -> the scratch (backward)
     auto epilogue = [&](int layer) {
 #pragma unroll
-        for (int st = 0; st < 2; ++st) {
+        for (int st = 0; st < NT; ++st) {
             float hf[16];
             unsigned ph[8], pm[8], pl[8];
             relu_to(hf, acc[st]);
@@ -779,7 +791,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     WPre pre;
     if (own) {
         zero_acc(acc[0]); zero_acc(acc[1]);                              // :59 in_layer (bias rides in the constant-1 column)
-        fwd_run<W3, 6, 0>(acc, pre_in, wchunk(I::CW_IN, I::KS_IN, 0), e1x, I::E_ST, nullptr, nullptr, 0, vlo16);
+        fwd_run<W3, 6, 0, false, NT>(acc, pre_in, wchunk(I::CW_IN, I::KS_IN, 0), e1x, I::E_ST, nullptr, nullptr, 0, vlo16);
         wpre_load<W3, 0, JS>(pre, nullptr, wchunk(I::CW_M1, I::KS_M, 0), vlo16);
         epilogue(0);
     }
@@ -787,7 +799,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     WS_MARK(2);
     if (own) {
         load_bias(acc[0], SM + I::B_M1 + 32 * wave, hi); acc[1] = acc[0];    // :60 mid1
-        fwd_run<W3, 0, JS>(acc, pre, nullptr, nullptr, 0, wchunk(I::CW_M1, I::KS_M, 0), actx, I::ACT_ST, vlo16);
+        fwd_run<W3, 0, JS, false, NT>(acc, pre, nullptr, nullptr, 0, wchunk(I::CW_M1, I::KS_M, 0), actx, I::ACT_ST, vlo16);
         wpre_load<W3, 6, JS>(pre, wchunk(I::CW_CAT, I::KS_CAT, JS), wchunk(I::CW_CAT, I::KS_CAT, 0), vlo16);
     }
     __syncthreads();                                                     // everybody has read h1
@@ -796,7 +808,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     WS_MARK(3);
     if (own) {
         zero_acc(acc[0]); zero_acc(acc[1]);                              // :63-64 cat_layer: encoding part, then h2
-        fwd_run<W3, 6, JS>(acc, pre, wchunk(I::CW_CAT, I::KS_CAT, JS), e1x, I::E_ST, wchunk(I::CW_CAT, I::KS_CAT, 0), actx, I::ACT_ST, vlo16);
+        fwd_run<W3, 6, JS, false, NT>(acc, pre, wchunk(I::CW_CAT, I::KS_CAT, JS), e1x, I::E_ST, wchunk(I::CW_CAT, I::KS_CAT, 0), actx, I::ACT_ST, vlo16);
         wpre_load<W3, 0, JS>(pre, nullptr, wchunk(I::CW_M2, I::KS_M, 0), vlo16);
     }
     __syncthreads();
@@ -805,7 +817,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     WS_MARK(4);
     if (own) {
         load_bias(acc[0], SM + I::B_M2 + 32 * wave, hi); acc[1] = acc[0];    // :67 mid2
-        fwd_run<W3, 0, JS>(acc, pre, nullptr, nullptr, 0, wchunk(I::CW_M2, I::KS_M, 0), actx, I::ACT_ST, vlo16);
+        fwd_run<W3, 0, JS, false, NT>(acc, pre, nullptr, nullptr, 0, wchunk(I::CW_M2, I::KS_M, 0), actx, I::ACT_ST, vlo16);
         wpre_load<W3, 3, JS>(pre, wchunk(I::CW_C, I::KS_C, JS), wchunk(I::CW_C, I::KS_C, 0), vlo16);
     }
     __syncthreads();
@@ -814,12 +826,12 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     WS_MARK(5);
     if (own) {
         zero_acc(acc[0]); zero_acc(acc[1]);                              // :81 color_linear: second encoding group, then h4
-        fwd_run<W3, 3, JS>(acc, pre, wchunk(I::CW_C, I::KS_C, JS), e2x, I::E_ST, wchunk(I::CW_C, I::KS_C, 0), actx, I::ACT_ST, vlo16);
+        fwd_run<W3, 3, JS, false, NT>(acc, pre, wchunk(I::CW_C, I::KS_C, JS), e2x, I::E_ST, wchunk(I::CW_C, I::KS_C, 0), actx, I::ACT_ST, vlo16);
         epilogue(4);
     }
     __syncthreads();
     WS_MARK(6);
-    if (wave < 2 && hi == 0) {                                           // heads of tile `wave`: sum of the four waves' partials
+    if (wave < NT && hi == 0) {                                          // heads of tile `wave`: sum of the four waves' partials
         const int pt = 32 * wave + p31;
         if (pt < npts) {
             float v[4];
@@ -848,13 +860,13 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     unsigned ah[2][8], am[2][8];                                         // planes of an activation block coming back from the scratch
     auto fetch = [&](int layer) {
 #pragma unroll
-        for (int st = 0; st < 2; ++st) { acts_load_plane(ah[st], acts, tid16, layer, st, 0); acts_load_plane(am[st], acts, tid16, layer, st, 1); }
+        for (int st = 0; st < NT; ++st) { acts_load_plane(ah[st], acts, tid16, layer, st, 0); acts_load_plane(am[st], acts, tid16, layer, st, 1); }
         wv::sched_fence();
     };
     if (own) fetch(3);                                                   // h4: lands during the encoding transposes
     float d_raw[2], d_c0[2], d_c1[2], d_c2[2];
 #pragma unroll
-    for (int st = 0; st < 2; ++st) {
+    for (int st = 0; st < NT; ++st) {
         const float* row = cb + (32 * st + p31) * 8;                     // padding rows hold zeros
         d_raw[st] = row[0]; d_c0[st] = row[1]; d_c1[st] = row[2]; d_c2[st] = row[3];
     }
@@ -863,7 +875,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
         char* ef = lds + I::EF + lo16;
 #pragma unroll
         for (int j = 0; j < 10; ++j) {
-            if ((j & 3) != wave) continue;
+            if ((j & 3) != wave || j >= 5 * NT) continue;
             const int st = j / 5, eb = j - 5 * st;
             const char* src = eb < 3 ? e1x + st * I::E_ST + 2 * eb * I::XCH : e2x + st * I::E_ST + 2 * (eb - 3) * I::XCH;
             unsigned h[8], m[8], f[16];
@@ -883,7 +895,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     unsigned dF[2][16];
     float dv[2][16];
 #pragma unroll
-    for (int st = 0; st < 2; ++st) {
+    for (int st = 0; st < NT; ++st) {
         unsigned dh[8], dm[8], dl[8];
 #pragma unroll
         for (int r = 0; r < 16; ++r) dv[st][r] = 0.0f;
@@ -906,13 +918,13 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     f32x16 accw, accd[2];
     float dproj[2][11];
 #pragma unroll
-    for (int st = 0; st < 2; ++st)
+    for (int st = 0; st < NT; ++st)
 #pragma unroll
         for (int i = 0; i < 11; ++i) dproj[st][i] = 0.0f;
     // the fetched activation block (ah, am) -> its F-form images, the layer input of everybody's weight gradients
     auto publish_x = [&]() {
 #pragma unroll
-        for (int st = 0; st < 2; ++st) {
+        for (int st = 0; st < NT; ++st) {
             unsigned xF[16];
             to_F<4>(xF, tile, ah[st], am[st], p31, hi, TL);
             put_F(xf_own + st * I::XF_ST, xF);
@@ -921,7 +933,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     // the wave's delta block (float32 registers dv[st]) -> planes -> P-form image + F-form registers dF
     auto publish_d = [&]() {
 #pragma unroll
-        for (int st = 0; st < 2; ++st) {
+        for (int st = 0; st < NT; ++st) {
             unsigned dh[8], dm[8], dl[8];
             split_planes<16, 2>(dv[st], dh, dm, dl);
             put_image<2, I::DCH>(dlt_own + st * I::DLT_ST, dh, dm, dl);
@@ -935,13 +947,13 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     };
     auto dprop_hidden = [&](int ct_base, bool add_alpha) {
 #pragma unroll
-        for (int st = 0; st < 2; ++st) {
+        for (int st = 0; st < NT; ++st) {
             if (add_alpha) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) accd[st][r] = SM[I::W_A + 32 * wave + phi(r, hi)] * d_raw[st];
             } else zero_acc(accd[st]);
         }
-        bwd_run<W3, JS>(accd, tp, hidden_ptr(ct_base), vlo16, dltx, I::DLT_ST);
+        bwd_run<W3, JS, NT>(accd, tp, hidden_ptr(ct_base), vlo16, dltx, I::DLT_ST);
     };
     // d-prop into an encoding block -> d(proj) through the cos factors (cfr: fetched at the phase start, with tpe)
     float cfr[2][16];
@@ -951,7 +963,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     auto enc_fetch = [&](int ct_chunk, int group, int blk) {
         tpre_load<W3>(tpe, enc_ptr(ct_chunk), vlo16);
 #pragma unroll
-        for (int st = 0; st < 2; ++st) {
+        for (int st = 0; st < NT; ++st) {
             const char* cfu = reinterpret_cast<const char*>(cfs + st * 66 * 64);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -965,9 +977,9 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     auto dprop_enc = [&](int ct_chunk, int group, int blk) {
         f32x16 acce[2];
         zero_acc(acce[0]); zero_acc(acce[1]);
-        bwd_run<W3, JS>(acce, tpe, enc_ptr(ct_chunk), vlo16, dltx, I::DLT_ST);
+        bwd_run<W3, JS, NT>(acce, tpe, enc_ptr(ct_chunk), vlo16, dltx, I::DLT_ST);
 #pragma unroll
-        for (int st = 0; st < 2; ++st) {
+        for (int st = 0; st < NT; ++st) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int R = 16 * blk + r;
@@ -983,12 +995,12 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
         publish_x();                                                     // h4 block: color_linear's weight-gradient operand
         fetch(4);                                                        // hc
         wv::wave_lds_fence();
-        fimg_load(xi, xf_own, I::XF_ST);
-        dw_mm_pair(accw, dF, xi);
+        fimg_load<NT>(xi, xf_own, I::XF_ST);
+        dw_mm_pair<NT>(accw, dF, xi);
         if (hi == 0) store_one(out + L.f[8] + 32 * wave + p31, accw[0], first);
         if (wave == 0) {
             f32x16 accb;
-            db_pair(accb, dF);
+            db_pair<NT>(accb, dF);
             if (lane == 0) {
                 store_one(out + L.f[9], accb[0], first);
                 store_one(out + L.f[13] + 0, accb[1], first); store_one(out + L.f[13] + 1, accb[2], first); store_one(out + L.f[13] + 2, accb[3], first);
@@ -996,9 +1008,10 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
         }
         unsigned x0[16], x1[16];
         to_F<4>(x0, tile, ah[0], am[0], p31, hi, TL);
-        to_F<4>(x1, tile, ah[1], am[1], p31, hi, TL);
+        if (NT == 2) to_F<4>(x1, tile, ah[1], am[1], p31, hi, TL);
         zero_acc(accw);
-        dw_mm_s(accw, dF[0], x0); dw_mm_s(accw, dF[1], x1);
+        dw_mm_s(accw, dF[0], x0);
+        if (NT == 2) dw_mm_s(accw, dF[1], x1);
         if (hi == 0) {
             store_one(out + L.f[12] + 0 * H + 32 * wave + p31, accw[1], first);
             store_one(out + L.f[12] + 1 * H + 32 * wave + p31, accw[2], first);
@@ -1008,7 +1021,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     // -- delta 0 = d hc (through the ReLU; ah = hc's hi plane) --
     if (own) {
 #pragma unroll
-        for (int st = 0; st < 2; ++st) {
+        for (int st = 0; st < NT; ++st) {
             f32x16 v;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -1030,7 +1043,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     if (wave == EC1) enc_fetch(I::CT_C + (NB + 1) * JS, 2, 1);
     WS_DMARK(1);
     if (own)
-        dw_layer<NB + 2>(dF, first,
+        dw_layer<NB + 2, NT>(dF, first,
             [&](int kb, const char*& p, int& st) { if (kb < NB) xf_img(kb, p, st); else { p = efx + (3 + kb - NB) * 4096; st = I::EF_ST; } },
             [&](int mode, int kb, const f32x16& v, float (&old)[16]) {
                 WS_IO3(mode, kb < NB, (block_io<0, H + kEmb2, M>(outW_c + 32 * kb, nullptr, v, old, 0, 32, p31, hi)),
@@ -1044,7 +1057,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
         dprop_hidden(I::CT_C, true);
         WS_DMARK(4);
 #pragma unroll
-        for (int st = 0; st < 2; ++st) mask_by(dv[st], accd[st], ah[st]);  // delta 1 = d h4
+        for (int st = 0; st < NT; ++st) mask_by(dv[st], accd[st], ah[st]);  // delta 1 = d h4
         fetch(2);                                                        // h3: mid2's input and the mask of delta 2
         tpre_load<W3>(tp, hidden_ptr(I::CT_M2), vlo16);
     }
@@ -1060,17 +1073,17 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     WS_MARK(10);
     // mid2
     if (own) {
-        dw_layer<NB>(dF, first, xf_img, [&](int mode, int kb, const f32x16& v, float (&old)[16]) {
+        dw_layer<NB, NT>(dF, first, xf_img, [&](int mode, int kb, const f32x16& v, float (&old)[16]) {
             WS_IO3(mode, true, (block_io<0, H, M>(outW_m2 + 32 * kb, nullptr, v, old, 0, 32, p31, hi)), (void)0);
         });
         WS_DMARK(10);
-        db_pair(accw, dF);
+        db_pair<NT>(accw, dF);
         if (p31 == 0) store_rows<1>(out + L.f[7] + 32 * wave, (unsigned)(4 * hi), accw, first);
         WS_DMARK(11);
         dprop_hidden(I::CT_M2, false);
         WS_DMARK(12);
 #pragma unroll
-        for (int st = 0; st < 2; ++st) mask_by(dv[st], accd[st], ah[st]);  // delta 2 = d h3
+        for (int st = 0; st < NT; ++st) mask_by(dv[st], accd[st], ah[st]);  // delta 2 = d h3
         WS_DMARK(13);
         fetch(1);                                                        // h2
         tpre_load<W3>(tp, hidden_ptr(I::CT_CAT), vlo16);
@@ -1086,7 +1099,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     WS_DMARK(15);
     // cat_layer
     if (own)
-        dw_layer<NB + 3>(dF, first,
+        dw_layer<NB + 3, NT>(dF, first,
             [&](int kb, const char*& p, int& st) { if (kb < NB) xf_img(kb, p, st); else { p = efx + (kb - NB) * 4096; st = I::EF_ST; } },
             [&](int mode, int kb, const f32x16& v, float (&old)[16]) {
                 WS_IO3(mode, kb < NB, (block_io<0, H + kEmb1, M>(outW_cat + 32 * kb, nullptr, v, old, 0, 32, p31, hi)),
@@ -1098,7 +1111,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     if (own) {
         dprop_hidden(I::CT_CAT, false);
 #pragma unroll
-        for (int st = 0; st < 2; ++st) mask_by(dv[st], accd[st], ah[st]);  // delta 3 = d h2
+        for (int st = 0; st < NT; ++st) mask_by(dv[st], accd[st], ah[st]);  // delta 3 = d h2
         fetch(0);                                                        // h1
         tpre_load<W3>(tp, hidden_ptr(I::CT_M1), vlo16);
     }
@@ -1108,14 +1121,14 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     WS_MARK(12);
     // mid1
     if (own) {
-        dw_layer<NB>(dF, first, xf_img, [&](int mode, int kb, const f32x16& v, float (&old)[16]) {
+        dw_layer<NB, NT>(dF, first, xf_img, [&](int mode, int kb, const f32x16& v, float (&old)[16]) {
             WS_IO3(mode, true, (block_io<0, H, M>(outW_m1 + 32 * kb, nullptr, v, old, 0, 32, p31, hi)), (void)0);
         });
-        db_pair(accw, dF);
+        db_pair<NT>(accw, dF);
         if (p31 == 0) store_rows<1>(out + L.f[3] + 32 * wave, (unsigned)(4 * hi), accw, first);
         dprop_hidden(I::CT_M1, false);
 #pragma unroll
-        for (int st = 0; st < 2; ++st) mask_by(dv[st], accd[st], ah[st]);  // delta 4 = d h1
+        for (int st = 0; st < NT; ++st) mask_by(dv[st], accd[st], ah[st]);  // delta 4 = d h1
     }
     if (wave == 0) enc_fetch(I::CT_IN + 0 * JS, 1, 0);
     if (wave == 2) enc_fetch(I::CT_IN + 1 * JS, 1, 1);
@@ -1126,7 +1139,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     WS_MARK(13);
     // in_layer
     if (own)
-        dw_layer<3>(dF, first, [&](int kb, const char*& p, int& st) { p = efx + kb * 4096; st = I::EF_ST; },
+        dw_layer<3, NT>(dF, first, [&](int kb, const char*& p, int& st) { p = efx + kb * 4096; st = I::EF_ST; },
                     [&](int mode, int kb, const f32x16& v, float (&old)[16]) {
                         WS_IO3(mode, true, (block_io<1, kEmb1, M>(outW_in, out + L.f[1] + 32 * wave, v, old, kb, kEmb1, p31, hi)), (void)0);
                     });
@@ -1140,13 +1153,13 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     {
         float* px = reinterpret_cast<float*>(lds + I::XF);               // [wave][tile][11][64]
 #pragma unroll
-        for (int st = 0; st < 2; ++st)
+        for (int st = 0; st < NT; ++st)
 #pragma unroll
             for (int i = 0; i < 11; ++i) px[((wave * 2 + st) * 11 + i) * 64 + lane] = dproj[st][i];
         __syncthreads();
         if (wave == 0) {
 #pragma unroll
-            for (int st = 0; st < 2; ++st) {
+            for (int st = 0; st < NT; ++st) {
                 unsigned dh[8], dm[8], dl[8];
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
@@ -1156,8 +1169,8 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
                 to_F<4>(dF[st], tile, dh, dm, p31, hi, TL);
             }
             FImg xi;
-            fimg_load(xi, efx + 2 * 4096, I::EF_ST);
-            dw_mm_pair(accw, dF, xi);
+            fimg_load<NT>(xi, efx + 2 * 4096, I::EF_ST);
+            dw_mm_pair<NT>(accw, dF, xi);
             if (p31 >= 24 && p31 < 27) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {

@@ -94,7 +94,7 @@ class VmapStep:
     def __init__(self, n_obj: int, rays: int, samples: int, hidden: int, device="cuda:0", max_steps: int = 32,
                  color_scaling: float = 5.0, opacity_scaling: float = 10.0, weights: str = "f32", tuning: Optional[dict] = None):
         """``tuning``: optional overrides of the automatic launch plan for measurements / A-B tests (fields of
-        ``vmapstep_tuning``: workgroups_per_object, kernel, generic_finalize).  They belong to THIS operator (the C library
+        ``vmapstep_tuning``: workgroups_per_object, kernel, generic_finalize, ws_flags).  They belong to THIS operator (the C library
         keeps no tuning state).  The operator may live on any GPU of the process: every C call runs on the device that owns
         the stream it is given (``torch.cuda.current_stream(self.device)``), whatever device is current on the thread."""
         self.lib = _lib.load()
