@@ -1,13 +1,18 @@
 // sim_runtime.cpp - TEST INFRASTRUCTURE: fiber scheduler of the CPU SIMT executor (see sim_runtime.h).
 #include "sim_runtime.h"
 
+#include <algorithm>
+#include <atomic>
+#include <thread>
+
 namespace sim {
 
-Block* g_block = nullptr;
-Fiber* g_cur = nullptr;
-ucontext_t g_sched;
-Idx3 g_blockIdx{0, 0, 0}, g_gridDim{1, 1, 1}, g_blockDim{1, 1, 1};
-long g_yields = 0;
+thread_local Block* g_block = nullptr;
+thread_local Fiber* g_cur = nullptr;
+thread_local ucontext_t g_sched;
+thread_local Idx3 g_blockIdx{0, 0, 0};
+Idx3 g_gridDim{1, 1, 1}, g_blockDim{1, 1, 1};
+thread_local long g_yields = 0;
 
 static const std::function<void()>* g_body = nullptr;
 
@@ -17,17 +22,16 @@ static void trampoline() {
     swapcontext(&g_cur->ctx, &g_sched);
 }
 
-void launch(unsigned grid, unsigned block, size_t lds_bytes, const std::function<void()>& body) {
+// the workgroups of a launch are independent (no kernel of this repository communicates between workgroups inside a launch), so
+// they are dealt to a few OS threads; inside a workgroup everything stays on one thread, cooperative and deterministic
+static void run_blocks(unsigned first, unsigned stride, unsigned grid, unsigned block, size_t lds_bytes) {
     constexpr size_t kStack = 256 * 1024;
     Block blk;
     blk.nthreads = (int)block;
     blk.fibers.resize(block);
     blk.lds.resize(lds_bytes + 64);
     std::vector<char> stacks((size_t)block * kStack);
-    g_gridDim = {grid, 1, 1};
-    g_blockDim = {block, 1, 1};
-    g_body = &body;
-    for (unsigned b = 0; b < grid; ++b) {
+    for (unsigned b = first; b < grid; b += stride) {
         g_blockIdx = {b, 0, 0};
         std::memset(blk.lds.data(), 0xFF, blk.lds.size());   // 0xFFFFFFFF = NaN: poison
         blk.block_bar = Barrier{(int)block, 0, 0};
@@ -52,19 +56,31 @@ void launch(unsigned grid, unsigned block, size_t lds_bytes, const std::function
         unsigned remaining = block;
         long guard = 0;
         while (remaining) {
-            unsigned progressed = 0;
             for (unsigned t = 0; t < block; ++t) {
                 Fiber& f = blk.fibers[t];
                 if (f.done) continue;
                 g_cur = &f;
                 swapcontext(&g_sched, &f.ctx);
-                if (f.done) { --remaining; ++progressed; }
+                if (f.done) --remaining;
             }
             if (++guard > 50000000L) { std::fprintf(stderr, "sim: deadlock (barrier mismatch?)\n"); std::abort(); }
         }
     }
     g_block = nullptr;
     g_cur = nullptr;
+}
+
+void launch(unsigned grid, unsigned block, size_t lds_bytes, const std::function<void()>& body) {
+    g_gridDim = {grid, 1, 1};
+    g_blockDim = {block, 1, 1};
+    g_body = &body;
+    unsigned nt = std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+    if (const char* e = std::getenv("VMSIM_THREADS")) nt = (unsigned)std::max(1, std::atoi(e));
+    nt = std::min(nt, grid);
+    if (nt <= 1) { run_blocks(0, 1, grid, block, lds_bytes); return; }
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; ++t) th.emplace_back(run_blocks, t, nt, grid, block, lds_bytes);
+    for (auto& x : th) x.join();
 }
 
 }  // namespace sim

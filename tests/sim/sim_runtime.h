@@ -1,7 +1,7 @@
 // sim_runtime.h - TEST INFRASTRUCTURE: a tiny SIMT executor for running the HIP kernel *source* on a CPU.
 //
-// One workgroup at a time; every work-item is a ucontext fiber scheduled round-robin, cooperative (no
-// preemption), single OS thread, fully deterministic.  A wave is 64 consecutive fibers; wave-collective
+// Workgroups are independent and dealt to a few OS threads; inside a workgroup every work-item is a ucontext fiber
+// scheduled round-robin on ONE thread, cooperative (no preemption), fully deterministic.  A wave is 64 consecutive fibers; wave-collective
 // operations (the matrix instruction, lane exchanges) and barriers are rendezvous points at which a
 // fiber yields until all participants have arrived.  LDS is a per-block byte array filled with
 // signalling garbage (NaN patterns) so that reads of unwritten shared memory surface as NaNs.
@@ -48,11 +48,12 @@ struct Block {
     std::vector<unsigned char> lds;
 };
 
-extern Block* g_block;
-extern Fiber* g_cur;
-extern ucontext_t g_sched;
-extern Idx3 g_blockIdx, g_gridDim, g_blockDim;
-extern long g_yields;
+extern thread_local Block* g_block;
+extern thread_local Fiber* g_cur;
+extern thread_local ucontext_t g_sched;
+extern thread_local Idx3 g_blockIdx;
+extern Idx3 g_gridDim, g_blockDim;
+extern thread_local long g_yields;
 
 inline void yield() {
     ++g_yields;

@@ -42,7 +42,7 @@ def build(force=False):
     pool = [h for h in pool if h != os.path.join(csrc, "wave_ops.h")]
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     cxx = CLANG if os.path.exists(CLANG) else "clang++"
-    flags = [cxx, "-std=c++17", "-O2", "-mfma", "-ffp-contract=fast", "-fPIC", "-I", SIM, "-I", os.path.join(SIM, "include"),
+    flags = [cxx, "-std=c++17", "-O2", "-mfma", "-ffp-contract=fast", "-fPIC", "-pthread", "-I", SIM, "-I", os.path.join(SIM, "include"),
              "-I", csrc, "-Wno-unused-value", "-Wno-psabi", "-Wno-pass-failed"]
     procs, objs = [], []
     for u in UNITS:
@@ -55,7 +55,7 @@ def build(force=False):
     if failed:
         raise subprocess.CalledProcessError(1, f"simulator build: {failed}")
     if force or procs or not os.path.exists(OUT) or any(os.path.getmtime(OUT) < os.path.getmtime(o) for o in objs):
-        subprocess.run([cxx, "-shared", "-fPIC", "-o", OUT + ".tmp"] + objs, check=True)
+        subprocess.run([cxx, "-shared", "-fPIC", "-pthread", "-o", OUT + ".tmp"] + objs, check=True)
         os.replace(OUT + ".tmp", OUT)
     return OUT
 
