@@ -141,6 +141,9 @@ def main():
     if dist:
         import torch.distributed as td
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:                                  # VMAP_BENCH_FORCE_DIST=1 without a launcher: a one-rank group
+            for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_PORT", "29533")):
+                os.environ.setdefault(k, v)
         td.init_process_group("nccl", device_id=dev)
 
     cfg = synth.CONFIGS[args.config]

@@ -252,10 +252,15 @@ typedef struct vmapstep_sample_randoms {     /* test mode, device pointers, any 
     const float* g_z;          /* [n][F*P][n_bins]  */
 } vmapstep_sample_randoms;
 
+/* `workspace` (optional, >= vmapstep_sample_workspace_bytes(n_obj), 4-byte aligned): with it the frame is sampled by as many
+ * workgroups per object as fill the chip (two launches: the objects' maximum sampled depths - the one quantity that couples an
+ * object's rays, vmap.py:391 - joined by an order-independent atomic max, then the samples); without it one workgroup per
+ * object does everything.  Same pixels, same samples, same bits either way. */
+int vmapstep_sample_workspace_bytes(int32_t n_obj, size_t* bytes);
 int vmapstep_sample_frame(const vmapstep_sample_cfg* cfg, const vmapstep_sample_object* objects_device, int32_t n_obj,
                           float* pcs, float* z, float* gt_depth, float* gt_rgb, uint8_t* sem, uint8_t* depth_mask,
                           uint64_t seed, uint32_t frame_counter, const vmapstep_sample_randoms* test_randoms,
-                          void* stream);
+                          void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- inference query -------------------------------------------------------------------
  * Occupancy sigmoid(alpha) and colour of ONE object's field (object `obj_index` of the stacked tensors) at `n_points`

@@ -22,7 +22,11 @@ struct sim_tid_proxy { unsigned x, y, z; };
 inline void __syncthreads() { sim::barrier_wait(sim::g_block->block_bar); }
 inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
 inline int atomicOr(int* p, int v) { int o = *p; *p = o | v; return o; }
-inline int atomicMax(int* p, int v) { int o = *p; if (v > o) *p = v; return o; }
+inline int atomicMax(int* p, int v) {                       // workgroups run on several OS threads: a real atomic
+    int o = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (v > o && !__atomic_compare_exchange_n(p, &o, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    return o;
+}
 
 inline int min(int a, int b) { return a < b ? a : b; }
 inline int max(int a, int b) { return a > b ? a : b; }

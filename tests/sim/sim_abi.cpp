@@ -18,6 +18,8 @@ void fc_sizes(int H, int* sz) {
 extern "C" int vmsim_lds_bytes() { return vk::Lds32::BYTES; }
 static int g_wide = 0;
 extern "C" void vmsim_set_wide(int w) { g_wide = w; }
+static int g_sample_split = 0;
+extern "C" void vmsim_set_sample_split(int nsplit) { g_sample_split = nsplit; }   // > 1: the split form of the sampler (two launches)
 static int g_split = 0;
 extern "C" void vmsim_set_split(int on) { g_split = on; }   // hidden 32: 1 = step_main_s32 (split-bf16 matrix pipe) instead of step_main_h32   
 
@@ -148,6 +150,8 @@ extern "C" int vmsim_sample(const vs::SampleObject* objs, int n_obj, int W, int 
     a.seed_lo = (unsigned)seed; a.seed_hi = (unsigned)(seed >> 32); a.frame_counter = frame_counter;
     a.rnd.kf_ids = kf_ids; a.rnd.u_w = u_w; a.rnd.u_h = u_h; a.rnd.u_z = u_z; a.rnd.g_z = g_z;
     a.pcs = pcs; a.z = z; a.gt_depth = gt_depth; a.gt_rgb = gt_rgb; a.sem = sem; a.depth_mask = dmask;
+    std::vector<int> obj_max(n_obj, 0);
+    if (g_sample_split > 1) { a.nsplit = g_sample_split; a.obj_max = obj_max.data(); }
     sl::sample(a, n_obj, (long long)F * P);
     return 0;
 }

@@ -3,6 +3,12 @@
 
 namespace sl {
 void sample(const vs::SampleArgs& a, int n_obj, long long rays) {
+    if (a.obj_max) {
+        for (int k = 0; k < n_obj; ++k) a.obj_max[k] = (int)0x80808080u;
+        sim::launch(n_obj * a.nsplit, vs::kWG, vs::kWG * 4, [&] { vs::frame_depth_max(a); });
+        sim::launch(n_obj * a.nsplit, vs::kWG, vs::kWG * 4, [&] { vs::frame_sample<false>(a); });
+        return;
+    }
     if (rays <= vs::kMaxStagedRays) sim::launch(n_obj, vs::kWG, (3 * (size_t)rays + vs::kWG) * 4, [&] { vs::frame_sample<true>(a); });
     else sim::launch(n_obj, vs::kWG, vs::kWG * 4, [&] { vs::frame_sample<false>(a); });
 }

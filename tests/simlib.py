@@ -42,7 +42,7 @@ def build(force=False):
     pool = [h for h in pool if h != os.path.join(csrc, "wave_ops.h")]
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     cxx = CLANG if os.path.exists(CLANG) else "clang++"
-    flags = [cxx, "-std=c++17", "-O2", "-mfma", "-ffp-contract=fast", "-fPIC", "-pthread", "-I", SIM, "-I", os.path.join(SIM, "include"),
+    flags = [cxx, "-std=c++17", "-O2", "-mfma", "-ffp-contract=fast-honor-pragmas", "-fPIC", "-pthread", "-I", SIM, "-I", os.path.join(SIM, "include"),
              "-I", csrc, "-Wno-unused-value", "-Wno-psabi", "-Wno-pass-failed"]
     procs, objs = [], []
     for u in UNITS:
@@ -135,10 +135,12 @@ class _SimSampleObject(ctypes.Structure):
                 ("obj_id", ctypes.c_int32), ("slots", ctypes.c_void_p), ("inst", ctypes.c_void_p)]
 
 
-def sim_sample(scenes, rnds, seed=0, frame_counter=0, eps=0.1, stop_eps=0.05):
+def sim_sample(scenes, rnds, seed=0, frame_counter=0, eps=0.1, stop_eps=0.05, nsplit=0):
     """Run frame_sample on the simulator for a list of scenes (same W,H,F,P,n1,n2); rnds = list of per-ray random dicts
-    (test mode) or None (Philox mode).  Returns dict of arrays with a leading object dimension."""
+    (test mode) or None (Philox mode).  nsplit > 1: the split form (frame_depth_max + frame_sample over ray slices).
+    Returns dict of arrays with a leading object dimension."""
     L = lib()
+    L.vmsim_set_sample_split(int(nsplit))
     assert L.vmsim_sample_object_size() == ctypes.sizeof(_SimSampleObject)
     n = len(scenes)
     s0 = scenes[0]

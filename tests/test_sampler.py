@@ -201,3 +201,60 @@ def test_gpu_sampler_background_frame_size():
                          a["sem"], a["depth_mask"], opt=st, n_steps=20)
     torch.cuda.synchronize()
     assert torch.isfinite(res.loss).all()
+
+
+@pytest.mark.parametrize("name,nsplit", [("obj", 3), ("twokf", 2), ("bg", 4)])
+def test_sim_split_sampler_equals_the_one_workgroup_form(name, nsplit):
+    """The split form (frame_depth_max joins the per-slice depth maxima with an atomic max, frame_sample then works on ray slices -
+    several workgroups per object) gives the SAME bits as one workgroup per object, in test mode (== the oracle) and in Philox
+    mode: every value is a pure function of (object, ray) and the object's maximum depth."""
+    sc = sampler_cases.build_scene(name)
+    rnd = sampler_cases.draw_randoms(sc)
+    one = simlib.sim_sample([sc, sc], [rnd, rnd], eps=EPS, stop_eps=STOP)
+    spl = simlib.sim_sample([sc, sc], [rnd, rnd], eps=EPS, stop_eps=STOP, nsplit=nsplit)
+    for k in one:
+        assert np.array_equal(one[k], spl[k]), k
+    _check_against_oracle(spl, 1, _oracle(sc, rnd))
+    a = simlib.sim_sample([sc], None, seed=9, frame_counter=2, eps=EPS, stop_eps=STOP)
+    b = simlib.sim_sample([sc], None, seed=9, frame_counter=2, eps=EPS, stop_eps=STOP, nsplit=nsplit)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+
+
+@pytest.mark.gpu
+def test_gpu_split_sampler_is_bit_identical_to_one_workgroup_per_object():
+    """FrameSampler(split=True) (the default: a workspace for the objects' depth maxima, as many workgroups per object as fill the
+    chip) against split=False on the device: identical tensors, in test mode and in Philox mode; reuse_outputs hands back the
+    same buffers every frame."""
+    import torch
+    from vmap_amd import sampler
+    dev = "cuda:0"
+    scenes = [sampler_cases.build_scene("obj") for _ in range(5)]
+    for i, sc in enumerate(scenes):
+        scenes[i] = dict(sc, depth=np.where(sc["depth"] > 0, sc["depth"] + 0.05 * i, 0).astype(np.float32))
+    rnds = [sampler_cases.draw_randoms(sc) for sc in scenes]
+    s0 = scenes[0]
+    fx, fy, cx, cy = s0["intr"]
+    objs = [dict(rgbs=torch.from_numpy(sc["rgbs"]).to(dev), depth=torch.from_numpy(sc["depth"]).to(dev),
+                 t_wc=torch.from_numpy(sc["t_wc"]).to(dev), bbox=torch.from_numpy(sc["bbox"]).to(dev),
+                 n_keyframes=sc["K"], last2=sc["last2"], center=sc["center"]) for sc in scenes]
+    tr = {k: torch.from_numpy(np.stack([r[k] for r in rnds]).astype(np.int32 if k == "kf_ids" else np.float32)).to(dev)
+          for k in ("kf_ids", "u_w", "u_h", "u_z", "g_z")}
+    outs = []
+    for split in (False, True):
+        smp = sampler.FrameSampler(s0["W"], s0["H"], s0["F"], s0["P"], s0["n1"], s0["n2"], fx, fy, cx, cy, min_depth=s0["min_bound"],
+                                   surface_eps=EPS, stop_eps=STOP, device=dev, seed=11, split=split, reuse_outputs=True)
+        smp.set_objects(objs)
+        t = {k: v.clone() for k, v in smp.sample(test_randoms=tr).items()}
+        smp.frame_counter = 7
+        first = smp.sample()
+        p = {k: v.clone() for k, v in first.items()}
+        again = smp.sample()
+        assert all(again[k].data_ptr() == first[k].data_ptr() for k in first)          # reuse_outputs
+        outs.append((t, p))
+    torch.cuda.synchronize()
+    for a, b in zip(outs[0], outs[1]):
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+    for k, (sc, rnd) in enumerate(zip(scenes, rnds)):
+        _check_against_oracle({kk: v.cpu().numpy() for kk, v in outs[1][0].items()}, k, _oracle(sc, rnd))

@@ -28,19 +28,25 @@ for k in range(n):
     bbox = torch.tensor([[100.0, 900.0, 50.0, 600.0]], device=dev).repeat(K, 1).contiguous()
     objs.append(dict(rgbs=rgbs, depth=depth, t_wc=t_wc, bbox=bbox, n_keyframes=K, last2=(K - 2, K - 1), center=(0.0, 0.0, 0.0)))
 
-smp = sampler.FrameSampler(W, H, F, P, n1, n2, fx, fy, cx, cy, min_depth=min_b, surface_eps=eps, stop_eps=stop_eps, device=dev)
-smp.set_objects(objs)
-for _ in range(3):
-    out = smp.sample()
-torch.cuda.synchronize()
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record()
-N = 50
-for _ in range(N):
-    out = smp.sample()
-e1.record()
-torch.cuda.synchronize()
-hip_ms = e0.elapsed_time(e1) / N
+def time_sampler(split):
+    smp = sampler.FrameSampler(W, H, F, P, n1, n2, fx, fy, cx, cy, min_depth=min_b, surface_eps=eps, stop_eps=stop_eps, device=dev,
+                               split=split, reuse_outputs=True)
+    smp.set_objects(objs)
+    for _ in range(3):
+        smp.sample()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    N = 50
+    for _ in range(N):
+        smp.sample()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / N
+
+
+one_wg_ms = time_sampler(False)      # one workgroup per object (rounds 1-2)
+hip_ms = time_sampler(True)          # split form: many workgroups per object (round 3, the default)
 
 # eager PyTorch port of the reference loop (same ops, per object)
 idx_w_c = torch.arange(W, device=dev)
@@ -119,6 +125,6 @@ ref_ms = (time.perf_counter() - t0) / M * 1e3
 rays = n * F * P
 written = rays * ((n1 + n2) * 16 + 4 + 12 + 2)
 print(json.dumps({"what": "one frame of ray samples for all objects (20 objects x 100 frames x 24 px, 10 samples/ray)",
-                  "hip_ms": hip_ms, "hip_rays_per_s": rays / (hip_ms * 1e-3), "hip_write_GBs": written / (hip_ms * 1e-3) / 1e9,
+                  "hip_ms": hip_ms, "hip_ms_one_workgroup_per_object": one_wg_ms, "hip_rays_per_s": rays / (hip_ms * 1e-3), "hip_write_GBs": written / (hip_ms * 1e-3) / 1e9,
                   "eager_pytorch_rocm_ms": ref_ms, "speedup": ref_ms / hip_ms,
                   "bytes_written_per_frame": written, "device": torch.cuda.get_device_name(0)}))

@@ -87,6 +87,7 @@ EXPORTS = (
     "vmapstep_profile_main_kernel", "vmapstep_profile_phases", "vmapstep_prepare", "vmapstep_train_steps_prepared",
     "vmapstep_workspace_counts_offset", "vmapstep_fwd_bwd_prepared", "vmapstep_sample_frame",
     "vmapstep_query_workspace_bytes", "vmapstep_query_points", "vmapstep_profile_train_steps", "vmapstep_adamw_apply",
+    "vmapstep_sample_workspace_bytes",
 )
 
 _lib = None
@@ -135,7 +136,9 @@ def load():
     lib.vmapstep_workspace_counts_offset.argtypes = [ctypes.POINTER(Shape), ctypes.c_int32, ctypes.POINTER(ctypes.c_size_t)]
     lib.vmapstep_sample_frame.argtypes = [ctypes.POINTER(SampleCfg), ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-                                          ctypes.c_uint64, ctypes.c_uint32, ctypes.POINTER(SampleRandoms), ctypes.c_void_p]
+                                          ctypes.c_uint64, ctypes.c_uint32, ctypes.POINTER(SampleRandoms), ctypes.c_void_p, ctypes.c_size_t,
+                                          ctypes.c_void_p]
+    lib.vmapstep_sample_workspace_bytes.argtypes = [ctypes.c_int32, ctypes.POINTER(ctypes.c_size_t)]
     lib.vmapstep_query_workspace_bytes.argtypes = [ctypes.c_int32, ctypes.POINTER(ctypes.c_size_t)]
     lib.vmapstep_query_points.argtypes = [ctypes.c_int32, ctypes.POINTER(Params), ctypes.POINTER(Tensor), ctypes.c_int32,
                                           ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64), ctypes.c_void_p,
@@ -155,7 +158,8 @@ def load():
                "vmapstep_train_steps", "vmapstep_profile_main_kernel",
                "vmapstep_profile_phases", "vmapstep_prepare", "vmapstep_train_steps_prepared",
                "vmapstep_workspace_counts_offset", "vmapstep_fwd_bwd_prepared", "vmapstep_sample_frame",
-               "vmapstep_query_workspace_bytes", "vmapstep_query_points", "vmapstep_profile_train_steps", "vmapstep_adamw_apply"):
+               "vmapstep_query_workspace_bytes", "vmapstep_query_points", "vmapstep_profile_train_steps", "vmapstep_adamw_apply",
+               "vmapstep_sample_workspace_bytes"):
         getattr(lib, fn).restype = ctypes.c_int
     if lib.vmapstep_abi_version() != ABI_VERSION:
         raise VmapStepError(f"ABI mismatch: library {lib.vmapstep_abi_version()} != binding {ABI_VERSION}")

@@ -35,6 +35,15 @@ int query_points(int hidden, const vk::StepArgs& pack, const vk::QueryArgs& q, l
 }
 
 int sample_frame(const vs::SampleArgs& a, int n_obj, long long rays_per_object, hipStream_t st) {
+    if (a.obj_max) {
+        // split form: nsplit workgroups per object; launch 1 joins the per-slice depth maxima, launch 2 samples
+        hipError_t e = hipMemsetAsync(a.obj_max, 0x80, (size_t)n_obj * sizeof(int), st);
+        if (e != hipSuccess) return fail(-4, "hipMemsetAsync(obj_max): %s", hipGetErrorString(e));
+        hipLaunchKernelGGL(vs::frame_depth_max<>, dim3(n_obj * a.nsplit), dim3(vs::kWG), vs::kWG * sizeof(float), st, a);
+        if (int rc = launched("frame_depth_max")) return rc;
+        hipLaunchKernelGGL(vs::frame_sample<false>, dim3(n_obj * a.nsplit), dim3(vs::kWG), vs::kWG * sizeof(float), st, a);
+        return launched("frame_sample");
+    }
     if (rays_per_object <= vs::kMaxStagedRays) {
         const size_t lds = (3 * (size_t)rays_per_object + vs::kWG) * sizeof(float);
         if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(vs::frame_sample<true>), 160 * 1024, "frame_sample")) return rc;

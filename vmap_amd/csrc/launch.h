@@ -47,6 +47,6 @@ int finalize_ws(const vk::FinalizeArgs& f, const vk::FinalizeHot& h, const int* 
 
 // k_misc.hip: inference query and the frame sampler
 int query_points(int hidden, const vk::StepArgs& pack, const vk::QueryArgs& q, long long n_points, hipStream_t st);
-int sample_frame(const vs::SampleArgs& a, int n_obj, long long rays_per_object, hipStream_t st);
+int sample_frame(const vs::SampleArgs& a, int n_obj, long long rays_per_object, hipStream_t st);   // a.obj_max != null: the split form (two launches)
 
 }  // namespace vl

@@ -21,6 +21,11 @@
 
 namespace vs {
 
+// Every product and sum of this file is rounded on its own, like the elementwise tensor ops of vmap.py:343-457 it restates -
+// and so that the instantiations / launch forms of the sampler (staged, unstaged, split) cannot differ by a fused
+// multiply-add (they did, by one ulp of a bin edge, until this pragma).  The build's default (fast) is restored at the end.
+#pragma clang fp contract(off)
+
 constexpr int kWG = 256;
 constexpr int kMaxS = 32;
 
@@ -55,7 +60,15 @@ struct SampleArgs {
     unsigned seed_lo, seed_hi, frame_counter;
     SampleRandoms rnd;
     float* pcs; float* z; float* gt_depth; float* gt_rgb; unsigned char* sem; unsigned char* depth_mask;   // [n][F*P]...
+    // Split form (a workspace was given): nsplit workgroups per object, each on a contiguous slice of the object's rays.  The one
+    // quantity that couples an object's rays - its maximum sampled depth (phase B) - comes from a first launch (frame_depth_max:
+    // per-slice maxima joined by an order-independent integer atomic max into obj_max[k]).  nsplit = 0 / obj_max = null: one
+    // workgroup per object does everything.
+    int nsplit; int* obj_max;
 };
+// float <-> int keys whose signed order is the float order (for the atomic max; any finite float)
+__device__ __forceinline__ int depth_key(float f) { const int i = (int)__float_as_uint(f); return i >= 0 ? i : i ^ 0x7FFFFFFF; }
+__device__ __forceinline__ float key_depth(int k) { return __uint_as_float((unsigned)(k >= 0 ? k : k ^ 0x7FFFFFFF)); }
 
 struct U4 { unsigned x, y, z, w; };
 
@@ -120,15 +133,41 @@ __device__ __forceinline__ void pick_pixel(const SampleArgs& a, const SampleObje
     }
 }
 
+// Split form, launch 1: workgroup (object k, slice) -> max sampled depth of the slice -> atomic max into obj_max[k] (the caller
+// memsets obj_max to 0x80 bytes first: a key below every depth).  Same pick_pixel as phase A, so the same pixels as launch 2.
+template <int = 0>
+__global__ __launch_bounds__(kWG) void frame_depth_max(const SampleArgs a) {
+    float* s_red = wv::lds_base();
+    const int tid = threadIdx.x, k = blockIdx.x / a.nsplit, part = blockIdx.x - k * a.nsplit;
+    const SampleObject ob = a.objs[k];
+    const int FP = a.F * a.P, per = (FP + a.nsplit - 1) / a.nsplit, r1 = min(FP, (part + 1) * per);
+    float dmax = -3.0e38f;
+    for (int ray = part * per + tid; ray < r1; ray += kWG) {
+        unsigned px, rgba;
+        float d;
+        pick_pixel(a, ob, k, ray, FP, px, rgba, d);
+        dmax = fmaxf(dmax, d);
+    }
+    s_red[tid] = dmax;
+    __syncthreads();
+    for (int w = kWG / 2; w > 0; w >>= 1) {
+        if (tid < w) s_red[tid] = fmaxf(s_red[tid], s_red[tid + w]);
+        __syncthreads();
+    }
+    if (tid == 0) atomicMax(a.obj_max + k, depth_key(s_red[0]));
+}
+
 // STAGED: phase A's per-ray results are kept in LDS for phase C (3 dwords per ray: F * P <= kMaxStagedRays); otherwise phase C
 // evaluates phase A again (the background model's frame: 200 frames x 120 pixels = 24000 rays, train.py:197, cfg.py:67-69).
 constexpr int kMaxStagedRays = 12000;
 template <bool STAGED>
 __global__ __launch_bounds__(kWG) void frame_sample(const SampleArgs a) {
     float* lds = wv::lds_base();
-    const int tid = threadIdx.x, k = blockIdx.x;
+    const bool split = !STAGED && a.obj_max != nullptr;                // launch 2 of the split form: phases A / B were launch 1
+    const int tid = threadIdx.x, k = split ? blockIdx.x / a.nsplit : blockIdx.x, part = split ? blockIdx.x - k * a.nsplit : 0;
     const SampleObject ob = a.objs[k];
     const int FP = a.F * a.P, S = a.n1 + a.n2;
+    const int per = split ? (FP + a.nsplit - 1) / a.nsplit : FP, ray_begin = part * per, ray_end = min(FP, ray_begin + per);
     const int NST = STAGED ? FP : 0;
     float* s_dep = lds;                                       // [FP]
     unsigned* s_pix = reinterpret_cast<unsigned*>(lds + NST); // [FP]  iw | ih << 12 | kf << 24
@@ -137,6 +176,7 @@ __global__ __launch_bounds__(kWG) void frame_sample(const SampleArgs a) {
 
     // ---- A: pixel choice + gathers ----
     float dmax = -3.0e38f;
+    if (!split)
     for (int ray = tid; ray < FP; ray += kWG) {
         unsigned px, rgba;
         float d;
@@ -149,16 +189,21 @@ __global__ __launch_bounds__(kWG) void frame_sample(const SampleArgs a) {
         dmax = fmaxf(dmax, d);
     }
     // ---- B: max sampled depth of this object (vmap.py:391) ----
-    s_red[tid] = dmax;
-    __syncthreads();
-    for (int w = kWG / 2; w > 0; w >>= 1) {
-        if (tid < w) s_red[tid] = fmaxf(s_red[tid], s_red[tid + w]);
+    float max_bound;
+    if (split) {
+        max_bound = key_depth(a.obj_max[k]);
+    } else {
+        s_red[tid] = dmax;
         __syncthreads();
+        for (int w = kWG / 2; w > 0; w >>= 1) {
+            if (tid < w) s_red[tid] = fmaxf(s_red[tid], s_red[tid + w]);
+            __syncthreads();
+        }
+        max_bound = s_red[0];
     }
-    const float max_bound = s_red[0];
 
     // ---- C: depth samples and points ----
-    for (int ray = tid; ray < FP; ray += kWG) {
+    for (int ray = ray_begin + tid; ray < ray_end; ray += kWG) {
         unsigned px, rgba;
         float d;
         if (STAGED) { px = s_pix[ray]; rgba = s_rgba[ray]; d = s_dep[ray]; }
@@ -254,5 +299,7 @@ __global__ __launch_bounds__(kWG) void frame_sample(const SampleArgs a) {
         a.depth_mask[row] = invalid ? 0 : 1;                                          // valid_depth_mask
     }
 }
+
+#pragma clang fp contract(fast)
 
 }  // namespace vs

@@ -732,10 +732,16 @@ int vmapstep_query_points(int32_t hidden, const vmapstep_params* params, const v
 
 static_assert(sizeof(vmapstep_sample_object) == sizeof(vs::SampleObject), "sample object table layout");
 
+int vmapstep_sample_workspace_bytes(int32_t n_obj, size_t* bytes) {
+    if (!bytes || n_obj < 1) return fail(VMAPSTEP_ERR_ARGUMENT, "null / non-positive argument");
+    *bytes = align_up((size_t)n_obj * sizeof(int));
+    return VMAPSTEP_OK;
+}
+
 int vmapstep_sample_frame(const vmapstep_sample_cfg* cfg, const vmapstep_sample_object* objects_device, int32_t n_obj,
                           float* pcs, float* z, float* gt_depth, float* gt_rgb, uint8_t* sem, uint8_t* depth_mask,
                           uint64_t seed, uint32_t frame_counter, const vmapstep_sample_randoms* test_randoms,
-                          void* stream) {
+                          void* workspace, size_t workspace_bytes, void* stream) {
     if (!cfg || !objects_device || !pcs || !z || !gt_depth || !gt_rgb || !sem || !depth_mask)
         return fail(VMAPSTEP_ERR_ARGUMENT, "null argument");
     const int S = cfg->n_bins_cam2surface + cfg->n_bins;
@@ -757,6 +763,15 @@ int vmapstep_sample_frame(const vmapstep_sample_cfg* cfg, const vmapstep_sample_
         a.rnd.u_z = test_randoms->u_z; a.rnd.g_z = test_randoms->g_z;
     }
     a.pcs = pcs; a.z = z; a.gt_depth = gt_depth; a.gt_rgb = gt_rgb; a.sem = sem; a.depth_mask = depth_mask;
+    if (workspace) {
+        // split form: as many workgroups per object as fill the chip, at most one ray per thread
+        if (reinterpret_cast<uintptr_t>(workspace) % sizeof(int) || workspace_bytes < (size_t)n_obj * sizeof(int))
+            return fail(VMAPSTEP_ERR_WORKSPACE, "sampler workspace: need %zu bytes (vmapstep_sample_workspace_bytes)", (size_t)n_obj * sizeof(int));
+        const long long per_obj_max = (FP + vs::kWG - 1) / vs::kWG;
+        long long ns = std::max(1, 512 / n_obj);
+        if (ns > per_obj_max) ns = per_obj_max;
+        if (ns > 1) { a.nsplit = (int)ns; a.obj_max = static_cast<int*>(workspace); }
+    }
     VMAPSTEP_ON_STREAM_DEVICE(stream);
     return vl::sample_frame(a, n_obj, FP, static_cast<hipStream_t>(stream));
 }

@@ -20,7 +20,10 @@ from . import _lib
 
 class FrameSampler:
     def __init__(self, width, height, frames, samples_per_frame, n_bins_cam2surface, n_bins, fx, fy, cx, cy,
-                 min_depth=0.0, surface_eps=0.1, stop_eps=0.05, device="cuda:0", seed=0):
+                 min_depth=0.0, surface_eps=0.1, stop_eps=0.05, device="cuda:0", seed=0, reuse_outputs=False, split=True):
+        """``reuse_outputs``: ``sample()`` writes into the SAME six tensors every frame (a consumer that binds its frame buffers -
+        ``step.BoundFrame``, ``driver.HipMapper`` - then marshals them once); ``split``: many workgroups per object (a small
+        workspace holds the objects' maximum depths between the two launches) instead of one."""
         self.lib = _lib.load()
         self.device = torch.device(device)
         self.cfg = _lib.SampleCfg(width, height, frames, samples_per_frame, n_bins_cam2surface, n_bins,
@@ -31,6 +34,8 @@ class FrameSampler:
         self._table = None
         self._keep = None
         self.n_obj = 0
+        self.reuse_outputs, self.split = bool(reuse_outputs), bool(split)
+        self._out, self._ws = None, None
 
     def set_objects(self, objects: Sequence[dict]):
         """objects: per object EITHER the reference's own buffers - dict(rgbs u8 [K,W,H,4], depth f32 [K,W,H], t_wc f32
@@ -73,6 +78,11 @@ class FrameSampler:
         self._table = torch.from_numpy(raw).to(self.device)
         self._keep = keep
         self.n_obj = n
+        self._out, self._ws = None, None
+        if self.split:
+            nb = ctypes.c_size_t(0)
+            _lib.check(self.lib.vmapstep_sample_workspace_bytes(n, ctypes.byref(nb)))
+            self._ws = torch.empty(nb.value, dtype=torch.uint8, device=self.device)
 
     def sample(self, test_randoms: Optional[dict] = None):
         """One frame of samples for all objects -> dict(pcs [n,F*P,S,3], z [n,F*P,S], gt_depth [n,F*P], gt_rgb [n,F*P,3],
@@ -81,9 +91,13 @@ class FrameSampler:
         if self._table is None:
             raise RuntimeError("set_objects() first")
         n, FP, S, dev = self.n_obj, self.F * self.P, self.S, self.device
-        out = dict(pcs=torch.empty(n, FP, S, 3, device=dev), z=torch.empty(n, FP, S, device=dev),
-                   gt_depth=torch.empty(n, FP, device=dev), gt_rgb=torch.empty(n, FP, 3, device=dev),
-                   sem=torch.empty(n, FP, dtype=torch.uint8, device=dev), depth_mask=torch.empty(n, FP, dtype=torch.uint8, device=dev))
+        out = self._out
+        if out is None:
+            out = dict(pcs=torch.empty(n, FP, S, 3, device=dev), z=torch.empty(n, FP, S, device=dev),
+                       gt_depth=torch.empty(n, FP, device=dev), gt_rgb=torch.empty(n, FP, 3, device=dev),
+                       sem=torch.empty(n, FP, dtype=torch.uint8, device=dev), depth_mask=torch.empty(n, FP, dtype=torch.uint8, device=dev))
+            if self.reuse_outputs:
+                self._out = out
         rnd = None
         if test_randoms is not None:
             rnd = _lib.SampleRandoms(*[test_randoms[k].data_ptr() if test_randoms.get(k) is not None else None
@@ -92,6 +106,8 @@ class FrameSampler:
                                                   out["pcs"].data_ptr(), out["z"].data_ptr(), out["gt_depth"].data_ptr(),
                                                   out["gt_rgb"].data_ptr(), out["sem"].data_ptr(), out["depth_mask"].data_ptr(),
                                                   self.seed, self.frame_counter, ctypes.byref(rnd) if rnd is not None else None,
+                                                  self._ws.data_ptr() if self._ws is not None else None,
+                                                  self._ws.numel() if self._ws is not None else 0,
                                                   torch.cuda.current_stream(self.device).cuda_stream))
         self.frame_counter += 1
         return out
