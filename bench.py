@@ -337,7 +337,7 @@ def main():
         try:
             # the committed counter file of the kernel this run used
             if args.config == "replica_room0_vmap" and split:
-                pmc_file, key = "r02d_pmc_counters_step_main_s32_first.json", "hbm_traffic_bytes_per_launch_step_main"
+                pmc_file, key = "r03a_pmc_counters_step_main_s32.json", "hbm_traffic_bytes_per_launch_step_main"
             elif args.config == "replica_room0_vmap":
                 pmc_file, key = "r01m_pmc_counters.json", "hbm_traffic_bytes_per_launch_step_main"
             elif args.config == "background" and args.kernel == "auto":
@@ -414,7 +414,8 @@ def main():
                          "floor_us": floor_us, "floor_note": floor_note,
                          "traffic": traffic,
                          "traffic_source": ("copied from the committed rocprofv3 --pmc passes of this kernel (profiles/" + pmc_file +
-                                            "), not observed in this run") if traffic is not None else None,
+                                            ": separate FETCH_SIZE / WRITE_SIZE passes over tests/tools/run_steps.py, FETCH doubled per MI355X_MICROARCH.md), "
+                                            "not observed in this run - counters cannot be sampled from inside the process") if traffic is not None else None,
                          "kernel_ms": k_ms, "kernel_ms_stream_event_pair": k_ms_pair,
                          "kernel_ms_note": "kernel_ms = average of the dispatches' own begin -> end timestamps (events attached to the launch, "
                                            "hipExtLaunchKernel) over the real prep / main / finalize sequence = what rocprofv3 --kernel-trace reports "
