@@ -161,7 +161,7 @@ extern "C" int vmsim_sample_object_size() { return (int)sizeof(vs::SampleObject)
 extern "C" int vmsim_query(const float* const* fc, const float* B, const float* scale, const float* pts, long long n_pts,
                            float* occ, float* rgb, int grid, int H) {
     const vk::GenLayout GL = vk::gen_layout(H);
-    std::vector<float> img(GL.imgp, NAN);
+    std::vector<float> img(H == 32 ? vk::Img32s::BYTES / 4 : GL.imgp, NAN);
     vk::StepArgs a{};
     a.n_obj = 1; a.hidden = H; a.prep_steps = 0;
     for (int t = 0; t < 14; ++t) a.fc[t] = {const_cast<float*>(fc[t]), 0};

@@ -1,18 +1,23 @@
 // k_misc.hip - the kernels either side of the step: the inference query (query_kernels.h) and the
 // batched frame sampler (sample_kernels.h; row 1).  gfx950 only.
 #include "launch.h"
+#include "query_split_kernels.h"
 
 namespace vl {
 
 int query_points(int hidden, const vk::StepArgs& pack, const vk::QueryArgs& q, long long n_points, hipStream_t st) {
-    // this object's parameter image: step_prep's pack role with zero mask-statistics blocks
-    hipLaunchKernelGGL(vk::step_prep<>, dim3(vk::gen_layout(hidden).imgp / 1024), dim3(vk::kWG), 3 * vk::kWG * sizeof(int), st, pack);
     const long long chunks = (n_points + vk::kMaxPts - 1) / vk::kMaxPts;
     if (hidden == 32) {
-        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(vk::field_query_h32<2>), vk::Lds32::IMGP * sizeof(float), "field_query_h32")) return rc;
-        const int grid = (int)(chunks < 512 ? chunks : 512);          // two resident workgroups per CU (236 registers each)
-        hipLaunchKernelGGL(vk::field_query_h32<2>, dim3(grid), dim3(vk::kWG), vk::Lds32::IMGP * sizeof(float), st, q);
-    } else {
+        // this object's SPLIT image (step_prep_s32's pack role, zero mask-statistics blocks), then the bf16-pipe query
+        hipLaunchKernelGGL(vk::step_prep_s32<>, dim3(vk::kSplitPackBlocks), dim3(vk::kWG), 3 * vk::kWG * sizeof(int), st, pack);
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(vk::field_query_s32<>), vk::kQuerySplitLds, "field_query_s32")) return rc;
+        const int grid = (int)(chunks < 512 ? chunks : 512);          // two resident workgroups per CU (2 x 80 KiB of LDS)
+        hipLaunchKernelGGL(vk::field_query_s32<>, dim3(grid), dim3(vk::kWG), vk::kQuerySplitLds, st, q);
+        return launched("field_query_s32");
+    }
+    // this object's parameter image: step_prep's pack role with zero mask-statistics blocks
+    hipLaunchKernelGGL(vk::step_prep<>, dim3(vk::gen_layout(hidden).imgp / 1024), dim3(vk::kWG), 3 * vk::kWG * sizeof(int), st, pack);
+    {
         const int grid = (int)(chunks < 256 ? chunks : 256);
         const int nb = hidden / 32;
         const size_t lds = nb > 4 ? (size_t)nb * 1024 * vk::kWaves * sizeof(float) : 0;   // second activation set (NB > 4)

@@ -2,9 +2,10 @@
 //
 // Replaces the chunked torch.no_grad() loop of the reference's Trainer.eval_points (trainer.py:77-95: pe -> fc_occ_map
 // -> sigmoid, 100 000 points per chunk) that mesh extraction calls on a dense grid (render_rays.py:98-122, up to 256^3
-// points per object).  Same forward arithmetic as step_main_h32 (encoding, five hidden layers on the exact-fp32 matrix
-// instruction, two heads); persistent workgroups: the parameter image is DMA'd into LDS once per workgroup, then each
-// wave streams 32-point tiles.  Output 16 B per point against 22.3 kFLOP per point: bound by the fp32 matrix rate.
+// points per object).  Hidden 32: field_query_s32 (query_split_kernels.h: the forward of step_main_s32 on the bf16 matrix
+// pipe, float32-equivalent; it replaced the exact-fp32 field_query_h32 of rounds 1-2).  Any other width 32 k <= 256:
+// field_query_gen below (exact-fp32 matrix instruction, weights streamed from the object's L2-resident image).
+// Persistent workgroups, each wave streams 32-point tiles; 16 B written per point against 22.3 kFLOP at hidden 32.
 #pragma once
 #include "step_kernels.h"
 
@@ -18,117 +19,6 @@ struct QueryArgs {
     float* occ;                        // [N]    sigmoid(alpha)   (render_rays.py:4-8 occupancy_activation)
     float* rgb;                        // [N,3]  sigmoid(raw colour)
 };
-
-template <int WPE>
-__global__ __launch_bounds__(kWG) WV_WAVES_PER_SIMD(WPE) void field_query_h32(const QueryArgs a) {
-    using L = Lds32;
-    constexpr int H = 32;
-    float* lds = wv::lds_base();
-    float* W = lds + L::WGT;
-    const int tid_k = threadIdx.x;
-    const float scale = a.scale[0];
-    const float* Bg = a.wimg + L::PE_B;
-    {
-        const int lane = tid_k & 63, wave = tid_k >> 6;
-        const float* src = a.wimg + wave * 256 + lane * 4;
-#pragma unroll
-        for (int c = 0; c < L::DMA_ROUNDS; ++c) wv::glds16(src + c * 1024, W + c * 1024 + wave * 256);
-    }
-    bool first = true;
-    for (long long chunk = blockIdx.x; chunk * kMaxPts < a.n_pts; chunk += gridDim.x) {
-        // lane coordinates opaque per tile (keeps the body's LDS addresses and lane masks out of the loop pre-header)
-        const int tid = wv::opaque_iter(tid_k), lane = tid & 63, wave = tid >> 6, p31 = lane & 31, hi = lane >> 5;
-        const long long pt = chunk * kMaxPts + wave * 32 + p31;
-        const bool valid = pt < a.n_pts;
-        float t[3] = {0.0f, 0.0f, 0.0f};
-        if (valid) {
-            const float* px = a.pts + pt * a.pts_sn;
-            t[0] = px[0] / scale;
-            t[1] = px[a.pts_sc] / scale;
-            t[2] = px[2 * a.pts_sc] / scale;
-        }
-        float proj[kDirs];
-#pragma unroll
-        for (int d = 0; d < kDirs; ++d)
-            proj[d] = fmaf(t[2], Bg[3 * d + 2], fmaf(t[1], Bg[3 * d + 1], t[0] * Bg[3 * d]));
-        // the far-point decision (accurate range reduction) is made once per wave and tile, like step_main_h32
-        float amax = 0.0f;
-#pragma unroll
-        for (int d = 0; d < kDirs; ++d) amax = fmaxf(amax, fabsf(proj[d]));
-        const bool big = wv::wave_any(!(amax * (32.0f * kPi) < kSinCosFastLimit));
-        float e1a[16], e1b[16], e1c[16], cf[16];
-        if (__builtin_expect(!big, 1)) {
-            pe_block<16, false>(e1a, cf, 0, kEmb1, 0, t, proj, hi);
-            pe_block<16, false>(e1b, cf, 0, kEmb1, 1, t, proj, hi);
-            pe_block<12, false>(e1c, cf, 0, kEmb1, 2, t, proj, hi);
-        } else {
-            pe_block<16, true>(e1a, cf, 0, kEmb1, 0, t, proj, hi);
-            pe_block<16, true>(e1b, cf, 0, kEmb1, 1, t, proj, hi);
-            pe_block<12, true>(e1c, cf, 0, kEmb1, 2, t, proj, hi);
-        }
-        if (first) {
-            __syncthreads();            // parameter image landed (uniform: every workgroup has at least one chunk)
-            first = false;
-        }
-        float h1[16], h2[16], h4[16], hc[16];
-        f32x16 acc;
-        {
-            const float* w = W + L::W_IN + p31 * L::LD_IN + 4 * hi;
-            load_bias(acc, W + L::B_IN, hi);
-            fwd_mm<4>(acc, w, e1a); fwd_mm<4>(acc, w + 32, e1b); fwd_mm<3>(acc, w + 64, e1c);
-            relu_to(h1, acc);
-        }
-        {
-            load_bias(acc, W + L::B_M1, hi);
-            fwd_mm<4>(acc, W + L::W_M1 + p31 * L::LD_M + 4 * hi, h1);
-            relu_to(h2, acc);
-        }
-        {
-            const float* w = W + L::W_CAT + p31 * L::LD_CAT + 4 * hi;
-            load_bias(acc, W + L::B_CAT, hi);
-            fwd_mm<4>(acc, w, h2); fwd_mm<4>(acc, w + H, e1a); fwd_mm<4>(acc, w + H + 32, e1b); fwd_mm<3>(acc, w + H + 64, e1c);
-            relu_to(h1, acc);           // h3 (h1 is dead)
-        }
-        {
-            load_bias(acc, W + L::B_M2, hi);
-            fwd_mm<4>(acc, W + L::W_M2 + p31 * L::LD_M + 4 * hi, h1);
-            relu_to(h4, acc);
-        }
-        {
-            // the colour head's share of the encoding is produced here, after the first 87 features are dead, so the
-            // kernel fits 168 registers (3 waves per SIMD: one wave's sincos overlaps another's matrix instructions)
-            float e2a[16], e2b[16];
-            if (__builtin_expect(!big, 1)) {
-                pe_block<16, false>(e2a, cf, kEmb1, kEmb2, 0, t, proj, hi);
-                pe_block<6, false>(e2b, cf, kEmb1, kEmb2, 1, t, proj, hi);
-            } else {
-                pe_block<16, true>(e2a, cf, kEmb1, kEmb2, 0, t, proj, hi);
-                pe_block<6, true>(e2b, cf, kEmb1, kEmb2, 1, t, proj, hi);
-            }
-            const float* w = W + L::W_C + p31 * L::LD_C + 4 * hi;
-            load_bias(acc, W + L::B_C, hi);
-            fwd_mm<4>(acc, w, h4); fwd_mm<4>(acc, w + H, e2a); fwd_mm<2>(acc, w + H + 32, e2b);
-            relu_to(hc, acc);
-        }
-        float ra = 0.0f, r0 = 0.0f, r1 = 0.0f, r2 = 0.0f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int j = phi(r, hi);
-            ra = fmaf(W[L::W_A + j], h4[r], ra);
-            r0 = fmaf(W[L::W_OC + j], hc[r], r0);
-            r1 = fmaf(W[L::W_OC + H + j], hc[r], r1);
-            r2 = fmaf(W[L::W_OC + 2 * H + j], hc[r], r2);
-        }
-        ra += wv::swap_half(ra); r0 += wv::swap_half(r0); r1 += wv::swap_half(r1); r2 += wv::swap_half(r2);
-        ra += W[L::B_A]; r0 += W[L::B_OC]; r1 += W[L::B_OC + 1]; r2 += W[L::B_OC + 2];
-        if (valid && hi == 0) {
-            a.occ[pt] = sigmoidf_acc(ra * 10.0f);
-            a.rgb[3 * pt + 0] = sigmoidf_acc(r0);
-            a.rgb[3 * pt + 1] = sigmoidf_acc(r1);
-            a.rgb[3 * pt + 2] = sigmoidf_acc(r2);
-        }
-    }
-}
 
 // Any hidden width H = 32 * NB (NB = 2..8: the background model's 128, iMAP's 256, ...).  Same arithmetic; the weights
 // are read straight from the object's parameter image in global memory (L2-resident: 0.4-1.3 MB), 16 bytes per lane and

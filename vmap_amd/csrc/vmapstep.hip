@@ -698,7 +698,8 @@ int vmapstep_query_workspace_bytes(int32_t hidden, size_t* bytes) {
     if (!bytes) return fail(VMAPSTEP_ERR_ARGUMENT, "bytes is null");
     if (hidden < 32 || hidden > 256 || hidden % 32 != 0)
         return fail(VMAPSTEP_ERR_UNSUPPORTED, "hidden=%d: supported widths are multiples of 32 up to 256", hidden);
-    *bytes = align_up((size_t)vk::gen_layout(hidden).imgp * sizeof(float));
+    // hidden 32: the split image of field_query_s32 (80 KiB); other widths: the float32 image of field_query_gen
+    *bytes = hidden == 32 ? align_up((size_t)vk::Img32s::BYTES) : align_up((size_t)vk::gen_layout(hidden).imgp * sizeof(float));
     return VMAPSTEP_OK;
 }
 
