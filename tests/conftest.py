@@ -49,34 +49,50 @@ def round_bf16(a):
     return u.astype(np.uint32).view(np.float32).reshape(np.shape(a))
 
 
-def kink_aware(got, ref, n_obj, signed=False):
+def kink_aware(got, ref, n_obj, signed=False, tol=1e-4):
     """ReLU-kink accounting (oracle.vmap_oracle.kink_deltas): ``ref`` = an oracle result computed with ``kinks=True``, ``got`` = another
-    float32 implementation's result.  Per object, the derivative bit of every kink-adjacent hidden unit is solved for by least
-    squares (one unknown per ambiguous entry against the object's ~10^4..10^5 gradient elements), REQUIRED to round to 0 or 1,
-    and the rounded combination is added to the oracle's gradients.  Returns ({key: corrected oracle gradient}, flipped bits,
-    ambiguous entries, worst effect of rounding a beta, in units of the affected tensor's max).
+    float32 implementation's result.  Per object, while the difference exceeds ``tol`` / 4 of a tensor's max: the ONE candidate bit
+    whose flip explains most of the remaining difference is taken, provided its coefficient (a one-unknown least squares against
+    the object's ~10^4..10^5 gradient elements) is within 0.25 of 1 (``signed``: of +-1) - matching pursuit, because the flips are
+    few and the deltas of different sample points nearly orthogonal, while a joint least squares over hundreds of candidates fits
+    rounding noise with near-collinear columns.  Returns ({key: corrected oracle gradient}, flipped bits, ambiguous entries, worst
+    distance of an applied coefficient from +-1 weighted by its effect, in units of the affected tensor's max).
 
     ``signed``: ``ref``'s gradients come from a THIRD implementation (a reference fixture) while its ``kink_deltas`` are the
     oracle's: a bit may then differ from the oracle's state in ``ref``, in ``got`` or in both, so each coefficient is the
     difference of two bits, in {-1, 0, +1}."""
     shapes = [np.shape(ref[k]) for k in GRAD_KEYS]
     flat = lambda d, k: np.concatenate([np.asarray(d[key], np.float64)[k].ravel() for key in GRAD_KEYS])
-    # per-element scale of an object's flat gradient vector: the max of the tensor the element belongs to (the tolerance is per tensor)
     corr = {key: np.array(ref[key], dtype=np.float64) for key in GRAD_KEYS}
     flipped, worst = 0, 0.0
     for k in range(n_obj):
+        # per-element scale of an object's flat gradient vector: the max of the tensor the element belongs to (the tolerance is per tensor)
         scale = np.concatenate([np.full(int(np.prod(shp[1:])), np.abs(np.asarray(ref[key])[k]).max() + 1e-30)
                                 for key, shp in zip(GRAD_KEYS, shapes)])
-        # an entry whose flip moves no tensor by 1e-7 of its max (dead downstream path, masked ray) is not ambiguous in effect
-        D = [d for (ko, d) in ref["kink_deltas"] if ko == k and np.abs(d / scale).max() > 1e-7]
-        if not D:
+        r = (flat(got, k) - flat(ref, k)) / scale
+        # an entry whose flip moves no tensor by tol / 4 of its max cannot be what separates the two results
+        D = [d / scale for (ko, d) in ref["kink_deltas"] if ko == k and np.abs(d / scale).max() > tol / 4]
+        if not D or np.abs(r).max() < tol / 4:
             continue
         A = np.stack(D, axis=1)
-        beta, *_ = np.linalg.lstsq(A / scale[:, None], (flat(got, k) - flat(ref, k)) / scale, rcond=None)
-        rb = np.clip(np.round(beta), -1 if signed else 0, 1)
-        worst = max(worst, float((np.abs(beta - rb) * np.abs(A / scale[:, None]).max(axis=0)).max()))
-        flipped += int(np.abs(rb).sum())
-        add = A @ rb
+        nrm = (A * A).sum(axis=0)
+        used = np.zeros(A.shape[1], dtype=bool)
+        add = np.zeros_like(r)
+        for _ in range(A.shape[1]):
+            if np.abs(r).max() < tol / 4:
+                break
+            beta = (A * r[:, None]).sum(axis=0) / nrm
+            rb = np.clip(np.round(beta), -1 if signed else 0, 1)
+            gain = np.where((rb != 0) & ~used & (np.abs(beta - rb) < 0.25), (2 * beta * rb - rb * rb) * nrm, -np.inf)
+            j = int(np.argmax(gain))
+            if not np.isfinite(gain[j]) or gain[j] <= 0:
+                break
+            used[j] = True
+            r = r - rb[j] * A[:, j]
+            add += rb[j] * A[:, j]
+            flipped += 1
+            worst = max(worst, float(abs(beta[j] - rb[j]) * np.abs(A[:, j]).max()))
+        add = add * scale
         o = 0
         for key, shp in zip(GRAD_KEYS, shapes):
             sz = int(np.prod(shp[1:]))

@@ -127,8 +127,7 @@ def _assert_grads_match_oracle_up_to_kinks(s, o, n_obj, tol=2e-4, signed=False):
     of flipping its derivative bit; the kernel's gradients must equal the oracle's plus a 0/1 combination of those changes
     (conftest.kink_aware: measured on the 5 x 300 x 14 hidden-128 case 3 flipped bits of 276 candidates take the raw
     difference from 3.5e-2 to 4e-6)."""
-    corr, flipped, cand, worst = kink_aware(s, o, n_obj, signed=signed)
-    assert worst < tol / 2, (worst, flipped, cand)              # every solved bit is 0 or 1 (a fractional bit may only absorb noise)
+    corr, flipped, cand, worst = kink_aware(s, o, n_obj, signed=signed, tol=tol)
     for k in GRAD_KEYS:
         assert not np.isnan(s[k]).any(), k
         assert relerr(s[k], corr[k]) < tol, (k, flipped, cand)
@@ -818,3 +817,43 @@ def test_device_step_count_survives_mixed_host_and_device_calls():
     assert torch.equal(outs[0][0], outs[1][0])
     for x, y in zip(outs[0][1], outs[1][1]):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("config,weights", [("scannet0024_vmap", "bf16"), ("stress_256x64", "bf16"), ("background", "f32")])
+def test_full_size_properties_of_the_other_baseline_configs(config, weights):
+    """BASELINE configs[3] (50 objects, hidden 32, bf16 weights: the multi-pass kernel), configs[4] (hidden 64, 256 rays per object,
+    bf16 weights: multi-round step_main_wp; 32 of its 256 objects = one GPU's share at 8 GPUs) and the background model's full
+    batch (1 x 1200 rays x 14, hidden 128: step_main_ws, two rounds per workgroup) AT THEIR FULL PER-GPU SIZES, through
+    size-independent properties: objects are independent units (permuting them permutes every output), ray order inside an
+    object is a pure summation order, two runs are bit-identical - and, full size, the numpy oracle with its ReLU kinks
+    accounted for (on bfloat16-rounded weights where the configuration says so)."""
+    from conftest import round_bf16
+    cfg = synth.CONFIGS[config]
+    n, R, S, H = (32 if config == "stress_256x64" else cfg["n_obj"]), cfg["R"], cfg["S"], cfg["H"]
+    fc, B, sc = synth.make_params(n, H, scale=cfg["scale"], seed=700)
+    batch = synth.make_batch(n, R, S, seed=701)
+    c = dict(n=n, R=R, S=S, H=H, fc=fc, B=B, scale=sc, batch=batch)
+    op = step.VmapStep(n, R, S, H, device=DEV, weights=weights)
+    s = _run(c, op=op)
+    s2 = _run(c, op=op)
+    for k in RENDER_KEYS + ["var"] + GRAD_KEYS:
+        assert np.array_equal(s[k], s2[k]), k                                     # no atomics, ordered sums: bit-repeatable
+    rnd = round_bf16 if weights == "bf16" else (lambda a: a)
+    o = vo.training_step([rnd(a) for a in fc], rnd(B), sc, batch, dtype=np.float32, kinks=True)
+    assert abs(s["loss"] - o["loss"]) <= 5e-5 * abs(o["loss"])
+    for k in RENDER_KEYS + ["var"]:
+        assert relerr(s[k], o[k]) < 2e-5, k
+    _assert_grads_match_oracle_up_to_kinks(s, o, n)
+    if n > 1:
+        perm = np.random.default_rng(0).permutation(n)
+        cp = dict(c, fc=[a[perm] for a in fc], B=B[perm], scale=sc[perm], batch={k: np.ascontiguousarray(v[perm]) for k, v in batch.items()})
+        sp = _run(cp, op=op)
+        assert sp["loss"] == pytest.approx(s["loss"], rel=2e-6)
+        for k in RENDER_KEYS + GRAD_KEYS:
+            assert relerr(sp[k], s[k][perm]) < 2e-6, k
+    rperm = np.random.default_rng(1).permutation(R)
+    cr = dict(c, batch={k: np.ascontiguousarray(v[:, rperm]) for k, v in batch.items()})
+    sr = _run(cr, op=op)
+    assert relerr(sr["render_depth"], s["render_depth"][:, rperm]) < 1e-6
+    for k in GRAD_KEYS:
+        assert relerr(sr[k], s[k]) < 5e-5, k

@@ -62,8 +62,8 @@ def test_relu_kinks_account_for_the_whole_numpy_vs_aten_gradient_gap(H, seed, mi
     raw = max(relerr(got[k], o[k]) for k in GRAD_KEYS)
     corr, flipped, cand, worst = kink_aware(got, o, n)
     assert raw >= min_raw and (flipped > 0) == (raw > 1e-4), (raw, flipped, cand)
-    assert worst < 1e-5
-    assert max(relerr(got[k], corr[k]) for k in GRAD_KEYS) < 1e-5
+    assert flipped <= 4 and worst < 1e-4                       # a handful of bits, each coefficient within rounding of 1
+    assert max(relerr(got[k], corr[k]) for k in GRAD_KEYS) < 2.5e-5
 
 
 @pytest.mark.parametrize("name", ["bg128_frame", "bg128_frame_bf16", "scannet50_frame_bf16"])
