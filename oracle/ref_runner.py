@@ -154,7 +154,7 @@ def reference_step(fc_np, B_np, scale_np, batch, H, dtype=torch.float32, strateg
 
 
 def reference_frame(fc_np, B_np, scale_np, frame, H, rays_per_step, n_steps, dtype=torch.float32,
-                    lr=1e-3, weight_decay=0.013, weights_bf16=False):
+                    lr=1e-3, weight_decay=0.013, weights_bf16=False, strategy="vmap"):
     """The reference's OWN step loop over one frame (train.py:270-326, vmap strategy): the per-frame sample tensors
     ``[n, n_steps * rays_per_step, ...]`` are sliced with ``data_idx = slice(i * R, (i + 1) * R)`` on dimension 1 (strided
     views, exactly like train.py:271-277), every step is vmap(pe) -> vmap(fc) -> loss.step_batch_loss -> backward ->
@@ -203,8 +203,17 @@ def reference_frame(fc_np, B_np, scale_np, frame, H, rays_per_step, n_steps, dty
             run_fc, run_pe = fc_param, pe_param
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            emb = vmap(pe_model)(run_pe, pe_buffer, pcs)                         # train.py:293
-            alpha, color = vmap(fc_model)(run_fc, fc_buffer, emb)                # train.py:294
+            if strategy == "vmap":
+                emb = vmap(pe_model)(run_pe, pe_buffer, pcs)                     # train.py:293
+                alpha, color = vmap(fc_model)(run_fc, fc_buffer, emb)            # train.py:294
+            else:                                                                # "forloop", train.py:278-290: the reference's other path
+                al, co = [], []
+                for k in range(len(fc_models)):
+                    e = pe_model([p[k] for p in run_pe], [b[k] for b in pe_buffer], pcs[k])
+                    a_k, c_k = fc_model([p[k] for p in run_fc], [b[k] for b in fc_buffer], e)
+                    al.append(a_k)
+                    co.append(c_k)
+                alpha, color = torch.stack(al), torch.stack(co)
         l, _ = loss_mod.step_batch_loss(alpha, color, gt_depth.detach(), gt_rgb.detach(), sem.detach(), dmask.detach(),
                                         z.detach())                             # train.py:303-306
         if l.requires_grad:

@@ -42,6 +42,11 @@ def main(names=None):
         r64 = ref_runner.reference_frame(c["fc"], c["B"], c["scale"], c["frame"], c["H"], c["R"], c["n_steps"], torch.float64,
                                          weights_bf16=bf16)
         out = {"losses": r32["losses"], "f64_losses": r64["losses"], "keep": np.array(keep)}
+        if name == "cfg2_frame20":
+            # the reference's OTHER float32 path over the same frame (training_strategy "forloop", train.py:278-290): how far two
+            # float32 evaluations of the reference itself drift apart over 20 steps - the yardstick for the kernel's own drift
+            out["forloop_losses"] = ref_runner.reference_frame(c["fc"], c["B"], c["scale"], c["frame"], c["H"], c["R"], c["n_steps"],
+                                                               torch.float32, strategy="forloop")["losses"]
         for t in list(range(14)) + ["B"]:
             k = f"fc{t}" if t != "B" else "B"
             out[f"p_{k}"] = r32[f"p_{k}"][keep].astype(np.float32)

@@ -652,18 +652,21 @@ def test_table_driven_finalize_is_bit_identical_to_generic_finalize(name, weight
 
 
 FRAME_TOL = {   # (relative loss tolerance for steps < 5, for later steps, q99 / median of |final parameter - reference|)
-    # The variance-normalised depth loss is ill-conditioned at random init (the reference's own float32 and float64 runs
-    # differ by up to 30 % per step, see the fixture's f64_losses): summation-order noise is amplified step by step, so
-    # the bound widens after the first steps; the parameters themselves stay within a few Adam steps (lr = 1e-3).
-    "cfg2_frame20": (2e-4, 3e-2, 3e-4, 2e-5),
-    "scannet50_frame": (2e-4, 2e-4, 2e-5, 2e-6),
-    "h64_r256_frame": (2e-4, 2e-4, 2e-5, 2e-6),
-    "bg128_frame": (2e-4, 2e-4, 2e-5, 2e-6),
-    # bf16 run-time weights over fp32 masters: an AdamW step (lr 1e-3) is about one bfloat16 ulp of a typical weight, so a master
-    # that differs from the reference's by 1e-7 occasionally rounds to the other neighbour - a 2^-9 relative change of ONE weight
-    # of the run-time image.  The first step (same masters, same rounding) is held to 2e-5 / 1e-4 like the fp32 frames.
-    "scannet50_frame_bf16": (1e-3, 1e-3, 2e-5, 2e-6),
-    "h64_r256_frame_bf16": (1e-3, 1e-3, 2e-5, 2e-6),
+    # Measured per step (tests/tools/frame_drift.py, profiles/r03n_frame_drift.json): over the 20 steps of the headline frame the
+    # default kernel stays within 2.3e-5 of the reference's loop (the exact-fp32 kernel within 3.1e-6; the reference's own float32
+    # and float64 runs differ by up to 30 % per step on this ill-conditioned loss, but its two float32 paths - vmap / forloop -
+    # agree to 3e-7, and so, nearly, does this kernel).  Bounds: 5e-5 for the first steps, north_star's 1e-4 to the end.
+    "cfg2_frame20": (5e-5, 1e-4, 3e-4, 2e-5),
+    "scannet50_frame": (5e-5, 1e-4, 2e-5, 2e-6),
+    "h64_r256_frame": (5e-5, 1e-4, 2e-5, 2e-6),
+    "bg128_frame": (5e-5, 1e-4, 2e-5, 2e-6),
+    # bf16 run-time weights over fp32 masters (measured: 3.3e-6 / 7.8e-7 at the two object shapes).  bg128_frame_bf16: the
+    # reference's fixture and this kernel sit on opposite sides of ONE ReLU kink in step 0 (accounted for bit by bit in the
+    # first-step gradient check below); the two trajectories then separate as far as one hidden unit's gradient moves the
+    # masters across bfloat16 rounding boundaries: 6.6e-5, 2.5e-4 in steps 2, 3 (the exact-fp32 kernel, on the reference's side
+    # of the kink: 4e-7) - bounded at 1e-3.
+    "scannet50_frame_bf16": (5e-5, 1e-4, 2e-5, 2e-6),
+    "h64_r256_frame_bf16": (5e-5, 1e-4, 2e-5, 2e-6),
     "bg128_frame_bf16": (1e-3, 1e-3, 2e-5, 2e-6),
 }
 

@@ -86,3 +86,14 @@ def test_torch_port_tracks_reference_frame_trajectories(name):
     for t, p in enumerate(tr.fc + [tr.B]):
         d = np.abs(p.detach().numpy()[keep].astype(np.float64) - g[f"p_fc{t}" if t < 14 else "p_B"])
         assert np.quantile(d, 0.999) < 1e-6 and d.max() <= c["n_steps"] * 1.2e-3, t
+
+
+def test_reference_forloop_and_vmap_trajectories_agree_over_the_headline_frame():
+    """tests/golden/cfg2_frame20.npz holds the per-step losses of BOTH float32 paths of the reference (training_strategy "vmap"
+    and "forloop", train.py:278-294) over the 20 steps of the headline frame: they stay within 1e-6 of each other, while the
+    float64 run differs by up to 30 % per step.  So the ill-conditioning of the variance-normalised depth loss amplifies a change
+    of PRECISION, not float32 summation-order noise - which is why the GPU tier can hold the kernel's whole trajectory to 1e-4."""
+    g = load_golden("cfg2_frame20")
+    rel = np.abs(g["forloop_losses"] - g["losses"]) / np.abs(g["losses"])
+    assert rel.max() < 1e-6
+    assert (np.abs(g["f64_losses"] - g["losses"]) / np.abs(g["losses"])).max() > 0.1
