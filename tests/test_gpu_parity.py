@@ -860,3 +860,41 @@ def test_full_size_properties_of_the_other_baseline_configs(config, weights):
     assert relerr(sr["render_depth"], s["render_depth"][:, rperm]) < 1e-6
     for k in GRAD_KEYS:
         assert relerr(sr[k], s[k]) < 5e-5, k
+
+
+def test_hipmapper_binds_frames_with_stable_buffers_and_stays_bit_identical():
+    """driver.HipMapper.train_frame: the first frame on a set of buffers takes the plain path, the second binds them
+    (step.BoundFrame: arguments marshalled once), later frames reuse the binding; a caller that hands over fresh tensors every
+    frame stays on the plain path.  Same kernels either way: slabs and losses bit-identical over four frames; a re-stack
+    (new object) drops the binding."""
+    from vmap_amd.driver import HipMapper
+    from vmap_amd.trainer import SimpleConfig, Trainer
+    cfg = SimpleConfig(training_device=DEV, n_iter_per_frame=4)
+    n, R, S = 3, 24, 10
+
+    def build():
+        torch.manual_seed(11)
+        m = HipMapper(cfg, device=DEV)
+        for _ in range(n):
+            m.add_object(Trainer(SimpleConfig(training_device=DEV, hidden_feature_size=32)))
+        return m
+
+    keys = ("pcs", "z", "gt_depth", "gt_rgb", "sem", "depth_mask")
+    frames = [synth.make_batch(n, R * 4, S, seed=50 + i) for i in range(4)]
+    a, b = build(), build()
+    stable = tuple(torch.from_numpy(frames[0][k]).to(DEV) for k in keys)           # one set of buffers, refilled per frame
+    la, lb = [], []
+    for i, fr in enumerate(frames):
+        for t, k in zip(stable, keys):
+            t.copy_(torch.from_numpy(fr[k]).to(DEV))
+        la.append(a.train_frame(*stable).loss.clone())
+        lb.append(b.train_frame(*(torch.from_numpy(fr[k]).to(DEV) for k in keys)).loss.clone())   # fresh tensors
+        assert ("obj" in a._bound) == (i >= 1) and "obj" not in b._bound
+    torch.cuda.synchronize()
+    assert torch.equal(torch.stack(la), torch.stack(lb)) and torch.equal(a.slab, b.slab)
+    assert a.opt.step == b.opt.step == 16
+    a.add_object(Trainer(SimpleConfig(training_device=DEV, hidden_feature_size=32)))
+    fr = synth.make_batch(n + 1, R * 4, S, seed=60)
+    res = a.train_frame(*(torch.from_numpy(fr[k]).to(DEV) for k in keys))
+    torch.cuda.synchronize()
+    assert "obj" not in a._bound and a.opt.step == 4 and bool(torch.isfinite(res.loss).all())
