@@ -101,14 +101,29 @@ class SharedBackgroundHip:
 
     @torch.no_grad()
     def prepare_frame(self, pcs, z, gt_depth, gt_rgb, sem, depth_mask, n_steps: int):
-        """Inputs: THIS rank's rays of a whole frame, ``[n_steps * R_local, ...]``.  One collective: the mask counts of all steps."""
+        """Inputs: THIS rank's rays of a whole frame, ``[n_steps * R_local, ...]``.  One collective: the mask counts of all steps.
+        Also marshals the frame's C arguments ONCE (parameter / gradient blocks, one batch block per step, the output blocks): at
+        8 ranks a step is ~0.1 ms of device time, which per-step Python marshalling (~0.2 ms) would exceed."""
+        import ctypes
+        from . import _lib
         u = lambda x: x.unsqueeze(0)
         self._frame = tuple(u(x) for x in (pcs, z, gt_depth, gt_rgb, sem, depth_mask))
-        counts, flags = self.op.prepare_frame(self.views[:14], self.views[14], *self._frame, n_steps=n_steps, ray_step=self.rays_local)
+        op = self.op
+        counts, flags = op.prepare_frame(self.views[:14], self.views[14], *self._frame, n_steps=n_steps, ray_step=self.rays_local)
         if self.world_size > 1:
             dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=self.group)        # [n_steps, 1, 4] float32, once per frame
         flags[:, :3] = (counts[:, :, :3] == 0).any(dim=1).to(torch.int32)
         self._n_steps = n_steps
+        R = self.rays_local
+        self._pp = op._params(self.views[:14], self.views[14])
+        self._gp = op._params(self.gviews[:14], self.gviews[14], "grads")
+        self._sc = _lib.Tensor(self.scale.data_ptr(), 0)
+        self._bt = [op._batch(*(x[:, i * R:(i + 1) * R] for x in self._frame)) for i in range(n_steps)]
+        self._local = (torch.empty(1, dtype=torch.float32, device=self.buf.device), torch.empty(4, dtype=torch.int32, device=self.buf.device))
+        self._out_fb = _lib.Outputs(self._local[0].data_ptr(), self._local[1].data_ptr(), None, None, None, None, self.terms.data_ptr())
+        self._out_ap = [_lib.Outputs(self.losses[i:i + 1].data_ptr(), self.flags[i].data_ptr(), None, None, None, None, None)
+                        for i in range(n_steps)]
+        self._byref = ctypes.byref
 
     @torch.no_grad()
     def step_prepared(self, i: int) -> torch.Tensor:
@@ -116,15 +131,20 @@ class SharedBackgroundHip:
 
         The forward/backward launch leaves this rank's gradients AND its three loss terms in ``self.buf``; after the all-reduce
         ``vmapstep_adamw_apply`` updates the replica and, in the same launch, evaluates the step's global loss and the
-        "loss explode" test (render_rays.py:88-90) on the SUMMED terms - no launch besides the two and the collective."""
-        R = self.rays_local
-        batch = tuple(x[:, i * R:(i + 1) * R] for x in self._frame)
-        self.op.fwd_bwd(self.views[:14], self.views[14], self.scale, *batch, grads_fc=self.gviews[:14], grad_B=self.gviews[14],
-                        prepared_step=i, loss_terms=self.terms)
+        "loss explode" test (render_rays.py:88-90) on the SUMMED terms - no launch besides the two and the collective.  Host
+        side: two C calls on blocks marshalled by ``prepare_frame`` and one ``all_reduce``."""
+        from . import _lib
+        op, opt, br = self.op, self.opt, self._byref
+        st = op._stream()
+        _lib.check(op.lib.vmapstep_fwd_bwd_prepared(br(op.shape), br(self._pp), br(self._sc), br(self._bt[i]), i, op.color_scaling,
+                                                    op.opacity_scaling, br(self._gp), br(self._out_fb), op._ws_ptr, op._ws_bytes, st))
         if self.world_size > 1:
             dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=self.group)      # ONE message: gradients + loss terms
-        self.op.adamw_apply(self.views[:14], self.views[14], self.gslab, self.opt, loss_terms=self.terms, step_index=i,
-                            loss_out=self.losses[i:i + 1], flags_out=self.flags[i])
+        oc = opt.c_struct()
+        _lib.check(op.lib.vmapstep_adamw_apply(br(op.shape), br(self._pp), self.gslab.data_ptr(), opt.padded, br(oc), self.terms.data_ptr(),
+                                               i, op.color_scaling, op.opacity_scaling, br(self._out_ap[i]), op._ws_ptr, op._ws_bytes, st))
+        opt.step += 1
+        opt.note_host_steps(1)
         return self.losses[i]
 
     def train_frame(self, pcs, z, gt_depth, gt_rgb, sem, depth_mask, n_steps: int) -> torch.Tensor:
