@@ -341,7 +341,7 @@ def main():
             elif args.config == "replica_room0_vmap":
                 pmc_file, key = "r01m_pmc_counters.json", "hbm_traffic_bytes_per_launch_step_main"
             elif args.config == "background" and args.kernel == "auto":
-                pmc_file, key = "r02j_pmc_counters_background_ws.json", "hbm_traffic_bytes_per_launch_step_main_ws"
+                pmc_file, key = "r03q_pmc_counters_background_ws.json", "hbm_traffic_bytes_per_launch_step_main_ws"
             if pmc_file:
                 with open(os.path.join(ROOT, "profiles", pmc_file)) as fh:
                     traffic = json.load(fh)["_notes"][key]
@@ -364,6 +364,19 @@ def main():
             floor_us = (296 * 32 + 3838 * 4.8) / 2400.0
             floor_note = ("sum of one tile's matrix (296 x 32 clk) and vector (3838 x 4.8 clk) issue time on its SIMD at 2.4 GHz: the part of "
                           "kernel_ms no schedule of this tiling can remove; kernel_ms - floor_us = waits, barriers, issue stalls, launch ramp")
+        if wsk and H == 128 and args.weights == "f32" and not wp:
+            # the same sum for one 64-point round of step_main_ws (hardware counters, profiles/r02j_pmc_counters_background_ws.json:
+            # 1185 matrix + 6149 vector instructions per wave and round), times the rounds the busiest workgroup runs
+            nt = 1 if n * ((R + (32 // S) - 1) // (32 // S)) <= 256 else 2
+            rounds_total = n * ((R + (32 * nt // S) - 1) // (32 * nt // S))
+            rounds_per_wg = -(-rounds_total // min(rounds_total, 256))
+            if nt == 2:
+                per = -(-rounds_total // 256)
+                rounds_per_wg = per
+            floor_us = rounds_per_wg * (1185 * 32 + 6149 * 4.8) * (0.5 if nt == 1 else 1.0) / 2400.0
+            floor_note = (f"{rounds_per_wg} round(s) per workgroup x (1185 matrix x 32 clk + 6149 vector x 4.8 clk per wave and 64-point round"
+                          + (", halved for single-tile rounds" if nt == 1 else "") + ") at 2.4 GHz: issue time only; the round's LDS (~38 k clk) and "
+                          "vector-memory (~35-45 k clk) phases run in between, not underneath (DESIGN 3.1f)")
         # forward+backward only (no optimiser), same loop structure
         gfc = [torch.zeros_like(t) for t in tfc]
         gB = torch.zeros_like(tB)

@@ -14,7 +14,9 @@ acc = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(os.path.join(ROOT, "gpurun_out", "pmc", "*", "p_counter_collection.csv")):
     for row in csv.DictReader(open(f)):
         name = row["Kernel_Name"]
-        key = ("step_main_s32" if "step_main_s32" in name else "step_finalize_s32" if "step_finalize_s32" in name
+        key = ("step_main_ws" if "step_main_ws" in name else "step_finalize_ws" if "step_finalize_ws" in name
+               else "step_prep_ws" if "step_prep_ws" in name
+               else "step_main_s32" if "step_main_s32" in name else "step_finalize_s32" if "step_finalize_s32" in name
                else "step_prep_s32" if "step_prep_s32" in name
                else "step_main_h32" if "step_main_h32" in name else "step_finalize_h32" if "step_finalize_h32" in name
                else "step_finalize" if "step_finalize" in name
@@ -22,11 +24,16 @@ for f in glob.glob(os.path.join(ROOT, "gpurun_out", "pmc", "*", "p_counter_colle
         if key:
             acc[key][row["Counter_Name"]].append(float(row["Counter_Value"]))
 out = {k: {c: sum(v) / len(v) for c, v in sorted(cs.items())} for k, cs in acc.items()}
-m = out.get("step_main_s32", out.get("step_main_h32", {}))
+m = out.get("step_main_ws", out.get("step_main_s32", out.get("step_main_h32", {})))
 notes = {"units": "FETCH_SIZE/WRITE_SIZE in KiB per dispatch (rocprofv3), other counters summed over the chip per dispatch",
          "collection": "rocprofv3 --kernel-trace --pmc <group> in 7 separate passes over tests/tools/run_steps.py replica_room0_vmap 40"}
 if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
     notes["hbm_traffic_bytes_per_launch_step_main"] = (2.0 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024.0
+    if "step_main_ws" in out:
+        notes["hbm_traffic_bytes_per_launch_step_main_ws"] = notes["hbm_traffic_bytes_per_launch_step_main"]
+        f = out.get("step_finalize_ws", {})
+        if "FETCH_SIZE" in f and "WRITE_SIZE" in f:
+            notes["hbm_traffic_bytes_per_launch_step_finalize_ws"] = (2.0 * f["FETCH_SIZE"] + f["WRITE_SIZE"]) * 1024.0
     notes["correction"] = "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950), WRITE_SIZE uncorrected"
 if "SQ_VALU_MFMA_BUSY_CYCLES" in m and "SQ_BUSY_CYCLES" in m:
     notes["mfma_busy_fraction_of_occupied_simds"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * m["SQ_WAVE_CYCLES"]) if m.get("SQ_WAVE_CYCLES") else None
