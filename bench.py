@@ -136,15 +136,23 @@ def main():
     # VMAP_BENCH_FORCE_DIST=1 exercises the N>1 code path (process group, flag all-reduce, max-over-ranks timing) with a
     # single rank - the only way to run it on a 1-GPU box
     dist = world > 1 or os.environ.get("VMAP_BENCH_FORCE_DIST") == "1"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # VMAP_BENCH_BACKEND=gloo: a dry run of the N > 1 code path on a box with fewer GPUs than ranks (RCCL refuses two ranks on one
+    # device; gloo carries device tensors through the host) - ranks then share devices (local_rank modulo the device count).
+    # Timings of such a run mean nothing; it exists to exercise the multi-rank plumbing of this file.
+    backend = os.environ.get("VMAP_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if dist:
         import torch.distributed as td
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if world == 1:                                  # VMAP_BENCH_FORCE_DIST=1 without a launcher: a one-rank group
             for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_PORT", "29533")):
                 os.environ.setdefault(k, v)
-        td.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            td.init_process_group("nccl", device_id=dev)
+        else:
+            td.init_process_group(backend)
 
     cfg = synth.CONFIGS[args.config]
     n, R, S, H = cfg["n_obj"], cfg["R"], cfg["S"], cfg["H"]
@@ -208,7 +216,8 @@ def main():
         bloc = tuple(torch.from_numpy(np.ascontiguousarray(bframe[k][0][idx])).to(dev) for k in ("pcs", "z", "gt_depth", "gt_rgb", "sem", "depth_mask"))
         bg_stream = torch.cuda.Stream(device=dev)
         with torch.cuda.stream(bg_stream):
-            bg = parallel.SharedBackgroundHip(bfc, bpe, bR, bcfg["S"], dev, max_steps=ipf)
+            bg_group = td.new_group() if world > 1 else None          # its own communicator: independent of the objects' flag reduction
+            bg = parallel.SharedBackgroundHip(bfc, bpe, bR, bcfg["S"], dev, max_steps=ipf, group=bg_group)
         bg_info = {"hidden": bcfg["H"], "rays_per_step_all_ranks": bR * world, "rays_per_step_this_rank": bR, "samples_per_ray": bcfg["S"],
                    "collectives": "per frame: one all_reduce(SUM) of the [steps, 4] mask counts; per step: ONE all_reduce(SUM) of "
                                   f"[gradient slab | loss terms] = {bg.buf.numel() * 4} bytes between two launches "
@@ -223,16 +232,19 @@ def main():
             fork = torch.cuda.Event()
             fork.record(cur)
             bg_stream.wait_event(fork)
+            # The objects' frame call is ISSUED first: its one collective (the flag reduction) must not queue behind the
+            # background frame's 1 + k all-reduces (the background has its own process group, and the host order is the same
+            # on every rank, so the two communicators cannot cross).
+            if bound is not None:
+                bound.train_steps(k)
+            else:
+                op.train_steps(tfc, tB, tsc, *fargs, opt=opt, n_steps=k, flag_reduce=flag_reduce)
             with torch.cuda.stream(bg_stream):
                 bg.prepare_frame(*bloc, n_steps=k)
                 for i in range(k):
                     bg.step_prepared(i)
                 join = torch.cuda.Event()
                 join.record(bg_stream)
-            if bound is not None:
-                bound.train_steps(k)
-            else:
-                op.train_steps(tfc, tB, tsc, *fargs, opt=opt, n_steps=k, flag_reduce=flag_reduce)
             cur.wait_event(join)
             done += k
 
@@ -240,11 +252,23 @@ def main():
     if args.preheat_ms > 0:
         # Untimed device pre-heat (NOT part of the W warm-up steps and NOT timed): the same frame call repeated for
         # ~preheat_ms so that the clocks / power state are those of a running mapper rather than of an idle chip.
+        # With several ranks every frame call contains a collective (the flag reduction), so the NUMBER of pre-heat frames must
+        # be the same on every rank: it is fixed from a timed probe (MAX over ranks), not by each rank's own clock.
+        run(ipf)
+        torch.cuda.synchronize()
         t_ph = time.perf_counter()
-        while (time.perf_counter() - t_ph) * 1e3 < args.preheat_ms:
+        run(ipf)
+        torch.cuda.synchronize()
+        frames = max(1, int(np.ceil(args.preheat_ms * 1e-3 / max(time.perf_counter() - t_ph, 1e-6))))
+        if dist:
+            t = torch.tensor([frames], dtype=torch.int64, device=dev)
+            td.all_reduce(t, op=td.ReduceOp.MAX)
+            frames = int(t.item())
+        frames = min(frames, 4000)
+        for _ in range(frames):
             run(ipf)
-            preheat_steps += ipf
-            torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        preheat_steps = (frames + 2) * ipf
     run(args.warmup)
     barrier()
     t0 = time.perf_counter()
@@ -288,7 +312,7 @@ def main():
                               "preheat_ms": args.preheat_ms, "timed_only": True}), flush=True)
         return
     # who took part (so that a scaling run can show its N ranks): device of every rank + the RCCL version torch links
-    devices = [torch.cuda.get_device_name(dev) + f" (cuda:{local_rank})"]
+    devices = [torch.cuda.get_device_name(dev) + f" (cuda:{dev_index})"]
     rccl_version = None
     if dist:
         gathered = [None] * world
@@ -441,7 +465,7 @@ def main():
             "fwd_bwd_only": {"ms_per_step_host_launched": fb_ms, "rays_per_s": n * R / (fb_ms * 1e-3)},
             "preheat": {"ms": args.preheat_ms, "steps": preheat_steps, "timed": False},
             "with_background": with_bg,
-            "world": {"world_size": world, "devices": devices, "rccl": rccl_version},
+            "world": {"world_size": world, "devices": devices, "rccl": rccl_version, "backend": backend if dist else None},
             "frame_call": ("marshalled per call" if bound is None else
                            "bound (arguments marshalled once), replayed as a hipGraph per frame (device-resident optimiser step count)" if bound.graph
                            else "bound (arguments marshalled once), launched kernel by kernel"),

@@ -185,3 +185,27 @@ def test_operator_on_a_non_current_device():
     assert abs(float(res.loss[0]) - float(g["loss"])) <= 2e-5 * abs(float(g["loss"]))
     for k, t in zip(GRAD_KEYS, gfc + [gB]):
         assert relerr(t.cpu().numpy(), g[k]) < 1e-4, k
+
+
+def test_bench_runs_with_two_ranks_on_one_gpu(tmp_path):
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank), with the gloo dry-run backend
+    so that both ranks can share cuda:0: the object shards' flag reduction inside the pre-heat / warm-up / timed loops, the
+    background replicas on their own group and stream, the max-over-ranks timing and rank 0's JSON line.  (A pre-heat loop
+    that ran until each rank's own clock said stop once gave the ranks different collective counts: a hang under RCCL.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VMAP_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "40", "--warmup", "5",
+           "--preheat-ms", "30", "--profile-reps", "20", "--no-cpu-baseline", "--no-gpu-baseline"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 2 and j["steps"] == 40 and j["scaling"] == "weak"
+    assert j["value"] > 0 and j["with_background"]["rays_per_step_this_rank"] == 600
+    assert j["world"]["world_size"] == 2 and len(j["world"]["devices"]) == 2 and j["world"]["backend"] == "gloo"
