@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--kernel", default="auto", choices=["auto", "gen", "wide", "f32", "ws1", "wp"])   # measurement: hidden 128 / 256 kernels; f32 = hidden 32
                                                                                                  # on the exact-fp32 matrix instruction (step_main_h32)
     ap.add_argument("--ws-two-tile", action="store_true")           # measurement: step_main_ws never uses single-tile rounds (tuning.ws_flags = 1; A/B)
+    ap.add_argument("--ws-flags", type=int, default=0)               # measurement: tuning.ws_flags as is (4 = never three-tile rounds: the round-2 plan)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--slab", action="store_true")                   # the 15 stacked tensors as views of one [n, P] slab (measurement;
                                                                      # default: separately allocated, utils.update_vmap's own layout)
@@ -170,8 +171,8 @@ def main():
     if args.kernel != "auto":
         from vmap_amd import _lib
         tuning = {"kernel": {"gen": _lib.KERNEL_GEN, "wide": _lib.KERNEL_WIDE4, "f32": _lib.KERNEL_H32_F32, "ws1": _lib.KERNEL_WS1, "wp": _lib.KERNEL_WP}[args.kernel]}
-    if args.ws_two_tile:
-        tuning = dict(tuning or {}, ws_flags=1)
+    if args.ws_two_tile or args.ws_flags:
+        tuning = dict(tuning or {}, ws_flags=(1 if args.ws_two_tile else 0) | args.ws_flags)
     op = step.VmapStep(n, R, S, H, device=dev, max_steps=ipf, weights=args.weights, tuning=tuning)
     opt = step.FusedAdamWState(n, H, dev, lr=1e-3, weight_decay=0.013)
     fargs = (fr["pcs"], fr["z"], fr["gt_depth"], fr["gt_rgb"], fr["sem"], fr["depth_mask"])
@@ -339,10 +340,21 @@ def main():
         split = H == 32 and args.kernel != "f32"
         wsk = H in (64, 128) and args.kernel in ("auto", "ws1", "wp") and S <= 64
         wp = wsk and (args.kernel == "wp" or (args.kernel == "auto" and H == 64))
+        # tiles per round of step_main_ws (the launch plan's rule, vmapstep.hip make_plan)
+        ws_nt = 2
+        if wsk and not wp:
+            rounds_of = lambda g: n * ((R + max(g, 1) - 1) // max(g, 1))
+            flags = (1 if args.ws_two_tile else 0) | args.ws_flags
+            if H == 128 and flags & 2:
+                ws_nt = 3
+            elif rounds_of(32 // S) <= 256 and 32 // S >= 1 and not flags & 1:
+                ws_nt = 1
+            elif H == 128 and rounds_of(64 // S) > 256 and rounds_of(96 // S) <= 256 and not flags & 4:
+                ws_nt = 3
         kernel_name = ("step_main_s32 (hidden 32: bf16 matrix pipe, split operands: 6 products forward, 3 backward)" if split else
                        "step_main_h32 (hidden 32: exact-fp32 matrix instruction)" if H == 32 else
-                       (("step_main_wp" if wp else "step_main_ws") + f" (hidden {H}: bf16 matrix pipe, split operands, two 32-point tiles per "
-                        "workgroup round, " + ("two waves" if wp else "one wave") + " per output block)") if wsk else
+                       (("step_main_wp" if wp else "step_main_ws") + f" (hidden {H}: bf16 matrix pipe, split operands, {('one', 'two', 'three')[ws_nt - 1]} 32-point "
+                        f"tile{'s' if ws_nt > 1 else ''} per workgroup round, " + ("two waves" if wp else "one wave") + " per output block)") if wsk else
                        ("step_main_wide<4>" if (args.kernel == "wide" or (args.kernel == "auto" and H % 128 == 0 and n * ((R + 32 // S - 1) // (32 // S)) <= 256))
                         else "step_main_gen") + f" (hidden {H}: exact-fp32 matrix instruction)")
         on_bf16_pipe = split or wsk
@@ -377,7 +389,8 @@ def main():
             per_tile = 288 if args.weights == "f32" else 195
             mm_per_launch = n * ((R + (128 // S) - 1) // (128 // S)) * 4 * per_tile
         elif wsk and H == 128:
-            mm_per_launch = n * ((R + (64 // S) - 1) // (64 // S)) * 4 * (1185 if args.weights == "f32" else 807)
+            gq = (32 * ws_nt) // S
+            mm_per_launch = n * ((R + gq - 1) // gq) * 4 * (1185 if args.weights == "f32" else 807) * ws_nt // 2
         if mm_per_launch:
             executed_tflops = mm_per_launch * 32768 / (k_ms * 1e-3) / 1e12
         # Floor of THIS formulation at hidden 32 (one 32-point tile per wave, one wave per SIMD): a SIMD's time is the SUM of its matrix
@@ -391,15 +404,12 @@ def main():
         if wsk and H == 128 and args.weights == "f32" and not wp:
             # the same sum for one 64-point round of step_main_ws (hardware counters, profiles/r02j_pmc_counters_background_ws.json:
             # 1185 matrix + 6149 vector instructions per wave and round), times the rounds the busiest workgroup runs
-            nt = 1 if n * ((R + (32 // S) - 1) // (32 // S)) <= 256 else 2
+            nt = ws_nt
             rounds_total = n * ((R + (32 * nt // S) - 1) // (32 * nt // S))
-            rounds_per_wg = -(-rounds_total // min(rounds_total, 256))
-            if nt == 2:
-                per = -(-rounds_total // 256)
-                rounds_per_wg = per
-            floor_us = rounds_per_wg * (1185 * 32 + 6149 * 4.8) * (0.5 if nt == 1 else 1.0) / 2400.0
+            rounds_per_wg = -(-rounds_total // 256)
+            floor_us = rounds_per_wg * (1185 * 32 + 6149 * 4.8) * (nt / 2.0) / 2400.0
             floor_note = (f"{rounds_per_wg} round(s) per workgroup x (1185 matrix x 32 clk + 6149 vector x 4.8 clk per wave and 64-point round"
-                          + (", halved for single-tile rounds" if nt == 1 else "") + ") at 2.4 GHz: issue time only; the round's LDS (~38 k clk) and "
+                          + (f", x {nt}/2 for {nt}-tile rounds" if nt != 2 else "") + ") at 2.4 GHz: issue time only; the round's LDS (~38 k clk) and "
                           "vector-memory (~35-45 k clk) phases run in between, not underneath (DESIGN 3.1f)")
         # forward+backward only (no optimiser), same loop structure
         gfc = [torch.zeros_like(t) for t in tfc]

@@ -49,11 +49,11 @@ extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req, int xcd
     const bool split = g_split && H == 32;
     const bool wp = g_wide == 4 && (H == 128 || H == 64);    // step_main_wp (two waves per output block)
     const bool ws = (g_wide == 3 || g_wide == 4) && (H == 128 || H == 64);    // step_main_ws / _wp (split-bf16 matrix pipe, hidden 128 / 64)
-    if (ws && G * S > vk::ImgWs<4>::kPts) return -3;
+    if (ws && G * S > (g_wide == 3 && H == 128 ? 96 : vk::ImgWs<4>::kPts)) return -3;   // step_main_ws at hidden 128: up to three 32-point tiles per round
     std::vector<float> wimg((size_t)n * (split ? vk::Img32s::BYTES / 4 : ws ? (H == 128 ? vk::ImgWs<4>::BYTES : vk::ImgWs<2>::BYTES) / 4 : GL.imgp), NAN);
 
     vk::StepArgs a{};
-    a.tiles = (g_wide == 3 && G * S <= 32) ? 1 : 2;           // step_main_ws: single-tile rounds when the caller's ray groups fit one tile
+    a.tiles = g_wide == 3 ? (G * S <= 32 ? 1 : G * S <= 64 ? 2 : 3) : 2;   // step_main_ws: the fewest 32-point tiles that hold the caller's ray groups
     a.n_obj = n; a.R = R; a.S = S; a.G = G; a.NG = NG; a.NW = NW; a.PP = PP; a.prep_steps = 1; a.prep_ray_step = 0; a.xcd_affine = (xcd_affine && H == 32) ? 1 : 0; a.hidden = H; a.weights_bf16 = weights_bf16;
     for (int t = 0; t < 14; ++t) a.fc[t] = {const_cast<float*>(fc[t]), sz[t]};
     a.pe_B = {const_cast<float*>(B), 63};
@@ -75,7 +75,7 @@ extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req, int xcd
 
     std::vector<char> ws_scratch;
     if (ws) {
-        ws_scratch.assign((size_t)n * NW * (wp ? (H == 128 ? vk::LdsWp<4>::WG_SCRATCH : vk::LdsWp<2>::WG_SCRATCH) : vk::ImgWs<4>::WG_SCRATCH), (char)0xFF);
+        ws_scratch.assign((size_t)n * NW * (wp ? (H == 128 ? vk::LdsWp<4>::WG_SCRATCH : vk::LdsWp<2>::WG_SCRATCH) : (size_t)vk::kWsScratchMax), (char)0xFF);
         wa.s = a; wa.scratch = ws_scratch.data(); wa.tab_wt = tab_wt.data();
         sl::prep_ws(wa);
     } else if (split) sl::prep_s32(a);

@@ -12,6 +12,17 @@ template <int NT>
 void main_ws_t(const vk::WsArgs& wa, bool bwd);
 }
 void main_ws(const vk::WsArgs& wa, bool bwd) {
+    if (wa.s.tiles == 3 && wa.s.hidden == 128) {             // three-tile rounds: hidden 128 only
+        const int grid = wa.s.n_obj * wa.s.NW, lb = vk::LdsWs<4, 3>::LDS_BYTES;
+        if (wa.s.weights_bf16) {
+            if (bwd) sim::launch(grid, vk::kWG, lb, [&] { vk::step_main_ws<4, true, false, false, 3>(wa); });
+            else     sim::launch(grid, vk::kWG, lb, [&] { vk::step_main_ws<4, false, false, false, 3>(wa); });
+        } else {
+            if (bwd) sim::launch(grid, vk::kWG, lb, [&] { vk::step_main_ws<4, true, true, false, 3>(wa); });
+            else     sim::launch(grid, vk::kWG, lb, [&] { vk::step_main_ws<4, false, true, false, 3>(wa); });
+        }
+        return;
+    }
     if (wa.s.tiles == 1) main_ws_t<1>(wa, bwd); else main_ws_t<2>(wa, bwd);
 }
 namespace {

@@ -160,6 +160,13 @@ def test_hidden128_kernel_matches_oracle_on_seeded_shapes(n, R, S, seed, H):
     w2 = _run(c, tuning={"kernel": _lib.KERNEL_WS1, "ws_flags": 1})    # ... two-tile rounds
     _assert_grads_match_oracle_up_to_kinks(w1, o, n)
     _assert_grads_match_oracle_up_to_kinks(w2, o, n)
+    if H == 128:
+        w3 = _run(c, tuning={"kernel": _lib.KERNEL_WS1, "ws_flags": 2})    # ... three-tile rounds (hidden 128)
+        _assert_grads_match_oracle_up_to_kinks(w3, o, n)
+        for k in RENDER_KEYS:
+            assert relerr(w3[k], e[k]) < 2e-5, k
+        for k in GRAD_KEYS:
+            assert relerr(w3[k], e[k]) < 1e-4, k
     for k in RENDER_KEYS:
         assert relerr(s[k], e[k]) < 2e-5, k
         assert relerr(w1[k], e[k]) < 2e-5, k
@@ -432,7 +439,8 @@ def test_unsupported_hidden_width_fails_loudly():
                                          ("bg_h128_s14", "gen"), ("imap_h256", "gen"), ("bg_h128_s14", "wide_multipass"),
                                          ("bg_h128_s14", "ws"), ("bg_h128_s14", "ws_multipass"), ("h64", "ws"), ("h64", "ws_multipass"),
                                          ("bg_h128_s14", "ws1"), ("bg_h128_s14", "ws1_multipass"), ("h64", "ws1"), ("h64", "ws1_multipass"),
-                                         ("bg_h128_s14", "ws1_two_tile"), ("bg_h128_s14", "ws1_two_tile_multipass"), ("h64", "ws1_two_tile")])
+                                         ("bg_h128_s14", "ws1_two_tile"), ("bg_h128_s14", "ws1_two_tile_multipass"), ("h64", "ws1_two_tile"),
+                                         ("bg_h128_s14", "ws1_three_tile"), ("bg_h128_s14", "ws1_three_tile_multipass")])
 def test_generic_width_kernel_matches_reference_fixture(name, kernel):
     """hidden = 64 / 128 (background model shapes) / 256 (iMAP, BASELINE configs[0]): step_main_wide (tile per
     workgroup, also with fewer workgroups than ray groups), step_main_gen, and - hidden 64 / 128 -
@@ -443,9 +451,11 @@ def test_generic_width_kernel_matches_reference_fixture(name, kernel):
     tuning = {"kernel": {"gen": _lib.KERNEL_GEN, "wide": _lib.KERNEL_WIDE4, "wide_multipass": _lib.KERNEL_WIDE4,
                          "ws": _lib.KERNEL_WP, "ws_multipass": _lib.KERNEL_WP,         # step_main_wp (two waves per output block)
                          "ws1": _lib.KERNEL_WS1, "ws1_multipass": _lib.KERNEL_WS1,            # step_main_ws (one wave per block): small batches
-                         "ws1_two_tile": _lib.KERNEL_WS1, "ws1_two_tile_multipass": _lib.KERNEL_WS1}[kernel],   # run single-tile rounds, ws_flags = 1: two-tile rounds
-              "workgroups_per_object": {"wide_multipass": 3, "ws_multipass": 3, "ws1_multipass": 3, "ws1_two_tile_multipass": 3}.get(kernel, 0),
-              "ws_flags": 1 if "two_tile" in kernel else 0}
+                         "ws1_two_tile": _lib.KERNEL_WS1, "ws1_two_tile_multipass": _lib.KERNEL_WS1,   # run single-tile rounds, ws_flags = 1: two-tile rounds
+                         "ws1_three_tile": _lib.KERNEL_WS1, "ws1_three_tile_multipass": _lib.KERNEL_WS1}[kernel],   # ws_flags = 2: three-tile rounds
+              "workgroups_per_object": {"wide_multipass": 3, "ws_multipass": 3, "ws1_multipass": 3, "ws1_two_tile_multipass": 3,
+                                        "ws1_three_tile_multipass": 3}.get(kernel, 0),
+              "ws_flags": 1 if "two_tile" in kernel else 2 if "three_tile" in kernel else 0}
     s = _run(c, tuning=tuning)
     assert abs(s["loss"] - float(g["loss"])) <= 2e-5 * abs(float(g["loss"]))
     for k in RENDER_KEYS:
@@ -680,6 +690,23 @@ def test_frame_trajectory_matches_reference_step_loop(name):
     (hidden 128, 14 samples: step_main_ws, several rounds per workgroup).  <name>_bf16: weight_dtype = bf16 at the SAME shapes
     (50 objects: step_main_s32<BWD, MULTI, ., W3 = false>; 32 x 256 rays at hidden 64: multi-round step_main_wp<2, ., W3 = false>)
     against the reference loop run with bfloat16-rounded run-time weights over full-precision masters."""
+    # bg128_frame (240 rays = 120 tiles) runs step_main_ws with single-tile rounds by default; its f32 "f32" leg of the module's
+    # kernel parametrisation runs the two-tile form instead, so that both are held to the reference's own loop
+    two_tile = name.startswith("bg128") and step.VmapStep.default_tuning is not None
+    _check_frame_trajectory(name, {"ws_flags": 1} if two_tile else None)
+
+
+@pytest.mark.parametrize("name", ["bg128_frame", "bg128_frame_bf16"])
+def test_background_frame_with_three_tile_rounds(name):
+    """The same frame fixtures through step_main_ws<4, ., ., ., NT = 3> (tuning.ws_flags = 2; 240 rays = 40 rounds of 6 rays): the
+    form a ONE-GPU background step (1200 rays) runs - forward, loss, backward, fused AdamW and the maintained W / W^T images
+    over the frame's steps against the reference's own loop, float32 and bfloat16 run-time weights."""
+    if step.VmapStep.default_tuning is not None:
+        pytest.skip("hidden 128: the module's hidden-32 kernel legs do not apply; run once")
+    _check_frame_trajectory(name, {"ws_flags": 2})
+
+
+def _check_frame_trajectory(name, tuning):
     bf16 = name.endswith("_bf16")
     c = cases.build_frame_case(name[:-5] if bf16 else name)
     g = load_golden(name)
@@ -688,10 +715,7 @@ def test_frame_trajectory_matches_reference_step_loop(name):
     B = torch.from_numpy(c["B"]).to(DEV)
     sc = torch.from_numpy(c["scale"]).to(DEV)
     fr = {k: torch.from_numpy(v).to(DEV) for k, v in c["frame"].items()}
-    # bg128_frame (240 rays = 120 tiles) runs step_main_ws with single-tile rounds by default; its f32 "f32" leg of the module's
-    # kernel parametrisation runs the two-tile form instead, so that both are held to the reference's own loop
-    two_tile = name.startswith("bg128") and step.VmapStep.default_tuning is not None
-    op = step.VmapStep(n, R, S, H, device=DEV, max_steps=steps, weights="bf16" if bf16 else "f32", tuning={"ws_flags": 1} if two_tile else None)
+    op = step.VmapStep(n, R, S, H, device=DEV, max_steps=steps, weights="bf16" if bf16 else "f32", tuning=tuning)
     st = step.FusedAdamWState(n, H, DEV)
     # first-step gradients (same state): fixture parity of the strided slice [0, R)
     gfc = [torch.zeros_like(t) for t in fc]
@@ -822,11 +846,13 @@ def test_device_step_count_survives_mixed_host_and_device_calls():
         assert torch.equal(x, y)
 
 
-@pytest.mark.parametrize("config,weights", [("scannet0024_vmap", "bf16"), ("stress_256x64", "bf16"), ("background", "f32")])
-def test_full_size_properties_of_the_other_baseline_configs(config, weights):
+@pytest.mark.parametrize("config,weights,tuning", [("scannet0024_vmap", "bf16", None), ("stress_256x64", "bf16", None), ("background", "f32", None),
+                                                   ("background", "f32", {"ws_flags": 4}), ("background", "bf16", None)])
+def test_full_size_properties_of_the_other_baseline_configs(config, weights, tuning):
     """BASELINE configs[3] (50 objects, hidden 32, bf16 weights: the multi-pass kernel), configs[4] (hidden 64, 256 rays per object,
     bf16 weights: multi-round step_main_wp; 32 of its 256 objects = one GPU's share at 8 GPUs) and the background model's full
-    batch (1 x 1200 rays x 14, hidden 128: step_main_ws, two rounds per workgroup) AT THEIR FULL PER-GPU SIZES, through
+    batch (1 x 1200 rays x 14, hidden 128: step_main_ws - 200 three-tile rounds, one per workgroup, the automatic plan; with
+    tuning.ws_flags = 4 the former plan: 150 workgroups x two two-tile rounds) AT THEIR FULL PER-GPU SIZES, through
     size-independent properties: objects are independent units (permuting them permutes every output), ray order inside an
     object is a pure summation order, two runs are bit-identical - and, full size, the numpy oracle with its ReLU kinks
     accounted for (on bfloat16-rounded weights where the configuration says so)."""
@@ -836,7 +862,7 @@ def test_full_size_properties_of_the_other_baseline_configs(config, weights):
     fc, B, sc = synth.make_params(n, H, scale=cfg["scale"], seed=700)
     batch = synth.make_batch(n, R, S, seed=701)
     c = dict(n=n, R=R, S=S, H=H, fc=fc, B=B, scale=sc, batch=batch)
-    op = step.VmapStep(n, R, S, H, device=DEV, weights=weights)
+    op = step.VmapStep(n, R, S, H, device=DEV, weights=weights, tuning=tuning)
     s = _run(c, op=op)
     s2 = _run(c, op=op)
     for k in RENDER_KEYS + ["var"] + GRAD_KEYS:

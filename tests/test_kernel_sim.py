@@ -314,3 +314,21 @@ def test_sim_ws_single_tile_rounds_match_reference(name, G, nw, bf16):
     for k in GRAD_KEYS:
         assert not np.isnan(s[k]).any(), k
         assert relerr(s[k], g[k]) < 1e-4, k
+
+
+@pytest.mark.parametrize("G,nw,bf16", [(6, 0, 0), (6, 3, 0), (5, 0, 1), (5, 4, 0)])
+def test_sim_ws_three_tile_rounds_match_reference(G, nw, bf16):
+    """step_main_ws<4, ., ., ., NT = 3>: rounds of THREE 32-point tiles (hidden 128; ray groups of G rays with 64 < G S <= 96:
+    6 x 14 = 84 points, 5 x 14 = 70 with a partly filled third tile and a ragged last round; several rounds per workgroup adding
+    into its row) - the form the launch plan picks when two-tile rounds outnumber the compute units and three-tile rounds do
+    not (the 1200-ray background batch).  Its LDS map differs from the two-tile form's (heads' partial sums over the layer-input
+    images, second-group F images in the scratch); same fixtures."""
+    c = cases.build_case("bg_h128_s14")
+    g = load_golden("bg_h128_s14" + ("_bf16" if bf16 else ""))
+    s = simlib.sim_step(c, wide=3, G=G, NW=nw, weights_bf16=bf16)
+    assert abs(s["loss"] - float(g["loss"])) <= 2e-5 * abs(float(g["loss"]))
+    for k in RENDER_KEYS:
+        assert relerr(s[k], g[k]) < 2e-5, k
+    for k in GRAD_KEYS:
+        assert not np.isnan(s[k]).any(), k
+        assert relerr(s[k], g[k]) < 1e-4, k

@@ -8,18 +8,21 @@ namespace vl {
 namespace {
 template <int NB, bool BWD, bool W3, bool STAMPS, int NT>
 int main_t(const vk::StepArgs& a, hipStream_t st) {
-    using I = vk::ImgWs<NB>;
+    using LD = vk::LdsWs<NB, NT>;
     auto kern = vk::step_main_ws<NB, BWD, W3, STAMPS, NT>;
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), I::LDS_BYTES, "step_main_ws")) return rc;
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LD::LDS_BYTES, "step_main_ws")) return rc;
     vk::WsArgs ga;
     ga.s = a;
     ga.scratch = reinterpret_cast<char*>(a.gen_scratch);
     ga.tab_wt = a.tab_wt;
-    VL_LAUNCH_MAIN(kern, dim3(a.n_obj * a.NW), dim3(vk::kWG), I::LDS_BYTES, st, ga);
+    VL_LAUNCH_MAIN(kern, dim3(a.n_obj * a.NW), dim3(vk::kWG), LD::LDS_BYTES, st, ga);
     return launched("step_main_ws");
 }
 template <int NB, bool BWD, bool W3, bool STAMPS>
 int main_v(const vk::StepArgs& a, hipStream_t st) {
+    if constexpr (NB == 4) {
+        if (a.tiles == 3) return main_t<NB, BWD, W3, STAMPS, 3>(a, st);      // three-tile rounds: hidden 128 only
+    }
     return a.tiles == 1 ? main_t<NB, BWD, W3, STAMPS, 1>(a, st) : main_t<NB, BWD, W3, STAMPS, 2>(a, st);
 }
 template <int NB>

@@ -86,7 +86,7 @@ void make_layout(int H, Layout& L) {
 
 struct Plan {
     int G, NG, NW;
-    int tiles;         // step_main_ws: 32-point tiles per round (2, or 1 = single-tile rounds when every tile gets a compute unit of its own)
+    int tiles;         // step_main_ws: 32-point tiles per round (2; 1 = single-tile rounds when every tile gets a compute unit of its own; 3: see make_plan)
     size_t off_stats, off_flags, off_ploss, off_imgtab, off_pgrad, off_wimg, off_scratch, total;
     bool generic;      // hidden != 32: step_main_gen (global-memory activations) instead of step_main_h32
     bool split;        // hidden 32 on the bf16 matrix pipe with split operands (step_main_s32; the default at hidden 32)
@@ -164,12 +164,21 @@ int make_plan(const vmapstep_shape* sh, int max_steps, Plan& pl, const Layout& L
         return fail(VMAPSTEP_ERR_UNSUPPORTED, "VMAPSTEP_KERNEL_WS1 / _WP: hidden 64 / 128 with at most 64 samples per ray");
     pl.G = (pl.wide >= 3 ? vk::ImgWs<4>::kPts : pl.wide == 1 ? vk::kWideTile : vk::kMaxPts) / sh->samples;
     pl.tiles = 2;
-    if (pl.wide == 3 && tun.workgroups_per_object <= 0 && !(tun.ws_flags & 1)) {
-        // step_main_ws on a mostly idle chip (the ray-sharded background model of a multi-GPU run: 150 rays per rank at 8 ranks): if
-        // every 32-point tile can have a compute unit of its own, single-tile rounds (about 0.65 of a two-tile round's time) halve
-        // the points per workgroup; the extra partial-gradient rows cost the finalize ~0.1 us each (profiles/r03j_*)
-        const int g1 = 32 / sh->samples;
-        if (g1 >= 1 && (long long)sh->n_obj * ((sh->rays + g1 - 1) / g1) <= 256) { pl.G = g1; pl.tiles = 1; }
+    if (pl.wide == 3) {
+        // step_main_ws, tiles per round.  The kernel's time is the busiest workgroup's rounds, one workgroup per compute unit:
+        //  * a mostly idle chip (the ray-sharded background model of a multi-GPU run: 150 rays per rank at 8 ranks): if every
+        //    32-point tile can have a compute unit of its own, single-tile rounds (about 0.77 of a two-tile round's time) halve
+        //    the points per workgroup; the extra partial-gradient rows cost the finalize ~0.1 us each (profiles/r03j_*);
+        //  * more two-tile rounds than compute units (the 1200-ray background batch of ONE GPU: 300 rounds): three-tile rounds
+        //    (hidden 128) if they give every workgroup exactly one round (200) - no second round, no read-modify-write of its
+        //    gradient row (profiles/r03u_*).
+        // tuning.ws_flags: bit 0 = never single-tile rounds, bit 1 = always three-tile rounds (hidden 128; tests), bit 2 = never
+        const int g1 = 32 / sh->samples, g2 = pl.G, g3 = 96 / sh->samples;
+        const bool autoplan = tun.workgroups_per_object <= 0;
+        auto rounds = [&](int g) { return g >= 1 ? (long long)sh->n_obj * ((sh->rays + std::min(g, sh->rays) - 1) / std::min(g, sh->rays)) : (1LL << 40); };
+        if (sh->hidden == 128 && (tun.ws_flags & 2)) { pl.G = g3; pl.tiles = 3; }
+        else if (autoplan && !(tun.ws_flags & 1) && rounds(g1) <= 256) { pl.G = g1; pl.tiles = 1; }
+        else if (autoplan && sh->hidden == 128 && !(tun.ws_flags & 4) && rounds(g2) > 256 && rounds(g3) <= 256) { pl.G = g3; pl.tiles = 3; }
     }
     if (pl.G > sh->rays) pl.G = sh->rays;
     pl.NG = (sh->rays + pl.G - 1) / pl.G;
@@ -200,7 +209,7 @@ int make_plan(const vmapstep_shape* sh, int max_steps, Plan& pl, const Layout& L
                                                                                    : (size_t)sh->n_obj * GL.imgp * sizeof(float));
     pl.off_scratch = o;
     if (pl.wide >= 3) o += align_up((size_t)sh->n_obj * nw_cap * (pl.wide == 4 ? (sh->hidden == 128 ? vk::LdsWp<4>::WG_SCRATCH : vk::LdsWp<2>::WG_SCRATCH)
-                                                                                 : vk::ImgWs<4>::WG_SCRATCH));
+                                                                                 : (size_t)vk::kWsScratchMax));
     else if (pl.generic)   // register-image scratch: per wave (step_main_gen) or per workgroup (step_main_wide)
         o += align_up((size_t)sh->n_obj * nw_cap * (pl.wide == 1 ? 1 : vk::kWaves) * vk::gen_wave_blocks(GL.NB) * vk::kBlk * sizeof(float));
     pl.off_flags = o; o += align_up((size_t)kMaxFrameSteps * 4 * sizeof(int));

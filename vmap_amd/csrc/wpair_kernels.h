@@ -61,13 +61,6 @@ __device__ __forceinline__ void acc_recv_add(f32x16& a, const char* slot) {
         a[4 * c] += v[0]; a[4 * c + 1] += v[1]; a[4 * c + 2] += v[2]; a[4 * c + 3] += v[3];
     }
 }
-// the two tiles' F-form images of one block from global memory (the encoding blocks)
-__device__ __forceinline__ void fimg_load_g(FImg& o, const char* ubase, int xst, unsigned voff) {
-#pragma unroll
-    for (int st = 0; st < 2; ++st)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) o.c[st][c] = ldgu(ubase + st * xst + c * 1024, voff);
-}
 // weight-gradient blocks kb = kh, kh + 2, ... < N of one layer; xload(img, kb) fills the block's two F images, io(mode, kb, acc,
 // old): block_io of the layer.  One block at a time (the partner wave on the SIMD covers the LDS round trip; registers are
 // 256 per wave here); later rounds read the earlier sums in front of the matrix instructions.

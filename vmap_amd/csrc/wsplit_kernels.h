@@ -66,6 +66,53 @@ struct ImgWs {
 };
 static_assert(ImgWs<4>::LDS_BYTES <= 160 * 1024 && ImgWs<2>::LDS_BYTES <= 160 * 1024, "LDS budget");
 
+// LDS and scratch maps of step_main_ws<NB, ., ., ., NT>.  NT = 1, 2: the two-tile map of ImgWs<NB> (single-tile rounds leave the
+// second tile's slots unused).  NT = 3 (hidden 128 only): three tiles = 96 points per round, for batches whose two-tile rounds
+// outnumber the compute units (the 1200-ray background batch of ONE GPU: 300 two-tile rounds on 256 compute units = two rounds
+// for the busiest workgroups and a read-modify-write of the 377 KB gradient row; 200 three-tile rounds = one round each).  The
+// forward images of three tiles (72 + 81 KB) leave 7 KB: the heads' partial sums overlay the layer-input images (one more
+// barrier behind color_linear), and in the backward pass the F-form images of the SECOND encoding group (used once, by
+// color_linear's weight gradients) wait in the workgroup's scratch instead of LDS.
+template <int NB, int NT>
+struct LdsWs {
+    using I = ImgWs<NB>;
+    static_assert(NT >= 1 && NT <= 3, "tiles per round");
+    static_assert(NT < 3 || NB == 4, "three-tile rounds: hidden 128");
+    static constexpr int TT = NT < 2 ? 2 : NT;                             // tile slots of the maps
+    static constexpr bool WIDE3 = NT == 3;
+    static constexpr bool HP_ALIAS = WIDE3, EF2_GLOBAL = WIDE3;
+    static constexpr int XCH = I::XCH, DCH = I::DCH;
+    static constexpr int ACT_ST = I::ACT_ST, E_ST = I::E_ST, E2_OFF = I::E2_OFF, DLT_ST = I::DLT_ST, XF_ST = I::XF_ST;
+    static constexpr int EF_BLOCKS = EF2_GLOBAL ? 3 : 5, EF_ST = EF_BLOCKS * 4096;  // encoding F-form blocks per tile held in LDS
+    static constexpr int TILES_BYTES = kWaves * Img32s::TILE;             // one transpose tile per wave
+    static constexpr int HP_BYTES = kWaves * TT * 32 * 4 * 4, CB_BYTES = 32 * TT * 8 * 4;
+    // forward
+    static constexpr int ACT = 0;
+    static constexpr int EIM = WIDE3 ? TT * ACT_ST : I::EIM;
+    // backward
+    static constexpr int EF = 0;
+    static constexpr int SCRT = WIDE3 ? EF + TT * EF_ST : I::SCRT;
+    static constexpr int DLT = WIDE3 ? SCRT + TILES_BYTES : I::DLT;
+    static constexpr int XF = DLT + TT * DLT_ST;
+    static constexpr int HP = WIDE3 ? ACT : I::HP;
+    static constexpr int CBO = WIDE3 ? EIM + TT * E_ST : I::CBO;
+    static constexpr int LOSS = CBO + CB_BYTES;
+    static constexpr int LDS_BYTES = LOSS + kWaves * 4 * 4;
+    static_assert(!WIDE3 || XF + TT * XF_ST <= CBO, "backward images end in front of the composite buffer");
+    static_assert(WIDE3 || (LOSS == I::LOSS && LDS_BYTES == I::LDS_BYTES), "NT <= 2: the map of ImgWs");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+    static constexpr int kPts = 32 * (NT < 2 ? 2 : NT);                    // sample-point slots of a round's composite buffer
+    // scratch per workgroup: cos factors [tile][66][lane]; activation planes [layer][tile][plane][step][256 threads][16 B];
+    // (three-tile rounds) F-form images of the second encoding group [tile][2][4 KiB]
+    static constexpr int CF_BYTES = TT * 66 * 64 * 4;
+    static constexpr int ACTS_OFF = (CF_BYTES + 4095) / 4096 * 4096;
+    static constexpr int EF2_OFF = ACTS_OFF + 5 * TT * 2 * 2 * 4096;
+    static constexpr int WG_SCRATCH = EF2_OFF + (EF2_GLOBAL ? TT * 2 * 4096 : 0);
+    static_assert(WIDE3 || (ACTS_OFF == I::ACTS_OFF && WG_SCRATCH == I::WG_SCRATCH), "NT <= 2: the scratch map of ImgWs");
+};
+constexpr int kWsScratchMax = LdsWs<4, 3>::WG_SCRATCH;                  // the largest of the forms (host-side sizing)
+static_assert(kWsScratchMax >= ImgWs<4>::WG_SCRATCH && kWsScratchMax >= ImgWs<2>::WG_SCRATCH, "scratch sizing");
+
 struct WsArgs {
     StepArgs s;
     char* scratch;                 // [workgroups][WG_SCRATCH]
@@ -360,7 +407,8 @@ __device__ __forceinline__ u32x4 lds16(const char* p) { return *reinterpret_cast
 // chunks (3 planes each from LDS) for 12 matrix instructions.  Rings: weights two steps ahead (L2 latency), LDS one step.
 // The first two weight chunks of a run are fetched by the caller BEFORE the epilogue / barrier in front of the run (WPre).
 struct WOp { u32x4 p[3]; };
-struct XOp { u32x4 x[2][3]; };
+constexpr int kWsT = 3;                                                 // tile slots of the operand structs (unused ones vanish)
+struct XOp { u32x4 x[kWsT][3]; };
 struct WPre { WOp w[2]; };
 template <bool W3>
 __device__ __forceinline__ void wop_load(WOp& o, const char* ubase, unsigned voff) {
@@ -383,8 +431,8 @@ __device__ __forceinline__ void xop_load_g(XOp& o, const char* ubase, int xst, u
         for (int pl = 0; pl < 3; ++pl) o.x[st][pl] = ldgu(ubase + st * xst + pl * 1024, voff);
 }
 // six (bf16 weights: three) products per tile, smallest terms first; the two tiles' chains alternate
-template <bool W3, int NT = 2>
-__device__ __forceinline__ void fop_mm(f32x16 (&acc)[2], const WOp& w, const XOp& o) {
+template <bool W3, int NT = 2, int NA>
+__device__ __forceinline__ void fop_mm(f32x16 (&acc)[NA], const WOp& w, const XOp& o) {
 #pragma unroll
     for (int st = 0; st < NT; ++st) acc[st] = wv::mfma_bf16(w.p[0], o.x[st][2], acc[st]);
     if (W3) {
@@ -411,8 +459,8 @@ __device__ __forceinline__ void wpre_load(WPre& p, const char* wa, const char* w
     wv::sched_fence();
 }
 // XAG: the first part's inputs come from global memory (xa = wave-uniform base) instead of LDS
-template <bool W3, int NA, int NB2, bool XAG = false, int NT = 2>
-__device__ __forceinline__ void fwd_run(f32x16 (&acc)[2], const WPre& pre, const char* wa, const char* xa, int xsta,
+template <bool W3, int NA, int NB2, bool XAG = false, int NT = 2, int NACC>
+__device__ __forceinline__ void fwd_run(f32x16 (&acc)[NACC], const WPre& pre, const char* wa, const char* xa, int xsta,
                                         const char* wb, const char* xb, int xstb, unsigned voff) {
     constexpr int NST = NA + NB2;
     WOp w[3];
@@ -436,7 +484,7 @@ __device__ __forceinline__ void fwd_run(f32x16 (&acc)[2], const WPre& pre, const
 // d-prop of one input block for both tiles: acc[st] += W^T[kb] . delta[st]; W^T chunks at gwt + sp * 2048 (2 planes), delta
 // chunks at d + sp * 2048 (tile 1: + dst); the first three W^T chunks come from the caller (TPre)
 struct TOp { u32x4 p[2]; };
-struct DOp { u32x4 d[2][2]; };
+struct DOp { u32x4 d[kWsT][2]; };
 struct TPre { TOp w[3]; };
 template <bool W3>
 __device__ __forceinline__ void top_load(TOp& o, const char* ubase, unsigned voff) {
@@ -455,8 +503,8 @@ __device__ __forceinline__ void dop_load(DOp& o, const char* d, int dst) {
 #pragma unroll
     for (int st = 0; st < NT; ++st) { o.d[st][0] = lds16(d + st * dst); o.d[st][1] = lds16(d + st * dst + 1024); }
 }
-template <bool W3, int NT = 2>
-__device__ __forceinline__ void bop_mm(f32x16 (&acc)[2], const TOp& w, const DOp& o) {
+template <bool W3, int NT = 2, int NA>
+__device__ __forceinline__ void bop_mm(f32x16 (&acc)[NA], const TOp& w, const DOp& o) {
 #pragma unroll
     for (int st = 0; st < NT; ++st) acc[st] = wv::mfma_bf16(w.p[0], o.d[st][1], acc[st]);
     if (W3) {
@@ -466,8 +514,8 @@ __device__ __forceinline__ void bop_mm(f32x16 (&acc)[2], const TOp& w, const DOp
 #pragma unroll
     for (int st = 0; st < NT; ++st) acc[st] = wv::mfma_bf16(w.p[0], o.d[st][0], acc[st]);
 }
-template <bool W3, int NST, int NT = 2>
-__device__ __forceinline__ void bwd_run(f32x16 (&acc)[2], const TPre& pre, const char* gwt, unsigned voff, const char* d, int dst) {
+template <bool W3, int NST, int NT = 2, int NA>
+__device__ __forceinline__ void bwd_run(f32x16 (&acc)[NA], const TPre& pre, const char* gwt, unsigned voff, const char* d, int dst) {
     TOp w[4];
     DOp dd[2];
     w[0] = pre.w[0]; w[1] = pre.w[1]; w[2] = pre.w[2];
@@ -494,16 +542,18 @@ __device__ __forceinline__ void put_image(char* img, const unsigned (&h)[8], con
 }
 // the activation planes in the workgroup's scratch: ubase = scratch + ACTS_OFF (uniform), voff = tid * 16; chunk
 // ((layer * 2 + st) * 2 + plane) * 2 + step
+template <int TT = 2>
 __device__ __forceinline__ void acts_store(char* ubase, unsigned voff, int layer, int st, const unsigned (&h)[8], const unsigned (&m)[8]) {
-    char* q = ubase + (layer * 2 + st) * 4 * 4096;
+    char* q = ubase + (layer * TT + st) * 4 * 4096;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         *reinterpret_cast<u32x4*>(q + s * 4096 + voff) = u32x4{h[4 * s], h[4 * s + 1], h[4 * s + 2], h[4 * s + 3]};
         *reinterpret_cast<u32x4*>(q + (2 + s) * 4096 + voff) = u32x4{m[4 * s], m[4 * s + 1], m[4 * s + 2], m[4 * s + 3]};
     }
 }
+template <int TT = 2>
 __device__ __forceinline__ void acts_load_plane(unsigned (&h)[8], const char* ubase, unsigned voff, int layer, int st, int plane) {
-    const char* q = ubase + ((layer * 2 + st) * 2 + plane) * 2 * 4096;
+    const char* q = ubase + ((layer * TT + st) * 2 + plane) * 2 * 4096;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         const u32x4 v = ldgu(q + s * 4096, voff);
@@ -521,7 +571,7 @@ __device__ __forceinline__ void put_F(char* img, const unsigned (&f)[16]) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) *reinterpret_cast<u32x4*>(img + c * 1024) = u32x4{f[4 * c], f[4 * c + 1], f[4 * c + 2], f[4 * c + 3]};
 }
-struct FImg { u32x4 c[2][4]; };                                          // the two tiles' F-form images of one block
+struct FImg { u32x4 c[kWsT][4]; };                                       // the tiles' F-form images of one block
 template <int NT = 2>
 __device__ __forceinline__ void fimg_load(FImg& o, const char* img, int xst) {
 #pragma unroll
@@ -529,9 +579,21 @@ __device__ __forceinline__ void fimg_load(FImg& o, const char* img, int xst) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) o.c[st][c] = lds16(img + st * xst + c * 1024);
 }
-// one weight-gradient block over the round's two tiles: acc = sum_tiles dY^T X (F-form: c[0..1] hi plane steps, c[2..3] mid)
+// the same from images in global memory (ubase wave-uniform, voff = lane * 16)
 template <int NT = 2>
-__device__ __forceinline__ void dw_mm_pair(f32x16& acc, const unsigned (&dF)[2][16], const FImg& x) {
+__device__ __forceinline__ void fimg_load_g(FImg& o, const char* ubase, int xst, unsigned voff) {
+#pragma unroll
+    for (int st = 0; st < NT; ++st)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o.c[st][c] = ldgu(ubase + st * xst + c * 1024, voff);
+}
+__device__ __forceinline__ void put_F_g(char* ubase, unsigned voff, const unsigned (&f)[16]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) *reinterpret_cast<u32x4*>(ubase + c * 1024 + voff) = u32x4{f[4 * c], f[4 * c + 1], f[4 * c + 2], f[4 * c + 3]};
+}
+// one weight-gradient block over the round's two tiles: acc = sum_tiles dY^T X (F-form: c[0..1] hi plane steps, c[2..3] mid)
+template <int NT = 2, int ND>
+__device__ __forceinline__ void dw_mm_pair(f32x16& acc, const unsigned (&dF)[ND][16], const FImg& x) {
     zero_acc(acc);
 #pragma unroll
     for (int st = 0; st < NT; ++st)
@@ -545,8 +607,8 @@ __device__ __forceinline__ void dw_mm_pair(f32x16& acc, const unsigned (&dF)[2][
         }
 }
 // bias gradient of a layer without constant-1 input column: dY^T . ones
-template <int NT = 2>
-__device__ __forceinline__ void db_pair(f32x16& acc, const unsigned (&dF)[2][16]) {
+template <int NT = 2, int ND>
+__device__ __forceinline__ void db_pair(f32x16& acc, const unsigned (&dF)[ND][16]) {
     const u32x4 ones = u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
     zero_acc(acc);
 #pragma unroll
@@ -601,15 +663,20 @@ __device__ __forceinline__ void mask_by(float (&d)[16], const f32x16& v, const u
 // weight-gradient blocks of one layer: N input blocks (images at ximg(kb), tile 1: + xst(kb)).  Stage kb: LDS reads of block
 // kb + 1 and (later rounds) the global reads of block kb's earlier sums go out, the matrix instructions of block kb run, the
 // stores of block kb - 1 retire.  io(mode, kb, acc, old): block_io of the layer.
-template <int N, int NT = 2, class XI, class IO>
-__device__ __forceinline__ void dw_layer(const unsigned (&dF)[2][16], bool first, XI&& ximg, IO&& io) {
+// Blocks kb >= NG come from global memory: ximg returns their wave-uniform base, voff = lane * 16.
+template <int N, int NT = 2, int NG = 99, int ND, class XI, class IO>
+__device__ __forceinline__ void dw_layer(const unsigned (&dF)[ND][16], bool first, XI&& ximg, IO&& io, unsigned voff = 0u) {
     FImg x[2];
     f32x16 acc[2];
     float old[2][16];
-    { const char* p; int st; ximg(0, p, st); fimg_load<NT>(x[0], p, st); }
+    { const char* p; int st; ximg(0, p, st); if (0 >= NG) fimg_load_g<NT>(x[0], p, st, voff); else fimg_load<NT>(x[0], p, st); }
 #pragma unroll
     for (int kb = 0; kb < N; ++kb) {
-        if (kb + 1 < N) { const char* p; int st; ximg(kb + 1, p, st); fimg_load<NT>(x[(kb + 1) & 1], p, st); }
+        if (kb + 1 < N) {
+            const char* p; int st;
+            ximg(kb + 1, p, st);
+            if (kb + 1 >= NG) fimg_load_g<NT>(x[(kb + 1) & 1], p, st, voff); else fimg_load<NT>(x[(kb + 1) & 1], p, st);
+        }
         if (!first) io(1, kb, acc[kb & 1], old[kb & 1]);
         wv::sched_fence();
         dw_mm_pair<NT>(acc[kb & 1], dF, x[kb & 1]);
@@ -631,8 +698,8 @@ __device__ __forceinline__ void dw_layer(const unsigned (&dF)[2][16], bool first
 template <int NB, bool BWD, bool W3, bool STAMPS = false, int NT = 2>
 __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     static_assert(NB == 4 || NB == 2, "one output block per wave, at most four");
-    static_assert(NT == 1 || NT == 2, "one or two 32-point tiles per round");
     using I = ImgWs<NB>;
+    using LD = LdsWs<NB, NT>;                                            // LDS / scratch maps of this form
     constexpr int H = I::H, JS = I::JS;
     const StepArgs& a = ga.s;
     const GenLayout L = gen_layout(H);
@@ -641,14 +708,14 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     const int obj = blockIdx.x / a.NW, wgo = blockIdx.x - obj * a.NW;
     const char* gimg = reinterpret_cast<const char*>(a.wimg) + (long long)obj * I::BYTES;
     const float* SM = reinterpret_cast<const float*>(gimg + I::SMALL_OFF);
-    float* loss_cells = reinterpret_cast<float*>(lds + I::LOSS);
+    float* loss_cells = reinterpret_cast<float*>(lds + LD::LOSS);
     if (tid_k < kWaves * 4) loss_cells[tid_k] = 0.0f;
     float* out_k = a.part_grad + ((long long)(obj * a.NW + wgo)) * a.PP;
-    float* cb = reinterpret_cast<float*>(lds + I::CBO);
-    float* hp = reinterpret_cast<float*>(lds + I::HP);
+    float* cb = reinterpret_cast<float*>(lds + LD::CBO);
+    float* hp = reinterpret_cast<float*>(lds + LD::HP);
     const float scale = a.pe_scale.p[obj * a.pe_scale.stride];
     const float* Bg = SM + I::PE_B;
-    char* wgs_k = ga.scratch + (long long)blockIdx.x * I::WG_SCRATCH;
+    char* wgs_k = ga.scratch + (long long)blockIdx.x * LD::WG_SCRATCH;
     unsigned* tmark = STAMPS && a.timing ? a.timing + ((long long)blockIdx.x * kWaves + (tid_k >> 6)) * kMarks : nullptr;
 #define WS_MARK(i) do { if constexpr (STAMPS) { if (tmark && first && (tid_k & 63) == 0) tmark[i] = wv::clock32(); } } while (0)
 #define WS_DMARK(i) do { } while (0)
@@ -665,14 +732,14 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     WS_MARK(0);
     const int tid = wv::opaque_iter(tid_k), lane = tid & 63, wave = wv::uniform(tid >> 6), p31 = lane & 31, hi = lane >> 5;
     const TrLane TL = tr_lane(lane);
-    char* tile = lds + I::SCRT + wave * Img32s::TILE;
-    char* acts = wgs + I::ACTS_OFF;                                      // + tid * 16 per thread
+    char* tile = lds + LD::SCRT + wave * Img32s::TILE;
+    char* acts = wgs + LD::ACTS_OFF;                                      // + tid * 16 per thread
     const unsigned tid16 = (unsigned)tid * 16u;
     const int lo16 = lane * 16;
     const unsigned vlo16 = (unsigned)lane * 16u;
     const bool own = NB == 4 || wave < NB;                               // this wave owns output block `wave` of every layer (NB = 4: all four, known at compile time)
     __syncthreads();                                                     // previous round done with LDS
-    for (int i = tid; i < I::kPts * 8; i += kWG) cb[i] = 0.0f;
+    for (int i = tid; i < LD::kPts * 8; i += kWG) cb[i] = 0.0f;
     const int ray0 = grp * a.G;
     const int nrays = min(a.G, a.R - ray0);
     const int npts = nrays * a.S;                                        // <= 32 NT
@@ -687,8 +754,9 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     WPre pre_in;                                                         // in_layer's first weight chunks: fetched behind the encoding
     if (own) wpre_load<W3, 6, 0>(pre_in, gW + ((long long)(I::CW_IN + wave * I::KS_IN)) * I::XCH, nullptr, vlo16);
     // ---- encoding (embedding.py:82-91): wave = (tile est, direction half dhalf); owner-lane slots as in step_main_s32 ----
-    if (NT == 2 || (wave & 1) == 0) {                                    // single-tile rounds: the waves of tile 1 have no encoding to do
-        const int est = wave & 1, dhalf = wave >> 1;
+    // jobs (tile est, direction half dhalf): two tiles - one per wave; one tile - waves 0 and 2; three tiles - six jobs, waves 0 and 1
+    // take two
+    auto encode = [&](int est, int dhalf) __attribute__((always_inline)) {
         const int pt = 32 * est + p31;
         const bool valid = pt < npts;
         const int lray = valid ? pt / a.S : 0, smp = valid ? pt - lray * a.S : 0, ray = ray0 + lray;
@@ -710,8 +778,8 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
             amax = fmaxf(amax, fabsf(proj[ii]));
         }
         const bool fast = !wv::wave_any(!(amax * (32.0f * kPi) < kSinCosFastLimit));
-        char* e1img = lds + I::EIM + est * I::E_ST + lo16;
-        char* e2img = e1img + I::E2_OFF;
+        char* e1img = lds + LD::EIM + est * LD::E_ST + lo16;
+        char* e2img = e1img + LD::E2_OFF;
         float* cf_out = cfs + est * 66 * 64 + lane;
 #pragma unroll
         for (int ii = 0; ii < 6; ++ii) {
@@ -745,15 +813,22 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
             *reinterpret_cast<unsigned*>(q2 + 1024) = m2[0];
             *reinterpret_cast<unsigned*>(q2 + 2048) = l2[0];
         }
+    };
+    if (NT == 3) {
+        encode(wave == 3 ? 0 : wave, wave == 3 ? 1 : 0);
+        if (wave < 2) encode(wave + 1, 1);
+    } else if (NT == 2 || (wave & 1) == 0) {                             // single-tile rounds: the waves of tile 1 have no encoding to do
+        encode(wave & 1, wave >> 1);
     }
     __syncthreads();
     WS_MARK(1);
     // ---- forward (model.py:59-83): wave w = output block w of every layer, both tiles ----
-    const char* e1x = lds + I::EIM + lo16;
-    const char* e2x = e1x + I::E2_OFF;
-    const char* actx = lds + I::ACT + lo16;
-    char* act_own = lds + I::ACT + wave * 2 * I::XCH + lo16;             // this wave's block of the layer-input images (tile 0)
-    f32x16 acc[2];
+    const char* e1x = lds + LD::EIM + lo16;
+    const char* e2x = e1x + LD::E2_OFF;
+    const char* actx = lds + LD::ACT + lo16;
+    char* act_own = lds + LD::ACT + wave * 2 * I::XCH + lo16;             // this wave's block of the layer-input images (tile 0)
+    f32x16 acc[kWsT];
+    float hpart[kWsT][4];                                                // the heads' partial sums of this wave's block (hi = 0 lanes)
     // epilogue of a layer: ReLU, the heads' partial sums, split into planes; planes -> the next layer's input images (lo
     // included) and, hi / mid, -> the scratch (backward)
     auto epilogue = [&](int layer) {
@@ -776,30 +851,37 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
                 }
                 r0 += wv::swap_half(r0);
                 if (layer == 4) { r1 += wv::swap_half(r1); r2 += wv::swap_half(r2); }
-                if (hi == 0) {
-                    float* cell = hp + ((wave * 2 + st) * 32 + p31) * 4;
+                if (LD::HP_ALIAS) {                                      // the cells overlay images still in use: kept until flush_heads()
+                    // opaque: evaluated HERE (otherwise the sums sink into the guarded flush and keep hf alive over a whole layer)
+                    if (layer == 3) hpart[st][0] = wv::opaque(r0);
+                    else { hpart[st][1] = wv::opaque(r0); hpart[st][2] = wv::opaque(r1); hpart[st][3] = wv::opaque(r2); }
+                } else if (hi == 0) {
+                    float* cell = hp + ((wave * LD::TT + st) * 32 + p31) * 4;
                     if (layer == 3) cell[0] = r0;
                     else { cell[1] = r0; cell[2] = r1; cell[3] = r2; }
                 }
             }
             split_planes<16, 3>(hf, ph, pm, pl);
-            if (layer < 4) put_image<3, I::XCH>(act_own + st * I::ACT_ST, ph, pm, pl);
-            if (BWD) acts_store(acts, tid16, layer, st, ph, pm);
+            if (layer < 4) put_image<3, I::XCH>(act_own + st * LD::ACT_ST, ph, pm, pl);
+            if (BWD) acts_store<LD::TT>(acts, tid16, layer, st, ph, pm);
         }
     };
     auto wchunk = [&](int base, int ks, int s) { return gW + ((long long)(base + wave * ks + s)) * I::XCH; };     // wave-uniform
     WPre pre;
     if (own) {
-        zero_acc(acc[0]); zero_acc(acc[1]);                              // :59 in_layer (bias rides in the constant-1 column)
-        fwd_run<W3, 6, 0, false, NT>(acc, pre_in, wchunk(I::CW_IN, I::KS_IN, 0), e1x, I::E_ST, nullptr, nullptr, 0, vlo16);
+#pragma unroll
+        for (int st = 0; st < NT; ++st) zero_acc(acc[st]);               // :59 in_layer (bias rides in the constant-1 column)
+        fwd_run<W3, 6, 0, false, NT>(acc, pre_in, wchunk(I::CW_IN, I::KS_IN, 0), e1x, LD::E_ST, nullptr, nullptr, 0, vlo16);
         wpre_load<W3, 0, JS>(pre, nullptr, wchunk(I::CW_M1, I::KS_M, 0), vlo16);
         epilogue(0);
     }
     __syncthreads();
     WS_MARK(2);
     if (own) {
-        load_bias(acc[0], SM + I::B_M1 + 32 * wave, hi); acc[1] = acc[0];    // :60 mid1
-        fwd_run<W3, 0, JS, false, NT>(acc, pre, nullptr, nullptr, 0, wchunk(I::CW_M1, I::KS_M, 0), actx, I::ACT_ST, vlo16);
+        load_bias(acc[0], SM + I::B_M1 + 32 * wave, hi);                 // :60 mid1
+#pragma unroll
+        for (int st = 1; st < NT; ++st) acc[st] = acc[0];
+        fwd_run<W3, 0, JS, false, NT>(acc, pre, nullptr, nullptr, 0, wchunk(I::CW_M1, I::KS_M, 0), actx, LD::ACT_ST, vlo16);
         wpre_load<W3, 6, JS>(pre, wchunk(I::CW_CAT, I::KS_CAT, JS), wchunk(I::CW_CAT, I::KS_CAT, 0), vlo16);
     }
     __syncthreads();                                                     // everybody has read h1
@@ -807,8 +889,9 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     __syncthreads();
     WS_MARK(3);
     if (own) {
-        zero_acc(acc[0]); zero_acc(acc[1]);                              // :63-64 cat_layer: encoding part, then h2
-        fwd_run<W3, 6, JS, false, NT>(acc, pre, wchunk(I::CW_CAT, I::KS_CAT, JS), e1x, I::E_ST, wchunk(I::CW_CAT, I::KS_CAT, 0), actx, I::ACT_ST, vlo16);
+#pragma unroll
+        for (int st = 0; st < NT; ++st) zero_acc(acc[st]);               // :63-64 cat_layer: encoding part, then h2
+        fwd_run<W3, 6, JS, false, NT>(acc, pre, wchunk(I::CW_CAT, I::KS_CAT, JS), e1x, LD::E_ST, wchunk(I::CW_CAT, I::KS_CAT, 0), actx, LD::ACT_ST, vlo16);
         wpre_load<W3, 0, JS>(pre, nullptr, wchunk(I::CW_M2, I::KS_M, 0), vlo16);
     }
     __syncthreads();
@@ -816,8 +899,10 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     __syncthreads();
     WS_MARK(4);
     if (own) {
-        load_bias(acc[0], SM + I::B_M2 + 32 * wave, hi); acc[1] = acc[0];    // :67 mid2
-        fwd_run<W3, 0, JS, false, NT>(acc, pre, nullptr, nullptr, 0, wchunk(I::CW_M2, I::KS_M, 0), actx, I::ACT_ST, vlo16);
+        load_bias(acc[0], SM + I::B_M2 + 32 * wave, hi);                 // :67 mid2
+#pragma unroll
+        for (int st = 1; st < NT; ++st) acc[st] = acc[0];
+        fwd_run<W3, 0, JS, false, NT>(acc, pre, nullptr, nullptr, 0, wchunk(I::CW_M2, I::KS_M, 0), actx, LD::ACT_ST, vlo16);
         wpre_load<W3, 3, JS>(pre, wchunk(I::CW_C, I::KS_C, JS), wchunk(I::CW_C, I::KS_C, 0), vlo16);
     }
     __syncthreads();
@@ -825,9 +910,18 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     __syncthreads();
     WS_MARK(5);
     if (own) {
-        zero_acc(acc[0]); zero_acc(acc[1]);                              // :81 color_linear: second encoding group, then h4
-        fwd_run<W3, 3, JS, false, NT>(acc, pre, wchunk(I::CW_C, I::KS_C, JS), e2x, I::E_ST, wchunk(I::CW_C, I::KS_C, 0), actx, I::ACT_ST, vlo16);
+#pragma unroll
+        for (int st = 0; st < NT; ++st) zero_acc(acc[st]);               // :81 color_linear: second encoding group, then h4
+        fwd_run<W3, 3, JS, false, NT>(acc, pre, wchunk(I::CW_C, I::KS_C, JS), e2x, LD::E_ST, wchunk(I::CW_C, I::KS_C, 0), actx, LD::ACT_ST, vlo16);
         epilogue(4);
+    }
+    if (LD::HP_ALIAS) {
+        __syncthreads();                                                 // everybody has read h4: its images make room for the heads' cells
+        if (own && hi == 0) {
+#pragma unroll
+            for (int st = 0; st < NT; ++st)
+                *reinterpret_cast<wv::f32x4*>(hp + ((wave * LD::TT + st) * 32 + p31) * 4) = wv::f32x4{hpart[st][0], hpart[st][1], hpart[st][2], hpart[st][3]};
+        }
     }
     __syncthreads();
     WS_MARK(6);
@@ -837,8 +931,8 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
             float v[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                v[c] = hp[((0 * 2 + wave) * 32 + p31) * 4 + c] + hp[((1 * 2 + wave) * 32 + p31) * 4 + c];
-                if (NB == 4) v[c] += hp[((2 * 2 + wave) * 32 + p31) * 4 + c] + hp[((3 * 2 + wave) * 32 + p31) * 4 + c];
+                v[c] = hp[((0 * LD::TT + wave) * 32 + p31) * 4 + c] + hp[((1 * LD::TT + wave) * 32 + p31) * 4 + c];
+                if (NB == 4) v[c] += hp[((2 * LD::TT + wave) * 32 + p31) * 4 + c] + hp[((3 * LD::TT + wave) * 32 + p31) * 4 + c];
             }
             float* row = cb + pt * 8;
             row[6] = zv;
@@ -857,14 +951,14 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     WS_MARK(7);
     if (BWD) {
     // ---- backward ----
-    unsigned ah[2][8], am[2][8];                                         // planes of an activation block coming back from the scratch
+    unsigned ah[kWsT][8], am[kWsT][8];                                         // planes of an activation block coming back from the scratch
     auto fetch = [&](int layer) {
 #pragma unroll
-        for (int st = 0; st < NT; ++st) { acts_load_plane(ah[st], acts, tid16, layer, st, 0); acts_load_plane(am[st], acts, tid16, layer, st, 1); }
+        for (int st = 0; st < NT; ++st) { acts_load_plane<LD::TT>(ah[st], acts, tid16, layer, st, 0); acts_load_plane<LD::TT>(am[st], acts, tid16, layer, st, 1); }
         wv::sched_fence();
     };
     if (own) fetch(3);                                                   // h4: lands during the encoding transposes
-    float d_raw[2], d_c0[2], d_c1[2], d_c2[2];
+    float d_raw[kWsT], d_c0[kWsT], d_c1[kWsT], d_c2[kWsT];
 #pragma unroll
     for (int st = 0; st < NT; ++st) {
         const float* row = cb + (32 * st + p31) * 8;                     // padding rows hold zeros
@@ -872,12 +966,12 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     }
     // F-form images of the ten encoding blocks (weight-gradient operands), from the P-form images of the forward; dealt round-robin
     {
-        char* ef = lds + I::EF + lo16;
+        char* ef = lds + LD::EF + lo16;
 #pragma unroll
-        for (int j = 0; j < 10; ++j) {
-            if ((j & 3) != wave || j >= 5 * NT) continue;
+        for (int j = 0; j < 5 * NT; ++j) {
+            if ((j & 3) != wave) continue;
             const int st = j / 5, eb = j - 5 * st;
-            const char* src = eb < 3 ? e1x + st * I::E_ST + 2 * eb * I::XCH : e2x + st * I::E_ST + 2 * (eb - 3) * I::XCH;
+            const char* src = eb < 3 ? e1x + st * LD::E_ST + 2 * eb * I::XCH : e2x + st * LD::E_ST + 2 * (eb - 3) * I::XCH;
             unsigned h[8], m[8], f[16];
             const u32x4 h0 = lds16(src), m0 = lds16(src + 1024);
             h[0] = h0[0]; h[1] = h0[1]; h[2] = h0[2]; h[3] = h0[3]; m[0] = m0[0]; m[1] = m0[1]; m[2] = m0[2]; m[3] = m0[3];
@@ -888,12 +982,13 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
                 h[4] = h[5] = h[6] = h[7] = 0u; m[4] = m[5] = m[6] = m[7] = 0u;
             }
             to_F<4>(f, tile, h, m, p31, hi, TL);
-            put_F(ef + st * I::EF_ST + eb * 4096, f);
+            if (LD::EF2_GLOBAL && eb >= 3) put_F_g(wgs + LD::EF2_OFF + (st * 2 + eb - 3) * 4096, vlo16, f);
+            else put_F(ef + st * LD::EF_ST + eb * 4096, f);
         }
     }
     // F-form of the heads' delta (features 0..3 = d raw alpha, d raw colour), both tiles: every wave for itself
-    unsigned dF[2][16];
-    float dv[2][16];
+    unsigned dF[kWsT][16];
+    float dv[kWsT][16];
 #pragma unroll
     for (int st = 0; st < NT; ++st) {
         unsigned dh[8], dm[8], dl[8];
@@ -910,13 +1005,13 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     float* outW_cat = out + L.f[4] + (long long)32 * wave * (H + kEmb1);
     float* outW_m1 = out + L.f[2] + (long long)32 * wave * H;
     float* outW_in = out + L.f[0] + (long long)32 * wave * kEmb1;
-    char* dlt_own = lds + I::DLT + wave * 2 * I::DCH + lo16;
-    const char* dltx = lds + I::DLT + lo16;
-    char* xf_own = lds + I::XF + wave * 4096 + lo16;
-    const char* xfx = lds + I::XF + lo16;
-    const char* efx = lds + I::EF + lo16;
-    f32x16 accw, accd[2];
-    float dproj[2][11];
+    char* dlt_own = lds + LD::DLT + wave * 2 * I::DCH + lo16;
+    const char* dltx = lds + LD::DLT + lo16;
+    char* xf_own = lds + LD::XF + wave * 4096 + lo16;
+    const char* xfx = lds + LD::XF + lo16;
+    const char* efx = lds + LD::EF + lo16;
+    f32x16 accw, accd[kWsT];
+    float dproj[kWsT][11];
 #pragma unroll
     for (int st = 0; st < NT; ++st)
 #pragma unroll
@@ -927,7 +1022,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
         for (int st = 0; st < NT; ++st) {
             unsigned xF[16];
             to_F<4>(xF, tile, ah[st], am[st], p31, hi, TL);
-            put_F(xf_own + st * I::XF_ST, xF);
+            put_F(xf_own + st * LD::XF_ST, xF);
         }
     };
     // the wave's delta block (float32 registers dv[st]) -> planes -> P-form image + F-form registers dF
@@ -936,7 +1031,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
         for (int st = 0; st < NT; ++st) {
             unsigned dh[8], dm[8], dl[8];
             split_planes<16, 2>(dv[st], dh, dm, dl);
-            put_image<2, I::DCH>(dlt_own + st * I::DLT_ST, dh, dm, dl);
+            put_image<2, I::DCH>(dlt_own + st * LD::DLT_ST, dh, dm, dl);
             to_F<4>(dF[st], tile, dh, dm, p31, hi, TL);
         }
     };
@@ -953,10 +1048,10 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
                 for (int r = 0; r < 16; ++r) accd[st][r] = SM[I::W_A + 32 * wave + phi(r, hi)] * d_raw[st];
             } else zero_acc(accd[st]);
         }
-        bwd_run<W3, JS, NT>(accd, tp, hidden_ptr(ct_base), vlo16, dltx, I::DLT_ST);
+        bwd_run<W3, JS, NT>(accd, tp, hidden_ptr(ct_base), vlo16, dltx, LD::DLT_ST);
     };
     // d-prop into an encoding block -> d(proj) through the cos factors (cfr: fetched at the phase start, with tpe)
-    float cfr[2][16];
+    float cfr[kWsT][16];
     auto enc_ptr = [&](int ct_chunk) {
         return gWT + (long long)ct_chunk * I::DCH;
     };
@@ -975,9 +1070,10 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
         wv::sched_fence();
     };
     auto dprop_enc = [&](int ct_chunk, int group, int blk) {
-        f32x16 acce[2];
-        zero_acc(acce[0]); zero_acc(acce[1]);
-        bwd_run<W3, JS, NT>(acce, tpe, enc_ptr(ct_chunk), vlo16, dltx, I::DLT_ST);
+        f32x16 acce[kWsT];
+#pragma unroll
+        for (int st = 0; st < NT; ++st) zero_acc(acce[st]);
+        bwd_run<W3, JS, NT>(acce, tpe, enc_ptr(ct_chunk), vlo16, dltx, LD::DLT_ST);
 #pragma unroll
         for (int st = 0; st < NT; ++st) {
 #pragma unroll
@@ -988,14 +1084,14 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
             }
         }
     };
-    auto xf_img = [&](int kb, const char*& p, int& st) { p = xfx + kb * 4096; st = I::XF_ST; };
+    auto xf_img = [&](int kb, const char*& p, int& st) { p = xfx + kb * 4096; st = LD::XF_ST; };
     // -- heads: d W_a = (d raw)^T h4, d W_oc = (d colour)^T hc; rows 0..3 of one block each --
     if (own) {
         FImg xi;
         publish_x();                                                     // h4 block: color_linear's weight-gradient operand
         fetch(4);                                                        // hc
         wv::wave_lds_fence();
-        fimg_load<NT>(xi, xf_own, I::XF_ST);
+        fimg_load<NT>(xi, xf_own, LD::XF_ST);
         dw_mm_pair<NT>(accw, dF, xi);
         if (hi == 0) store_one(out + L.f[8] + 32 * wave + p31, accw[0], first);
         if (wave == 0) {
@@ -1006,12 +1102,13 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
                 store_one(out + L.f[13] + 0, accb[1], first); store_one(out + L.f[13] + 1, accb[2], first); store_one(out + L.f[13] + 2, accb[3], first);
             }
         }
-        unsigned x0[16], x1[16];
-        to_F<4>(x0, tile, ah[0], am[0], p31, hi, TL);
-        if (NT == 2) to_F<4>(x1, tile, ah[1], am[1], p31, hi, TL);
         zero_acc(accw);
-        dw_mm_s(accw, dF[0], x0);
-        if (NT == 2) dw_mm_s(accw, dF[1], x1);
+#pragma unroll
+        for (int st = 0; st < NT; ++st) {
+            unsigned x0[16];
+            to_F<4>(x0, tile, ah[st], am[st], p31, hi, TL);
+            dw_mm_s(accw, dF[st], x0);
+        }
         if (hi == 0) {
             store_one(out + L.f[12] + 0 * H + 32 * wave + p31, accw[1], first);
             store_one(out + L.f[12] + 1 * H + 32 * wave + p31, accw[2], first);
@@ -1043,12 +1140,16 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     if (wave == EC1) enc_fetch(I::CT_C + (NB + 1) * JS, 2, 1);
     WS_DMARK(1);
     if (own)
-        dw_layer<NB + 2, NT>(dF, first,
-            [&](int kb, const char*& p, int& st) { if (kb < NB) xf_img(kb, p, st); else { p = efx + (3 + kb - NB) * 4096; st = I::EF_ST; } },
+        dw_layer<NB + 2, NT, LD::EF2_GLOBAL ? NB : 99>(dF, first,
+            [&](int kb, const char*& p, int& st) {
+                if (kb < NB) xf_img(kb, p, st);
+                else if (LD::EF2_GLOBAL) { p = wgs + LD::EF2_OFF + (kb - NB) * 4096; st = 2 * 4096; }
+                else { p = efx + (3 + kb - NB) * 4096; st = LD::EF_ST; }
+            },
             [&](int mode, int kb, const f32x16& v, float (&old)[16]) {
                 WS_IO3(mode, kb < NB, (block_io<0, H + kEmb2, M>(outW_c + 32 * kb, nullptr, v, old, 0, 32, p31, hi)),
                        (block_io<2, H + kEmb2, M>(outW_c + H, out + L.f[11] + 32 * wave, v, old, kb - NB, kEmb2, p31, hi)));
-            });
+            }, vlo16);
     WS_DMARK(2);
     if (wave == EC0) dprop_enc(I::CT_C + (NB + 0) * JS, 2, 0);
     if (wave == EC1) dprop_enc(I::CT_C + (NB + 1) * JS, 2, 1);
@@ -1100,7 +1201,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     // cat_layer
     if (own)
         dw_layer<NB + 3, NT>(dF, first,
-            [&](int kb, const char*& p, int& st) { if (kb < NB) xf_img(kb, p, st); else { p = efx + (kb - NB) * 4096; st = I::EF_ST; } },
+            [&](int kb, const char*& p, int& st) { if (kb < NB) xf_img(kb, p, st); else { p = efx + (kb - NB) * 4096; st = LD::EF_ST; } },
             [&](int mode, int kb, const f32x16& v, float (&old)[16]) {
                 WS_IO3(mode, kb < NB, (block_io<0, H + kEmb1, M>(outW_cat + 32 * kb, nullptr, v, old, 0, 32, p31, hi)),
                        (block_io<1, H + kEmb1, M>(outW_cat + H, out + L.f[5] + 32 * wave, v, old, kb - NB, kEmb1, p31, hi)));
@@ -1139,7 +1240,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     WS_MARK(13);
     // in_layer
     if (own)
-        dw_layer<3, NT>(dF, first, [&](int kb, const char*& p, int& st) { p = efx + kb * 4096; st = I::EF_ST; },
+        dw_layer<3, NT>(dF, first, [&](int kb, const char*& p, int& st) { p = efx + kb * 4096; st = LD::EF_ST; },
                     [&](int mode, int kb, const f32x16& v, float (&old)[16]) {
                         WS_IO3(mode, true, (block_io<1, kEmb1, M>(outW_in, out + L.f[1] + 32 * wave, v, old, kb, kEmb1, p31, hi)), (void)0);
                     });
@@ -1151,11 +1252,11 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     __syncthreads();
     WS_MARK(14);
     {
-        float* px = reinterpret_cast<float*>(lds + I::XF);               // [wave][tile][11][64]
+        float* px = reinterpret_cast<float*>(lds + LD::XF);               // [wave][tile][11][64]
 #pragma unroll
         for (int st = 0; st < NT; ++st)
 #pragma unroll
-            for (int i = 0; i < 11; ++i) px[((wave * 2 + st) * 11 + i) * 64 + lane] = dproj[st][i];
+            for (int i = 0; i < 11; ++i) px[((wave * LD::TT + st) * 11 + i) * 64 + lane] = dproj[st][i];
         __syncthreads();
         if (wave == 0) {
 #pragma unroll
@@ -1163,13 +1264,13 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
                 unsigned dh[8], dm[8], dl[8];
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    dv[st][r] = r < 11 ? (px[((0 * 2 + st) * 11 + r) * 64 + lane] + px[((1 * 2 + st) * 11 + r) * 64 + lane]) +
-                                         (px[((2 * 2 + st) * 11 + r) * 64 + lane] + px[((3 * 2 + st) * 11 + r) * 64 + lane]) : 0.0f;
+                    dv[st][r] = r < 11 ? (px[((0 * LD::TT + st) * 11 + r) * 64 + lane] + px[((1 * LD::TT + st) * 11 + r) * 64 + lane]) +
+                                         (px[((2 * LD::TT + st) * 11 + r) * 64 + lane] + px[((3 * LD::TT + st) * 11 + r) * 64 + lane]) : 0.0f;
                 split_planes<16, 2>(dv[st], dh, dm, dl);
                 to_F<4>(dF[st], tile, dh, dm, p31, hi, TL);
             }
             FImg xi;
-            fimg_load<NT>(xi, efx + 2 * 4096, I::EF_ST);
+            fimg_load<NT>(xi, efx + 2 * 4096, LD::EF_ST);
             dw_mm_pair<NT>(accw, dF, xi);
             if (p31 >= 24 && p31 < 27) {
 #pragma unroll
