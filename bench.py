@@ -376,8 +376,9 @@ def main():
                 pmc_file, key = "r03m_pmc_counters_step_main_s32.json", "hbm_traffic_bytes_per_launch_step_main"
             elif args.config == "replica_room0_vmap":
                 pmc_file, key = "r01m_pmc_counters.json", "hbm_traffic_bytes_per_launch_step_main"
-            elif args.config == "background" and args.kernel == "auto":
-                pmc_file, key = "r03q_pmc_counters_background_ws.json", "hbm_traffic_bytes_per_launch_step_main_ws"
+            elif args.config == "background" and args.kernel == "auto" and args.weights == "f32":
+                # three-tile rounds (the automatic plan): r03x; the round-2 plan (--ws-flags 4): r03q
+                pmc_file, key = ("r03x_pmc_counters_background_ws.json" if ws_nt == 3 else "r03q_pmc_counters_background_ws.json"), "hbm_traffic_bytes_per_launch_step_main_ws"
             if pmc_file:
                 with open(os.path.join(ROOT, "profiles", pmc_file)) as fh:
                     traffic = json.load(fh)["_notes"][key]

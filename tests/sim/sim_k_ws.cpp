@@ -52,7 +52,7 @@ void main_ws_t(const vk::WsArgs& wa, bool bwd) {
 }  // namespace
 void finalize_ws(const vk::FinalizeArgs& f, const vk::FinalizeHot& h, const int* tab_wt) {
     const int grid = f.n_obj * vk::ws_finalize_blocks(f.PP) + 1;
-    if (f.hidden == 128) sim::launch(grid, vk::kWG, 4 * vk::kWG * 4, [&] { vk::step_finalize_ws<4>(f, h, tab_wt); });
-    else sim::launch(grid, vk::kWG, 4 * vk::kWG * 4, [&] { vk::step_finalize_ws<2>(f, h, tab_wt); });
+    if (f.hidden == 128) sim::launch(grid, vk::kFinThreads, vk::kFinThreads * 16, [&] { vk::step_finalize_ws<4>(f, h, tab_wt); });
+    else sim::launch(grid, vk::kFinThreads, vk::kFinThreads * 16, [&] { vk::step_finalize_ws<2>(f, h, tab_wt); });
 }
 }  // namespace sl

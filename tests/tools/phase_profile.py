@@ -29,13 +29,14 @@ tB, tsc = torch.from_numpy(B).to(dev), torch.from_numpy(sc).to(dev)
 tb = {k: torch.from_numpy(v).to(dev) for k, v in batch.items()}
 from vmap_amd import _lib  # noqa: E402
 kern = sys.argv[2] if len(sys.argv) > 2 else "split"       # split (default kernel at hidden 32) | f32
-op = step.VmapStep(n, R, S, H, device=dev, tuning={"kernel": _lib.KERNEL_H32_F32} if kern == "f32" else None)
+ws_flags = int(sys.argv[3]) if len(sys.argv) > 3 else 0      # hidden 128: tuning.ws_flags (4 = never three-tile rounds)
+op = step.VmapStep(n, R, S, H, device=dev, tuning={"kernel": _lib.KERNEL_H32_F32} if kern == "f32" else {"ws_flags": ws_flags} if ws_flags else None)
 args = (tfc, tB, tsc, tb["pcs"], tb["z"], tb["gt_depth"], tb["gt_rgb"], tb["sem"], tb["depth_mask"])
 for _ in range(3):
     t = op.profile_phases(*args)
 t = op.profile_phases(*args).astype(np.float64)          # [WG, 4 waves, 16]
 d = np.diff(t, axis=-1)
-print(f"config {name} kernel {kern}: {t.shape[0]} workgroups; kernel span {t.max():.0f} clocks; per-phase clocks (median / p90 / max over waves)")
+print(f"config {name} kernel {kern} ws_flags {ws_flags}: {t.shape[0]} workgroups; kernel span {t.max():.0f} clocks; per-phase clocks (median / p90 / max over waves)")
 tot = 0.0
 for i in range(15):
     x = d[:, :, i].ravel()
@@ -44,4 +45,8 @@ for i in range(15):
 print(f"  sum of medians {tot:.0f}; wave-0 first stamp spread across WGs {np.ptp(t[:, 0, 0]):.0f}; "
       f"last stamp median {np.median(t[:, :, 15]):.0f} max {t[:, :, 15].max():.0f}")
 json.dump({"config": name, "median": np.median(d.reshape(-1, 15), axis=0).tolist(), "names": NAMES[1:]},
-          open(os.path.join(ROOT, "gpurun_out", f"phases_{name}_{kern}.json"), "w"))
+          open(os.path.join(ROOT, "gpurun_out", f"phases_{name}_{kern}_{ws_flags}.json"), "w"))
+if H == 128:
+    print("  per wave (median over workgroups):")
+    for w in range(4):
+        print(f"    wave {w}: " + " ".join(f"{np.median(d[:, w, i]):7.0f}" for i in range(15)))

@@ -56,9 +56,9 @@ int prep_ws(const vk::StepArgs& a, int n_steps, hipStream_t st) {
 int finalize_ws(const vk::FinalizeArgs& f, const vk::FinalizeHot& h, const int* tab_wt, hipStream_t st) {
     const int grid = f.n_obj * vk::ws_finalize_blocks(f.PP) + 1;
     if (f.hidden == 128)
-        hipLaunchKernelGGL(vk::step_finalize_ws<4>, dim3(grid), dim3(vk::kWG), 4 * vk::kWG * sizeof(float), st, f, h, tab_wt);
+        hipLaunchKernelGGL(vk::step_finalize_ws<4>, dim3(grid), dim3(vk::kFinThreads), vk::kFinThreads * 4 * sizeof(float), st, f, h, tab_wt);
     else
-        hipLaunchKernelGGL(vk::step_finalize_ws<2>, dim3(grid), dim3(vk::kWG), 4 * vk::kWG * sizeof(float), st, f, h, tab_wt);
+        hipLaunchKernelGGL(vk::step_finalize_ws<2>, dim3(grid), dim3(vk::kFinThreads), vk::kFinThreads * 4 * sizeof(float), st, f, h, tab_wt);
     return launched("step_finalize_ws");
 }
 

@@ -1043,7 +1043,8 @@ __device__ __forceinline__ void finalize_loss(const FinalizeArgs& a) {
     int* redi = reinterpret_cast<int*>(red + kWG);
     float loss = 0.0f;
     int explode = 0;
-    for (int k = threadIdx.x; k < a.n_obj; k += kWG) {
+    const bool act = threadIdx.x < kWG;  // blocks wider than kWG threads (step_finalize_ws): the extra waves only take part in the barriers
+    for (int k = act ? (int)threadIdx.x : a.n_obj; k < a.n_obj; k += kWG) {
         float ld = 0.0f, lc = 0.0f, lo = 0.0f;
         for (int q = 0; q < a.NW; ++q) {
             const float* pl = a.part_loss + ((long long)k * a.NW + q) * 4;
@@ -1054,8 +1055,10 @@ __device__ __forceinline__ void finalize_loss(const FinalizeArgs& a) {
         loss += lb;
         if (a.terms_out) { a.terms_out[4 * k] = ld; a.terms_out[4 * k + 1] = lc; a.terms_out[4 * k + 2] = lo; a.terms_out[4 * k + 3] = lb; }
     }
-    red[threadIdx.x] = loss;
-    redi[threadIdx.x] = explode;
+    if (act) {
+        red[threadIdx.x] = loss;
+        redi[threadIdx.x] = explode;
+    }
     __syncthreads();
     for (int w = kWG / 2; w > 0; w >>= 1) {
         if ((int)threadIdx.x < w) {

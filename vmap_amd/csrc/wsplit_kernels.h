@@ -308,14 +308,17 @@ __device__ __forceinline__ void ws_image_store(char* img, int locw, int locwt, f
 }
 
 // blocks per object of step_finalize_ws: kFinQuads quads of parameters per block, kFinGroups threads per quad
-constexpr int kFinGroups = 4, kFinQuads = kWG / kFinGroups;
+#ifndef VK_FIN_GROUPS
+#define VK_FIN_GROUPS 4
+#endif
+constexpr int kFinGroups = VK_FIN_GROUPS, kFinQuads = 64, kFinThreads = kFinGroups * kFinQuads;   // one wave per row group
 __host__ __device__ inline int ws_finalize_blocks(int PP) { return (PP / 4 + kFinQuads - 1) / kFinQuads; }
 
 // Gradients to the caller's tensors (if given), AdamW + image rewrite (if do_adam).
 // The partial gradients are NW rows of PP floats per object (one per workgroup of step_main_ws, up to 256): a quad's four
 // threads sum a quarter of the rows each (loads eight deep), a fixed tree through LDS joins them - same order every run.
 template <int NB>
-__global__ __launch_bounds__(kWG) void step_finalize_ws(const FinalizeArgs a, const FinalizeHot hh, const int* tab_wt) {
+__global__ __launch_bounds__(kFinThreads) void step_finalize_ws(const FinalizeArgs a, const FinalizeHot hh, const int* tab_wt) {
     typedef int i32x4 __attribute__((ext_vector_type(4)));
     const int quads = a.PP / 4;
     const int blocks_per_obj = ws_finalize_blocks(a.PP);
@@ -346,8 +349,15 @@ __global__ __launch_bounds__(kWG) void step_finalize_ws(const FinalizeArgs a, co
     }
     __syncthreads();
     if (rg != 0 || !live) return;
-    static_assert(kFinGroups == 4, "the join below is a four-way tree");
-    const wv::f32x4 g = (red[ql] + red[kFinQuads + ql]) + (red[2 * kFinQuads + ql] + red[3 * kFinQuads + ql]);
+    static_assert((kFinGroups & (kFinGroups - 1)) == 0 && kFinGroups >= 4 && kFinGroups <= 16, "the join below is a pairwise tree");
+    wv::f32x4 jn[kFinGroups];
+#pragma unroll
+    for (int i = 0; i < kFinGroups; ++i) jn[i] = red[i * kFinQuads + ql];
+#pragma unroll
+    for (int w = 1; w < kFinGroups; w *= 2)
+#pragma unroll
+        for (int i = 0; i < kFinGroups; i += 2 * w) jn[i] = jn[i] + jn[i + w];
+    const wv::f32x4 g = jn[0];
     const long long s = (long long)obj * hh.PP + 4 * q;
     int ten[4], off[4];
 #pragma unroll
