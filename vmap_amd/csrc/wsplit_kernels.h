@@ -309,14 +309,24 @@ __device__ __forceinline__ void ws_image_store(char* img, int locw, int locwt, f
 
 // blocks per object of step_finalize_ws: kFinQuads quads of parameters per block, kFinGroups threads per quad
 #ifndef VK_FIN_GROUPS
-#define VK_FIN_GROUPS 4
+#define VK_FIN_GROUPS 8
 #endif
-constexpr int kFinGroups = VK_FIN_GROUPS, kFinQuads = 64, kFinThreads = kFinGroups * kFinQuads;   // one wave per row group
+#ifdef VK_FIN_NT
+#define VK_FIN_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define VK_FIN_LOAD(p) (*(p))
+#endif
+#ifndef VK_FIN_QUADS
+#define VK_FIN_QUADS 128
+#endif
+constexpr int kFinGroups = VK_FIN_GROUPS, kFinQuads = VK_FIN_QUADS, kFinThreads = kFinGroups * kFinQuads;   // 8 row groups x 128 quads: 1024 threads
 __host__ __device__ inline int ws_finalize_blocks(int PP) { return (PP / 4 + kFinQuads - 1) / kFinQuads; }
 
 // Gradients to the caller's tensors (if given), AdamW + image rewrite (if do_adam).
-// The partial gradients are NW rows of PP floats per object (one per workgroup of step_main_ws, up to 256): a quad's four
-// threads sum a quarter of the rows each (loads eight deep), a fixed tree through LDS joins them - same order every run.
+// The partial gradients are NW rows of PP floats per object (one per workgroup of step_main_ws, up to 256): a block covers
+// kFinQuads consecutive quads of every row (2 KiB contiguous per row: measured 27.1 us at 64 quads, 21.0 at 128, 21.6 at 256
+// for 200 rows - the row reads want contiguity more than blocks, profiles/r03y_*), its kFinGroups row groups sum a share of the
+// rows each (loads eight deep), a fixed pairwise tree through LDS joins them - same order every run.
 template <int NB>
 __global__ __launch_bounds__(kFinThreads) void step_finalize_ws(const FinalizeArgs a, const FinalizeHot hh, const int* tab_wt) {
     typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -340,11 +350,11 @@ __global__ __launch_bounds__(kFinThreads) void step_finalize_ws(const FinalizeAr
         for (; u0 + 8 <= u_end; u0 += 8) {
             wv::f32x4 t[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) t[u] = pg[(u0 + u) * qs];
+            for (int u = 0; u < 8; ++u) t[u] = VK_FIN_LOAD(pg + (u0 + u) * qs);
 #pragma unroll
             for (int u = 0; u < 8; ++u) g += t[u];
         }
-        for (; u0 < u_end; ++u0) g += pg[u0 * qs];
+        for (; u0 < u_end; ++u0) g += VK_FIN_LOAD(pg + u0 * qs);
         red[rg * kFinQuads + ql] = g;
     }
     __syncthreads();
