@@ -14,11 +14,14 @@ void main_ws_t(const vk::WsArgs& wa, bool bwd);
 void main_ws(const vk::WsArgs& wa, bool bwd) {
     if (wa.s.tiles == 3 && wa.s.hidden == 128) {             // three-tile rounds: hidden 128 only
         const int grid = wa.s.n_obj * wa.s.NW, lb = vk::LdsWs<4, 3>::LDS_BYTES;
+        const bool one = wa.s.NG == wa.s.NW;                 // the single-round specialisation, as the library picks it
         if (wa.s.weights_bf16) {
-            if (bwd) sim::launch(grid, vk::kWG, lb, [&] { vk::step_main_ws<4, true, false, false, 3>(wa); });
+            if (bwd && one) sim::launch(grid, vk::kWG, lb, [&] { vk::step_main_ws<4, true, false, false, 3, true>(wa); });
+            else if (bwd) sim::launch(grid, vk::kWG, lb, [&] { vk::step_main_ws<4, true, false, false, 3>(wa); });
             else     sim::launch(grid, vk::kWG, lb, [&] { vk::step_main_ws<4, false, false, false, 3>(wa); });
         } else {
-            if (bwd) sim::launch(grid, vk::kWG, lb, [&] { vk::step_main_ws<4, true, true, false, 3>(wa); });
+            if (bwd && one) sim::launch(grid, vk::kWG, lb, [&] { vk::step_main_ws<4, true, true, false, 3, true>(wa); });
+            else if (bwd) sim::launch(grid, vk::kWG, lb, [&] { vk::step_main_ws<4, true, true, false, 3>(wa); });
             else     sim::launch(grid, vk::kWG, lb, [&] { vk::step_main_ws<4, false, true, false, 3>(wa); });
         }
         return;
@@ -31,6 +34,12 @@ void main_ws_t(const vk::WsArgs& wa, bool bwd) {
     const int grid = wa.s.n_obj * wa.s.NW;
     if (wa.s.hidden == 128) {
         const int lb = vk::ImgWs<4>::LDS_BYTES;
+        const bool one = wa.s.NG == wa.s.NW;
+        if (bwd && one) {
+            if (wa.s.weights_bf16) sim::launch(grid, vk::kWG, lb, [&] { vk::step_main_ws<4, true, false, false, NT, true>(wa); });
+            else sim::launch(grid, vk::kWG, lb, [&] { vk::step_main_ws<4, true, true, false, NT, true>(wa); });
+            return;
+        }
         if (wa.s.weights_bf16) {
             if (bwd) sim::launch(grid, vk::kWG, lb, [&] { vk::step_main_ws<4, true, false, false, NT>(wa); });
             else     sim::launch(grid, vk::kWG, lb, [&] { vk::step_main_ws<4, false, false, false, NT>(wa); });

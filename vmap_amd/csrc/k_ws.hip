@@ -6,10 +6,20 @@
 namespace vl {
 
 namespace {
+template <int NB, bool BWD, bool W3, bool STAMPS, int NT, bool ONE>
+int main_o(const vk::StepArgs& a, hipStream_t st);
+// hidden 128, training: the single-round specialisation when the plan gives every workgroup exactly one round
 template <int NB, bool BWD, bool W3, bool STAMPS, int NT>
 int main_t(const vk::StepArgs& a, hipStream_t st) {
+    if constexpr (NB == 4 && BWD && !STAMPS) {
+        if (a.NG == a.NW) return main_o<NB, BWD, W3, STAMPS, NT, true>(a, st);
+    }
+    return main_o<NB, BWD, W3, STAMPS, NT, false>(a, st);
+}
+template <int NB, bool BWD, bool W3, bool STAMPS, int NT, bool ONE>
+int main_o(const vk::StepArgs& a, hipStream_t st) {
     using LD = vk::LdsWs<NB, NT>;
-    auto kern = vk::step_main_ws<NB, BWD, W3, STAMPS, NT>;
+    auto kern = vk::step_main_ws<NB, BWD, W3, STAMPS, NT, ONE>;
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LD::LDS_BYTES, "step_main_ws")) return rc;
     vk::WsArgs ga;
     ga.s = a;

@@ -715,7 +715,9 @@ __device__ __forceinline__ void dw_layer(const unsigned (&dF)[ND][16], bool firs
 // launch plan when every tile of the batch gets a workgroup of its own on an otherwise idle chip: the ray-sharded background
 // model of a multi-GPU run (150 rays per rank at 8 ranks = 38 two-tile rounds on 38 of 256 compute units, or 75 single-tile
 // rounds on 75), where the step is one round's LATENCY.
-template <int NB, bool BWD, bool W3, bool STAMPS = false, int NT = 2>
+// ONE: every workgroup runs exactly ONE round (NW = NG: the plans of the latency-bound batches) - `first` is a constant, the
+// read-modify-write form of the gradient stores and the round loop disappear.
+template <int NB, bool BWD, bool W3, bool STAMPS = false, int NT = 2, bool ONE = false>
 __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     static_assert(NB == 4 || NB == 2, "one output block per wave, at most four");
     using I = ImgWs<NB>;
@@ -740,8 +742,8 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
 #define WS_MARK(i) do { if constexpr (STAMPS) { if (tmark && first && (tid_k & 63) == 0) tmark[i] = wv::clock32(); } } while (0)
 #define WS_DMARK(i) do { } while (0)
 
-    for (int grp = wgo; grp < a.NG; grp += a.NW) {
-    const bool first = grp == wgo;
+    for (int grp = wgo; grp < (ONE ? wgo + 1 : a.NG); grp += a.NW) {
+    const bool first = ONE ? true : grp == wgo;
     // per-round copies of the wave-uniform bases (see wv::opaque_uzero)
     const unsigned uz = wv::opaque_uzero();
     const char* gW = gimg + uz;
@@ -774,8 +776,9 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     WPre pre_in;                                                         // in_layer's first weight chunks: fetched behind the encoding
     if (own) wpre_load<W3, 6, 0>(pre_in, gW + ((long long)(I::CW_IN + wave * I::KS_IN)) * I::XCH, nullptr, vlo16);
     // ---- encoding (embedding.py:82-91): wave = (tile est, direction half dhalf); owner-lane slots as in step_main_s32 ----
-    // jobs (tile est, direction half dhalf): two tiles - one per wave; one tile - waves 0 and 2; three tiles - six jobs, waves 0 and 1
-    // take two
+    // jobs (tile est, direction half dhalf) of six direction slots each: two tiles - one per wave; one tile - waves 0 and 2; three
+    // tiles - six jobs, waves 0 and 1 take two (cutting the jobs into halves, three per wave, is slower: 13.8 -> 15.5 k clocks -
+    // a job's cost is mostly its set-up, profiles/r04a_*)
     auto encode = [&](int est, int dhalf) __attribute__((always_inline)) {
         const int pt = 32 * est + p31;
         const bool valid = pt < npts;
