@@ -779,15 +779,20 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     // jobs (tile est, direction half dhalf) of six direction slots each: two tiles - one per wave; one tile - waves 0 and 2; three
     // tiles - six jobs, waves 0 and 1 take two (cutting the jobs into halves, three per wave, is slower: 13.8 -> 15.5 k clocks -
     // a job's cost is mostly its set-up, profiles/r04a_*)
-    auto encode = [&](int est, int dhalf) __attribute__((always_inline)) {
+    struct Pt3 { float x[3]; };
+    auto load_point = [&](int est) __attribute__((always_inline)) {      // this lane's sample point of tile est (zeros for padding lanes)
         const int pt = 32 * est + p31;
         const bool valid = pt < npts;
         const int lray = valid ? pt / a.S : 0, smp = valid ? pt - lray * a.S : 0, ray = ray0 + lray;
-        float px3[3] = {0.0f, 0.0f, 0.0f};
+        Pt3 q = {{0.0f, 0.0f, 0.0f}};
         if (valid) {
             const float* px = a.pcs + obj * a.pcs_so + ray * a.pcs_sr + smp * a.pcs_ss;
-            px3[0] = px[0]; px3[1] = px[a.pcs_sc]; px3[2] = px[2 * a.pcs_sc];
+            q.x[0] = px[0]; q.x[1] = px[a.pcs_sc]; q.x[2] = px[2 * a.pcs_sc];
         }
+        return q;
+    };
+    auto encode = [&](int est, int dhalf, const Pt3& q) __attribute__((always_inline)) {
+        const float* px3 = q.x;
         const float t[3] = {px3[0] / scale, px3[1] / scale, px3[2] / scale};          // embedding.py:83
         // this wave's directions: slots i = 6 dhalf + ii; lane half hi = 0 owns directions 0..10, hi = 1 directions 11..20;
         // slot 11 = (x, y, z, 1) / the constant of the second group
@@ -838,10 +843,15 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
         }
     };
     if (NT == 3) {
-        encode(wave == 3 ? 0 : wave, wave == 3 ? 1 : 0);
-        if (wave < 2) encode(wave + 1, 1);
+        // both jobs' points are requested before the first job's arithmetic (a second exposed memory round trip otherwise)
+        const int est_a = wave == 3 ? 0 : wave, est_b = wave + 1;
+        const Pt3 qa = load_point(est_a);
+        Pt3 qb = {{0.0f, 0.0f, 0.0f}};
+        if (wave < 2) qb = load_point(est_b);
+        encode(est_a, wave == 3 ? 1 : 0, qa);
+        if (wave < 2) encode(est_b, 1, qb);
     } else if (NT == 2 || (wave & 1) == 0) {                             // single-tile rounds: the waves of tile 1 have no encoding to do
-        encode(wave & 1, wave >> 1);
+        encode(wave & 1, wave >> 1, load_point(wave & 1));
     }
     __syncthreads();
     WS_MARK(1);
