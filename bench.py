@@ -338,14 +338,17 @@ def main():
                                                              # the quantity a rocprofv3 --kernel-trace reports per dispatch (profiles/)
         k_ms_pair = sum(p[1] for p in pairs) / reps          # a pair of stream events around the launch (includes the events' own cost)
         split = H == 32 and args.kernel != "f32"
-        wsk = H in (64, 128) and args.kernel in ("auto", "ws1", "wp") and S <= 64
+        ws8 = H == 256 and S <= 32 and args.kernel in ("auto", "ws1") and (args.kernel == "ws1" or n * ((R + max(32 // S, 1) - 1) // max(32 // S, 1)) <= 256)
+        wsk = (H in (64, 128) and args.kernel in ("auto", "ws1", "wp") and S <= 64) or ws8
         wp = wsk and (args.kernel == "wp" or (args.kernel == "auto" and H == 64))
         # tiles per round of step_main_ws (the launch plan's rule, vmapstep.hip make_plan)
         ws_nt = 2
         if wsk and not wp:
             rounds_of = lambda g: n * ((R + max(g, 1) - 1) // max(g, 1))
             flags = (1 if args.ws_two_tile else 0) | args.ws_flags
-            if H == 128 and flags & 2:
+            if ws8:
+                ws_nt = 1
+            elif H == 128 and flags & 2:
                 ws_nt = 3
             elif rounds_of(32 // S) <= 256 and 32 // S >= 1 and not flags & 1:
                 ws_nt = 1
@@ -354,7 +357,7 @@ def main():
         kernel_name = ("step_main_s32 (hidden 32: bf16 matrix pipe, split operands: 6 products forward, 3 backward)" if split else
                        "step_main_h32 (hidden 32: exact-fp32 matrix instruction)" if H == 32 else
                        (("step_main_wp" if wp else "step_main_ws") + f" (hidden {H}: bf16 matrix pipe, split operands, {('one', 'two', 'three')[ws_nt - 1]} 32-point "
-                        f"tile{'s' if ws_nt > 1 else ''} per workgroup round, " + ("two waves" if wp else "one wave") + " per output block)") if wsk else
+                        f"tile{'s' if ws_nt > 1 else ''} per workgroup round, " + ("two waves" if wp else "one wave") + " per output block" + (", eight waves" if ws8 else "") + ")") if wsk else
                        ("step_main_wide<4>" if (args.kernel == "wide" or (args.kernel == "auto" and H % 128 == 0 and n * ((R + 32 // S - 1) // (32 // S)) <= 256))
                         else "step_main_gen") + f" (hidden {H}: exact-fp32 matrix instruction)")
         on_bf16_pipe = split or wsk

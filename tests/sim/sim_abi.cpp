@@ -48,9 +48,9 @@ extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req, int xcd
     const vk::GenLayout GL = vk::gen_layout(H);
     const bool split = g_split && H == 32;
     const bool wp = g_wide == 4 && (H == 128 || H == 64);    // step_main_wp (two waves per output block)
-    const bool ws = (g_wide == 3 || g_wide == 4) && (H == 128 || H == 64);    // step_main_ws / _wp (split-bf16 matrix pipe, hidden 128 / 64)
-    if (ws && G * S > (g_wide == 3 && H == 128 ? 96 : vk::ImgWs<4>::kPts)) return -3;   // step_main_ws at hidden 128: up to three 32-point tiles per round
-    std::vector<float> wimg((size_t)n * (split ? vk::Img32s::BYTES / 4 : ws ? (H == 128 ? vk::ImgWs<4>::BYTES : vk::ImgWs<2>::BYTES) / 4 : GL.imgp), NAN);
+    const bool ws = ((g_wide == 3 || g_wide == 4) && (H == 128 || H == 64)) || (g_wide == 3 && H == 256);    // step_main_ws / _wp (split-bf16 matrix pipe, hidden 128 / 64; _ws also 256)
+    if (ws && G * S > (H == 256 ? 32 : g_wide == 3 && H == 128 ? 96 : vk::ImgWs<4>::kPts)) return -3;   // step_main_ws at hidden 128: up to three 32-point tiles per round
+    std::vector<float> wimg((size_t)n * (split ? vk::Img32s::BYTES / 4 : ws ? (H == 256 ? vk::ImgWs<8>::BYTES : H == 128 ? vk::ImgWs<4>::BYTES : vk::ImgWs<2>::BYTES) / 4 : GL.imgp), NAN);
 
     vk::StepArgs a{};
     a.tiles = g_wide == 3 ? (G * S <= 32 ? 1 : G * S <= 64 ? 2 : 3) : 2;   // step_main_ws: the fewest 32-point tiles that hold the caller's ray groups

@@ -4,6 +4,7 @@
 namespace sl {
 void prep_ws(const vk::WsArgs& wa) {
     const int n = wa.s.n_obj;
+    if (wa.s.hidden == 256) return prep_ws8(wa);
     if (wa.s.hidden == 128) sim::launch(wa.s.prep_steps + n * vk::ws_pack_blocks<4>(), vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep_ws<4>(wa); });
     else sim::launch(wa.s.prep_steps + n * vk::ws_pack_blocks<2>(), vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep_ws<2>(wa); });
 }
@@ -12,6 +13,7 @@ template <int NT>
 void main_ws_t(const vk::WsArgs& wa, bool bwd);
 }
 void main_ws(const vk::WsArgs& wa, bool bwd) {
+    if (wa.s.hidden == 256) return main_ws8(wa, bwd);
     if (wa.s.tiles == 3 && wa.s.hidden == 128) {             // three-tile rounds: hidden 128 only
         const int grid = wa.s.n_obj * wa.s.NW, lb = vk::LdsWs<4, 3>::LDS_BYTES;
         const bool one = wa.s.NG == wa.s.NW;                 // the single-round specialisation, as the library picks it
@@ -61,6 +63,7 @@ void main_ws_t(const vk::WsArgs& wa, bool bwd) {
 }  // namespace
 void finalize_ws(const vk::FinalizeArgs& f, const vk::FinalizeHot& h, const int* tab_wt) {
     const int grid = f.n_obj * vk::ws_finalize_blocks(f.PP) + 1;
+    if (f.hidden == 256) return finalize_ws8(f, h, tab_wt, grid);
     if (f.hidden == 128) sim::launch(grid, vk::kFinThreads, vk::kFinThreads * 16, [&] { vk::step_finalize_ws<4>(f, h, tab_wt); });
     else sim::launch(grid, vk::kFinThreads, vk::kFinThreads * 16, [&] { vk::step_finalize_ws<2>(f, h, tab_wt); });
 }

@@ -22,6 +22,10 @@ void prep_ws(const vk::WsArgs& wa);
 void main_ws(const vk::WsArgs& wa, bool bwd);
 void main_wp(const vk::WsArgs& wa, bool bwd);
 void finalize_ws(const vk::FinalizeArgs& f, const vk::FinalizeHot& h, const int* tab_wt);
+// sim_k_ws8.cpp: hidden 256 (eight waves), called through prep_ws / main_ws / finalize_ws
+void prep_ws8(const vk::WsArgs& wa);
+void main_ws8(const vk::WsArgs& wa, bool bwd);
+void finalize_ws8(const vk::FinalizeArgs& f, const vk::FinalizeHot& h, const int* tab_wt, int grid);
 // sim_k_misc.cpp
 void sample(const vs::SampleArgs& a, int n_obj, long long rays);
 int query(int H, const vk::StepArgs& pack, const vk::QueryArgs& q, int grid);

@@ -14,7 +14,7 @@ OUT = os.path.join(SIM, "_build", "libvmsim.so")
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 
 
-UNITS = ("sim_abi", "sim_runtime", "sim_k_f32", "sim_k_s32", "sim_k_ws", "sim_k_wp", "sim_k_misc")
+UNITS = ("sim_abi", "sim_runtime", "sim_k_f32", "sim_k_s32", "sim_k_ws", "sim_k_ws8", "sim_k_wp", "sim_k_misc")
 
 
 def _deps(src, pool):

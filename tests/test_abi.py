@@ -85,7 +85,8 @@ def test_step_operator_refuses_cpu():
 def test_kernel_choice_per_width_shows_in_the_workspace_plan():
     """hidden 64 / 128 with at most 64 samples per ray run on the split-bf16 kernels (step_main_wp / step_main_ws): their
     workspace carries the W / W^T images and per-workgroup scratch, the exact-fp32 kernels' does not; VMAPSTEP_KERNEL_WS1 /
-    _WP are refused where those kernels do not exist (hidden 32, 256, long rays)."""
+    _WP are refused where those kernels do not exist (hidden 32, hidden 256 with more than 32 samples per ray or as _WP, long
+    rays); hidden 256 with short rays runs step_main_ws with eight waves while every tile gets a compute unit (round 3)."""
     lib = _lib.load()
 
     def need(shape, kernel=None):
@@ -103,9 +104,18 @@ def test_kernel_choice_per_width_shows_in_the_workspace_plan():
         rc_p, wp = need(_lib.Shape(1, 1200, 14, H, 0), _lib.KERNEL_WP)
         assert (rc_a, rc_g, rc_1, rc_p) == (0, 0, 0, 0)
         assert auto in (ws1, wp) and auto != gen
-    for sh in (_lib.Shape(4, 120, 10, 32, 0), _lib.Shape(1, 100, 14, 256, 0), _lib.Shape(1, 8, 100, 128, 0)):
+    for sh in (_lib.Shape(4, 120, 10, 32, 0), _lib.Shape(1, 100, 40, 256, 0), _lib.Shape(1, 8, 100, 128, 0)):
         assert need(sh, _lib.KERNEL_WS1)[0] != 0
         assert b"WS1" in lib.vmapstep_last_error()
+    assert need(_lib.Shape(1, 100, 14, 256, 0), _lib.KERNEL_WP)[0] != 0
+    # hidden 256: the automatic plan = the eight-wave step_main_ws for 50 tiles, the exact-fp32 kernels for 3000
+    rc_a, auto = need(_lib.Shape(1, 100, 14, 256, 0))
+    rc_1, ws1 = need(_lib.Shape(1, 100, 14, 256, 0), _lib.KERNEL_WS1)
+    rc_g, gen = need(_lib.Shape(1, 100, 14, 256, 0), _lib.KERNEL_GEN)
+    assert (rc_a, rc_1, rc_g) == (0, 0, 0) and auto == ws1 and auto != gen
+    rc_a, auto = need(_lib.Shape(1, 6000, 14, 256, 0))
+    rc_g, gen = need(_lib.Shape(1, 6000, 14, 256, 0), _lib.KERNEL_GEN)
+    assert (rc_a, rc_g) == (0, 0) and auto == gen
 
 
 def test_adamw_apply_checks_its_arguments_without_a_device():

@@ -177,6 +177,36 @@ def test_hidden128_kernel_matches_oracle_on_seeded_shapes(n, R, S, seed, H):
         assert relerr(w2[k], e[k]) < 1e-4, k
 
 
+@pytest.mark.parametrize("n,R,S,seed", [(1, 1, 14, 21), (3, 9, 14, 22), (2, 37, 10, 23), (1, 21, 3, 24), (2, 7, 20, 25), (1, 5, 32, 26), (1, 100, 14, 27)])
+def test_hidden256_kernel_matches_oracle_on_seeded_shapes(n, R, S, seed):
+    """step_main_ws<8> (hidden 256, eight waves, single-tile rounds: the automatic choice while every round gets a compute unit) on
+    ragged shapes - single ray, partly filled tiles, one ray per round (S = 20, 32 = its limit), long rays through the general
+    compositing path, several objects - against the oracle with its ReLU kinks accounted for, the exact-fp32 general kernel,
+    and itself with several rounds per workgroup."""
+    H = 256
+    fc, B, sc = synth.make_params(n, H, seed=500 + seed)
+    batch = synth.make_batch(n, R, S, seed=600 + seed)
+    c = dict(n=n, R=R, S=S, H=H, fc=fc, B=B, scale=sc, batch=batch)
+    s = _run(c)                                                          # automatic plan
+    o = vo.training_step(fc, B, sc, batch, dtype=np.float32, kinks=True)
+    assert abs(s["loss"] - o["loss"]) <= 5e-5 * abs(o["loss"])
+    for k in RENDER_KEYS + ["var"]:
+        assert relerr(s[k], o[k]) < 2e-5, k
+    _assert_grads_match_oracle_up_to_kinks(s, o, n)
+    e = _run(c, tuning={"kernel": _lib.KERNEL_GEN})
+    m = _run(c, tuning={"kernel": _lib.KERNEL_WS1, "workgroups_per_object": 2})   # several rounds per workgroup
+    _assert_grads_match_oracle_up_to_kinks(m, o, n)
+    for k in RENDER_KEYS:
+        assert relerr(s[k], e[k]) < 2e-5, k
+        assert relerr(m[k], e[k]) < 2e-5, k
+    for k in GRAD_KEYS:
+        assert relerr(s[k], e[k]) < 1e-4, k
+        assert relerr(m[k], e[k]) < 1e-4, k
+    s2 = _run(c)
+    for k in GRAD_KEYS:
+        assert np.array_equal(s[k], s2[k]), k                                     # bit-repeatable
+
+
 def test_render_only_equals_fwd_bwd_renders():
     c = cases.build_case("ragged")
     a, b = _run(c), _run(c, fn="render")
@@ -440,7 +470,8 @@ def test_unsupported_hidden_width_fails_loudly():
                                          ("bg_h128_s14", "ws"), ("bg_h128_s14", "ws_multipass"), ("h64", "ws"), ("h64", "ws_multipass"),
                                          ("bg_h128_s14", "ws1"), ("bg_h128_s14", "ws1_multipass"), ("h64", "ws1"), ("h64", "ws1_multipass"),
                                          ("bg_h128_s14", "ws1_two_tile"), ("bg_h128_s14", "ws1_two_tile_multipass"), ("h64", "ws1_two_tile"),
-                                         ("bg_h128_s14", "ws1_three_tile"), ("bg_h128_s14", "ws1_three_tile_multipass")])
+                                         ("bg_h128_s14", "ws1_three_tile"), ("bg_h128_s14", "ws1_three_tile_multipass"),
+                                         ("imap_h256", "auto"), ("imap_h256", "ws1"), ("imap_h256", "ws1_multipass")])
 def test_generic_width_kernel_matches_reference_fixture(name, kernel):
     """hidden = 64 / 128 (background model shapes) / 256 (iMAP, BASELINE configs[0]): step_main_wide (tile per
     workgroup, also with fewer workgroups than ray groups), step_main_gen, and - hidden 64 / 128 -
@@ -448,7 +479,8 @@ def test_generic_width_kernel_matches_reference_fixture(name, kernel):
     choice: the first at hidden 64, the second at hidden 128)."""
     c = cases.build_case(name)
     g = load_golden(name)
-    tuning = {"kernel": {"gen": _lib.KERNEL_GEN, "wide": _lib.KERNEL_WIDE4, "wide_multipass": _lib.KERNEL_WIDE4,
+    tuning = {"kernel": {"auto": _lib.KERNEL_AUTO,                                 # imap_h256: step_main_ws<8> (eight waves), round 3
+                         "gen": _lib.KERNEL_GEN, "wide": _lib.KERNEL_WIDE4, "wide_multipass": _lib.KERNEL_WIDE4,
                          "ws": _lib.KERNEL_WP, "ws_multipass": _lib.KERNEL_WP,         # step_main_wp (two waves per output block)
                          "ws1": _lib.KERNEL_WS1, "ws1_multipass": _lib.KERNEL_WS1,            # step_main_ws (one wave per block): small batches
                          "ws1_two_tile": _lib.KERNEL_WS1, "ws1_two_tile_multipass": _lib.KERNEL_WS1,   # run single-tile rounds, ws_flags = 1: two-tile rounds
@@ -541,6 +573,36 @@ def test_shared_background_hip_tracks_the_aten_port_over_a_frame():
     hip.write_back()
     for p, q in zip(list(fc.parameters()) + [pe.B_layer.weight], ref.fc + [ref.B]):
         d = (p.detach().cpu() - q.detach()[0]).abs()
+        assert float(d.max()) <= steps * 1.1e-3 and float(d.median()) < 1e-6
+
+
+@pytest.mark.parametrize("weights", ["f32", "bf16"])
+def test_hidden256_frame_tracks_the_aten_port(weights):
+    """The iMAP field (hidden 256, BASELINE configs[0]: ONE model for the whole scene) over a frame of 6 distinct steps through
+    vmapstep_train_steps on step_main_ws<8> + step_finalize_ws<8> (fused AdamW, W / W^T images kept current) against the ATen
+    port of the oracle (torch.optim.AdamW; bf16: run-time weights rounded from the float32 masters every step)."""
+    from oracle import vmap_oracle_torch as vt
+    n, R, S, H, steps = 1, 100, 14, 256, 6
+    fc, B, sc = synth.make_params(n, H, scale=10.0, seed=801)
+    b = synth.make_batch(n, R * steps, S, seed=802)
+    ref = vt.CpuTrainer(fc, B, sc, weights_bf16=weights == "bf16")
+    ref_losses = []
+    for i in range(steps):
+        l, _, _ = ref.step({k: np.ascontiguousarray(v[:, i * R:(i + 1) * R]) for k, v in b.items()})
+        ref_losses.append(float(l))
+    tfc = [torch.from_numpy(a).to(DEV) for a in fc]
+    tB, tsc = torch.from_numpy(B).to(DEV), torch.from_numpy(sc).to(DEV)
+    fr = {k: torch.from_numpy(v).to(DEV) for k, v in b.items()}
+    op = step.VmapStep(n, R, S, H, device=DEV, max_steps=steps, weights=weights)
+    st = step.FusedAdamWState(n, H, DEV)
+    res = op.train_steps(tfc, tB, tsc, fr["pcs"], fr["z"], fr["gt_depth"], fr["gt_rgb"], fr["sem"], fr["depth_mask"], opt=st, n_steps=steps)
+    torch.cuda.synchronize()
+    losses = res.loss.cpu().numpy()
+    assert int(res.flags[:, 3].max()) == 0
+    for i in range(steps):
+        assert losses[i] == pytest.approx(ref_losses[i], rel=2e-4), (i, losses, ref_losses)
+    for p, q in zip(tfc + [tB], ref.fc + [ref.B]):
+        d = (p.cpu() - q.detach()).abs()
         assert float(d.max()) <= steps * 1.1e-3 and float(d.median()) < 1e-6
 
 
@@ -759,7 +821,7 @@ def _check_frame_trajectory(name, tuning):
 
 
 @pytest.mark.parametrize("weights,case", [("f32", "scannet_scale"), ("bf16", "scannet_scale"), ("f32", "bg_h128_s14"), ("bf16", "bg_h128_s14"),
-                                          ("f32", "h64"), ("bf16", "h64")])
+                                          ("f32", "h64"), ("bf16", "h64"), ("f32", "imap_h256"), ("bf16", "imap_h256")])
 def test_parameter_image_kept_by_finalize_equals_freshly_packed_image(weights, case):
     """The finalize kernel rewrites the packed parameter image (split planes / float32 image) element by element after
     every AdamW update; a new frame call packs it from the parameter tensors.  Two steps in ONE call (step 2 reads the

@@ -332,3 +332,27 @@ def test_sim_ws_three_tile_rounds_match_reference(G, nw, bf16):
     for k in GRAD_KEYS:
         assert not np.isnan(s[k]).any(), k
         assert relerr(s[k], g[k]) < 1e-4, k
+
+
+@pytest.mark.parametrize("G,nw,bf16", [(2, 0, 0), (2, 7, 0), (1, 0, 1)])
+def test_sim_ws_hidden256_matches_reference(G, nw, bf16):
+    """step_main_ws<8>: hidden 256 (the iMAP field, BASELINE configs[0]) on the bf16 matrix pipe with split operands - EIGHT waves,
+    one output block each, single-tile rounds (G S <= 32); one round per workgroup (the single-round specialisation the launch plan
+    uses) and several rounds adding into the row; bfloat16 run-time weights against the float32 oracle on the rounded weights."""
+    c = cases.build_case("imap_h256")
+    if bf16:
+        from conftest import round_bf16
+        fc_r = [round_bf16(a) for a in c["fc"]]
+        B_r = round_bf16(c["B"])
+        o = vo.training_step(fc_r, B_r, c["scale"], c["batch"], dtype=np.float32)
+        g = {k: o[k] for k in RENDER_KEYS + GRAD_KEYS}
+        g["loss"] = o["loss"]
+    else:
+        g = load_golden("imap_h256")
+    s = simlib.sim_step(c, wide=3, G=G, NW=nw, weights_bf16=bf16)
+    assert abs(s["loss"] - float(g["loss"])) <= 2e-5 * abs(float(g["loss"]))
+    for k in RENDER_KEYS:
+        assert relerr(s[k], g[k]) < 2e-5, k
+    for k in GRAD_KEYS:
+        assert not np.isnan(s[k]).any(), k
+        assert relerr(s[k], g[k]) < 1e-4, k

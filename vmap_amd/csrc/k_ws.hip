@@ -44,6 +44,7 @@ int main_nb(const vk::StepArgs& a, bool bwd, bool stamps, hipStream_t st) {
 }  // namespace
 
 int main_ws(const vk::StepArgs& a, bool bwd, bool stamps, hipStream_t st) {
+    if (a.hidden == 256) return main_ws8(a, bwd, st);                    // k_ws8.hip (eight waves)
     return a.hidden == 128 ? main_nb<4>(a, bwd, stamps, st) : main_nb<2>(a, bwd, stamps, st);
 }
 
@@ -56,6 +57,7 @@ int prep_ws(const vk::StepArgs& a, int n_steps, hipStream_t st) {
     // parameters without a place in the W^T image (biases, heads, B) keep -1 in its table
     hipError_t e = hipMemsetAsync(a.tab_wt, 0xFF, (size_t)a.PP * sizeof(int), st);
     if (e != hipSuccess) return fail(-4, "hipMemsetAsync(tab_wt): %s", hipGetErrorString(e));
+    if (a.hidden == 256) return prep_ws8(ga, n_steps, st);
     if (a.hidden == 128)
         hipLaunchKernelGGL(vk::step_prep_ws<4>, dim3(n_steps + a.n_obj * vk::ws_pack_blocks<4>()), dim3(vk::kWG), 3 * vk::kWG * sizeof(int), st, ga);
     else
@@ -65,6 +67,7 @@ int prep_ws(const vk::StepArgs& a, int n_steps, hipStream_t st) {
 
 int finalize_ws(const vk::FinalizeArgs& f, const vk::FinalizeHot& h, const int* tab_wt, hipStream_t st) {
     const int grid = f.n_obj * vk::ws_finalize_blocks(f.PP) + 1;
+    if (f.hidden == 256) return finalize_ws8(f, h, tab_wt, grid, st);
     if (f.hidden == 128)
         hipLaunchKernelGGL(vk::step_finalize_ws<4>, dim3(grid), dim3(vk::kFinThreads), vk::kFinThreads * 4 * sizeof(float), st, f, h, tab_wt);
     else

@@ -1,5 +1,5 @@
 // launch.h - host-side launchers of the kernel families, one translation unit per family so that hipcc compiles them side
-// by side (build(): vmapstep.hip = the C ABI, k_f32.hip, k_s32.hip, k_ws.hip, k_wp.hip, k_misc.hip; no device code crosses
+// by side (build(): vmapstep.hip = the C ABI, k_f32.hip, k_s32.hip, k_ws.hip, k_ws8.hip, k_wp.hip, k_misc.hip; no device code crosses
 // a unit, so no relocatable device code is needed).  Every function only ENQUEUES on `st` and returns a vmapstep status.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -8,6 +8,8 @@
 #include "query_kernels.h"
 #include "sample_kernels.h"
 #include "step_kernels.h"
+
+namespace vk { struct WsArgs; }
 
 namespace vl {
 
@@ -44,6 +46,10 @@ int main_ws(const vk::StepArgs& a, bool bwd, bool stamps, hipStream_t st);
 int main_wp(const vk::StepArgs& a, bool bwd, bool stamps, hipStream_t st);
 int prep_ws(const vk::StepArgs& a, int n_steps, hipStream_t st);
 int finalize_ws(const vk::FinalizeArgs& f, const vk::FinalizeHot& h, const int* tab_wt, hipStream_t st);
+// k_ws8.hip: hidden 256 on the same scheme with eight waves (called through main_ws / prep_ws / finalize_ws)
+int main_ws8(const vk::StepArgs& a, bool bwd, hipStream_t st);
+int prep_ws8(const vk::WsArgs& ga, int n_steps, hipStream_t st);
+int finalize_ws8(const vk::FinalizeArgs& f, const vk::FinalizeHot& h, const int* tab_wt, int grid, hipStream_t st);
 
 // k_misc.hip: inference query and the frame sampler
 int query_points(int hidden, const vk::StepArgs& pack, const vk::QueryArgs& q, long long n_points, hipStream_t st);

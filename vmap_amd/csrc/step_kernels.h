@@ -664,13 +664,13 @@ __device__ __forceinline__ RayMeta load_ray_meta(const StepArgs& a, int obj, int
     return m;
 }
 
-template <bool BWD>
+template <bool BWD, int NWAVES = kWaves>
 __device__ __forceinline__ void composite_phase(const StepArgs& a, float* cb, float* loss_cells, int obj, int ray0, int nrays,
                                                 int wave, int lane, int tid, const RayMeta& pre) {
     // ---- per-ray compositing, loss and d loss / d raw  (loss.py:24-60, render_rays.py:26-96) ----
     if (__builtin_expect(a.S <= 16, 1)) {
         // 16 lanes per ray: lane i of a group holds sample i; products/sums are scans and butterflies
-        for (int g0 = 4 * wave; g0 < nrays; g0 += 4 * kWaves) {      // wave-uniform trip count
+        for (int g0 = 4 * wave; g0 < nrays; g0 += 4 * NWAVES) {      // wave-uniform trip count
             const int g = g0 + (lane >> 4), i = lane & 15;
             const bool on = g < nrays && i < a.S;
             const int rr = ray0 + min(g, nrays - 1);

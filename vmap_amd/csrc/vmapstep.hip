@@ -160,8 +160,14 @@ int make_plan(const vmapstep_shape* sh, int max_steps, Plan& pl, const Layout& L
         else if (force == VMAPSTEP_KERNEL_WS1) pl.wide = 3;
         else if (force == VMAPSTEP_KERNEL_WP) pl.wide = 4;
     }
+    // hidden 256 (the iMAP field): step_main_ws<8> - eight waves, single-tile rounds - when every round gets a compute unit of its
+    // own (one round per workgroup); larger batches stay on the exact-fp32 kernels
+    if (pl.generic && sh->hidden == 256 && sh->samples <= 32 && (force == VMAPSTEP_KERNEL_AUTO || force == VMAPSTEP_KERNEL_WS1)) {
+        const int g1 = std::min(32 / sh->samples, sh->rays);
+        if (force == VMAPSTEP_KERNEL_WS1 || (long long)sh->n_obj * ((sh->rays + g1 - 1) / g1) <= 256) pl.wide = 3;
+    }
     if ((force == VMAPSTEP_KERNEL_WS1 || force == VMAPSTEP_KERNEL_WP) && pl.wide < 3)
-        return fail(VMAPSTEP_ERR_UNSUPPORTED, "VMAPSTEP_KERNEL_WS1 / _WP: hidden 64 / 128 with at most 64 samples per ray");
+        return fail(VMAPSTEP_ERR_UNSUPPORTED, "VMAPSTEP_KERNEL_WS1 / _WP: hidden 64 / 128 with at most 64 samples per ray (_WS1 also hidden 256 with at most 32)");
     pl.G = (pl.wide >= 3 ? vk::ImgWs<4>::kPts : pl.wide == 1 ? vk::kWideTile : vk::kMaxPts) / sh->samples;
     pl.tiles = 2;
     if (pl.wide == 3) {
@@ -176,7 +182,8 @@ int make_plan(const vmapstep_shape* sh, int max_steps, Plan& pl, const Layout& L
         const int g1 = 32 / sh->samples, g2 = pl.G, g3 = 96 / sh->samples;
         const bool autoplan = tun.workgroups_per_object <= 0;
         auto rounds = [&](int g) { return g >= 1 ? (long long)sh->n_obj * ((sh->rays + std::min(g, sh->rays) - 1) / std::min(g, sh->rays)) : (1LL << 40); };
-        if (sh->hidden == 128 && (tun.ws_flags & 2)) { pl.G = g3; pl.tiles = 3; }
+        if (sh->hidden == 256) { pl.G = g1; pl.tiles = 1; }
+        else if (sh->hidden == 128 && (tun.ws_flags & 2)) { pl.G = g3; pl.tiles = 3; }
         else if (autoplan && !(tun.ws_flags & 1) && rounds(g1) <= 256) { pl.G = g1; pl.tiles = 1; }
         else if (autoplan && sh->hidden == 128 && !(tun.ws_flags & 4) && rounds(g2) > 256 && rounds(g3) <= 256) { pl.G = g3; pl.tiles = 3; }
     }
@@ -205,7 +212,7 @@ int make_plan(const vmapstep_shape* sh, int max_steps, Plan& pl, const Layout& L
     pl.off_imgtab = o; o += pl.wide >= 3 ? 2 * align_up((size_t)L.PP * sizeof(int)) : pl.generic ? 0 : align_up((size_t)L.PP * sizeof(int));
     pl.off_pgrad = o; o += align_up((size_t)sh->n_obj * nw_cap * L.PP * sizeof(float));
     const vk::GenLayout GL = vk::gen_layout(sh->hidden);
-    pl.off_wimg = o; o += align_up(pl.split ? (size_t)sh->n_obj * vk::Img32s::BYTES : pl.wide >= 3 ? (size_t)sh->n_obj * (sh->hidden == 128 ? vk::ImgWs<4>::BYTES : vk::ImgWs<2>::BYTES)
+    pl.off_wimg = o; o += align_up(pl.split ? (size_t)sh->n_obj * vk::Img32s::BYTES : pl.wide >= 3 ? (size_t)sh->n_obj * (sh->hidden == 256 ? vk::ImgWs<8>::BYTES : sh->hidden == 128 ? vk::ImgWs<4>::BYTES : vk::ImgWs<2>::BYTES)
                                                                                    : (size_t)sh->n_obj * GL.imgp * sizeof(float));
     pl.off_scratch = o;
     if (pl.wide >= 3) o += align_up((size_t)sh->n_obj * nw_cap * (pl.wide == 4 ? (sh->hidden == 128 ? vk::LdsWp<4>::WG_SCRATCH : vk::LdsWp<2>::WG_SCRATCH)
@@ -689,7 +696,8 @@ int vmapstep_profile_phases(const vmapstep_shape* shape, const vmapstep_params* 
     if ((rc = check_batch(batch))) return rc;
     if (!pe_scale || !pe_scale->ptr) return fail(VMAPSTEP_ERR_ARGUMENT, "pe_scale is null");
     if (!timing || !n_workgroups) return fail(VMAPSTEP_ERR_ARGUMENT, "timing / n_workgroups is null");
-    if (pl.generic && pl.wide < 3) return fail(VMAPSTEP_ERR_UNSUPPORTED, "phase stamps exist in the hidden=32 kernels and step_main_ws only");
+    if (pl.generic && (pl.wide < 3 || shape->hidden == 256))
+        return fail(VMAPSTEP_ERR_UNSUPPORTED, "phase stamps exist in the hidden=32 kernels and step_main_ws / _wp at hidden 64 / 128 only");
     const size_t need = (size_t)8 * ((shape->n_obj + 7) / 8) * pl.NW * vk::kWaves * vk::kMarks;
     if (timing_elems < need) return fail(VMAPSTEP_ERR_ARGUMENT, "timing buffer %zu < %zu elements", timing_elems, need);
     if ((rc = check_ws(workspace, workspace_bytes, pl))) return rc;

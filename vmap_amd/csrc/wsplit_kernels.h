@@ -73,45 +73,54 @@ static_assert(ImgWs<4>::LDS_BYTES <= 160 * 1024 && ImgWs<2>::LDS_BYTES <= 160 * 
 // forward images of three tiles (72 + 81 KB) leave 7 KB: the heads' partial sums overlay the layer-input images (one more
 // barrier behind color_linear), and in the backward pass the F-form images of the SECOND encoding group (used once, by
 // color_linear's weight gradients) wait in the workgroup's scratch instead of LDS.
+// Hidden 256 (NB = 8; round 3): EIGHT waves, one output block each, two per SIMD; single-tile rounds only (the two-tile images of
+// eight blocks would need 200 KB), one-tile maps.
+template <int NB> __host__ __device__ constexpr int ws_waves() { return NB > 4 ? 8 : 4; }
 template <int NB, int NT>
 struct LdsWs {
     using I = ImgWs<NB>;
     static_assert(NT >= 1 && NT <= 3, "tiles per round");
     static_assert(NT < 3 || NB == 4, "three-tile rounds: hidden 128");
-    static constexpr int TT = NT < 2 ? 2 : NT;                             // tile slots of the maps
+    static_assert(NB <= 4 || NT == 1, "hidden 256: single-tile rounds");
+    static constexpr int NWV = ws_waves<NB>(), NTH = 64 * NWV;             // waves / threads of a workgroup
+    static constexpr int TT = NB > 4 ? 1 : NT < 2 ? 2 : NT;                // tile slots of the maps
     static constexpr bool WIDE3 = NT == 3;
     static constexpr bool HP_ALIAS = WIDE3, EF2_GLOBAL = WIDE3;
     static constexpr int XCH = I::XCH, DCH = I::DCH;
     static constexpr int ACT_ST = I::ACT_ST, E_ST = I::E_ST, E2_OFF = I::E2_OFF, DLT_ST = I::DLT_ST, XF_ST = I::XF_ST;
     static constexpr int EF_BLOCKS = EF2_GLOBAL ? 3 : 5, EF_ST = EF_BLOCKS * 4096;  // encoding F-form blocks per tile held in LDS
-    static constexpr int TILES_BYTES = kWaves * Img32s::TILE;             // one transpose tile per wave
-    static constexpr int HP_BYTES = kWaves * TT * 32 * 4 * 4, CB_BYTES = 32 * TT * 8 * 4;
+    static constexpr int TILES_BYTES = NWV * Img32s::TILE;                // one transpose tile per wave
+    static constexpr int HP_BYTES = NWV * TT * 32 * 4 * 4, CB_BYTES = 32 * TT * 8 * 4;
+    // two regions that the forward and the backward images share (all forms but three-tile rounds)
+    static constexpr int R0 = TT * ACT_ST > TT * EF_ST ? TT * ACT_ST : TT * EF_ST;
+    static constexpr int R1 = TT * E_ST > TT * (DLT_ST + XF_ST) ? TT * E_ST : TT * (DLT_ST + XF_ST);
     // forward
     static constexpr int ACT = 0;
-    static constexpr int EIM = WIDE3 ? TT * ACT_ST : I::EIM;
+    static constexpr int EIM = WIDE3 ? TT * ACT_ST : R0;
     // backward
     static constexpr int EF = 0;
-    static constexpr int SCRT = WIDE3 ? EF + TT * EF_ST : I::SCRT;
-    static constexpr int DLT = WIDE3 ? SCRT + TILES_BYTES : I::DLT;
+    static constexpr int SCRT = WIDE3 ? EF + TT * EF_ST : EIM + R1;
+    static constexpr int DLT = WIDE3 ? SCRT + TILES_BYTES : EIM;
     static constexpr int XF = DLT + TT * DLT_ST;
-    static constexpr int HP = WIDE3 ? ACT : I::HP;
-    static constexpr int CBO = WIDE3 ? EIM + TT * E_ST : I::CBO;
+    static constexpr int HP = WIDE3 ? ACT : SCRT + TILES_BYTES;
+    static constexpr int CBO = WIDE3 ? EIM + TT * E_ST : HP + HP_BYTES;
     static constexpr int LOSS = CBO + CB_BYTES;
-    static constexpr int LDS_BYTES = LOSS + kWaves * 4 * 4;
+    static constexpr int LDS_BYTES = LOSS + NWV * 4 * 4;
     static_assert(!WIDE3 || XF + TT * XF_ST <= CBO, "backward images end in front of the composite buffer");
-    static_assert(WIDE3 || (LOSS == I::LOSS && LDS_BYTES == I::LDS_BYTES), "NT <= 2: the map of ImgWs");
+    static_assert(WIDE3 || NB > 4 || (EIM == I::EIM && SCRT == I::SCRT && LOSS == I::LOSS && LDS_BYTES == I::LDS_BYTES), "NT <= 2: the map of ImgWs");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-    static constexpr int kPts = 32 * (NT < 2 ? 2 : NT);                    // sample-point slots of a round's composite buffer
-    // scratch per workgroup: cos factors [tile][66][lane]; activation planes [layer][tile][plane][step][256 threads][16 B];
+    static constexpr int kPts = 32 * TT;                                   // sample-point slots of a round's composite buffer
+    // scratch per workgroup: cos factors [tile][66][lane]; activation planes [layer][tile][plane][step][threads][16 B];
     // (three-tile rounds) F-form images of the second encoding group [tile][2][4 KiB]
+    static constexpr int CHUNK = NTH * 16;                                 // one 16-deep step of an activation plane, all threads
     static constexpr int CF_BYTES = TT * 66 * 64 * 4;
     static constexpr int ACTS_OFF = (CF_BYTES + 4095) / 4096 * 4096;
-    static constexpr int EF2_OFF = ACTS_OFF + 5 * TT * 2 * 2 * 4096;
+    static constexpr int EF2_OFF = ACTS_OFF + 5 * TT * 2 * 2 * CHUNK;
     static constexpr int WG_SCRATCH = EF2_OFF + (EF2_GLOBAL ? TT * 2 * 4096 : 0);
-    static_assert(WIDE3 || (ACTS_OFF == I::ACTS_OFF && WG_SCRATCH == I::WG_SCRATCH), "NT <= 2: the scratch map of ImgWs");
+    static_assert(WIDE3 || NB > 4 || (ACTS_OFF == I::ACTS_OFF && WG_SCRATCH == I::WG_SCRATCH), "NT <= 2: the scratch map of ImgWs");
 };
 constexpr int kWsScratchMax = LdsWs<4, 3>::WG_SCRATCH;                  // the largest of the forms (host-side sizing)
-static_assert(kWsScratchMax >= ImgWs<4>::WG_SCRATCH && kWsScratchMax >= ImgWs<2>::WG_SCRATCH, "scratch sizing");
+static_assert(kWsScratchMax >= ImgWs<4>::WG_SCRATCH && kWsScratchMax >= ImgWs<2>::WG_SCRATCH && kWsScratchMax >= LdsWs<8, 1>::WG_SCRATCH, "scratch sizing");
 
 struct WsArgs {
     StepArgs s;
@@ -562,21 +571,21 @@ __device__ __forceinline__ void put_image(char* img, const unsigned (&h)[8], con
 }
 // the activation planes in the workgroup's scratch: ubase = scratch + ACTS_OFF (uniform), voff = tid * 16; chunk
 // ((layer * 2 + st) * 2 + plane) * 2 + step
-template <int TT = 2>
+template <int TT = 2, int CH = 4096>
 __device__ __forceinline__ void acts_store(char* ubase, unsigned voff, int layer, int st, const unsigned (&h)[8], const unsigned (&m)[8]) {
-    char* q = ubase + (layer * TT + st) * 4 * 4096;
+    char* q = ubase + (layer * TT + st) * 4 * CH;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-        *reinterpret_cast<u32x4*>(q + s * 4096 + voff) = u32x4{h[4 * s], h[4 * s + 1], h[4 * s + 2], h[4 * s + 3]};
-        *reinterpret_cast<u32x4*>(q + (2 + s) * 4096 + voff) = u32x4{m[4 * s], m[4 * s + 1], m[4 * s + 2], m[4 * s + 3]};
+        *reinterpret_cast<u32x4*>(q + s * CH + voff) = u32x4{h[4 * s], h[4 * s + 1], h[4 * s + 2], h[4 * s + 3]};
+        *reinterpret_cast<u32x4*>(q + (2 + s) * CH + voff) = u32x4{m[4 * s], m[4 * s + 1], m[4 * s + 2], m[4 * s + 3]};
     }
 }
-template <int TT = 2>
+template <int TT = 2, int CH = 4096>
 __device__ __forceinline__ void acts_load_plane(unsigned (&h)[8], const char* ubase, unsigned voff, int layer, int st, int plane) {
-    const char* q = ubase + ((layer * TT + st) * 2 + plane) * 2 * 4096;
+    const char* q = ubase + ((layer * TT + st) * 2 + plane) * 2 * CH;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-        const u32x4 v = ldgu(q + s * 4096, voff);
+        const u32x4 v = ldgu(q + s * CH, voff);
         h[4 * s] = v[0]; h[4 * s + 1] = v[1]; h[4 * s + 2] = v[2]; h[4 * s + 3] = v[3];
     }
 }
@@ -718,10 +727,11 @@ __device__ __forceinline__ void dw_layer(const unsigned (&dF)[ND][16], bool firs
 // ONE: every workgroup runs exactly ONE round (NW = NG: the plans of the latency-bound batches) - `first` is a constant, the
 // read-modify-write form of the gradient stores and the round loop disappear.
 template <int NB, bool BWD, bool W3, bool STAMPS = false, int NT = 2, bool ONE = false>
-__global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
-    static_assert(NB == 4 || NB == 2, "one output block per wave, at most four");
+__global__ __launch_bounds__(64 * ws_waves<NB>(), 1) void step_main_ws(const WsArgs ga) {
+    static_assert(NB == 8 || NB == 4 || NB == 2, "one output block per wave: hidden 64 / 128 on four waves, 256 on eight");
     using I = ImgWs<NB>;
     using LD = LdsWs<NB, NT>;                                            // LDS / scratch maps of this form
+    constexpr int NWV = LD::NWV, NTH = LD::NTH;
     constexpr int H = I::H, JS = I::JS;
     const StepArgs& a = ga.s;
     const GenLayout L = gen_layout(H);
@@ -731,14 +741,14 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     const char* gimg = reinterpret_cast<const char*>(a.wimg) + (long long)obj * I::BYTES;
     const float* SM = reinterpret_cast<const float*>(gimg + I::SMALL_OFF);
     float* loss_cells = reinterpret_cast<float*>(lds + LD::LOSS);
-    if (tid_k < kWaves * 4) loss_cells[tid_k] = 0.0f;
+    if (tid_k < NWV * 4) loss_cells[tid_k] = 0.0f;
     float* out_k = a.part_grad + ((long long)(obj * a.NW + wgo)) * a.PP;
     float* cb = reinterpret_cast<float*>(lds + LD::CBO);
     float* hp = reinterpret_cast<float*>(lds + LD::HP);
     const float scale = a.pe_scale.p[obj * a.pe_scale.stride];
     const float* Bg = SM + I::PE_B;
     char* wgs_k = ga.scratch + (long long)blockIdx.x * LD::WG_SCRATCH;
-    unsigned* tmark = STAMPS && a.timing ? a.timing + ((long long)blockIdx.x * kWaves + (tid_k >> 6)) * kMarks : nullptr;
+    unsigned* tmark = STAMPS && a.timing ? a.timing + ((long long)blockIdx.x * NWV + (tid_k >> 6)) * kMarks : nullptr;
 #define WS_MARK(i) do { if constexpr (STAMPS) { if (tmark && first && (tid_k & 63) == 0) tmark[i] = wv::clock32(); } } while (0)
 #define WS_DMARK(i) do { } while (0)
 
@@ -759,9 +769,9 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     const unsigned tid16 = (unsigned)tid * 16u;
     const int lo16 = lane * 16;
     const unsigned vlo16 = (unsigned)lane * 16u;
-    const bool own = NB == 4 || wave < NB;                               // this wave owns output block `wave` of every layer (NB = 4: all four, known at compile time)
+    const bool own = NB >= NWV || wave < NB;                             // this wave owns output block `wave` of every layer (NB = 4, 8: all of them, known at compile time)
     __syncthreads();                                                     // previous round done with LDS
-    for (int i = tid; i < LD::kPts * 8; i += kWG) cb[i] = 0.0f;
+    for (int i = tid; i < LD::kPts * 8; i += NTH) cb[i] = 0.0f;
     const int ray0 = grp * a.G;
     const int nrays = min(a.G, a.R - ray0);
     const int npts = nrays * a.S;                                        // <= 32 NT
@@ -850,7 +860,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
         if (wave < 2) qb = load_point(est_b);
         encode(est_a, wave == 3 ? 1 : 0, qa);
         if (wave < 2) encode(est_b, 1, qb);
-    } else if (NT == 2 || (wave & 1) == 0) {                             // single-tile rounds: the waves of tile 1 have no encoding to do
+    } else if (wave < 4 && (NT == 2 || (wave & 1) == 0)) {               // single-tile rounds: the waves of tile 1 have no encoding to do
         encode(wave & 1, wave >> 1, load_point(wave & 1));
     }
     __syncthreads();
@@ -896,7 +906,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
             }
             split_planes<16, 3>(hf, ph, pm, pl);
             if (layer < 4) put_image<3, I::XCH>(act_own + st * LD::ACT_ST, ph, pm, pl);
-            if (BWD) acts_store<LD::TT>(acts, tid16, layer, st, ph, pm);
+            if (BWD) acts_store<LD::TT, LD::CHUNK>(acts, tid16, layer, st, ph, pm);
         }
     };
     auto wchunk = [&](int base, int ks, int s) { return gW + ((long long)(base + wave * ks + s)) * I::XCH; };     // wave-uniform
@@ -965,7 +975,9 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 v[c] = hp[((0 * LD::TT + wave) * 32 + p31) * 4 + c] + hp[((1 * LD::TT + wave) * 32 + p31) * 4 + c];
-                if (NB == 4) v[c] += hp[((2 * LD::TT + wave) * 32 + p31) * 4 + c] + hp[((3 * LD::TT + wave) * 32 + p31) * 4 + c];
+                if (NB >= 4) v[c] += hp[((2 * LD::TT + wave) * 32 + p31) * 4 + c] + hp[((3 * LD::TT + wave) * 32 + p31) * 4 + c];
+                if (NB == 8) v[c] += (hp[((4 * LD::TT + wave) * 32 + p31) * 4 + c] + hp[((5 * LD::TT + wave) * 32 + p31) * 4 + c]) +
+                                     (hp[((6 * LD::TT + wave) * 32 + p31) * 4 + c] + hp[((7 * LD::TT + wave) * 32 + p31) * 4 + c]);
             }
             float* row = cb + pt * 8;
             row[6] = zv;
@@ -978,7 +990,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     __syncthreads();
     {
         const StepArgs& al = wv::kernarg_late(ga).s;
-        composite_phase<BWD>(al, cb, loss_cells, obj, ray0, nrays, wave, lane, tid, rmeta);
+        composite_phase<BWD, NWV>(al, cb, loss_cells, obj, ray0, nrays, wave, lane, tid, rmeta);
     }
     __syncthreads();
     WS_MARK(7);
@@ -987,7 +999,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     unsigned ah[kWsT][8], am[kWsT][8];                                         // planes of an activation block coming back from the scratch
     auto fetch = [&](int layer) {
 #pragma unroll
-        for (int st = 0; st < NT; ++st) { acts_load_plane<LD::TT>(ah[st], acts, tid16, layer, st, 0); acts_load_plane<LD::TT>(am[st], acts, tid16, layer, st, 1); }
+        for (int st = 0; st < NT; ++st) { acts_load_plane<LD::TT, LD::CHUNK>(ah[st], acts, tid16, layer, st, 0); acts_load_plane<LD::TT, LD::CHUNK>(am[st], acts, tid16, layer, st, 1); }
         wv::sched_fence();
     };
     if (own) fetch(3);                                                   // h4: lands during the encoding transposes
@@ -1002,7 +1014,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
         char* ef = lds + LD::EF + lo16;
 #pragma unroll
         for (int j = 0; j < 5 * NT; ++j) {
-            if ((j & 3) != wave) continue;
+            if (j % NWV != wave) continue;
             const int st = j / 5, eb = j - 5 * st;
             const char* src = eb < 3 ? e1x + st * LD::E_ST + 2 * eb * I::XCH : e2x + st * LD::E_ST + 2 * (eb - 3) * I::XCH;
             unsigned h[8], m[8], f[16];
@@ -1167,7 +1179,7 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     WS_MARK(9);
     WS_DMARK(0);
     // color_linear: weight gradients (h4 blocks, second-group blocks + bias column), d-prop -> d h4 (+ W_a d raw), d(second group)
-    constexpr int EC0 = NB == 4 ? 0 : 2, EC1 = NB == 4 ? 1 : 3;          // the waves that d-prop color_linear's two encoding blocks
+    constexpr int EC0 = NB >= 4 ? 0 : 2, EC1 = NB >= 4 ? 1 : 3;          // the waves that d-prop color_linear's two encoding blocks
     if (own) tpre_load<W3>(tp, hidden_ptr(I::CT_C), vlo16);
     if (wave == EC0) enc_fetch(I::CT_C + (NB + 0) * JS, 2, 0);
     if (wave == EC1) enc_fetch(I::CT_C + (NB + 1) * JS, 2, 1);
@@ -1323,8 +1335,10 @@ __global__ __launch_bounds__(kWG, 1) void step_main_ws(const WsArgs ga) {
     if (tid_k == 0) {
         float* pl = a.part_loss + (obj * a.NW + wgo) * 4;
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
+        for (int k = 0; k < 3; ++k) {
             pl[k] = (loss_cells[k] + loss_cells[4 + k]) + (loss_cells[8 + k] + loss_cells[12 + k]);
+            if (NWV == 8) pl[k] += (loss_cells[16 + k] + loss_cells[20 + k]) + (loss_cells[24 + k] + loss_cells[28 + k]);
+        }
         pl[3] = 0.0f;
     }
 }
