@@ -217,8 +217,9 @@ def main():
         bloc = tuple(torch.from_numpy(np.ascontiguousarray(bframe[k][0][idx])).to(dev) for k in ("pcs", "z", "gt_depth", "gt_rgb", "sem", "depth_mask"))
         bg_stream = torch.cuda.Stream(device=dev)
         with torch.cuda.stream(bg_stream):
-            bg_group = td.new_group() if world > 1 else None          # its own communicator: independent of the objects' flag reduction
-            bg = parallel.SharedBackgroundHip(bfc, bpe, bR, bcfg["S"], dev, max_steps=ipf, group=bg_group)
+            # the default group for both stacks: ONE communicator, so collectives execute in the order every rank issues them
+            # (objects' flag reduction first, then the background frame's) - no two communicators in flight at once
+            bg = parallel.SharedBackgroundHip(bfc, bpe, bR, bcfg["S"], dev, max_steps=ipf)
         bg_info = {"hidden": bcfg["H"], "rays_per_step_all_ranks": bR * world, "rays_per_step_this_rank": bR, "samples_per_ray": bcfg["S"],
                    "collectives": "per frame: one all_reduce(SUM) of the [steps, 4] mask counts; per step: ONE all_reduce(SUM) of "
                                   f"[gradient slab | loss terms] = {bg.buf.numel() * 4} bytes between two launches "
@@ -234,8 +235,7 @@ def main():
             fork.record(cur)
             bg_stream.wait_event(fork)
             # The objects' frame call is ISSUED first: its one collective (the flag reduction) must not queue behind the
-            # background frame's 1 + k all-reduces (the background has its own process group, and the host order is the same
-            # on every rank, so the two communicators cannot cross).
+            # background frame's 1 + k all-reduces (one communicator: collectives run in issue order, the same on every rank).
             if bound is not None:
                 bound.train_steps(k)
             else:
