@@ -380,8 +380,8 @@ def main():
             elif args.config == "replica_room0_vmap":
                 pmc_file, key = "r01m_pmc_counters.json", "hbm_traffic_bytes_per_launch_step_main"
             elif args.config == "background" and args.kernel == "auto" and args.weights == "f32":
-                # three-tile rounds (the automatic plan): r03x; the round-2 plan (--ws-flags 4): r03q
-                pmc_file, key = ("r03x_pmc_counters_background_ws.json" if ws_nt == 3 else "r03q_pmc_counters_background_ws.json"), "hbm_traffic_bytes_per_launch_step_main_ws"
+                # three-tile rounds (the automatic plan): r04g; the round-2 plan (--ws-flags 4): r03q
+                pmc_file, key = ("r04g_pmc_counters_background_ws.json" if ws_nt == 3 else "r03q_pmc_counters_background_ws.json"), "hbm_traffic_bytes_per_launch_step_main_ws"
             if pmc_file:
                 with open(os.path.join(ROOT, "profiles", pmc_file)) as fh:
                     traffic = json.load(fh)["_notes"][key]
@@ -411,10 +411,18 @@ def main():
             nt = ws_nt
             rounds_total = n * ((R + (32 * nt // S) - 1) // (32 * nt // S))
             rounds_per_wg = -(-rounds_total // 256)
-            floor_us = rounds_per_wg * (1185 * 32 + 6149 * 4.8) * (nt / 2.0) / 2400.0
-            floor_note = (f"{rounds_per_wg} round(s) per workgroup x (1185 matrix x 32 clk + 6149 vector x 4.8 clk per wave and 64-point round"
-                          + (f", x {nt}/2 for {nt}-tile rounds" if nt != 2 else "") + ") at 2.4 GHz: issue time only; the round's LDS (~38 k clk) and "
-                          "vector-memory (~35-45 k clk) phases run in between, not underneath (DESIGN 3.1f)")
+            if nt == 3:
+                # the three-tile single-round form, counted afresh (profiles/r04g_pmc_counters_background_ws.json): 1778 matrix +
+                # 7535 vector instructions per wave and 96-point round
+                floor_us = rounds_per_wg * (1778 * 32 + 7535 * 4.8) / 2400.0
+                floor_note = (f"{rounds_per_wg} round(s) per workgroup x (1778 matrix x 32 clk + 7535 vector x 4.8 clk per wave and 96-point round, hardware "
+                              "counters of this kernel form) at 2.4 GHz: issue time only; the round's LDS and vector-memory phases run in between, not "
+                              "underneath (DESIGN 3.1f)")
+            else:
+                floor_us = rounds_per_wg * (1185 * 32 + 6149 * 4.8) * (nt / 2.0) / 2400.0
+                floor_note = (f"{rounds_per_wg} round(s) per workgroup x (1185 matrix x 32 clk + 6149 vector x 4.8 clk per wave and 64-point round"
+                              + (f", x {nt}/2 for {nt}-tile rounds" if nt != 2 else "") + ") at 2.4 GHz: issue time only; the round's LDS (~38 k clk) and "
+                              "vector-memory (~35-45 k clk) phases run in between, not underneath (DESIGN 3.1f)")
         # forward+backward only (no optimiser), same loop structure
         gfc = [torch.zeros_like(t) for t in tfc]
         gB = torch.zeros_like(tB)
