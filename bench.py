@@ -338,7 +338,7 @@ def main():
                                                              # the quantity a rocprofv3 --kernel-trace reports per dispatch (profiles/)
         k_ms_pair = sum(p[1] for p in pairs) / reps          # a pair of stream events around the launch (includes the events' own cost)
         split = H == 32 and args.kernel != "f32"
-        ws8 = H == 256 and S <= 32 and args.kernel in ("auto", "ws1") and (args.kernel == "ws1" or n * ((R + max(32 // S, 1) - 1) // max(32 // S, 1)) <= 256)
+        ws8 = H == 256 and S <= 32 and args.kernel in ("auto", "ws1")
         wsk = (H in (64, 128) and args.kernel in ("auto", "ws1", "wp") and S <= 64) or ws8
         wp = wsk and (args.kernel == "wp" or (args.kernel == "auto" and H == 64))
         # tiles per round of step_main_ws (the launch plan's rule, vmapstep.hip make_plan)

@@ -108,13 +108,15 @@ def test_kernel_choice_per_width_shows_in_the_workspace_plan():
         assert need(sh, _lib.KERNEL_WS1)[0] != 0
         assert b"WS1" in lib.vmapstep_last_error()
     assert need(_lib.Shape(1, 100, 14, 256, 0), _lib.KERNEL_WP)[0] != 0
-    # hidden 256: the automatic plan = the eight-wave step_main_ws for 50 tiles, the exact-fp32 kernels for 3000
-    rc_a, auto = need(_lib.Shape(1, 100, 14, 256, 0))
-    rc_1, ws1 = need(_lib.Shape(1, 100, 14, 256, 0), _lib.KERNEL_WS1)
-    rc_g, gen = need(_lib.Shape(1, 100, 14, 256, 0), _lib.KERNEL_GEN)
-    assert (rc_a, rc_1, rc_g) == (0, 0, 0) and auto == ws1 and auto != gen
-    rc_a, auto = need(_lib.Shape(1, 6000, 14, 256, 0))
-    rc_g, gen = need(_lib.Shape(1, 6000, 14, 256, 0), _lib.KERNEL_GEN)
+    # hidden 256 with short rays: the automatic plan = the eight-wave step_main_ws (one round per workgroup for 50 tiles, several for
+    # the reference's 4800-ray iMAP batch); long rays: the exact-fp32 kernels
+    for R in (100, 4800):
+        rc_a, auto = need(_lib.Shape(1, R, 14, 256, 0))
+        rc_1, ws1 = need(_lib.Shape(1, R, 14, 256, 0), _lib.KERNEL_WS1)
+        rc_g, gen = need(_lib.Shape(1, R, 14, 256, 0), _lib.KERNEL_GEN)
+        assert (rc_a, rc_1, rc_g) == (0, 0, 0) and auto == ws1 and auto != gen
+    rc_a, auto = need(_lib.Shape(1, 100, 40, 256, 0))
+    rc_g, gen = need(_lib.Shape(1, 100, 40, 256, 0), _lib.KERNEL_GEN)
     assert (rc_a, rc_g) == (0, 0) and auto == gen
 
 

@@ -177,12 +177,14 @@ def test_hidden128_kernel_matches_oracle_on_seeded_shapes(n, R, S, seed, H):
         assert relerr(w2[k], e[k]) < 1e-4, k
 
 
-@pytest.mark.parametrize("n,R,S,seed", [(1, 1, 14, 21), (3, 9, 14, 22), (2, 37, 10, 23), (1, 21, 3, 24), (2, 7, 20, 25), (1, 5, 32, 26), (1, 100, 14, 27)])
+@pytest.mark.parametrize("n,R,S,seed", [(1, 1, 14, 21), (3, 9, 14, 22), (2, 37, 10, 23), (1, 21, 3, 24), (2, 7, 20, 25), (1, 5, 32, 26), (1, 100, 14, 27),
+                                        (1, 600, 14, 28)])
 def test_hidden256_kernel_matches_oracle_on_seeded_shapes(n, R, S, seed):
-    """step_main_ws<8> (hidden 256, eight waves, single-tile rounds: the automatic choice while every round gets a compute unit) on
+    """step_main_ws<8> (hidden 256, eight waves, single-tile rounds: the automatic choice for rays of at most 32 samples) on
     ragged shapes - single ray, partly filled tiles, one ray per round (S = 20, 32 = its limit), long rays through the general
-    compositing path, several objects - against the oracle with its ReLU kinks accounted for, the exact-fp32 general kernel,
-    and itself with several rounds per workgroup."""
+    compositing path, several objects, more rounds than compute units (600 rays = 300 rounds: 150 workgroups x 2, the
+    multi-round form) - against the oracle with its ReLU kinks accounted for, the exact-fp32 general kernel, and itself with
+    several rounds per workgroup."""
     H = 256
     fc, B, sc = synth.make_params(n, H, seed=500 + seed)
     batch = synth.make_batch(n, R, S, seed=600 + seed)

@@ -160,12 +160,11 @@ int make_plan(const vmapstep_shape* sh, int max_steps, Plan& pl, const Layout& L
         else if (force == VMAPSTEP_KERNEL_WS1) pl.wide = 3;
         else if (force == VMAPSTEP_KERNEL_WP) pl.wide = 4;
     }
-    // hidden 256 (the iMAP field): step_main_ws<8> - eight waves, single-tile rounds - when every round gets a compute unit of its
-    // own (one round per workgroup); larger batches stay on the exact-fp32 kernels
-    if (pl.generic && sh->hidden == 256 && sh->samples <= 32 && (force == VMAPSTEP_KERNEL_AUTO || force == VMAPSTEP_KERNEL_WS1)) {
-        const int g1 = std::min(32 / sh->samples, sh->rays);
-        if (force == VMAPSTEP_KERNEL_WS1 || (long long)sh->n_obj * ((sh->rays + g1 - 1) / g1) <= 256) pl.wide = 3;
-    }
+    // hidden 256 (the iMAP field): step_main_ws<8> - eight waves, single-tile rounds.  One round per workgroup while every round
+    // gets a compute unit of its own (the 100-ray configuration: 0.232 -> 0.102 ms per step); with more rounds than compute units
+    // every further round re-reads and re-writes its 1.4 MB gradient row and the step becomes bound by that traffic - still ahead
+    // of the exact-fp32 kernels (the reference's own iMAP batch, 4800 rays: 3.50 -> 2.38 ms, profiles/r04i_*)
+    if (pl.generic && sh->hidden == 256 && sh->samples <= 32 && (force == VMAPSTEP_KERNEL_AUTO || force == VMAPSTEP_KERNEL_WS1)) pl.wide = 3;
     if ((force == VMAPSTEP_KERNEL_WS1 || force == VMAPSTEP_KERNEL_WP) && pl.wide < 3)
         return fail(VMAPSTEP_ERR_UNSUPPORTED, "VMAPSTEP_KERNEL_WS1 / _WP: hidden 64 / 128 with at most 64 samples per ray (_WS1 also hidden 256 with at most 32)");
     pl.G = (pl.wide >= 3 ? vk::ImgWs<4>::kPts : pl.wide == 1 ? vk::kWideTile : vk::kMaxPts) / sh->samples;

@@ -132,6 +132,8 @@ def make_batch(n_obj: int, R: int, S: int, seed: int = 1, n_cam2surf: int | None
 # BASELINE.json configs -> (n_obj, R, S, H, scale)
 CONFIGS = {
     "imap_plumbing": dict(n_obj=1, R=100, S=14, H=256, scale=10.0),     # configs[0] as worded
+    "imap_full": dict(n_obj=1, R=4800, S=14, H=256, scale=10.0),        # the reference's own iMAP batch (config_replica_room0_iMAP.json:
+                                                                        # n_per_optim 4800, 9 + 5 bins) - not a BASELINE config; measurement
     "replica_room0_vmap": dict(n_obj=20, R=120, S=10, H=32, scale=2.0),  # configs[1] (headline)
     "scannet0024_vmap": dict(n_obj=50, R=120, S=10, H=32, scale=3.0),    # configs[3] shapes
     "stress_256x64": dict(n_obj=256, R=256, S=10, H=64, scale=2.0),      # configs[4] shapes
