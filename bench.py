@@ -337,29 +337,20 @@ def main():
         k_ms = sum(p[0] for p in pairs) / reps               # the dispatch's own begin -> end timestamps (hipExtLaunchKernel events):
                                                              # the quantity a rocprofv3 --kernel-trace reports per dispatch (profiles/)
         k_ms_pair = sum(p[1] for p in pairs) / reps          # a pair of stream events around the launch (includes the events' own cost)
-        split = H == 32 and args.kernel != "f32"
-        ws8 = H == 256 and S <= 32 and args.kernel in ("auto", "ws1")
-        wsk = (H in (64, 128) and args.kernel in ("auto", "ws1", "wp") and S <= 64) or ws8
-        wp = wsk and (args.kernel == "wp" or (args.kernel == "auto" and H == 64))
-        # tiles per round of step_main_ws (the launch plan's rule, vmapstep.hip make_plan)
-        ws_nt = 2
-        if wsk and not wp:
-            rounds_of = lambda g: n * ((R + max(g, 1) - 1) // max(g, 1))
-            flags = (1 if args.ws_two_tile else 0) | args.ws_flags
-            if ws8:
-                ws_nt = 1
-            elif H == 128 and flags & 2:
-                ws_nt = 3
-            elif rounds_of(32 // S) <= 256 and 32 // S >= 1 and not flags & 1:
-                ws_nt = 1
-            elif H == 128 and rounds_of(64 // S) > 256 and rounds_of(96 // S) <= 256 and not flags & 4:
-                ws_nt = 3
+        # which kernel ran and how the batch was cut: asked from the library (vmapstep_describe_plan), not re-derived here
+        plan = op.plan()
+        pk = plan["kernel"]
+        split = pk == "step_main_s32"
+        wp = pk.startswith("step_main_wp")
+        wsk = wp or pk.startswith("step_main_ws")
+        ws8 = pk == "step_main_ws<8>"
+        ws_nt = plan["tiles_per_round"] if pk.startswith("step_main_ws") else 2
         kernel_name = ("step_main_s32 (hidden 32: bf16 matrix pipe, split operands: 6 products forward, 3 backward)" if split else
-                       "step_main_h32 (hidden 32: exact-fp32 matrix instruction)" if H == 32 else
+                       "step_main_h32 (hidden 32: exact-fp32 matrix instruction)" if pk == "step_main_h32" else
                        (("step_main_wp" if wp else "step_main_ws") + f" (hidden {H}: bf16 matrix pipe, split operands, {('one', 'two', 'three')[ws_nt - 1]} 32-point "
-                        f"tile{'s' if ws_nt > 1 else ''} per workgroup round, " + ("two waves" if wp else "one wave") + " per output block" + (", eight waves" if ws8 else "") + ")") if wsk else
-                       ("step_main_wide<4>" if (args.kernel == "wide" or (args.kernel == "auto" and H % 128 == 0 and n * ((R + 32 // S - 1) // (32 // S)) <= 256))
-                        else "step_main_gen") + f" (hidden {H}: exact-fp32 matrix instruction)")
+                        f"tile{'s' if ws_nt > 1 else ''} per workgroup round, " + ("two waves" if wp else "one wave") + " per output block" + (", eight waves" if ws8 else "")
+                        + (", one round per workgroup" if plan["single_round"] else f", {plan['rounds_per_object']} rounds on {plan['workgroups_per_object']} workgroups per object") + ")") if wsk else
+                       pk + f" (hidden {H}: exact-fp32 matrix instruction)")
         on_bf16_pipe = split or wsk
         dtype_label = ("f32 I/O, masters, accumulation" + ("" if args.weights == "f32" else " on bf16-rounded run-time weights") +
                        ("; matrix operands split into bf16 planes: forward 6 products (~2^-24, float32-equivalent), backward 3 (~2^-16)"
@@ -409,8 +400,7 @@ def main():
             # the same sum for one 64-point round of step_main_ws (hardware counters, profiles/r02j_pmc_counters_background_ws.json:
             # 1185 matrix + 6149 vector instructions per wave and round), times the rounds the busiest workgroup runs
             nt = ws_nt
-            rounds_total = n * ((R + (32 * nt // S) - 1) // (32 * nt // S))
-            rounds_per_wg = -(-rounds_total // 256)
+            rounds_per_wg = -(-plan["rounds_per_object"] // plan["workgroups_per_object"])
             if nt == 3:
                 # the three-tile single-round form, counted afresh (profiles/r04g_pmc_counters_background_ws.json): 1778 matrix +
                 # 7535 vector instructions per wave and 96-point round
@@ -470,7 +460,7 @@ def main():
                          "executed_pipe": ({"instruction": "v_mfma_f32_32x32x16_bf16", "peak_tflops": BF16_MFMA_PEAK_TFLOPS,
                                             "executed_tflops": executed_tflops, "matrix_instructions_per_launch": mm_per_launch}
                                            if executed_tflops else {"instruction": "v_mfma_f32_32x32x2_f32", "peak_tflops": FP32_MFMA_PEAK_TFLOPS}),
-                         "floor_us": floor_us, "floor_note": floor_note,
+                         "launch_plan": plan, "floor_us": floor_us, "floor_note": floor_note,
                          "traffic": traffic,
                          "traffic_source": ("copied from the committed rocprofv3 --pmc passes of this kernel (profiles/" + pmc_file +
                                             ": separate FETCH_SIZE / WRITE_SIZE passes over tests/tools/run_steps.py, FETCH doubled per MI355X_MICROARCH.md), "

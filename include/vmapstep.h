@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VMAPSTEP_ABI_VERSION 5
+#define VMAPSTEP_ABI_VERSION 6
 #define VMAPSTEP_NUM_FC 14 /* field-MLP tensors per object, nn.Module.parameters() order (model.py:28-49) */
 
 #define VMAPSTEP_OK 0
@@ -147,6 +147,19 @@ int vmapstep_param_layout(int32_t hidden, int64_t sizes[VMAPSTEP_NUM_FC + 1], in
 
 /* Bytes of scratch the calls below need for `shape` and up to `max_steps` steps per call (256-byte aligned). */
 int vmapstep_workspace_bytes(const vmapstep_shape* shape, int32_t max_steps, size_t* bytes);
+
+/* The launch plan the library derives from `shape` (and its tuning): which fused-step kernel runs and how the batch is cut
+ * into workgroups.  Diagnostics (ABI v6): logging, benchmarks and tests ask instead of re-deriving the rules; no device needed. */
+typedef struct vmapstep_plan_info {
+    char kernel[48];               /* e.g. "step_main_s32", "step_main_ws<4>", "step_main_wp<2>", "step_main_gen"            */
+    int32_t rays_per_round;        /* rays a workgroup takes per round (pass)                                                 */
+    int32_t rounds_per_object;     /* ceil(rays / rays_per_round)                                                             */
+    int32_t workgroups_per_object; /* = partial-gradient rows per object the finalize sums                                    */
+    int32_t tiles_per_round;       /* step_main_ws: 32-point tiles per round (1, 2 or 3); other kernels: 0                    */
+    int32_t waves_per_workgroup;
+    int32_t single_round;          /* 1: every workgroup runs exactly one round (the specialised kernel forms apply)          */
+} vmapstep_plan_info;
+int vmapstep_describe_plan(const vmapstep_shape* shape, int32_t max_steps, vmapstep_plan_info* info);
 
 /* One step of train.py:293-306 + :324: loss and the gradients of all 15 stacked tensors (written to `grads`,
  * which has the layout of `params`; replaces loss.backward() populating p.grad). */

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in _declared_functions():
         assert hasattr(lib, name), name
-    assert lib.vmapstep_abi_version() == 5
+    assert lib.vmapstep_abi_version() == 6
 
 
 @pytest.mark.parametrize("H", [32, 64, 128, 256])
@@ -129,3 +129,38 @@ def test_adamw_apply_checks_its_arguments_without_a_device():
     assert b"params" in lib.vmapstep_last_error()
     assert lib.vmapstep_adamw_apply(ctypes.byref(sh), None, None, 0, None, None, -1, 5.0, 10.0, None, None, 0, None) == -1
     assert b"step_index" in lib.vmapstep_last_error()
+
+
+def test_launch_plans_of_the_baseline_shapes():
+    """vmapstep_describe_plan (ABI v6): the plan rules pinned on the shapes the repository quotes - which fused-step kernel runs, how
+    many rays a round takes, how many workgroups (= partial-gradient rows) an object gets, and whether every workgroup runs exactly
+    one round (the specialised kernel forms).  No device needed."""
+    P = _lib.describe_plan
+    p = P(20, 120, 10, 32)                                   # BASELINE configs[1], the headline: 12 rays per workgroup, one pass
+    assert (p["kernel"], p["rays_per_round"], p["workgroups_per_object"], p["single_round"]) == ("step_main_s32", 12, 10, 1)
+    assert P(20, 120, 10, 32, tuning={"kernel": _lib.KERNEL_H32_F32})["kernel"] == "step_main_h32"
+    p = P(50, 120, 10, 32, weights_bf16=True)                # configs[3]: five workgroups per object, two passes each
+    assert (p["kernel"], p["workgroups_per_object"], p["rounds_per_object"], p["single_round"]) == ("step_main_s32", 5, 10, 0)
+    p = P(256, 256, 10, 64, weights_bf16=True)               # configs[4]: two workgroups per object (two per compute unit), 21-22 rounds each
+    assert (p["kernel"], p["rays_per_round"], p["workgroups_per_object"], p["rounds_per_object"], p["waves_per_workgroup"]) == ("step_main_wp<2>", 6, 2, 43, 4)
+    # the background model (hidden 128, 14 samples): tiles per round by batch size
+    p = P(1, 1200, 14, 128)                                  # one GPU: 300 two-tile rounds > 256 compute units -> 200 three-tile rounds
+    assert (p["kernel"], p["tiles_per_round"], p["rays_per_round"], p["workgroups_per_object"], p["single_round"]) == ("step_main_ws<4>", 3, 6, 200, 1)
+    p = P(1, 1200, 14, 128, tuning={"ws_flags": 4})          # the round-2 plan: 150 workgroups x two two-tile rounds
+    assert (p["tiles_per_round"], p["rays_per_round"], p["workgroups_per_object"], p["rounds_per_object"], p["single_round"]) == (2, 4, 150, 300, 0)
+    p = P(1, 600, 14, 128)                                   # 2 ranks: 150 two-tile rounds, one each
+    assert (p["tiles_per_round"], p["workgroups_per_object"], p["single_round"]) == (2, 150, 1)
+    for R, rounds in ((300, 150), (150, 75)):                # 4 / 8 ranks: every tile gets a compute unit -> single-tile rounds
+        p = P(1, R, 14, 128)
+        assert (p["tiles_per_round"], p["rays_per_round"], p["workgroups_per_object"], p["single_round"]) == (1, 2, rounds, 1)
+    assert P(1, 150, 14, 128, tuning={"ws_flags": 1})["tiles_per_round"] == 2
+    assert P(1, 150, 14, 128, tuning={"ws_flags": 2})["tiles_per_round"] == 3
+    # hidden 256 (the iMAP field): eight waves, single-tile rounds; long rays -> the exact-fp32 kernels
+    p = P(1, 100, 14, 256)
+    assert (p["kernel"], p["tiles_per_round"], p["waves_per_workgroup"], p["workgroups_per_object"], p["single_round"]) == ("step_main_ws<8>", 1, 8, 50, 1)
+    p = P(1, 4800, 14, 256)
+    assert (p["kernel"], p["workgroups_per_object"], p["rounds_per_object"], p["single_round"]) == ("step_main_ws<8>", 240, 2400, 0)   # ten rounds each: evenly spread
+    assert P(1, 100, 40, 256)["kernel"] in ("step_main_wide<4>", "step_main_gen")
+    assert P(1, 100, 14, 96)["kernel"] == "step_main_gen"
+    with pytest.raises(_lib.VmapStepError):
+        P(1, 100, 14, 48)

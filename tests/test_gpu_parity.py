@@ -69,7 +69,7 @@ def h32_kernel(request):
 
 def test_native_library_is_loaded():
     lib = _lib.load()
-    assert lib.vmapstep_abi_version() == _lib.ABI_VERSION == 5
+    assert lib.vmapstep_abi_version() == _lib.ABI_VERSION == 6
     assert torch.cuda.is_available()
     assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
 

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VMAPSTEP_LIBRARY", os.path.join(_HERE, "libvmapstep.so"))   # override: measurement builds only
 
 NUM_FC = 14
-ABI_VERSION = 5
+ABI_VERSION = 6
 WEIGHTS_F32, WEIGHTS_BF16 = 0, 1
 
 
@@ -29,6 +29,13 @@ class Shape(ctypes.Structure):
     _fields_ = [("n_obj", ctypes.c_int32), ("rays", ctypes.c_int32), ("samples", ctypes.c_int32),
                 ("hidden", ctypes.c_int32), ("weight_dtype", ctypes.c_int32), ("reserved", ctypes.c_int32),
                 ("tuning", ctypes.POINTER(Tuning))]
+
+
+class PlanInfo(ctypes.Structure):
+    """vmapstep_plan_info (ABI v6): the launch plan the library derives from a shape."""
+    _fields_ = [("kernel", ctypes.c_char * 48), ("rays_per_round", ctypes.c_int32), ("rounds_per_object", ctypes.c_int32),
+                ("workgroups_per_object", ctypes.c_int32), ("tiles_per_round", ctypes.c_int32), ("waves_per_workgroup", ctypes.c_int32),
+                ("single_round", ctypes.c_int32)]
 
 
 class Tensor(ctypes.Structure):
@@ -87,7 +94,7 @@ EXPORTS = (
     "vmapstep_profile_main_kernel", "vmapstep_profile_phases", "vmapstep_prepare", "vmapstep_train_steps_prepared",
     "vmapstep_workspace_counts_offset", "vmapstep_fwd_bwd_prepared", "vmapstep_sample_frame",
     "vmapstep_query_workspace_bytes", "vmapstep_query_points", "vmapstep_profile_train_steps", "vmapstep_adamw_apply",
-    "vmapstep_sample_workspace_bytes",
+    "vmapstep_sample_workspace_bytes", "vmapstep_describe_plan",
 )
 
 _lib = None
@@ -154,7 +161,8 @@ def load():
                                             ctypes.POINTER(Batch), ctypes.c_void_p, ctypes.c_size_t,
                                             ctypes.POINTER(ctypes.c_int32), ctypes.c_void_p, ctypes.c_size_t,
                                             ctypes.c_void_p]
-    for fn in ("vmapstep_param_layout", "vmapstep_workspace_bytes", "vmapstep_fwd_bwd", "vmapstep_render",
+    lib.vmapstep_describe_plan.argtypes = [ctypes.POINTER(Shape), ctypes.c_int32, ctypes.POINTER(PlanInfo)]
+    for fn in ("vmapstep_describe_plan", "vmapstep_param_layout", "vmapstep_workspace_bytes", "vmapstep_fwd_bwd", "vmapstep_render",
                "vmapstep_train_steps", "vmapstep_profile_main_kernel",
                "vmapstep_profile_phases", "vmapstep_prepare", "vmapstep_train_steps_prepared",
                "vmapstep_workspace_counts_offset", "vmapstep_fwd_bwd_prepared", "vmapstep_sample_frame",
@@ -165,6 +173,19 @@ def load():
         raise VmapStepError(f"ABI mismatch: library {lib.vmapstep_abi_version()} != binding {ABI_VERSION}")
     _lib = lib
     return lib
+
+
+def describe_plan(n_obj: int, rays: int, samples: int, hidden: int, weights_bf16: bool = False, max_steps: int = 20, tuning: dict = None) -> dict:
+    """The launch plan for a shape as a dict (kernel name, rays per round, rounds / workgroups per object, tiles per round, waves per
+    workgroup, single_round) - no device needed."""
+    lib = load()
+    sh = Shape(n_obj, rays, samples, hidden, WEIGHTS_BF16 if weights_bf16 else WEIGHTS_F32)
+    t = Tuning(**tuning) if tuning else None
+    if t is not None:
+        sh.tuning = ctypes.pointer(t)
+    info = PlanInfo()
+    check(lib.vmapstep_describe_plan(ctypes.byref(sh), max_steps, ctypes.byref(info)))
+    return {"kernel": info.kernel.decode(), **{k: int(getattr(info, k)) for k, _ in PlanInfo._fields_[1:]}}
 
 
 def check(rc: int):

@@ -414,6 +414,31 @@ int vmapstep_workspace_bytes(const vmapstep_shape* shape, int32_t max_steps, siz
     return VMAPSTEP_OK;
 }
 
+int vmapstep_describe_plan(const vmapstep_shape* shape, int32_t max_steps, vmapstep_plan_info* info) {
+    if (!info) return fail(VMAPSTEP_ERR_ARGUMENT, "info is null");
+    if (!shape) return fail(VMAPSTEP_ERR_ARGUMENT, "shape is null");
+    Layout L;
+    make_layout(shape->hidden, L);
+    Plan pl;
+    int rc = make_plan(shape, max_steps, pl, L);
+    if (rc) return rc;
+    std::memset(info, 0, sizeof(*info));
+    const int nb = shape->hidden / 32;
+    if (pl.split) std::snprintf(info->kernel, sizeof(info->kernel), "step_main_s32");
+    else if (!pl.generic) std::snprintf(info->kernel, sizeof(info->kernel), "step_main_h32");
+    else if (pl.wide == 3) std::snprintf(info->kernel, sizeof(info->kernel), "step_main_ws<%d>", nb);
+    else if (pl.wide == 4) std::snprintf(info->kernel, sizeof(info->kernel), "step_main_wp<%d>", nb);
+    else if (pl.wide == 1) std::snprintf(info->kernel, sizeof(info->kernel), "step_main_wide<4>");
+    else std::snprintf(info->kernel, sizeof(info->kernel), "step_main_gen");
+    info->rays_per_round = pl.G;
+    info->rounds_per_object = pl.NG;
+    info->workgroups_per_object = pl.NW;
+    info->tiles_per_round = pl.wide == 3 ? pl.tiles : 0;
+    info->waves_per_workgroup = pl.wide == 3 ? (nb > 4 ? 8 : 4) : pl.wide == 4 ? 2 * nb : 4;
+    info->single_round = pl.NG == pl.NW ? 1 : 0;
+    return VMAPSTEP_OK;
+}
+
 static int fwd_bwd_impl(const vmapstep_shape* shape, const vmapstep_params* params, const vmapstep_tensor* pe_scale,
                         const vmapstep_batch* batch, float color_scaling, float opacity_scaling,
                         const vmapstep_params* grads, const vmapstep_outputs* out,

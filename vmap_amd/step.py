@@ -179,6 +179,13 @@ class VmapStep:
             o.opacity, o.var = res.opacity.data_ptr(), res.var.data_ptr()
         return res, o
 
+    def plan(self) -> dict:
+        """The launch plan of this operator (``vmapstep_describe_plan``): kernel name, rays per round, rounds and workgroups per
+        object, tiles per round, waves per workgroup, single_round."""
+        info = _lib.PlanInfo()
+        _lib.check(self.lib.vmapstep_describe_plan(ctypes.byref(self.shape), self.max_steps, ctypes.byref(info)))
+        return {"kernel": info.kernel.decode(), **{k: int(getattr(info, k)) for k, _ in _lib.PlanInfo._fields_[1:]}}
+
     def _stream(self) -> int:
         # the current stream of THIS operator's device (not of whatever device happens to be current)
         return torch.cuda.current_stream(self.device).cuda_stream
