@@ -370,6 +370,8 @@ def main():
                 pmc_file, key = "r03m_pmc_counters_step_main_s32.json", "hbm_traffic_bytes_per_launch_step_main"
             elif args.config == "replica_room0_vmap":
                 pmc_file, key = "r01m_pmc_counters.json", "hbm_traffic_bytes_per_launch_step_main"
+            elif args.config == "imap_plumbing" and ws8 and args.weights == "f32":
+                pmc_file, key = "r04p_pmc_counters_imap_ws8.json", "hbm_traffic_bytes_per_launch_step_main_ws"
             elif args.config == "background" and args.kernel == "auto" and args.weights == "f32":
                 # three-tile rounds (the automatic plan): r04g; the round-2 plan (--ws-flags 4): r03q
                 pmc_file, key = ("r04g_pmc_counters_background_ws.json" if ws_nt == 3 else "r03q_pmc_counters_background_ws.json"), "hbm_traffic_bytes_per_launch_step_main_ws"
@@ -383,6 +385,9 @@ def main():
         if split:
             per_tile = 288 if args.weights == "f32" else 195
             mm_per_launch = n * ((R + (128 // S) - 1) // (128 // S)) * 4 * per_tile
+        elif ws8 and args.weights == "f32":
+            # 975 matrix instructions per wave and single-tile round (profiles/r04p_pmc_counters_imap_ws8.json), eight waves per round
+            mm_per_launch = n * plan["rounds_per_object"] * 8 * 975
         elif wsk and H == 128:
             gq = (32 * ws_nt) // S
             mm_per_launch = n * ((R + gq - 1) // gq) * 4 * (1185 if args.weights == "f32" else 807) * ws_nt // 2
@@ -396,6 +401,11 @@ def main():
             floor_us = (296 * 32 + 3838 * 4.8) / 2400.0
             floor_note = ("sum of one tile's matrix (296 x 32 clk) and vector (3838 x 4.8 clk) issue time on its SIMD at 2.4 GHz: the part of "
                           "kernel_ms no schedule of this tiling can remove; kernel_ms - floor_us = waits, barriers, issue stalls, launch ramp")
+        if ws8 and args.weights == "f32":
+            rounds_per_wg = -(-plan["rounds_per_object"] // plan["workgroups_per_object"])
+            floor_us = rounds_per_wg * 2 * (975 * 32 + 3418 * 4.8) / 2400.0
+            floor_note = (f"{rounds_per_wg} round(s) per workgroup x 2 waves per SIMD x (975 matrix x 32 clk + 3418 vector x 4.8 clk per wave and 32-point round, "
+                          "hardware counters of this kernel form) at 2.4 GHz: issue time of the busiest SIMD only")
         if wsk and H == 128 and args.weights == "f32" and not wp:
             # the same sum for one 64-point round of step_main_ws (hardware counters, profiles/r02j_pmc_counters_background_ws.json:
             # 1185 matrix + 6149 vector instructions per wave and round), times the rounds the busiest workgroup runs
