@@ -101,6 +101,202 @@ def gpu_eager_baseline(cfg, dev, budget_s=2.0):
                       f"torch {torch.__version__}"}
 
 
+def library_sha256():
+    import hashlib
+    from vmap_amd import _lib
+    try:
+        with open(_lib.LIB_PATH, "rb") as fh:
+            return hashlib.sha256(fh.read()).hexdigest()
+    except Exception:
+        return None
+
+
+def frame_leg(cfg, dev, ipf, obj_batch, reps=20):
+    """One REAL mapping frame of the configuration (`do_bg: 1`, train.py:270-326 + :308-316): the object stack and the
+    hidden-128 background model (1200 rays x 14 samples) through ``driver.HipMapper.train_frame_with_background`` - frames bound
+    once (no per-step Python), two streams, the caller's stream joins both.  Untimed in `value`; reported under `frame`."""
+    from vmap_amd.driver import HipMapper
+    from vmap_amd.trainer import SimpleConfig, Trainer
+    bcfg = synth.CONFIGS["background"]
+    m = HipMapper(SimpleConfig(training_device=str(dev), n_iter_per_frame=ipf), device=dev)
+    torch.manual_seed(3)
+    for _ in range(cfg["n_obj"]):
+        m.add_object(Trainer(SimpleConfig(training_device=str(dev), hidden_feature_size=cfg["H"], obj_scale=cfg["scale"])))
+    m.attach_background(Trainer(SimpleConfig(training_device=str(dev), hidden_feature_size=bcfg["H"], obj_scale=bcfg["scale"])),
+                        bcfg["R"], bcfg["S"])
+    bframe = synth.make_batch(1, bcfg["R"] * ipf, bcfg["S"], seed=77)
+    bg_batch = tuple(torch.from_numpy(bframe[k]).to(dev) for k in ("pcs", "z", "gt_depth", "gt_rgb", "sem", "depth_mask"))
+
+    def timed(fn):
+        for _ in range(3):                           # first call: plain path; second: binds the buffers; third: bound
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    b = m.bg
+    t_obj = timed(lambda: m.train_frame(*obj_batch))
+    t_bg = timed(lambda: m._frame_call("bg", b["op"], b["views"], b["scale"], bg_batch, b["opt"], ipf, bcfg["R"]))
+    t_two = timed(lambda: m.train_frame_with_background(obj_batch, bg_batch))
+    rays = cfg["n_obj"] * cfg["R"]
+    return {"what": f"one mapping frame = {ipf} steps of the {cfg['n_obj']} object fields (hidden {cfg['H']}) AND {ipf} steps of the background field "
+                    f"(hidden {bcfg['H']}, {bcfg['R']} rays x {bcfg['S']} samples) on two streams, driver.HipMapper.train_frame_with_background, "
+                    "frames bound once; host clock around whole frames; not part of `value`",
+            "objects_ms_per_frame": t_obj, "background_ms_per_frame": t_bg, "two_streams_ms_per_frame": t_two,
+            "ms_per_step": t_two / ipf, "object_rays_per_s": rays * ipf / (t_two * 1e-3),
+            "object_plus_background_rays_per_s": (rays + bcfg["R"]) * ipf / (t_two * 1e-3),
+            "background_plan": b["op"].plan()}
+
+
+def background_legs(args, cfg, dev, rank, world, ipf, dist, run_objects, rays_per_step):
+    """The shared background model (train.py:308-316; hidden 128, 1200 rays x 14 samples per step) trained NEXT TO the objects,
+    both ways SURVEY.md 8(e) names, each on its own stream beside the objects' frame calls:
+      ray_sharded    - parallel.SharedBackgroundHip: every rank 1/N of the rays, ONE all-reduce of [gradients | loss terms] per step
+      owner_computes - parallel.OwnerBackgroundHip: rank 0 all the rays with the plain frame call, ONE slab broadcast per frame
+    plus the collective of the first on its own (the measured counterpart of DESIGN.md section 4's prediction).  Every rank calls
+    this (collectives inside); all ranks get the same numbers (MAX over ranks), rank 0 reports them."""
+    import torch.distributed as td
+    from vmap_amd import fields, parallel
+    bcfg = synth.CONFIGS["background"]
+    torch.manual_seed(7)                                              # the same replica on every rank
+    bfc = fields.OccupancyMap(hidden_size=bcfg["H"])
+    bfc.apply(fields.init_weights)
+    bpe = fields.UniDirsEmbed(max_deg=5, scale=bcfg["scale"])
+    bR = bcfg["R"] // world                                           # this rank's share of the background rays of a step
+    bframe = synth.make_batch(1, bcfg["R"] * ipf, bcfg["S"], seed=77)
+    keys = ("pcs", "z", "gt_depth", "gt_rgb", "sem", "depth_mask")
+    idx = np.concatenate([np.arange(i * bcfg["R"] + rank, i * bcfg["R"] + bR * world, world) for i in range(ipf)])
+    bloc = tuple(torch.from_numpy(np.ascontiguousarray(bframe[k][0][idx])).to(dev) for k in keys)
+    bg_stream = torch.cuda.Stream(device=dev)
+    cur = torch.cuda.current_stream(dev)
+
+    def barrier():
+        if dist:
+            td.barrier()
+        torch.cuda.synchronize()
+
+    def timed(frame_fn, steps, warmup):
+        """frame_fn(k): k steps of the leg; host clock between barriers, MAX over ranks -> ms per step"""
+        done = 0
+        while done < warmup:
+            k = min(ipf, warmup - done); frame_fn(k); done += k
+        barrier()
+        t0 = time.perf_counter()
+        done = 0
+        while done < steps:
+            k = min(ipf, steps - done); frame_fn(k); done += k
+        barrier()
+        el = time.perf_counter() - t0
+        if dist:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            td.all_reduce(t, op=td.ReduceOp.MAX)
+            el = float(t.item())
+        return el / steps * 1e3
+
+    def beside_objects(bg_frame):
+        """objects on the current stream, the background frame on its own stream, joined per frame call.  The objects' frame call is
+        ISSUED first: its one collective (the flag reduction) must not queue behind the background frame's collectives (one
+        communicator: collectives run in issue order, the same on every rank)."""
+        def fn(k):
+            fork = torch.cuda.Event(); fork.record(cur)
+            bg_stream.wait_event(fork)
+            run_objects(k)
+            with torch.cuda.stream(bg_stream):
+                bg_frame(k)
+                join = torch.cuda.Event(); join.record(bg_stream)
+            cur.wait_event(join)
+        return fn
+
+    out = {"hidden": bcfg["H"], "rays_per_step_all_ranks": bR * world, "rays_per_step_this_rank": bR, "samples_per_ray": bcfg["S"]}
+    steps, warm = args.steps, args.warmup
+    # ---- ray-sharded replicas ----
+    with torch.cuda.stream(bg_stream):
+        # the default group for both stacks: ONE communicator, so collectives execute in the order every rank issues them
+        bg = parallel.SharedBackgroundHip(bfc, bpe, bR, bcfg["S"], dev, max_steps=ipf)
+
+    def sharded_frame(k):
+        bg.prepare_frame(*bloc, n_steps=k)
+        for i in range(k):
+            bg.step_prepared(i)
+
+    def alone(frame):
+        def fn(k):
+            with torch.cuda.stream(bg_stream):
+                frame(k)
+        return fn
+
+    ms_alone = timed(alone(sharded_frame), steps, warm)
+    ms_beside = timed(beside_objects(sharded_frame), steps, warm)
+    # the step's collective on its own, on the same stream: K all-reduces of the same buffer between two events
+    with torch.cuda.stream(bg_stream):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        K = 200
+        for _ in range(20):
+            if dist:
+                td.all_reduce(bg.buf)
+        e0.record(bg_stream)
+        for _ in range(K):
+            if dist:
+                td.all_reduce(bg.buf)
+        e1.record(bg_stream)
+    barrier()
+    ar_us = e0.elapsed_time(e1) / K * 1e3 if dist else 0.0
+    out["ray_sharded"] = {
+        "collectives": "per frame: one all_reduce(SUM) of the [steps, 4] mask counts; per step: ONE all_reduce(SUM) of "
+                       f"[gradient slab | loss terms] = {bg.buf.numel() * 4} bytes between two launches (forward/backward; AdamW + image rewrite + global loss/flags)",
+        "background_only_ms_per_step": ms_alone, "beside_objects_ms_per_step": ms_beside,
+        "allreduce_alone_us": ar_us, "launch_chain_without_collective_us_predicted": {1: 111.0, 2: 78.5, 4: 66.1, 8: 57.1}.get(world),
+        "predicted_ms_per_step_DESIGN_4": {1: 0.111, 2: 0.105, 4: 0.095, 8: "0.090-0.110"}.get(world),
+        "object_rays_per_s": rays_per_step / (ms_beside * 1e-3),
+        "object_plus_background_rays_per_s": (rays_per_step + bR * world) / (ms_beside * 1e-3),
+        "plan": bg.op.plan()}
+    # ---- owner-computes ----
+    ball = tuple(torch.from_numpy(np.ascontiguousarray(bframe[k][0])).to(dev) for k in keys) if rank == 0 else (None,) * 6
+    with torch.cuda.stream(bg_stream):
+        own = parallel.OwnerBackgroundHip(bfc, bpe, bcfg["R"], bcfg["S"], dev, owner=0, max_steps=ipf)
+    owner_frame = lambda k: own.train_frame(*ball, n_steps=k)
+    ms_alone = timed(alone(owner_frame), steps, warm)
+    ms_beside = timed(beside_objects(owner_frame), steps, warm)
+    out["owner_computes"] = {
+        "collectives": f"per frame: ONE broadcast of the [1, P] parameter slab = {own.slab.numel() * 4} bytes from rank 0; none on the step path",
+        "background_only_ms_per_step": ms_alone, "beside_objects_ms_per_step": ms_beside,
+        "object_rays_per_s": rays_per_step / (ms_beside * 1e-3),
+        "object_plus_background_rays_per_s": (rays_per_step + bcfg["R"]) / (ms_beside * 1e-3),
+        "plan": own.op.plan() if own.op is not None else None}
+    # compatibility with earlier rounds' records: the ray-sharded leg's figures at the top level
+    out.update({"ms_per_step": out["ray_sharded"]["beside_objects_ms_per_step"], "object_rays_per_s": out["ray_sharded"]["object_rays_per_s"],
+                "object_plus_background_rays_per_s": out["ray_sharded"]["object_plus_background_rays_per_s"]})
+    return out
+
+
+class Watchdog:
+    """The legs behind the scored measurement must not be able to lose it: if they have not finished within `seconds` (an RCCL
+    hang in a path that no 8-GPU node has run yet), every rank leaves through here - rank 0 after printing the line it has."""
+
+    def __init__(self, seconds, on_fire):
+        import threading
+        self.t = threading.Timer(seconds, on_fire)
+        self.t.daemon = True
+        self.t.start()
+
+    def cancel(self):
+        self.t.cancel()
+
+
+def emit(out):
+    # RCCL writes its banner through C stdio (buffered when stdout is a file): push it out first, the JSON line stays last
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -124,6 +320,11 @@ def main():
                                                                      # step) next to the objects, on a second stream; reported separately.
                                                                      # ON by default whenever WORLD_SIZE > 1 (the scaling run exercises RCCL)
     ap.add_argument("--no-background", action="store_true")
+    ap.add_argument("--pmc-file", default=None)                      # roofline.traffic from THIS file (tests/tools/pmc_summary.py output of the
+                                                                     # FETCH_SIZE / WRITE_SIZE passes tests/tools/gpu_bench_with_pmc.sh ran just before,
+                                                                     # over the same library) instead of the committed counter file
+    ap.add_argument("--bg-timeout", type=float, default=float(os.environ.get("VMAP_BENCH_BG_TIMEOUT", "120")))   # watchdog of the background legs (s)
+    ap.add_argument("--no-frame", action="store_true")              # skip the N = 1 `frame` leg (objects + background on two streams)
     ap.add_argument("--timed-only", action="store_true")            # skip the roofline / baseline legs (for kernel traces of the timed region)
     ap.add_argument("--unbound", action="store_true")               # marshal the arguments on every frame call (VmapStep.train_steps)
     ap.add_argument("--graph", action="store_true")                 # measurement: the bound frame call replayed as a hipGraph (bit-identical; no gain: profiles/r03i)
@@ -202,53 +403,6 @@ def main():
             td.barrier()
         torch.cuda.synchronize()
 
-    # ---- the shared background model (the north star's one collective): replicas + ray sharding ----
-    bg = None
-    if (args.with_background or world > 1) and not args.no_background:
-        from vmap_amd import fields, parallel
-        bcfg = synth.CONFIGS["background"]
-        torch.manual_seed(7)                                          # the same replica on every rank
-        bfc = fields.OccupancyMap(hidden_size=bcfg["H"])
-        bfc.apply(fields.init_weights)
-        bpe = fields.UniDirsEmbed(max_deg=5, scale=bcfg["scale"])
-        bR = bcfg["R"] // world                                       # this rank's share of the 1200 background rays of a step
-        bframe = synth.make_batch(1, bcfg["R"] * ipf, bcfg["S"], seed=77)
-        idx = np.concatenate([np.arange(i * bcfg["R"] + rank, i * bcfg["R"] + bR * world, world) for i in range(ipf)])
-        bloc = tuple(torch.from_numpy(np.ascontiguousarray(bframe[k][0][idx])).to(dev) for k in ("pcs", "z", "gt_depth", "gt_rgb", "sem", "depth_mask"))
-        bg_stream = torch.cuda.Stream(device=dev)
-        with torch.cuda.stream(bg_stream):
-            # the default group for both stacks: ONE communicator, so collectives execute in the order every rank issues them
-            # (objects' flag reduction first, then the background frame's) - no two communicators in flight at once
-            bg = parallel.SharedBackgroundHip(bfc, bpe, bR, bcfg["S"], dev, max_steps=ipf)
-        bg_info = {"hidden": bcfg["H"], "rays_per_step_all_ranks": bR * world, "rays_per_step_this_rank": bR, "samples_per_ray": bcfg["S"],
-                   "collectives": "per frame: one all_reduce(SUM) of the [steps, 4] mask counts; per step: ONE all_reduce(SUM) of "
-                                  f"[gradient slab | loss terms] = {bg.buf.numel() * 4} bytes between two launches "
-                                  "(forward/backward; AdamW + image rewrite + global loss/flags)"}
-
-    def run_with_bg(n_steps):
-        """objects on the current stream, the background frame on its own stream, joined per frame call"""
-        done = 0
-        cur = torch.cuda.current_stream(dev)
-        while done < n_steps:
-            k = min(ipf, n_steps - done)
-            fork = torch.cuda.Event()
-            fork.record(cur)
-            bg_stream.wait_event(fork)
-            # The objects' frame call is ISSUED first: its one collective (the flag reduction) must not queue behind the
-            # background frame's 1 + k all-reduces (one communicator: collectives run in issue order, the same on every rank).
-            if bound is not None:
-                bound.train_steps(k)
-            else:
-                op.train_steps(tfc, tB, tsc, *fargs, opt=opt, n_steps=k, flag_reduce=flag_reduce)
-            with torch.cuda.stream(bg_stream):
-                bg.prepare_frame(*bloc, n_steps=k)
-                for i in range(k):
-                    bg.step_prepared(i)
-                join = torch.cuda.Event()
-                join.record(bg_stream)
-            cur.wait_event(join)
-            done += k
-
     preheat_steps = 0
     if args.preheat_ms > 0:
         # Untimed device pre-heat (NOT part of the W warm-up steps and NOT timed): the same frame call repeated for
@@ -276,6 +430,7 @@ def main():
     run(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
+    elapsed_own = elapsed
     if dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         td.all_reduce(t, op=td.ReduceOp.MAX)
@@ -284,21 +439,14 @@ def main():
     rays_per_step = n * R * world
     value = rays_per_step / (elapsed / args.steps)
 
+    # every rank's own clock around the timed region (the line reports MAX over ranks as ms_per_step, per the contract)
+    per_rank_ms = [ms_per_step]
+    if dist:
+        t = torch.zeros(world, dtype=torch.float64, device=dev)
+        t[rank] = elapsed_own / args.steps * 1e3
+        td.all_reduce(t, op=td.ReduceOp.SUM)
+        per_rank_ms = [float(x) for x in t.tolist()]
     with_bg = None
-    if bg is not None:
-        run_with_bg(args.warmup)
-        barrier()
-        t0 = time.perf_counter()
-        run_with_bg(args.steps)
-        barrier()
-        el_bg = time.perf_counter() - t0
-        if dist:
-            t = torch.tensor([el_bg], dtype=torch.float64, device=dev)
-            td.all_reduce(t, op=td.ReduceOp.MAX)
-            el_bg = float(t.item())
-        with_bg = dict(bg_info, ms_per_step=el_bg / args.steps * 1e3,
-                       object_rays_per_s=rays_per_step / (el_bg / args.steps),
-                       object_plus_background_rays_per_s=(rays_per_step + bg_info["rays_per_step_all_ranks"]) / (el_bg / args.steps))
     if args.timed_only:
         if dist:
             td.barrier()
@@ -317,12 +465,19 @@ def main():
     rccl_version = None
     if dist:
         gathered = [None] * world
-        td.all_gather_object(gathered, devices[0])
-        devices = gathered
+        ident = (devices[0], str(torch.cuda.get_device_properties(dev).uuid) if hasattr(torch.cuda.get_device_properties(dev), "uuid") else f"index{dev_index}")
+        td.all_gather_object(gathered, ident)
+        devices = [g[0] for g in gathered]
         try:
             rccl_version = ".".join(str(x) for x in torch.cuda.nccl.version())
         except Exception:
             rccl_version = None
+        if backend == "nccl" and world > 1:
+            # a scaling run is one rank per GPU over RCCL, nothing else: fail loudly instead of reporting a number for another setup
+            if len({g[1] for g in gathered}) != world:
+                raise SystemExit(f"bench.py --gpus {world}: ranks share devices {gathered}")
+            if td.get_backend() != "nccl" or rccl_version is None:
+                raise SystemExit(f"bench.py --gpus {world}: backend {td.get_backend()} / RCCL version {rccl_version}")
     out = None
     if rank == 0:
         # ---- dominant kernel, timed live on the launch stream ----
@@ -380,6 +535,15 @@ def main():
                     traffic = json.load(fh)["_notes"][key]
         except Exception:
             traffic = None
+        lib_sha = library_sha256()
+        traffic_observed = None
+        if args.pmc_file:
+            # counters taken in the same gpurun, by the script that also launched this process (tests/tools/gpu_bench_with_pmc.sh)
+            with open(args.pmc_file) as fh:
+                notes = json.load(fh)["_notes"]
+            traffic = notes.get("hbm_traffic_bytes_per_launch_step_main")
+            traffic_observed = {"file": args.pmc_file, "library_sha256_of_the_counter_passes": notes.get("library_sha256"),
+                                "same_library": notes.get("library_sha256") == lib_sha, "workload": notes.get("workload")}
         # what the matrix pipe actually executes (bf16 kernels): instructions per 32-point tile / 64-point round x tiles x 32x32x16 x 2 FLOP
         executed_tflops, mm_per_launch = None, None
         if split:
@@ -472,9 +636,13 @@ def main():
                                            if executed_tflops else {"instruction": "v_mfma_f32_32x32x2_f32", "peak_tflops": FP32_MFMA_PEAK_TFLOPS}),
                          "launch_plan": plan, "floor_us": floor_us, "floor_note": floor_note,
                          "traffic": traffic,
-                         "traffic_source": ("copied from the committed rocprofv3 --pmc passes of this kernel (profiles/" + pmc_file +
-                                            ": separate FETCH_SIZE / WRITE_SIZE passes over tests/tools/run_steps.py, FETCH doubled per MI355X_MICROARCH.md), "
-                                            "not observed in this run - counters cannot be sampled from inside the process") if traffic is not None else None,
+                         "traffic_source": ("OBSERVED in this gpurun: FETCH_SIZE / WRITE_SIZE passes (rocprofv3 --pmc, separate passes, FETCH doubled per "
+                                            "MI355X_MICROARCH.md) over the library this process loaded, folded by tests/tools/pmc_summary.py: " + json.dumps(traffic_observed))
+                                           if traffic_observed else
+                                           (("copied from the committed rocprofv3 --pmc passes of this kernel (profiles/" + pmc_file +
+                                             ": separate FETCH_SIZE / WRITE_SIZE passes over tests/tools/run_steps.py, FETCH doubled per MI355X_MICROARCH.md), "
+                                             "not observed in this run - counters cannot be sampled from inside the process") if traffic is not None else None),
+                         "library_sha256": lib_sha,
                          "kernel_ms": k_ms, "kernel_ms_stream_event_pair": k_ms_pair,
                          "kernel_ms_note": "kernel_ms = average of the dispatches' own begin -> end timestamps (events attached to the launch, "
                                            "hipExtLaunchKernel) over the real prep / main / finalize sequence = what rocprofv3 --kernel-trace reports "
@@ -487,7 +655,9 @@ def main():
             "fwd_bwd_only": {"ms_per_step_host_launched": fb_ms, "rays_per_s": n * R / (fb_ms * 1e-3)},
             "preheat": {"ms": args.preheat_ms, "steps": preheat_steps, "timed": False},
             "with_background": with_bg,
-            "world": {"world_size": world, "devices": devices, "rccl": rccl_version, "backend": backend if dist else None},
+            "world": {"world_size": world, "devices": devices, "rccl": rccl_version, "backend": backend if dist else None,
+                      "ms_per_step_per_rank": per_rank_ms},
+            "frame": None,
             "frame_call": ("marshalled per call" if bound is None else
                            "bound (arguments marshalled once), replayed as a hipGraph per frame (device-resident optimiser step count)" if bound.graph
                            else "bound (arguments marshalled once), launched kernel by kernel"),
@@ -498,20 +668,42 @@ def main():
         if world == 1 and not args.no_gpu_baseline:
             out["gpu_eager_baseline"] = gpu_eager_baseline(cfg, dev)
             out["gpu_eager_baseline"]["speedup"] = value / out["gpu_eager_baseline"]["value"]
+            out["gpu_eager_baseline"]["speedup_is"] = "against the eager PyTorch-ROCm PORT of the step (oracle/vmap_oracle_torch.py), not the reference's functorch path"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
-    if dist:
-        td.barrier()                     # rank 0 measured the kernel / the baselines; everybody leaves together
-        td.destroy_process_group()       # (RCCL prints its version banner on stdout: the JSON line comes after it, last)
-    if rank == 0:
-        # RCCL writes its banner through C stdio (buffered when stdout is a file): push it out first, the JSON line stays last
+        if world == 1 and H == 32 and not args.no_frame:
+            # a REAL frame (objects + background model): driver-visible, untimed in `value`; a failure here cannot lose the line
+            try:
+                out["frame"] = frame_leg(cfg, dev, ipf, fargs)
+            except Exception as e:
+                out["frame"] = {"error": f"{type(e).__name__}: {e}"}
+    # ---- the shared background model next to the objects (N > 1, or --with-background): AFTER everything the scored line needs,
+    #      under a watchdog - this path (RCCL on a side stream, one communicator shared with the objects' flag reduction) has
+    #      never run on an 8-GPU node, and a hang or an exception in it must not take `value` with it ----
+    if (args.with_background or world > 1) and not args.no_background:
+        def on_timeout():
+            if rank == 0:
+                out["with_background"] = {"error": f"watchdog: the background legs did not finish within {args.bg_timeout:.0f} s (objects-only `value` above is unaffected)"}
+                emit(out)
+            os._exit(0)
+        dog = Watchdog(args.bg_timeout, on_timeout)
         try:
-            import ctypes
-            ctypes.CDLL(None).fflush(None)
-        except Exception:
-            pass
-        sys.stdout.flush()
-        print(json.dumps(out), flush=True)
+            res = background_legs(args, cfg, dev, rank, world, ipf, dist, run_objects=lambda k: (bound.train_steps(k) if bound is not None else
+                                  op.train_steps(tfc, tB, tsc, *fargs, opt=opt, n_steps=k, flag_reduce=flag_reduce)), rays_per_step=rays_per_step)
+            if rank == 0:
+                out["with_background"] = res
+        except Exception as e:                       # reported, never fatal
+            if rank == 0:
+                out["with_background"] = {"error": f"{type(e).__name__}: {e}"}
+        dog.cancel()
+    if dist:
+        # leaving together matters less than leaving: a rank whose background leg failed must not hang the others here
+        dog = Watchdog(60.0, lambda: (emit(out) if rank == 0 else None, os._exit(0)))
+        td.barrier()
+        td.destroy_process_group()       # (RCCL prints its version banner on stdout: the JSON line comes after it, last)
+        dog.cancel()
+    if rank == 0:
+        emit(out)
 
 
 if __name__ == "__main__":

@@ -14,7 +14,7 @@ acc = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(os.path.join(ROOT, "gpurun_out", "pmc", "*", "p_counter_collection.csv")):
     for row in csv.DictReader(open(f)):
         name = row["Kernel_Name"]
-        key = ("step_main_ws" if "step_main_ws" in name else "step_finalize_ws" if "step_finalize_ws" in name
+        key = ("step_main_wp" if "step_main_wp" in name else "step_main_ws" if "step_main_ws" in name else "step_finalize_ws" if "step_finalize_ws" in name
                else "step_prep_ws" if "step_prep_ws" in name
                else "step_main_s32" if "step_main_s32" in name else "step_finalize_s32" if "step_finalize_s32" in name
                else "step_prep_s32" if "step_prep_s32" in name
@@ -24,12 +24,17 @@ for f in glob.glob(os.path.join(ROOT, "gpurun_out", "pmc", "*", "p_counter_colle
         if key:
             acc[key][row["Counter_Name"]].append(float(row["Counter_Value"]))
 out = {k: {c: sum(v) / len(v) for c, v in sorted(cs.items())} for k, cs in acc.items()}
-m = out.get("step_main_ws", out.get("step_main_s32", out.get("step_main_h32", {})))
-notes = {"units": "FETCH_SIZE/WRITE_SIZE in KiB per dispatch (rocprofv3), other counters summed over the chip per dispatch",
+m = out.get("step_main_wp", out.get("step_main_ws", out.get("step_main_s32", out.get("step_main_h32", {}))))
+import hashlib
+try:
+    lib_sha = hashlib.sha256(open(os.path.join(ROOT, "vmap_amd", "libvmapstep.so"), "rb").read()).hexdigest()
+except OSError:
+    lib_sha = None
+notes = {"library_sha256": lib_sha, "workload": os.environ.get("PMC_WORKLOAD"), "units": "FETCH_SIZE/WRITE_SIZE in KiB per dispatch (rocprofv3), other counters summed over the chip per dispatch",
          "collection": "rocprofv3 --kernel-trace --pmc <group> in 7 separate passes over tests/tools/run_steps.py replica_room0_vmap 40"}
 if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
     notes["hbm_traffic_bytes_per_launch_step_main"] = (2.0 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024.0
-    if "step_main_ws" in out:
+    if "step_main_ws" in out or "step_main_wp" in out:
         notes["hbm_traffic_bytes_per_launch_step_main_ws"] = notes["hbm_traffic_bytes_per_launch_step_main"]
         f = out.get("step_finalize_ws", {})
         if "FETCH_SIZE" in f and "WRITE_SIZE" in f:

@@ -10,6 +10,7 @@ from vmap_amd import step, synth  # noqa: E402
 
 name = sys.argv[1] if len(sys.argv) > 1 else "replica_room0_vmap"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+weights = sys.argv[3] if len(sys.argv) > 3 else "f32"
 cfg = synth.CONFIGS[name]
 n, R, S, H = cfg["n_obj"], cfg["R"], cfg["S"], cfg["H"]
 fc, B, sc = synth.make_params(n, H, scale=cfg["scale"], seed=0)
@@ -18,7 +19,7 @@ dev = "cuda:0"
 tfc = [torch.from_numpy(a).to(dev) for a in fc]
 tB, tsc = torch.from_numpy(B).to(dev), torch.from_numpy(sc).to(dev)
 fr = {k: torch.from_numpy(v).to(dev) for k, v in frame.items()}
-op = step.VmapStep(n, R, S, H, device=dev, max_steps=20)
+op = step.VmapStep(n, R, S, H, device=dev, max_steps=20, weights=weights)
 opt = step.FusedAdamWState(n, H, dev)
 done = 0
 while done < steps:

@@ -604,12 +604,22 @@ static int train_steps_impl(const vmapstep_shape* shape, const vmapstep_params* 
     if (!pe_scale || !pe_scale->ptr) return fail(VMAPSTEP_ERR_ARGUMENT, "pe_scale is null");
     if (!opt || !opt->exp_avg || !opt->exp_avg_sq) return fail(VMAPSTEP_ERR_ARGUMENT, "optimiser state is required");
     if (!out || !out->loss || !out->flags) return fail(VMAPSTEP_ERR_ARGUMENT, "outputs.loss / outputs.flags are required");
-    std::vector<hipEvent_t> ev;
+    // measurement only: the events live in a guard, so that every exit path (a failed launch, a failed record, a failed create
+    // part-way through) destroys the ones that exist
+    struct Events {
+        std::vector<hipEvent_t> v;
+        ~Events() { for (hipEvent_t e : v) (void)hipEventDestroy(e); }
+        bool empty() const { return v.empty(); }
+        hipEvent_t operator[](size_t i) const { return v[i]; }
+    } ev;
     if (time_main_ms) {
-        ev.resize(4 * (size_t)n_steps);      // per step: stream events in front of / behind the launch, and the launch's own
+        ev.v.reserve(4 * (size_t)n_steps);   // per step: stream events in front of / behind the launch, and the launch's own
                                              // dispatch begin / end events (hipExtLaunchKernel)
-        for (auto& e : ev)
+        for (size_t i = 0; i < 4 * (size_t)n_steps; ++i) {
+            hipEvent_t e;
             if (hipEventCreate(&e) != hipSuccess) return fail(VMAPSTEP_ERR_DEVICE, "hipEventCreate failed");
+            ev.v.push_back(e);
+        }
     }
     for (int i = 0; i < n_steps; ++i) {
         fill_step_args(a, shape, pl, L, params, pe_scale, frame, (int64_t)i * ray_step, color_scaling, opacity_scaling, ws);
@@ -637,7 +647,6 @@ static int train_steps_impl(const vmapstep_shape* shape, const vmapstep_params* 
             sum_dispatch += ms;
             sum_pair += pair;
         }
-        for (auto& e : ev) ok = (hipEventDestroy(e) == hipSuccess) && ok;
         if (!ok) return fail(VMAPSTEP_ERR_DEVICE, "event timing of the step loop failed");
         time_main_ms[0] = (float)(sum_dispatch / n_steps);             // the dispatch's own begin -> end (= a kernel trace's duration)
         time_main_ms[1] = (float)(sum_pair / n_steps);                 // stream events recorded around the launch (includes their own cost)

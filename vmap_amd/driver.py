@@ -98,8 +98,9 @@ class HipMapper:
 
     def _frame_call(self, key, op, views, scale, batch, opt, iters, ray_step, render=False, flag_reduce=None):
         """``op.train_steps`` for a frame - through a ``step.BoundFrame`` when the caller hands over the SAME frame buffers as
-        last time (a sampler that writes into fixed tensors, ``vmap_amd.sampler.FrameSampler``): arguments marshalled once, and
-        on a single rank the frame call replayed as a hipGraph.  New buffers (or a new stack / operator) re-bind."""
+        last time (a sampler that writes into fixed tensors, ``vmap_amd.sampler.FrameSampler``): arguments marshalled once, the
+        kernels launched one by one on the device's current stream at every call (hipGraph replay is an opt-in of
+        ``VmapStep.bind(graph=True)`` and is not used here: measured no gain).  New buffers (or a new stack / operator) re-bind."""
         if render:                                   # rendered outputs are per-call tensors: the plain path
             return op.train_steps(views[:14], views[14], scale, *batch, opt=opt, n_steps=iters, ray_step=ray_step, render=True,
                                   flag_reduce=flag_reduce)

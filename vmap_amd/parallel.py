@@ -12,7 +12,9 @@ The two cross-object couplings of the reference are handled outside it:
   of the background rays with the HIP step (``SharedBackgroundHip``): the mask counts that normalise its loss are summed
   ONCE PER FRAME for all of its steps, and per step the gradients + loss travel in ONE all-reduce of a single flat buffer
   (94 403 fp32 = 378 KB at H=128: latency-bound on 153 GB/s xGMI links, hence one fused message instead of 15) between two
-  launches (forward/backward, fused AdamW + image rewrite).
+  launches (forward/backward, fused AdamW + image rewrite).  The alternative SURVEY.md 8(e) names is here too:
+  ``OwnerBackgroundHip`` - ONE rank trains the background on all of its rays with the plain frame call and broadcasts the
+  trained parameter slab once per frame (no collective on the step path); ``bench.py --gpus N`` measures both.
 """
 from __future__ import annotations
 
@@ -175,6 +177,68 @@ class SharedBackgroundHip:
     @torch.no_grad()
     def write_back(self):
         """Copy the trained slab into the modules (what train.py:331-338 does for the object fields)."""
+        fc, pe = self.modules
+        for p, v in zip(list(fc.parameters()) + [pe.B_layer.weight], self.views):
+            p.copy_(v[0].to(p.device))
+
+
+class OwnerBackgroundHip:
+    """The shared background model (train.py:308-316), OWNER-COMPUTES: rank ``owner`` trains it on ALL of a step's rays with
+    the plain frame call (``vmapstep_train_steps``: 1 + 2 n launches, nothing between the steps), every other rank does nothing
+    for it during the frame; ONE ``broadcast`` of the ``[1, P]`` parameter slab per FRAME (378 KB at hidden 128) hands the
+    trained weights to the other ranks' replicas (for rendering / meshing: no object's training reads the background field).
+
+    Against ``SharedBackgroundHip`` (ray shards + one all-reduce per STEP): no collective on the step path and a twentieth of
+    the messages, but the owner carries the whole 1200-ray step (0.10 ms on one MI355X against ~0.06 ms of launches + the
+    all-reduce at 8 ranks) next to its object shard.  The owner's result is bit-identical to single-GPU
+    training of the background model (same kernels, same plan); the replicas are bit-identical copies of it."""
+
+    def __init__(self, fc_occ_map: torch.nn.Module, pe: torch.nn.Module, rays: int, samples: int, device, owner: int = 0,
+                 lr=1e-3, weight_decay=0.013, group=None, max_steps: int = 32):
+        from . import layout, step
+        self.group, self.owner = group, owner
+        self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.modules = (fc_occ_map, pe)
+        H = fc_occ_map.hidden_size
+        dev = torch.device(device)
+        self.slab = torch.zeros(1, layout.param_count(H), dtype=torch.float32, device=dev)
+        offs = layout.flat_offsets(H)
+        shapes = list(layout.fc_shapes(H)) + [layout.PE_B_SHAPE]
+        src = list(fc_occ_map.parameters()) + [pe.B_layer.weight]
+        self.views = []
+        with torch.no_grad():
+            for t, shp in enumerate(shapes):
+                v = self.slab[:, offs[t]:offs[t] + layout.numel(shp)].view((1,) + tuple(shp))
+                v.copy_(src[t].detach().to(dev).unsqueeze(0))
+                self.views.append(v)
+        self.scale = pe.scale.detach().to(dev).reshape(1).clone()
+        self.rays, self.max_steps = rays, max_steps
+        self.is_owner = self.rank == owner
+        self.op = self.opt = None
+        if self.is_owner:                            # only the owner needs an operator, a workspace and optimiser state
+            self.op = step.VmapStep(1, rays, samples, H, device=dev, max_steps=max_steps)
+            self.opt = step.FusedAdamWState(1, H, dev, lr=lr, weight_decay=weight_decay)
+        self._bound, self._sig = None, None
+        self.result = None
+
+    @torch.no_grad()
+    def train_frame(self, pcs, z, gt_depth, gt_rgb, sem, depth_mask, n_steps: int, broadcast: bool = True):
+        """The frame's ``n_steps`` background steps on the owner (inputs: ALL rays of the frame, ``[n_steps * R, ...]``; other
+        ranks may pass None), then the slab broadcast.  Returns the owner's StepResult (loss [max_steps], flags) or None."""
+        if self.is_owner:
+            fr = tuple(x.unsqueeze(0) for x in (pcs, z, gt_depth, gt_rgb, sem, depth_mask))
+            sig = tuple((x.data_ptr(), tuple(x.shape), tuple(x.stride())) for x in fr)
+            if self._sig != sig:                     # new frame buffers: marshal once
+                self._bound = self.op.bind(self.views[:14], self.views[14], self.scale, *fr, opt=self.opt, ray_step=self.rays)
+                self._sig = sig
+            self.result = self._bound.train_steps(n_steps)
+        if broadcast and self.world_size > 1:
+            dist.broadcast(self.slab, src=self.owner if self.group is None else dist.get_global_rank(self.group, self.owner), group=self.group)
+        return self.result if self.is_owner else None
+
+    @torch.no_grad()
+    def write_back(self):
         fc, pe = self.modules
         for p, v in zip(list(fc.parameters()) + [pe.B_layer.weight], self.views):
             p.copy_(v[0].to(p.device))

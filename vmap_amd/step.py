@@ -67,12 +67,19 @@ class FusedAdamWState:
         # the C side forms them from the float32 members of vmapstep_adamw widened to double: do the same, bit for bit
         lr, b1, b2 = (float(np.float32(x)) for x in (self.lr, self.betas[0], self.betas[1]))
         last = None
+        saturated = False
         for t in range(1, max_len + 1):
             cur = (np.float32(lr / (1.0 - math.pow(b1, float(t)))), np.float32(math.sqrt(1.0 - math.pow(b2, float(t)))))
             rows.append(cur)
             if cur == (np.float32(lr), np.float32(1.0)) and cur == last:          # saturated at the exact limits
+                saturated = True
                 break
             last = cur
+        if not saturated:
+            # the kernels clamp the step count to the last entry: a table that stops short of the limits would hand later steps
+            # wrong bias corrections without a sound (beta2 = 0.9999 saturates near step 166 000)
+            raise ValueError(f"AdamW bias-correction table did not saturate within {max_len} steps (betas={self.betas}): "
+                             "pass a larger max_len to enable_device_steps()")
         dev = self.exp_avg.device
         self.bias_table = torch.tensor(np.asarray(rows, dtype=np.float32), device=dev).contiguous()
         self.step_counter = torch.tensor([self.step, 0], dtype=torch.int32, device=dev)
@@ -81,7 +88,10 @@ class FusedAdamWState:
         """A call that took the step count from the host (prepared / apply paths) advanced the optimiser by n steps: keep the
         device-side count in step (a tiny stream-ordered add; only when both kinds of calls are mixed on one state)."""
         if self.step_counter is not None:
-            self.step_counter[1] += n
+            # on the state's OWN device and that device's current stream (= the stream the operator's launches are on), whatever
+            # device is current on the calling thread
+            with torch.cuda.device(self.step_counter.device):
+                self.step_counter[1] += n
 
 
 class VmapStep:
@@ -257,15 +267,21 @@ class VmapStep:
         ``loss_terms`` (float32 [n, 4], the rank-summed ``fwd_bwd(..., loss_terms=)`` rows): the SAME launch also writes the
         step's global loss to ``loss_out[0]`` and its flags to ``flags_out[0:4]`` (the reduced empty-mask switches of prepared
         step ``step_index`` + render_rays.py:88-90's explode test on the summed terms)."""
-        if tuple(grad_slab.shape) != (self.n_obj, opt.padded) or grad_slab.dtype != torch.float32 or not grad_slab.is_contiguous():
-            raise ValueError(f"grad_slab: need contiguous float32 {(self.n_obj, opt.padded)}")
+        if tuple(grad_slab.shape) != (self.n_obj, opt.padded) or grad_slab.dtype != torch.float32 or not grad_slab.is_contiguous() \
+                or grad_slab.device != self.device:
+            raise ValueError(f"grad_slab: need contiguous float32 {(self.n_obj, opt.padded)} on {self.device}")
         pp = self._params(fc, B)
         oc = opt.c_struct()
         out, lt = None, None
         if loss_terms is not None:
+            # the same checks fwd_bwd applies to its loss_terms: the kernel reads n_obj rows of four floats through a raw pointer
+            if tuple(loss_terms.shape) != (self.n_obj, 4) or loss_terms.dtype != torch.float32 or not loss_terms.is_contiguous() \
+                    or loss_terms.device != self.device:
+                raise ValueError(f"loss_terms: need contiguous float32 {(self.n_obj, 4)} on {self.device}")
             if loss_out is None or flags_out is None or loss_out.dtype != torch.float32 or flags_out.dtype != torch.int32 \
-                    or flags_out.numel() < 4 or not flags_out.is_contiguous():
-                raise ValueError("loss_terms given: loss_out (float32 [>=1]) and flags_out (contiguous int32 [>=4]) are required")
+                    or loss_out.numel() < 1 or flags_out.numel() < 4 or not flags_out.is_contiguous() \
+                    or loss_out.device != self.device or flags_out.device != self.device:
+                raise ValueError(f"loss_terms given: loss_out (float32 [>=1]) and flags_out (contiguous int32 [>=4]) on {self.device} are required")
             out = ctypes.byref(_lib.Outputs(loss_out.data_ptr(), flags_out.data_ptr(), None, None, None, None, None))
             lt = loss_terms.data_ptr()
         _lib.check(self.lib.vmapstep_adamw_apply(ctypes.byref(self.shape), ctypes.byref(pp), grad_slab.data_ptr(), opt.padded,
@@ -384,7 +400,6 @@ class BoundFrame:
         self._sc = _lib.Tensor(pe_scale.data_ptr(), pe_scale.stride(0) if pe_scale.dim() else 0)
         self._bt = op._batch(pcs, z, gt_depth, gt_rgb, sem, depth_mask, rays_total=self.rays_total)
         self.result, self._out = op._outputs(op.max_steps, render)
-        self._stream = op._stream()
         self.graph = bool(graph) and flag_reduce is None
         self._graphs, self._warm = {}, set()
         if self.graph:
@@ -425,7 +440,9 @@ class BoundFrame:
             g.replay()
             opt.step += n_steps
             return self.result
-        on_device = self._call(n_steps, self._stream)    # first call: eager (sets the kernels' per-device attributes once)
+        # the CURRENT stream of the operator's device at every call (a stream frozen at bind time could be stale - or destroyed -
+        # by the time a later frame runs under another stream: nothing would order it against the sampler's writes)
+        on_device = self._call(n_steps, op._stream())    # first call of a graph-bound frame: eager (sets the kernels' per-device attributes once)
         self._warm.add(n_steps)
         opt.step += n_steps
         if not on_device:
@@ -435,7 +452,7 @@ class BoundFrame:
 
 def _bind(self, fc, B, pe_scale, pcs, z, gt_depth, gt_rgb, sem, depth_mask, opt: "FusedAdamWState", ray_step=None,
           render: bool = False, flag_reduce=None, graph: bool = False) -> BoundFrame:
-    """Marshal once, call many times: see ``BoundFrame``.  Bound to the CURRENT stream of the operator's device."""
+    """Marshal once, call many times: see ``BoundFrame``.  Every call runs on the operator's device's current stream."""
     return BoundFrame(self, fc, B, pe_scale, pcs, z, gt_depth, gt_rgb, sem, depth_mask, opt, ray_step, render, flag_reduce, graph)
 
 

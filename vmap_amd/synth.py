@@ -137,6 +137,7 @@ CONFIGS = {
     "replica_room0_vmap": dict(n_obj=20, R=120, S=10, H=32, scale=2.0),  # configs[1] (headline)
     "scannet0024_vmap": dict(n_obj=50, R=120, S=10, H=32, scale=3.0),    # configs[3] shapes
     "stress_256x64": dict(n_obj=256, R=256, S=10, H=64, scale=2.0),      # configs[4] shapes
+    "stress_rank8": dict(n_obj=32, R=256, S=10, H=64, scale=2.0),        # ... one rank's object shard of configs[4] on its 8 GPUs (measurement)
     "background": dict(n_obj=1, R=1200, S=14, H=128, scale=5.0),         # train.py:308-316
     "background_rank4": dict(n_obj=1, R=300, S=14, H=128, scale=5.0),    # ... one rank's ray shard of it at 4 / 8 GPUs (measurement:
     "background_rank8": dict(n_obj=1, R=150, S=14, H=128, scale=5.0),    # the latency of the ray-sharded step, parallel.SharedBackgroundHip)
