@@ -10,6 +10,14 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+# Operators with an explicit plan override (tuning=...) run on the measurement build of the library: the product carries only the
+# kernel forms automatic plans launch (tests/tools/libvmapstep_ab.so = the same sources with -DVMAPSTEP_AB, built by build()).
+AB_LIBRARY = os.path.join(ROOT, "tests", "tools", "libvmapstep_ab.so")
+if os.path.exists(AB_LIBRARY):
+    from vmap_amd import step as _step
+    _step.VmapStep.ab_library = AB_LIBRARY
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run through gpurun / the driver's GPU tier)")
     config.addinivalue_line("markers", "slow: CPU test that takes more than a few seconds")

@@ -86,8 +86,10 @@ def test_kernel_choice_per_width_shows_in_the_workspace_plan():
     """hidden 64 / 128 with at most 64 samples per ray run on the split-bf16 kernels (step_main_wp / step_main_ws): their
     workspace carries the W / W^T images and per-workgroup scratch, the exact-fp32 kernels' does not; VMAPSTEP_KERNEL_WS1 /
     _WP are refused where those kernels do not exist (hidden 32, hidden 256 with more than 32 samples per ray or as _WP, long
-    rays); hidden 256 with short rays runs step_main_ws with eight waves while every tile gets a compute unit (round 3)."""
-    lib = _lib.load()
+    rays); hidden 256 with short rays runs step_main_ws with eight waves while every tile gets a compute unit (round 3).
+    Plan overrides are a matter of the measurement build (tests/tools/libvmapstep_ab.so: the same plan code + the A/B kernel forms)."""
+    from conftest import AB_LIBRARY
+    lib = _lib.load(AB_LIBRARY)
 
     def need(shape, kernel=None):
         n = ctypes.c_size_t()
@@ -164,3 +166,34 @@ def test_launch_plans_of_the_baseline_shapes():
     assert P(1, 100, 14, 96)["kernel"] == "step_main_gen"
     with pytest.raises(_lib.VmapStepError):
         P(1, 100, 14, 48)
+
+
+def test_product_library_carries_the_planned_forms_only():
+    """Round 4: the product library ships the kernel forms AUTOMATIC plans launch (+ the exact-fp32 training references); the A/B
+    forms - step_main_ws at hidden 64, step_main_wp at hidden 128, step_main_wide<4>, three-tile rounds with several rounds per
+    workgroup - are refused by its plan with a message naming the measurement build, which accepts them; both builds make the same
+    plan for every automatic shape."""
+    from conftest import AB_LIBRARY
+    prod, ab = _lib.load(), _lib.load(AB_LIBRARY)
+
+    def plan(lib, shape, **tun):
+        n = ctypes.c_size_t()
+        if tun:
+            t = _lib.Tuning(**tun)
+            shape.tuning = ctypes.pointer(t)
+        return lib.vmapstep_workspace_bytes(ctypes.byref(shape), 20, ctypes.byref(n)), n.value
+
+    ab_only = [(_lib.Shape(1, 1200, 14, 64, 0), dict(kernel=_lib.KERNEL_WS1)), (_lib.Shape(1, 1200, 14, 128, 0), dict(kernel=_lib.KERNEL_WP)),
+               (_lib.Shape(1, 100, 14, 256, 0), dict(kernel=_lib.KERNEL_WIDE4)), (_lib.Shape(1, 1200, 14, 128, 0), dict(ws_flags=2, workgroups_per_object=50))]
+    for sh, tun in ab_only:
+        assert plan(prod, sh, **tun)[0] == -2 and b"measurement build" in prod.vmapstep_last_error(), tun
+        assert plan(ab, sh, **tun)[0] == 0, tun
+    for shape in ((20, 120, 10, 32), (50, 120, 10, 32), (256, 256, 10, 64), (32, 256, 10, 64), (1, 1200, 14, 128), (1, 600, 14, 128), (1, 150, 14, 128),
+                  (2, 1200, 14, 128), (1, 100, 14, 256), (1, 4800, 14, 256), (1, 100, 40, 256), (3, 50, 12, 96)):
+        for wd in (0, 1):
+            a, b = plan(prod, _lib.Shape(*shape, wd)), plan(ab, _lib.Shape(*shape, wd))
+            assert a[0] == 0 and a == b, shape
+    # explicit overrides that select forms the product does carry stay available on it
+    for sh, tun in [(_lib.Shape(20, 120, 10, 32, 0), dict(kernel=_lib.KERNEL_H32_F32)), (_lib.Shape(1, 1200, 14, 128, 0), dict(kernel=_lib.KERNEL_GEN)),
+                    (_lib.Shape(1, 1200, 14, 128, 0), dict(ws_flags=4)), (_lib.Shape(1, 150, 14, 128, 0), dict(ws_flags=1))]:
+        assert plan(prod, sh, **tun)[0] == 0, tun

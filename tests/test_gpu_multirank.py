@@ -94,43 +94,84 @@ def _train_background(rank, world, dev):
                 m=bg.opt.exp_avg.cpu().numpy(), steps=bg.opt.step)
 
 
-def _worker(rank, world, port, ret):
+def _train_background_owner(rank, world, dev):
+    """parallel.OwnerBackgroundHip: rank 0 trains on ALL rays with the plain frame call, one slab broadcast per frame."""
+    from vmap_amd import parallel
+    fc, pe, fr = _background()
+    own = parallel.OwnerBackgroundHip(fc, pe, BG["R"], BG["S"], dev, owner=0, max_steps=STEPS)
+    before = own.slab.clone()
+    full = tuple(torch.from_numpy(np.ascontiguousarray(fr[k])).to(dev) for k in KEYS) if rank == 0 else (None,) * 6
+    res = None
+    for _ in range(2):                                  # two frames: the second runs on the bound frame
+        res = own.train_frame(*full, n_steps=STEPS)
+    torch.cuda.synchronize()
+    return dict(slab=own.slab.cpu().numpy(), changed=not torch.equal(before, own.slab), has_op=own.op is not None,
+                losses=None if res is None else res.loss[:STEPS].cpu().numpy(), flags=None if res is None else res.flags[:STEPS].cpu().numpy())
+
+
+def _worker(rank, world, port, ret, backend="gloo"):
     import torch.distributed as dist
     from vmap_amd import parallel
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # gloo: both ranks share cuda:0 (RCCL refuses two ranks on one device); nccl: one device per rank, the real thing
+    dev = torch.device("cuda", rank if backend == "nccl" else 0)
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        dev = torch.device(DEV)
-        transport = "gloo on device tensors"
+        transport = "RCCL, one device per rank" if backend == "nccl" else "gloo on device tensors"
         try:
             probe = torch.ones(4, device=dev)
             dist.all_reduce(probe)
             assert float(probe[0]) == world
         except Exception as e:                      # a torch build whose gloo cannot take device tensors: stage through the host
+            if backend == "nccl":
+                raise
             transport = f"gloo through host copies ({type(e).__name__})"
-            native = dist.all_reduce
+            native, native_b = dist.all_reduce, dist.broadcast
 
             def staged(t, op=dist.ReduceOp.SUM, group=None, async_op=False):
                 h = t.detach().cpu()
                 native(h, op=op, group=group)
                 t.copy_(h)
 
+            def staged_b(t, src=0, group=None, async_op=False):
+                h = t.detach().cpu()
+                native_b(h, src=src, group=group)
+                t.copy_(h)
+
             parallel.dist.all_reduce = staged
+            parallel.dist.broadcast = staged_b
         c, frame = _object_frame()
         shard = parallel.ObjectShard(c["n"])
-        out = dict(transport=transport, objects=_train_objects(shard, c, frame, dev), background=_train_background(rank, world, dev))
+        out = dict(transport=transport, device=str(dev), objects=_train_objects(shard, c, frame, dev), background=_train_background(rank, world, dev),
+                   owner=_train_background_owner(rank, world, dev))
         ret[rank] = out
     finally:
         dist.destroy_process_group()
 
 
 def test_two_ranks_on_one_gpu_equal_the_single_rank_run():
+    _two_ranks_equal_the_single_rank_run("gloo")
+
+
+def test_two_ranks_on_two_gpus_over_rccl_equal_the_single_rank_run():
+    """The same assertions with the process group an 8-GPU run uses: backend "nccl" (= RCCL), one device per rank.  Needs two GPUs."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
+    _two_ranks_equal_the_single_rank_run("nccl")
+
+
+def _two_ranks_equal_the_single_rank_run(backend):
     world, port = 2, _free_port()
     ret = mp.Manager().dict()
-    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, ret, backend), nprocs=world, join=True)
     assert sorted(ret.keys()) == [0, 1]
+    if backend == "nccl":
+        assert {ret[0]["device"], ret[1]["device"]} == {"cuda:0", "cuda:1"}
     from vmap_amd import parallel
     dev = torch.device(DEV)
 
@@ -160,6 +201,13 @@ def test_two_ranks_on_one_gpu_equal_the_single_rank_run():
     d = np.abs(b0["slab"].astype(np.float64) - ref["slab"])
     assert d.max() <= STEPS * 1.2e-3 and np.median(d) < 1e-6                   # Adam sign flips on ~0 gradients only
     print("transport:", ret[0]["transport"])
+
+    # ---- owner-computes background: the owner = single-GPU training bit for bit, the other rank a bit-identical copy, no operator ----
+    o0, o1 = ret[0]["owner"], ret[1]["owner"]
+    one = _train_background_owner(0, 1, dev)
+    assert o0["has_op"] and not o1["has_op"] and o1["losses"] is None
+    assert o0["changed"] and np.array_equal(o0["slab"], o1["slab"]) and np.array_equal(o0["slab"], one["slab"])
+    assert np.array_equal(o0["losses"], one["losses"]) and int(o0["flags"][:, 3].max()) == 0
 
 
 def test_operator_on_a_non_current_device():
@@ -207,5 +255,9 @@ def test_bench_runs_with_two_ranks_on_one_gpu(tmp_path):
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     j = json.loads(line)
     assert j["n_gpus"] == 2 and j["steps"] == 40 and j["scaling"] == "weak"
-    assert j["value"] > 0 and j["with_background"]["rays_per_step_this_rank"] == 600
+    assert j["value"] > 0 and j["with_background"]["rays_per_step_this_rank"] == 600, j["with_background"]
+    wb = j["with_background"]
+    assert wb["ray_sharded"]["beside_objects_ms_per_step"] > 0 and wb["ray_sharded"]["allreduce_alone_us"] > 0
+    assert wb["owner_computes"]["beside_objects_ms_per_step"] > 0
+    assert len(j["world"]["ms_per_step_per_rank"]) == 2 and max(j["world"]["ms_per_step_per_rank"]) <= j["ms_per_step"] * 1.0001
     assert j["world"]["world_size"] == 2 and len(j["world"]["devices"]) == 2 and j["world"]["backend"] == "gloo"

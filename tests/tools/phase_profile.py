@@ -19,7 +19,7 @@ NAMES_WS = ["start", "encoding + barrier", "in_layer", "mid1", "cat_layer", "mid
 name = sys.argv[1] if len(sys.argv) > 1 else "replica_room0_vmap"
 cfg = synth.CONFIGS[name]
 n, R, S, H = cfg["n_obj"], cfg["R"], cfg["S"], cfg["H"]
-if H == 128:
+if H in (64, 128):
     NAMES = NAMES_WS
 fc, B, sc = synth.make_params(n, H, scale=cfg["scale"], seed=0)
 batch = synth.make_batch(n, R, S, seed=1)
@@ -28,9 +28,11 @@ tfc = [torch.from_numpy(a).to(dev) for a in fc]
 tB, tsc = torch.from_numpy(B).to(dev), torch.from_numpy(sc).to(dev)
 tb = {k: torch.from_numpy(v).to(dev) for k, v in batch.items()}
 from vmap_amd import _lib  # noqa: E402
+# the phase-stamp instantiations live in the measurement build of the library (tests/tools/libvmapstep_ab.so, built by build())
+step.VmapStep.ab_library = os.path.join(ROOT, "tests", "tools", "libvmapstep_ab.so")
 kern = sys.argv[2] if len(sys.argv) > 2 else "split"       # split (default kernel at hidden 32) | f32
 ws_flags = int(sys.argv[3]) if len(sys.argv) > 3 else 0      # hidden 128: tuning.ws_flags (4 = never three-tile rounds)
-op = step.VmapStep(n, R, S, H, device=dev, tuning={"kernel": _lib.KERNEL_H32_F32} if kern == "f32" else {"ws_flags": ws_flags} if ws_flags else None)
+op = step.VmapStep(n, R, S, H, device=dev, tuning={"kernel": _lib.KERNEL_H32_F32} if kern == "f32" else {"ws_flags": ws_flags})   # (an explicit tuning selects the measurement build)
 args = (tfc, tB, tsc, tb["pcs"], tb["z"], tb["gt_depth"], tb["gt_rgb"], tb["sem"], tb["depth_mask"])
 for _ in range(3):
     t = op.profile_phases(*args)

@@ -97,24 +97,25 @@ EXPORTS = (
     "vmapstep_sample_workspace_bytes", "vmapstep_describe_plan",
 )
 
-_lib = None
+_libs = {}
 
 
 class VmapStepError(RuntimeError):
     pass
 
 
-def load():
-    """Load the HIP library. Import torch first so that its libamdhip64 is the one both sides share."""
-    global _lib
-    if _lib is not None:
-        return _lib
+def load(path=None):
+    """Load the HIP library (``path``: another build of it - the measurement build of tests/tools - next to the product's; each is
+    loaded once). Import torch first so that its libamdhip64 is the one both sides share."""
+    path = os.path.abspath(path or LIB_PATH)
+    if path in _libs:
+        return _libs[path]
     import torch  # noqa: F401  (maps torch/lib/libamdhip64.so before our NEEDED entry is resolved)
-    if not os.path.exists(LIB_PATH):
+    if not os.path.exists(path):
         raise VmapStepError(
-            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback for the training step.")
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     lib.vmapstep_last_error.restype = ctypes.c_char_p
     lib.vmapstep_abi_version.restype = ctypes.c_int
     lib.vmapstep_param_layout.argtypes = [ctypes.c_int32, ctypes.POINTER(ctypes.c_int64),
@@ -171,7 +172,7 @@ def load():
         getattr(lib, fn).restype = ctypes.c_int
     if lib.vmapstep_abi_version() != ABI_VERSION:
         raise VmapStepError(f"ABI mismatch: library {lib.vmapstep_abi_version()} != binding {ABI_VERSION}")
-    _lib = lib
+    _libs[path] = lib
     return lib
 
 
@@ -188,7 +189,7 @@ def describe_plan(n_obj: int, rays: int, samples: int, hidden: int, weights_bf16
     return {"kernel": info.kernel.decode(), **{k: int(getattr(info, k)) for k, _ in PlanInfo._fields_[1:]}}
 
 
-def check(rc: int):
+def check(rc: int, lib=None):
     if rc != 0:
-        msg = load().vmapstep_last_error().decode("utf-8", "replace")
+        msg = (lib or load()).vmapstep_last_error().decode("utf-8", "replace")
         raise VmapStepError(f"vmapstep error {rc}: {msg}")

@@ -28,6 +28,7 @@ int main_gen(const vk::StepArgs& a, hipStream_t st) {
     VL_LAUNCH_MAIN(kern, dim3(a.n_obj * a.NW), dim3(vk::kWG), vk::LdsGen::bytes(GL.small_n), st, ga);
     return launched("step_main_gen");
 }
+#ifdef VMAPSTEP_AB
 template <bool BWD>
 int main_wide(const vk::StepArgs& a, hipStream_t st) {
     using LW = vk::LdsWide<4>;
@@ -41,17 +42,27 @@ int main_wide(const vk::StepArgs& a, hipStream_t st) {
     VL_LAUNCH_MAIN(kern, dim3(a.n_obj * a.NW), dim3(64 * LW::NWAVES), LW::bytes(GL.small_n), st, ga);
     return launched("step_main_wide");
 }
+#endif
 }  // namespace
 
 int main_f32(const vk::StepArgs& a, bool bwd, bool stamps, hipStream_t st) {
     if (stamps) return fail(-2, "phase stamps exist in the bf16-pipe kernels only (step_main_s32 / _ws / _wp)");
     if (a.hidden != 32) {
+#ifdef VMAPSTEP_AB
         if (a.wide == 1) return bwd ? main_wide<true>(a, st) : main_wide<false>(a, st);
+#else
+        if (a.wide == 1) return fail(-2, "this kernel form ships in the measurement build only (tests/tools/libvmapstep_ab.so: phase stamps and A/B forms no automatic plan launches)");
+#endif
         return bwd ? main_gen<true>(a, st) : main_gen<false>(a, st);
     }
     const bool multi = a.NW < a.NG;
     if (bwd) return multi ? main_h32<true, true, false>(a, st) : main_h32<true, false, false>(a, st);
+#ifdef VMAPSTEP_AB
     return multi ? main_h32<false, true, false>(a, st) : main_h32<false, false, false>(a, st);
+#else
+    // forward only (vmapstep_render) on the exact-fp32 kernel: an A/B form (the training forms above back bench.py's value_exact_fp32_kernel)
+    return fail(-2, "this kernel form ships in the measurement build only (tests/tools/libvmapstep_ab.so: phase stamps and A/B forms no automatic plan launches)");
+#endif
 }
 
 int prep_f32(const vk::StepArgs& a, int blocks, hipStream_t st) {

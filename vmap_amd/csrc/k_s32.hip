@@ -23,7 +23,11 @@ int main_bs(const vk::StepArgs& a, hipStream_t st) {
 }  // namespace
 
 int main_s32(const vk::StepArgs& a, bool bwd, bool stamps, hipStream_t st) {
+#ifdef VMAPSTEP_AB
     if (stamps) return main_bs<true, true>(a, st);
+#else
+    if (stamps) return fail(-2, "this kernel form ships in the measurement build only (tests/tools/libvmapstep_ab.so: phase stamps and A/B forms no automatic plan launches)");
+#endif
     return bwd ? main_bs<true, false>(a, st) : main_bs<false, false>(a, st);
 }
 

@@ -20,14 +20,23 @@ int main_v(const vk::StepArgs& a, hipStream_t st) {
 }
 template <int NB>
 int main_nb(const vk::StepArgs& a, bool bwd, bool stamps, hipStream_t st) {
+#ifdef VMAPSTEP_AB
     if (stamps) return main_v<NB, true, true, true>(a, st);
+#else
+    if (stamps) return fail(-2, "this kernel form ships in the measurement build only (tests/tools/libvmapstep_ab.so: phase stamps and A/B forms no automatic plan launches)");
+#endif
     if (a.weights_bf16) return bwd ? main_v<NB, true, false, false>(a, st) : main_v<NB, false, false, false>(a, st);
     return bwd ? main_v<NB, true, true, false>(a, st) : main_v<NB, false, true, false>(a, st);
 }
 }  // namespace
 
 int main_wp(const vk::StepArgs& a, bool bwd, bool stamps, hipStream_t st) {
-    return a.hidden == 128 ? main_nb<4>(a, bwd, stamps, st) : main_nb<2>(a, bwd, stamps, st);
+#ifdef VMAPSTEP_AB
+    if (a.hidden == 128) return main_nb<4>(a, bwd, stamps, st);          // hidden 128 on step_main_wp: A/B reference of step_main_ws<4>
+#else
+    if (a.hidden == 128) return fail(-2, "this kernel form ships in the measurement build only (tests/tools/libvmapstep_ab.so: phase stamps and A/B forms no automatic plan launches)");
+#endif
+    return main_nb<2>(a, bwd, stamps, st);
 }
 
 }  // namespace vl

@@ -14,6 +14,12 @@ int main_t(const vk::StepArgs& a, hipStream_t st) {
     if constexpr (NB == 4 && BWD && !STAMPS) {
         if (a.NG == a.NW) return main_o<NB, BWD, W3, STAMPS, NT, true>(a, st);
     }
+#ifndef VMAPSTEP_AB
+    // three-tile rounds with several rounds per workgroup: no automatic plan launches it (the plan takes three tiles exactly when they
+    // give every workgroup ONE round) - measurement build only
+    if constexpr (NT == 3 && BWD) return fail(-2, "this kernel form ships in the measurement build only (tests/tools/libvmapstep_ab.so: phase stamps and A/B forms no automatic plan launches)");
+    else
+#endif
     return main_o<NB, BWD, W3, STAMPS, NT, false>(a, st);
 }
 template <int NB, bool BWD, bool W3, bool STAMPS, int NT, bool ONE>
@@ -37,7 +43,11 @@ int main_v(const vk::StepArgs& a, hipStream_t st) {
 }
 template <int NB>
 int main_nb(const vk::StepArgs& a, bool bwd, bool stamps, hipStream_t st) {
+#ifdef VMAPSTEP_AB
     if (stamps) return main_v<NB, true, true, true>(a, st);
+#else
+    if (stamps) return fail(-2, "this kernel form ships in the measurement build only (tests/tools/libvmapstep_ab.so: phase stamps and A/B forms no automatic plan launches)");
+#endif
     if (a.weights_bf16) return bwd ? main_v<NB, true, false, false>(a, st) : main_v<NB, false, false, false>(a, st);
     return bwd ? main_v<NB, true, true, false>(a, st) : main_v<NB, false, true, false>(a, st);
 }
@@ -45,7 +55,12 @@ int main_nb(const vk::StepArgs& a, bool bwd, bool stamps, hipStream_t st) {
 
 int main_ws(const vk::StepArgs& a, bool bwd, bool stamps, hipStream_t st) {
     if (a.hidden == 256) return main_ws8(a, bwd, st);                    // k_ws8.hip (eight waves)
-    return a.hidden == 128 ? main_nb<4>(a, bwd, stamps, st) : main_nb<2>(a, bwd, stamps, st);
+    if (a.hidden == 128) return main_nb<4>(a, bwd, stamps, st);
+#ifdef VMAPSTEP_AB
+    return main_nb<2>(a, bwd, stamps, st);                               // hidden 64 on step_main_ws: A/B reference of step_main_wp<2>
+#else
+    return fail(-2, "this kernel form ships in the measurement build only (tests/tools/libvmapstep_ab.so: phase stamps and A/B forms no automatic plan launches)");
+#endif
 }
 
 int prep_ws(const vk::StepArgs& a, int n_steps, hipStream_t st) {

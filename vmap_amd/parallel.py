@@ -142,12 +142,12 @@ class SharedBackgroundHip:
         from . import _lib
         op, opt, br = self.op, self.opt, self._byref
         st = op._stream()
-        _lib.check(op.lib.vmapstep_fwd_bwd_prepared(br(op.shape), br(self._pp), br(self._sc), br(self._bt[i]), i, op.color_scaling,
+        _lib.check(lib=op.lib, rc=op.lib.vmapstep_fwd_bwd_prepared(br(op.shape), br(self._pp), br(self._sc), br(self._bt[i]), i, op.color_scaling,
                                                     op.opacity_scaling, br(self._gp), br(self._out_fb), op._ws_ptr, op._ws_bytes, st))
         if self.world_size > 1:
             dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=self.group)      # ONE message: gradients + loss terms
         oc = opt.c_struct()
-        _lib.check(op.lib.vmapstep_adamw_apply(br(op.shape), br(self._pp), self.gslab.data_ptr(), opt.padded, br(oc), self.terms.data_ptr(),
+        _lib.check(lib=op.lib, rc=op.lib.vmapstep_adamw_apply(br(op.shape), br(self._pp), self.gslab.data_ptr(), opt.padded, br(oc), self.terms.data_ptr(),
                                                i, op.color_scaling, op.opacity_scaling, br(self._out_ap[i]), op._ws_ptr, op._ws_bytes, st))
         opt.step += 1
         opt.note_host_steps(1)

@@ -100,6 +100,8 @@ class VmapStep:
     # measurement / test hook: plan overrides merged UNDER every new operator's own ``tuning`` (Python-side default only;
     # the C library keeps no tuning state)
     default_tuning: Optional[dict] = None
+    # test / tool hook: path of the measurement build (tests/tools/libvmapstep_ab.so: phase stamps + A/B kernel forms); None in products
+    ab_library: Optional[str] = None
 
     def __init__(self, n_obj: int, rays: int, samples: int, hidden: int, device="cuda:0", max_steps: int = 32,
                  color_scaling: float = 5.0, opacity_scaling: float = 10.0, weights: str = "f32", tuning: Optional[dict] = None):
@@ -107,7 +109,11 @@ class VmapStep:
         ``vmapstep_tuning``: workgroups_per_object, kernel, generic_finalize, ws_flags).  They belong to THIS operator (the C library
         keeps no tuning state).  The operator may live on any GPU of the process: every C call runs on the device that owns
         the stream it is given (``torch.cuda.current_stream(self.device)``), whatever device is current on the thread."""
-        self.lib = _lib.load()
+        tuning = {**(type(self).default_tuning or {}), **(tuning or {})}
+        # the product library carries the forms automatic plans launch; an operator with an explicit plan override runs on the
+        # measurement build when a test / tool registered one (VmapStep.ab_library) - otherwise on the product, which refuses
+        # forms it does not carry
+        self.lib = _lib.load(type(self).ab_library if (tuning and type(self).ab_library) else None)
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.VmapStepError("VmapStep runs on the GPU only (no CPU fallback)")
@@ -115,7 +121,6 @@ class VmapStep:
             raise ValueError("weights must be 'f32' or 'bf16'")
         self.shape = _lib.Shape(n_obj, rays, samples, hidden, _lib.WEIGHTS_BF16 if weights == "bf16" else _lib.WEIGHTS_F32)
         self._tuning = None
-        tuning = {**(type(self).default_tuning or {}), **(tuning or {})}
         if tuning:
             self._tuning = _lib.Tuning(**tuning)          # kept alive by the operator; the shape points at it
             self.shape.tuning = ctypes.pointer(self._tuning)
@@ -123,7 +128,7 @@ class VmapStep:
         self.max_steps = max_steps
         self.color_scaling, self.opacity_scaling = float(color_scaling), float(opacity_scaling)
         nbytes = ctypes.c_size_t(0)
-        _lib.check(self.lib.vmapstep_workspace_bytes(ctypes.byref(self.shape), max_steps, ctypes.byref(nbytes)))
+        _lib.check(lib=self.lib, rc=self.lib.vmapstep_workspace_bytes(ctypes.byref(self.shape), max_steps, ctypes.byref(nbytes)))
         self.workspace = torch.empty(nbytes.value + 256, dtype=torch.uint8, device=self.device)
         off = (-self.workspace.data_ptr()) % 256
         self._ws_ptr = self.workspace.data_ptr() + off
@@ -193,7 +198,7 @@ class VmapStep:
         """The launch plan of this operator (``vmapstep_describe_plan``): kernel name, rays per round, rounds and workgroups per
         object, tiles per round, waves per workgroup, single_round."""
         info = _lib.PlanInfo()
-        _lib.check(self.lib.vmapstep_describe_plan(ctypes.byref(self.shape), self.max_steps, ctypes.byref(info)))
+        _lib.check(lib=self.lib, rc=self.lib.vmapstep_describe_plan(ctypes.byref(self.shape), self.max_steps, ctypes.byref(info)))
         return {"kernel": info.kernel.decode(), **{k: int(getattr(info, k)) for k, _ in _lib.PlanInfo._fields_[1:]}}
 
     def _stream(self) -> int:
@@ -232,11 +237,11 @@ class VmapStep:
                 raise ValueError(f"loss_terms: need contiguous float32 {(self.n_obj, 4)} on {self.device}")
             out.loss_terms = loss_terms.data_ptr()
         if prepared_step is not None:
-            _lib.check(self.lib.vmapstep_fwd_bwd_prepared(ctypes.byref(self.shape), ctypes.byref(pp), ctypes.byref(sc), ctypes.byref(bt),
+            _lib.check(lib=self.lib, rc=self.lib.vmapstep_fwd_bwd_prepared(ctypes.byref(self.shape), ctypes.byref(pp), ctypes.byref(sc), ctypes.byref(bt),
                                                           int(prepared_step), self.color_scaling, self.opacity_scaling,
                                                           ctypes.byref(gp), ctypes.byref(out), self._ws_ptr, self._ws_bytes, self._stream()))
         else:
-            _lib.check(self.lib.vmapstep_fwd_bwd(ctypes.byref(self.shape), ctypes.byref(pp), ctypes.byref(sc), ctypes.byref(bt),
+            _lib.check(lib=self.lib, rc=self.lib.vmapstep_fwd_bwd(ctypes.byref(self.shape), ctypes.byref(pp), ctypes.byref(sc), ctypes.byref(bt),
                                                  self.color_scaling, self.opacity_scaling, ctypes.byref(gp), ctypes.byref(out),
                                                  self._ws_ptr, self._ws_bytes, self._stream()))
         return res
@@ -252,9 +257,9 @@ class VmapStep:
         pp = self._params(fc, B)
         bt = self._batch(pcs, z, gt_depth, gt_rgb, sem, depth_mask, rays_total=pcs.shape[1])
         foff, coff = ctypes.c_size_t(0), ctypes.c_size_t(0)
-        _lib.check(self.lib.vmapstep_prepare(ctypes.byref(self.shape), ctypes.byref(pp), ctypes.byref(bt), ray_step, n_steps,
+        _lib.check(lib=self.lib, rc=self.lib.vmapstep_prepare(ctypes.byref(self.shape), ctypes.byref(pp), ctypes.byref(bt), ray_step, n_steps,
                                              self._ws_ptr, self._ws_bytes, ctypes.byref(foff), self._stream()))
-        _lib.check(self.lib.vmapstep_workspace_counts_offset(ctypes.byref(self.shape), n_steps, ctypes.byref(coff)))
+        _lib.check(lib=self.lib, rc=self.lib.vmapstep_workspace_counts_offset(ctypes.byref(self.shape), n_steps, ctypes.byref(coff)))
         counts = self._ws_view(coff.value, n_steps * self.n_obj * 16).view(torch.float32).view(n_steps, self.n_obj, 4)
         flags = self._ws_view(foff.value, n_steps * 16).view(torch.int32).view(n_steps, 4)
         return counts, flags
@@ -284,7 +289,7 @@ class VmapStep:
                 raise ValueError(f"loss_terms given: loss_out (float32 [>=1]) and flags_out (contiguous int32 [>=4]) on {self.device} are required")
             out = ctypes.byref(_lib.Outputs(loss_out.data_ptr(), flags_out.data_ptr(), None, None, None, None, None))
             lt = loss_terms.data_ptr()
-        _lib.check(self.lib.vmapstep_adamw_apply(ctypes.byref(self.shape), ctypes.byref(pp), grad_slab.data_ptr(), opt.padded,
+        _lib.check(lib=self.lib, rc=self.lib.vmapstep_adamw_apply(ctypes.byref(self.shape), ctypes.byref(pp), grad_slab.data_ptr(), opt.padded,
                                                  ctypes.byref(oc), lt, int(step_index), self.color_scaling, self.opacity_scaling, out,
                                                  self._ws_ptr, self._ws_bytes, self._stream()))
         opt.step += 1
@@ -296,7 +301,7 @@ class VmapStep:
         sc = _lib.Tensor(pe_scale.data_ptr(), pe_scale.stride(0) if pe_scale.dim() else 0)
         bt = self._batch(pcs, z, gt_depth, gt_rgb, sem, depth_mask)
         res, out = self._outputs(1, True)
-        _lib.check(self.lib.vmapstep_render(ctypes.byref(self.shape), ctypes.byref(pp), ctypes.byref(sc),
+        _lib.check(lib=self.lib, rc=self.lib.vmapstep_render(ctypes.byref(self.shape), ctypes.byref(pp), ctypes.byref(sc),
                                             ctypes.byref(bt), self.color_scaling, self.opacity_scaling,
                                             ctypes.byref(out), self._ws_ptr, self._ws_bytes, self._stream()))
         return res
@@ -307,11 +312,11 @@ class VmapStep:
         sc = _lib.Tensor(pe_scale.data_ptr(), pe_scale.stride(0) if pe_scale.dim() else 0)
         bt = self._batch(pcs, z, gt_depth, gt_rgb, sem, depth_mask)
         args = (ctypes.byref(self.shape), ctypes.byref(pp), ctypes.byref(sc), ctypes.byref(bt))
-        _lib.check(self.lib.vmapstep_profile_main_kernel(*args, 3, self._ws_ptr, self._ws_bytes, self._stream()))
+        _lib.check(lib=self.lib, rc=self.lib.vmapstep_profile_main_kernel(*args, 3, self._ws_ptr, self._ws_bytes, self._stream()))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         e0.record()
-        _lib.check(self.lib.vmapstep_profile_main_kernel(*args, reps, self._ws_ptr, self._ws_bytes, self._stream()))
+        _lib.check(lib=self.lib, rc=self.lib.vmapstep_profile_main_kernel(*args, reps, self._ws_ptr, self._ws_bytes, self._stream()))
         e1.record()
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps
@@ -325,7 +330,7 @@ class VmapStep:
         cap = 8 * ((self.n_obj + 7) // 8) * 512 * 4 * 16      # up to 512 workgroups per object (step_main_wp at hidden 64: two per CU)
         buf = torch.zeros(cap, dtype=torch.int32, device=self.device)
         nwg = ctypes.c_int32(0)
-        _lib.check(self.lib.vmapstep_profile_phases(ctypes.byref(self.shape), ctypes.byref(pp), ctypes.byref(sc),
+        _lib.check(lib=self.lib, rc=self.lib.vmapstep_profile_phases(ctypes.byref(self.shape), ctypes.byref(pp), ctypes.byref(sc),
                                                     ctypes.byref(bt), buf.data_ptr(), cap, ctypes.byref(nwg),
                                                     self._ws_ptr, self._ws_bytes, self._stream()))
         torch.cuda.synchronize()
@@ -359,12 +364,12 @@ class VmapStep:
         fn = self.lib.vmapstep_train_steps
         if flag_reduce is not None:
             off = ctypes.c_size_t(0)
-            _lib.check(self.lib.vmapstep_prepare(ctypes.byref(self.shape), ctypes.byref(pp), ctypes.byref(bt), ray_step,
+            _lib.check(lib=self.lib, rc=self.lib.vmapstep_prepare(ctypes.byref(self.shape), ctypes.byref(pp), ctypes.byref(bt), ray_step,
                                                  n_steps, self._ws_ptr, self._ws_bytes, ctypes.byref(off), self._stream()))
             flags_view = self._ws_view(off.value, n_steps * 16).view(torch.int32).view(n_steps, 4)
             flag_reduce(flags_view)
             fn = self.lib.vmapstep_train_steps_prepared
-        _lib.check(fn(ctypes.byref(self.shape), ctypes.byref(pp), ctypes.byref(sc),
+        _lib.check(lib=self.lib, rc=fn(ctypes.byref(self.shape), ctypes.byref(pp), ctypes.byref(sc),
                       ctypes.byref(bt), ray_step, n_steps, self.color_scaling,
                       self.opacity_scaling, ctypes.byref(oc),
                       ctypes.byref(gp) if gp is not None else None, ctypes.byref(out),
@@ -411,13 +416,13 @@ class BoundFrame:
         fn = lib.vmapstep_train_steps
         if self.flag_reduce is not None:
             off = ctypes.c_size_t(0)
-            _lib.check(lib.vmapstep_prepare(sh, ctypes.byref(self._pp), ctypes.byref(self._bt), self.ray_step, n_steps,
+            _lib.check(lib=lib, rc=lib.vmapstep_prepare(sh, ctypes.byref(self._pp), ctypes.byref(self._bt), self.ray_step, n_steps,
                                             op._ws_ptr, op._ws_bytes, ctypes.byref(off), stream))
             self.flag_reduce(op._ws_view(off.value, n_steps * 16).view(torch.int32).view(n_steps, 4))
             fn = lib.vmapstep_train_steps_prepared
         on_device = opt.bias_table is not None and self.flag_reduce is None
         oc = opt.c_struct(device_steps=on_device)
-        _lib.check(fn(sh, ctypes.byref(self._pp), ctypes.byref(self._sc), ctypes.byref(self._bt), self.ray_step, n_steps,
+        _lib.check(lib=lib, rc=fn(sh, ctypes.byref(self._pp), ctypes.byref(self._sc), ctypes.byref(self._bt), self.ray_step, n_steps,
                       op.color_scaling, op.opacity_scaling, ctypes.byref(oc), None, ctypes.byref(self._out),
                       op._ws_ptr, op._ws_bytes, stream))
         return on_device
@@ -469,7 +474,7 @@ def _profile_train_steps(self, fc, B, pe_scale, pcs, z, gt_depth, gt_rgb, sem, d
     res, out = self._outputs(n_steps, False)
     oc = opt.c_struct()
     ms = (ctypes.c_float * 2)(0.0, 0.0)
-    _lib.check(self.lib.vmapstep_profile_train_steps(ctypes.byref(self.shape), ctypes.byref(pp), ctypes.byref(sc), ctypes.byref(bt),
+    _lib.check(lib=self.lib, rc=self.lib.vmapstep_profile_train_steps(ctypes.byref(self.shape), ctypes.byref(pp), ctypes.byref(sc), ctypes.byref(bt),
                                                      self.rays, n_steps, self.color_scaling, self.opacity_scaling, ctypes.byref(oc),
                                                      ctypes.byref(out), self._ws_ptr, self._ws_bytes, self._stream(), ms))
     opt.step += n_steps
