@@ -154,7 +154,7 @@ def reference_step(fc_np, B_np, scale_np, batch, H, dtype=torch.float32, strateg
 
 
 def reference_frame(fc_np, B_np, scale_np, frame, H, rays_per_step, n_steps, dtype=torch.float32,
-                    lr=1e-3, weight_decay=0.013, weights_bf16=False, strategy="vmap"):
+                    lr=1e-3, weight_decay=0.013, weights_bf16=False, strategy="vmap", first_step_grad_delta=None):
     """The reference's OWN step loop over one frame (train.py:270-326, vmap strategy): the per-frame sample tensors
     ``[n, n_steps * rays_per_step, ...]`` are sliced with ``data_idx = slice(i * R, (i + 1) * R)`` on dimension 1 (strided
     views, exactly like train.py:271-277), every step is vmap(pe) -> vmap(fc) -> loss.step_batch_loss -> backward ->
@@ -165,6 +165,12 @@ def reference_frame(fc_np, B_np, scale_np, frame, H, rays_per_step, n_steps, dty
     the unmodified reference modules on a copy of the masters rounded to bfloat16 (round-to-nearest-even, all 15
     tensors), and the gradients of that copy become the masters' ``.grad`` before ``AdamW.step()`` - the semantics of
     ``vmapstep_shape::weight_dtype = VMAPSTEP_WEIGHTS_BF16`` (include/vmapstep.h).
+
+    ``first_step_grad_delta`` (15 arrays shaped like the stacked tensors, or None): added to the FIRST step's gradients before
+    ``AdamW.step()`` - the trajectory the same loop follows when its float32 evaluation of step 0 lands on the other side of a
+    ReLU kink (a hidden unit whose pre-activation lies inside forward rounding of 0: value ~0 either way, derivative bit 0 or 1;
+    the delta is the exact effect of that bit, oracle.vmap_oracle.kink_deltas).  Both branches are valid float32 evaluations of
+    the reference; tests/golden/make_frame_goldens.py stores both where the reference's own run and the oracle disagree on a bit.
 
     Returns the per-step losses (float64 array), the final parameters and the gradients of the FIRST step."""
     mods = _import_reference()
@@ -224,6 +230,11 @@ def reference_frame(fc_np, B_np, scale_np, frame, H, rays_per_step, n_steps, dty
         if it == 0:
             first_grads = [(p.grad if p.grad is not None else torch.zeros_like(p)).detach().numpy().copy()
                            for p in list(fc_param) + list(pe_param)]
+            if first_step_grad_delta is not None:
+                with torch.no_grad():
+                    for p, d in zip(list(fc_param) + list(pe_param), first_step_grad_delta):
+                        if p.grad is not None:
+                            p.grad += torch.from_numpy(np.ascontiguousarray(d)).to(p.grad.dtype)
         opt.step()                                                               # train.py:325
         opt.zero_grad(set_to_none=True)                                          # train.py:326
         losses.append(float(l))

@@ -26,11 +26,13 @@ CASES = {
     "bg_h128_s14":   (1, 48, 14, 128, 5.0, 60, 61, 1.0, None),       # train.py:308-316 shapes (fewer rays)
     "imap_h256":     (1, 100, 14, 256, 10.0, 70, 71, 1.0, None),     # BASELINE configs[0]
     "scannet_scale": (6, 120, 10, 32, 3.0, 80, 81, 1.0, None),       # configs[3] obj_scale
+    "imap_full":     (1, 4800, 14, 256, 10.0, 72, 73, 1.0, None),    # the reference's OWN iMAP batch (config_replica_room0_iMAP.json:31 n_per_optim 4800):
+                                                                     # 2400 single-tile rounds on 240 workgroups - the multi-round step_main_ws<8> form
 }
 
 
 # step fixtures that also exist on bfloat16-rounded parameters (<name>_bf16.npz): BASELINE configs[3] / [4] weight mode
-BF16_CASES = ("scannet_scale", "h64", "bg_h128_s14")
+BF16_CASES = ("scannet_scale", "h64", "bg_h128_s14", "imap_full")
 
 
 def build_case(name):

@@ -54,6 +54,30 @@ def main(names=None):
             n = r32[f"p_{k}"].shape[0]
             out[f"pnorm_{k}"] = np.sqrt((r32[f"p_{k}"].astype(np.float64).reshape(n, -1) ** 2).sum(-1))
             out[f"f64_pnorm_{k}"] = np.sqrt((r64[f"p_{k}"].astype(np.float64).reshape(n, -1) ** 2).sum(-1))
+        # ---- the other side of a ReLU kink (round 4) ----
+        # Where the reference's own float32 run of step 0 and the numpy oracle disagree on the derivative bit of a kink-adjacent hidden
+        # unit, a second float32 implementation may follow either branch: find the bits (conftest.kink_aware on the first-step
+        # gradients), re-run the SAME unmodified reference loop with the first step's gradients moved to the oracle's side of those
+        # bits, and store that branch as alt_* next to the primary one.
+        from conftest import GRAD_KEYS, kink_aware, round_bf16
+        from oracle import vmap_oracle as vo
+        rnd = round_bf16 if bf16 else (lambda a: a)
+        sub = {k: np.ascontiguousarray(v[:, :c["R"]]) for k, v in c["frame"].items()}
+        o = vo.training_step([rnd(a) for a in c["fc"]], rnd(c["B"]), c["scale"], sub, dtype=np.float32, kinks=True)
+        ref0 = {(f"g_fc{t}" if t < 14 else "g_B"): r32[f"g0_fc{t}" if t < 14 else "g0_B"] for t in range(15)}
+        corr, flipped, cand, worst = kink_aware(ref0, o, c["n"], signed=False, tol=1e-4)
+        out["alt_flipped_bits"] = np.array(flipped)
+        if flipped:
+            delta = [np.asarray(o[k], np.float64) - corr[k] for k in GRAD_KEYS]           # reference side -> oracle side
+            alt = ref_runner.reference_frame(c["fc"], c["B"], c["scale"], c["frame"], c["H"], c["R"], c["n_steps"], torch.float32,
+                                             weights_bf16=bf16, first_step_grad_delta=[d.astype(np.float32) for d in delta])
+            out["alt_losses"] = alt["losses"]
+            for t in list(range(14)) + ["B"]:
+                k = f"fc{t}" if t != "B" else "B"
+                out[f"alt_p_{k}"] = alt[f"p_{k}"][keep].astype(np.float32)
+                out[f"alt_pnorm_{k}"] = np.sqrt((alt[f"p_{k}"].astype(np.float64).reshape(alt[f"p_{k}"].shape[0], -1) ** 2).sum(-1))
+            print(f"{name:16s} {flipped} kink bit(s) between the reference's run and the oracle: alternate branch stored, losses "
+                  f"{alt['losses'][0]:.4f} .. {alt['losses'][-1]:.4f}; max rel separation {np.abs(alt['losses'] / r32['losses'] - 1).max():.2e}")
         out["torch_version"] = np.array(torch.__version__)
         path = os.path.join(HERE, f"{name}.npz")
         np.savez_compressed(path, **out)

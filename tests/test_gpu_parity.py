@@ -119,6 +119,20 @@ def test_fwd_bwd_matches_oracle_on_seeded_shapes(n, R, S, seed):
     _assert_grads_match_oracle_up_to_kinks(s, o, n)
 
 
+def _assert_grads_match_aten_port_up_to_kinks(s, o, grads_t, n_obj, tol=1e-4):
+    """Gradients against the ATen PORT (the third-party kernels the reference runs; it reproduces the reference's frame trajectories
+    bit for bit) at north_star's 1e-4, ReLU kinks accounted for: the candidate list and the exact effect of each flip come from the
+    numpy oracle (``o`` computed with kinks=True); a bit may differ from the oracle's state in the port, in the kernel or in both,
+    hence SIGNED coefficients in {-1, 0, +1} (conftest.kink_aware)."""
+    ref = dict(o)
+    for k, g in zip(GRAD_KEYS, grads_t):
+        ref[k] = g.numpy() if hasattr(g, "numpy") else np.asarray(g)
+    corr, flipped, cand, worst = kink_aware(s, ref, n_obj, signed=True, tol=tol)
+    for k in GRAD_KEYS:
+        assert not np.isnan(s[k]).any(), k
+        assert relerr(s[k], corr[k]) < tol, (k, flipped, cand)
+
+
 def _assert_grads_match_oracle_up_to_kinks(s, o, n_obj, tol=2e-4, signed=False):
     """Gradients against the numpy oracle with the ReLU kinks ACCOUNTED FOR instead of tolerated (tolerance: north_star's 1e-4
     for the kernel + the 1e-4 tests/test_oracle_vs_golden.py allows the numpy restatement itself against the reference; the
@@ -155,14 +169,20 @@ def test_hidden128_kernel_matches_oracle_on_seeded_shapes(n, R, S, seed, H):
     for k in RENDER_KEYS + ["var"]:
         assert relerr(s[k], o[k]) < 2e-5, k
     _assert_grads_match_oracle_up_to_kinks(s, o, n)
+    _assert_grads_match_aten_port_up_to_kinks(s, o, grads_t, n)      # round 4: the ATen port at 1e-4, signed kink coefficients
+    a = _run(c)                                                       # the automatic plan (product library)
+    _assert_grads_match_aten_port_up_to_kinks(a, o, grads_t, n)
     e = _run(c, tuning={"kernel": _lib.KERNEL_GEN})
     w1 = _run(c, tuning={"kernel": _lib.KERNEL_WS1})              # step_main_ws: one wave per output block (single-tile rounds where they fit)
     w2 = _run(c, tuning={"kernel": _lib.KERNEL_WS1, "ws_flags": 1})    # ... two-tile rounds
     _assert_grads_match_oracle_up_to_kinks(w1, o, n)
     _assert_grads_match_oracle_up_to_kinks(w2, o, n)
+    _assert_grads_match_aten_port_up_to_kinks(w1, o, grads_t, n)
+    _assert_grads_match_aten_port_up_to_kinks(w2, o, grads_t, n)
     if H == 128:
         w3 = _run(c, tuning={"kernel": _lib.KERNEL_WS1, "ws_flags": 2})    # ... three-tile rounds (hidden 128)
         _assert_grads_match_oracle_up_to_kinks(w3, o, n)
+        _assert_grads_match_aten_port_up_to_kinks(w3, o, grads_t, n)
         for k in RENDER_KEYS:
             assert relerr(w3[k], e[k]) < 2e-5, k
         for k in GRAD_KEYS:
@@ -195,9 +215,14 @@ def test_hidden256_kernel_matches_oracle_on_seeded_shapes(n, R, S, seed):
     for k in RENDER_KEYS + ["var"]:
         assert relerr(s[k], o[k]) < 2e-5, k
     _assert_grads_match_oracle_up_to_kinks(s, o, n)
+    from oracle import vmap_oracle_torch as vt
+    loss_t, rend_t, grads_t = vt.CpuTrainer(fc, B, sc).step(batch, update=False)
+    assert abs(s["loss"] - float(loss_t)) <= 5e-5 * abs(float(loss_t))
+    _assert_grads_match_aten_port_up_to_kinks(s, o, grads_t, n)      # round 4: the ATen port at 1e-4, signed kink coefficients
     e = _run(c, tuning={"kernel": _lib.KERNEL_GEN})
     m = _run(c, tuning={"kernel": _lib.KERNEL_WS1, "workgroups_per_object": 2})   # several rounds per workgroup
     _assert_grads_match_oracle_up_to_kinks(m, o, n)
+    _assert_grads_match_aten_port_up_to_kinks(m, o, grads_t, n)
     for k in RENDER_KEYS:
         assert relerr(s[k], e[k]) < 2e-5, k
         assert relerr(m[k], e[k]) < 2e-5, k
@@ -500,6 +525,38 @@ def test_generic_width_kernel_matches_reference_fixture(name, kernel):
         assert relerr(s[k], g[k]) < 1e-4, k
 
 
+@pytest.mark.parametrize("weights", ["f32", "bf16"])
+def test_reference_imap_batch_matches_reference_fixture(weights):
+    """The reference's OWN iMAP batch (config_replica_room0_iMAP.json:31: n_per_optim 4800 rays x 14 samples, hidden 256): 2400
+    single-tile rounds on 240 workgroups = the MULTI-ROUND form of step_main_ws<8> (ten rounds per workgroup, read-modify-write of
+    its 1.4 MB gradient row), float32 weights and the bfloat16 form - against the unmodified reference run on the same inputs
+    (fixture imap_full / imap_full_bf16: loss, renders, all 15 gradient tensors).  Gradients at north_star's 1e-4; should the
+    reference's run and the kernel differ on the derivative bit of kink-adjacent hidden units (67 200 points x 1024 units), the
+    bits are accounted for one by one (signed coefficients, conftest.kink_aware)."""
+    if step.VmapStep.default_tuning is not None:
+        pytest.skip("hidden 256: the module's hidden-32 kernel legs do not apply; run once")
+    from conftest import round_bf16
+    bf16 = weights == "bf16"
+    c = cases.build_case("imap_full")
+    g = load_golden("imap_full_bf16" if bf16 else "imap_full")
+    op = step.VmapStep(c["n"], c["R"], c["S"], c["H"], device=DEV, weights=weights)
+    plan = op.plan()
+    assert plan["kernel"] == "step_main_ws<8>" and plan["single_round"] == 0 and plan["rounds_per_object"] == 2400
+    s = _run(c, op=op)
+    assert abs(s["loss"] - float(g["loss"])) <= 2e-5 * abs(float(g["loss"]))
+    for k in RENDER_KEYS:
+        assert relerr(s[k], g[k]) < 2e-5, k
+    assert relerr(s["var"], g["var"]) < _var_tol(g)
+    for k in GRAD_KEYS:
+        assert not np.isnan(s[k]).any(), k
+    if max(relerr(s[k], g[k]) for k in GRAD_KEYS) >= 1e-4:
+        rnd = round_bf16 if bf16 else (lambda a: a)
+        o = vo.training_step([rnd(a) for a in c["fc"]], rnd(c["B"]), c["scale"], c["batch"], dtype=np.float32, kinks=True)
+        fix = {k: g[k] for k in GRAD_KEYS}
+        fix["kink_deltas"] = o["kink_deltas"]
+        _assert_grads_match_oracle_up_to_kinks(s, fix, c["n"], tol=1e-4, signed=True)
+
+
 def test_generic_width_multi_pass_and_train_steps():
     """hidden = 64 with fewer workgroups than ray groups (partials accumulated over passes) + fused AdamW steps."""
     c = cases.build_case("h64")
@@ -735,14 +792,24 @@ FRAME_TOL = {   # (relative loss tolerance for steps < 5, for later steps, q99 /
     "h64_r256_frame": (5e-5, 1e-4, 2e-5, 2e-6),
     "bg128_frame": (5e-5, 1e-4, 2e-5, 2e-6),
     # bf16 run-time weights over fp32 masters (measured: 3.3e-6 / 7.8e-7 at the two object shapes).  bg128_frame_bf16: the
-    # reference's fixture and this kernel sit on opposite sides of ONE ReLU kink in step 0 (accounted for bit by bit in the
+    # reference's own run and this kernel sit on opposite sides of ONE ReLU kink in step 0 (accounted for bit by bit in the
     # first-step gradient check below); the two trajectories then separate as far as one hidden unit's gradient moves the
-    # masters across bfloat16 rounding boundaries: 6.6e-5, 2.5e-4 in steps 2, 3 (the exact-fp32 kernel, on the reference's side
-    # of the kink: 4e-7) - bounded at 1e-3.
+    # masters across bfloat16 rounding boundaries (6e-5 .. 2.5e-4).  Round 4: (i) the fixture holds BOTH branches of that bit - the
+    # reference's loop re-run with the first step's gradients on the other side (alt_*, tests/golden/make_frame_goldens.py): the
+    # kernel matches NEITHER better than the other, so the kink is not what separates them; (ii) what does was measured on the
+    # reference itself (profiles/round4c_bf16_master_rounding_sensitivity.json): perturbing its step-0 gradients by 1e-5 relative
+    # (the kernel's backward products are good to 2^-16) moves its own loss of step 3 by up to 6e-5 with bf16 run-time weights and
+    # by nothing (2e-7) with float32 weights - a master crossing a bfloat16 rounding boundary moves a run-time weight by 2^-8.
+    # Steps 0 and 1 (before any master can differ: Adam's first update is lr * sign(g)) are held to 5e-5 (measured: exact), the
+    # later steps of THIS fixture to 1e-3 - and test_bf16_frame_steps_teacher_forced holds every step of every bf16 frame to the
+    # real bar (loss 2e-5, gradients 1e-4) against the ATen port evaluated on the kernel's OWN masters of that step.
     "scannet50_frame_bf16": (5e-5, 1e-4, 2e-5, 2e-6),
     "h64_r256_frame_bf16": (5e-5, 1e-4, 2e-5, 2e-6),
-    "bg128_frame_bf16": (1e-3, 1e-3, 2e-5, 2e-6),
+    "bg128_frame_bf16": (5e-5, 1e-3, 2e-5, 2e-6),
 }
+# steps whose loss must meet the EARLY bound (the others the late one): bg128_frame_bf16 holds steps 0 and 1 to 5e-5 (measured: exact) -
+# from step 2 on a bf16-weights trajectory is as sensitive as profiles/round4c_bf16_master_rounding_sensitivity.json shows
+FRAME_EARLY_STEPS = {"bg128_frame_bf16": 2}
 
 
 @pytest.mark.parametrize("name", list(cases.FRAME_CASES) + [f"{n}_bf16" for n in cases.BF16_FRAME_CASES])
@@ -758,6 +825,44 @@ def test_frame_trajectory_matches_reference_step_loop(name):
     # kernel parametrisation runs the two-tile form instead, so that both are held to the reference's own loop
     two_tile = name.startswith("bg128") and step.VmapStep.default_tuning is not None
     _check_frame_trajectory(name, {"ws_flags": 1} if two_tile else None)
+
+
+@pytest.mark.parametrize("name", list(cases.BF16_FRAME_CASES))
+def test_bf16_frame_steps_teacher_forced(name):
+    """Every step of the bf16-weights frames held to north_star's bar WITHOUT the chaos of the mode's trajectory (a master that
+    crosses a bfloat16 rounding boundary moves a run-time weight by 2^-8: profiles/round4c_bf16_master_rounding_sensitivity.json):
+    before step i the kernel's OWN float32 masters are read back, the ATen port (the kernels the reference runs) evaluates loss and
+    gradients of step i's ray slice on their bfloat16 rounding, and the kernel's loss / gradients of the same step must agree to
+    2e-5 / 1e-4 (ReLU kinks accounted for, signed); then the kernel's fused AdamW advances the masters and the next step is checked
+    on the new ones."""
+    if step.VmapStep.default_tuning is not None and cases.FRAME_CASES[name][3] != 32:
+        pytest.skip("hidden 64 / 128: the module's hidden-32 kernel legs do not apply; run once")
+    from conftest import round_bf16
+    from oracle import vmap_oracle_torch as vt
+    c = cases.build_frame_case(name)
+    n, R, S, H, steps = c["n"], c["R"], c["S"], c["H"], c["n_steps"]
+    fc = [torch.from_numpy(a).to(DEV) for a in c["fc"]]
+    B = torch.from_numpy(c["B"]).to(DEV)
+    sc = torch.from_numpy(c["scale"]).to(DEV)
+    fr = {k: torch.from_numpy(v).to(DEV) for k, v in c["frame"].items()}
+    op = step.VmapStep(n, R, S, H, device=DEV, max_steps=1, weights="bf16")
+    st = step.FusedAdamWState(n, H, DEV)
+    keys = ("pcs", "z", "gt_depth", "gt_rgb", "sem", "depth_mask")
+    for i in range(steps):
+        sl = slice(i * R, (i + 1) * R)
+        masters = [t.cpu().numpy() for t in fc + [B]]
+        sub = {k: np.ascontiguousarray(v[:, sl]) for k, v in c["frame"].items()}
+        loss_t, _, grads_t = vt.CpuTrainer([round_bf16(a) for a in masters[:14]], round_bf16(masters[14]), c["scale"]).step(sub, update=False)
+        gfc = [torch.zeros_like(t) for t in fc]
+        gB = torch.zeros_like(B)
+        res = op.fwd_bwd(fc, B, sc, *(fr[k][:, sl] for k in keys), grads_fc=gfc, grad_B=gB)
+        torch.cuda.synchronize()
+        assert abs(float(res.loss[0]) - float(loss_t)) <= 2e-5 * abs(float(loss_t)), i
+        got = {(f"g_fc{t}" if t < 14 else "g_B"): (gfc[t] if t < 14 else gB).cpu().numpy() for t in range(15)}
+        if max(relerr(got[k], g_.numpy()) for k, g_ in zip(GRAD_KEYS, grads_t)) >= 1e-4:
+            o = vo.training_step([round_bf16(a) for a in masters[:14]], round_bf16(masters[14]), c["scale"], sub, dtype=np.float32, kinks=True)
+            _assert_grads_match_aten_port_up_to_kinks(got, o, grads_t, n)
+        op.train_steps(fc, B, sc, *(fr[k][:, sl] for k in keys), opt=st, n_steps=1)
 
 
 @pytest.mark.parametrize("name", ["bg128_frame", "bg128_frame_bf16"])
@@ -805,16 +910,23 @@ def _check_frame_trajectory(name, tuning):
     assert int(res.flags[:, 3].max()) == 0
     early, late, q99, med = FRAME_TOL[name]
     rel = np.abs(losses - g["losses"]) / np.abs(g["losses"])
+    pre = ""
+    if "alt_losses" in g.files:
+        # the fixture holds both sides of a ReLU kink of step 0 (two valid float32 evaluations of the reference's loop): the kernel
+        # is on one of them
+        rel_alt = np.abs(losses - g["alt_losses"]) / np.abs(g["alt_losses"])
+        if rel_alt.max() < rel.max():
+            rel, pre = rel_alt, "alt_"
     assert rel[0] <= 2e-5 or not bf16, rel
-    assert rel[:5].max() <= early, rel
+    assert rel[:FRAME_EARLY_STEPS.get(name, 5)].max() <= early, rel
     assert rel.max() <= late, rel
     diffs = []
     for t in range(15):
-        key = f"p_fc{t}" if t < 14 else "p_B"
+        key = pre + (f"p_fc{t}" if t < 14 else "p_B")
         got = (fc[t] if t < 14 else B).cpu().numpy()
         diffs.append(np.abs(got[keep].astype(np.float64) - g[key]).ravel())
         # every object (not only the kept ones): L2 norm of the final parameters per object and tensor
-        nk = f"pnorm_fc{t}" if t < 14 else "pnorm_B"
+        nk = pre + (f"pnorm_fc{t}" if t < 14 else "pnorm_B")
         pn = np.sqrt((got.astype(np.float64).reshape(n, -1) ** 2).sum(-1))
         assert np.abs(pn - g[nk]).max() <= 2e-3 * g[nk].max(), nk
     d = np.concatenate(diffs)
