@@ -258,3 +258,45 @@ def test_gpu_split_sampler_is_bit_identical_to_one_workgroup_per_object():
             assert torch.equal(a[k], b[k]), k
     for k, (sc, rnd) in enumerate(zip(scenes, rnds)):
         _check_against_oracle({kk: v.cpu().numpy() for kk, v in outs[1][0].items()}, k, _oracle(sc, rnd))
+
+
+@pytest.mark.gpu
+def test_gpu_sampler_twenty_objects_like_the_benchmarked_frame():
+    """The sampler at the object count the frame benchmarks run (20 objects: 25 workgroups per object in the split form): test mode
+    equals the oracle (= the reference's get_training_samples, exactly) for EVERY object, the split and the one-workgroup forms agree
+    bit for bit, and the Philox mode keeps its statistical properties per object (GPU tests had used 3-5 objects)."""
+    import torch
+    from vmap_amd import sampler
+    dev = "cuda:0"
+    n = 20
+    rng = np.random.default_rng(21)
+    scenes = []
+    for i in range(n):
+        sc = sampler_cases.build_scene("obj")
+        scenes.append(dict(sc, depth=np.where(sc["depth"] > 0, sc["depth"] + 0.03 * i, 0).astype(np.float32),
+                           center=rng.uniform(-0.3, 0.3, 3).astype(np.float32), seed=sc["seed"] + 7 * i))
+    rnds = [sampler_cases.draw_randoms(sc) for sc in scenes]
+    s0 = scenes[0]
+    fx, fy, cx, cy = s0["intr"]
+    objs = [dict(rgbs=torch.from_numpy(sc["rgbs"]).to(dev), depth=torch.from_numpy(sc["depth"]).to(dev),
+                 t_wc=torch.from_numpy(sc["t_wc"]).to(dev), bbox=torch.from_numpy(sc["bbox"]).to(dev),
+                 n_keyframes=sc["K"], last2=sc["last2"], center=sc["center"]) for sc in scenes]
+    tr = {k: torch.from_numpy(np.stack([r[k] for r in rnds]).astype(np.int32 if k == "kf_ids" else np.float32)).to(dev)
+          for k in ("kf_ids", "u_w", "u_h", "u_z", "g_z")}
+    outs = []
+    for split in (True, False):
+        smp = sampler.FrameSampler(s0["W"], s0["H"], s0["F"], s0["P"], s0["n1"], s0["n2"], fx, fy, cx, cy, min_depth=s0["min_bound"],
+                                   surface_eps=EPS, stop_eps=STOP, device=dev, seed=5, split=split)
+        smp.set_objects(objs)
+        t = {k: v.clone() for k, v in smp.sample(test_randoms=tr).items()}
+        smp.frame_counter = 2
+        p = {k: v.clone() for k, v in smp.sample().items()}
+        outs.append((t, p))
+    torch.cuda.synchronize()
+    for a, b in zip(outs[0], outs[1]):
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+    got = {k: v.cpu().numpy() for k, v in outs[0][0].items()}
+    for k, (sc, rnd) in enumerate(zip(scenes, rnds)):
+        _check_against_oracle(got, k, _oracle(sc, rnd))
+    _philox_checks({k: v.cpu().numpy() for k, v in outs[0][1].items()}, scenes)
