@@ -170,7 +170,7 @@ def background_legs(args, cfg, dev, rank, world, ipf, dist, run_objects, rays_pe
     keys = ("pcs", "z", "gt_depth", "gt_rgb", "sem", "depth_mask")
     idx = np.concatenate([np.arange(i * bcfg["R"] + rank, i * bcfg["R"] + bR * world, world) for i in range(ipf)])
     bloc = tuple(torch.from_numpy(np.ascontiguousarray(bframe[k][0][idx])).to(dev) for k in keys)
-    bg_stream = torch.cuda.Stream(device=dev, priority=-1)        # the background chain is the critical path (see driver.HipMapper.attach_background)
+    bg_stream = torch.cuda.Stream(device=dev)
     cur = torch.cuda.current_stream(dev)
 
     def barrier():

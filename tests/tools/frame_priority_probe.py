@@ -31,19 +31,36 @@ for _ in range(cfg["n_obj"]):
     m.add_object(Trainer(SimpleConfig(training_device=str(dev), hidden_feature_size=cfg["H"], obj_scale=cfg["scale"])))
 m.attach_background(Trainer(SimpleConfig(training_device=str(dev), hidden_feature_size=bcfg["H"], obj_scale=bcfg["scale"])), bcfg["R"], bcfg["S"])
 for rep in range(3):
-    for bg_prio, obj_prio in [(0, 0), (0, -1), (-1, 0), (-1, -1)]:
+    for bg_prio, obj_prio in [(0, 0), (0, -1), (-1, 0), (-1, -1), (-1, None), (0, None)]:
         m._bg_stream = streams[bg_prio][0]
-        obj_stream = streams[obj_prio][1]
-        with torch.cuda.stream(obj_stream):
-            for _ in range(4):
-                m.train_frame_with_background(ob, bb)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(30):
-                m.train_frame_with_background(ob, bb)
-            torch.cuda.synchronize()
-            ms = (time.perf_counter() - t0) / 30 * 1e3
+        obj_stream = streams[obj_prio][1] if obj_prio is not None else torch.cuda.default_stream(dev)     # None: the device's NULL stream
+        m._obj_stream = obj_stream
+        for _ in range(4):
+            m.train_frame_with_background(ob, bb)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(30):
+            m.train_frame_with_background(ob, bb)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 30 * 1e3
         rec = {"rep": rep, "background_stream_priority": bg_prio, "object_stream_priority": obj_prio, "two_streams_ms_per_frame": ms}
         print(json.dumps(rec), flush=True)
         out.append(rec)
+# the driver's own default (background stream high priority, objects on its own normal-priority stream, caller on the NULL stream)
+m2 = HipMapper(SimpleConfig(training_device=str(dev), n_iter_per_frame=ipf), device=dev)
+torch.manual_seed(3)
+for _ in range(cfg["n_obj"]):
+    m2.add_object(Trainer(SimpleConfig(training_device=str(dev), hidden_feature_size=cfg["H"], obj_scale=cfg["scale"])))
+m2.attach_background(Trainer(SimpleConfig(training_device=str(dev), hidden_feature_size=bcfg["H"], obj_scale=bcfg["scale"])), bcfg["R"], bcfg["S"])
+for rep in range(3):
+    for _ in range(4):
+        m2.train_frame_with_background(ob, bb)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(30):
+        m2.train_frame_with_background(ob, bb)
+    torch.cuda.synchronize()
+    rec = {"rep": rep, "driver_default": "HipMapper.train_frame_with_background called on the NULL stream", "two_streams_ms_per_frame": (time.perf_counter() - t0) / 30 * 1e3}
+    print(json.dumps(rec), flush=True)
+    out.append(rec)
 json.dump(out, open(os.path.join(ROOT, "gpurun_out", "frame_priority_probe.json"), "w"), indent=1)

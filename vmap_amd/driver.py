@@ -143,11 +143,10 @@ class HipMapper:
                        scale=trainer.pe.scale.detach().to(self.device).reshape(1).clone(),
                        opt=step.FusedAdamWState(1, H, self.device, lr=self.cfg.learning_rate, weight_decay=self.cfg.weight_decay),
                        op=step.VmapStep(1, rays, samples, H, device=self.device, max_steps=self.cfg.n_iter_per_frame))
-        # HIGH priority for the background stream: its kernel (200 workgroups, one whole compute unit each, 81 us) is the frame's
-        # critical path; at equal priority the dispatcher interleaves the objects' workgroups (200 x 23 us) with it and delays it,
-        # with the background preferred the object workgroups fill the 56 compute units it leaves idle and the gaps around its
-        # finalize: 2.36 -> 2.13 ms per frame at the Replica shapes, background alone 2.04 (profiles/round4b_frame_priority_probe.json)
-        self._bg_stream = torch.cuda.Stream(device=self.device, priority=-1)
+        # default priority: stream priorities were measured (tests/tools/frame_priority_probe.py, frame_stream_topology_probe.py,
+        # profiles/round4g_*): 2.13 ms per frame with this stream at high priority in one process history, 3.9-4.2 ms in another,
+        # 2.33-2.43 ms whatever the priorities in fresh processes - an artefact of which hardware queue a stream lands on, not a lever
+        self._bg_stream = torch.cuda.Stream(device=self.device)
 
     def train_frame_with_background(self, obj_batch, bg_batch, render: bool = False):
         """One frame of both stacks: ``obj_batch`` / ``bg_batch`` = (pcs, z, gt_depth, gt_rgb, sem, depth_mask) with the
