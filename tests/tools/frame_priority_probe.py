@@ -34,15 +34,15 @@ for rep in range(3):
     for bg_prio, obj_prio in [(0, 0), (0, -1), (-1, 0), (-1, -1), (-1, None), (0, None)]:
         m._bg_stream = streams[bg_prio][0]
         obj_stream = streams[obj_prio][1] if obj_prio is not None else torch.cuda.default_stream(dev)     # None: the device's NULL stream
-        m._obj_stream = obj_stream
-        for _ in range(4):
-            m.train_frame_with_background(ob, bb)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(30):
-            m.train_frame_with_background(ob, bb)
-        torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / 30 * 1e3
+        with torch.cuda.stream(obj_stream):                   # the mapper runs the objects on the caller's current stream
+            for _ in range(4):
+                m.train_frame_with_background(ob, bb)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(30):
+                m.train_frame_with_background(ob, bb)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / 30 * 1e3
         rec = {"rep": rep, "background_stream_priority": bg_prio, "object_stream_priority": obj_prio, "two_streams_ms_per_frame": ms}
         print(json.dumps(rec), flush=True)
         out.append(rec)
