@@ -522,7 +522,7 @@ def main():
         try:
             # the committed counter file of the kernel this run used
             if args.config == "replica_room0_vmap" and split:
-                pmc_file, key = "r03m_pmc_counters_step_main_s32.json", "hbm_traffic_bytes_per_launch_step_main"
+                pmc_file, key = "round4a_pmc_counters_step_main_s32.json", "hbm_traffic_bytes_per_launch_step_main"
             elif args.config == "replica_room0_vmap":
                 pmc_file, key = "r01m_pmc_counters.json", "hbm_traffic_bytes_per_launch_step_main"
             elif args.config == "imap_plumbing" and ws8 and args.weights == "f32":

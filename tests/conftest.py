@@ -82,24 +82,24 @@ def kink_aware(got, ref, n_obj, signed=False, tol=1e-4):
         D = [d / scale for (ko, d) in ref["kink_deltas"] if ko == k and np.abs(d / scale).max() > tol / 4]
         if not D or np.abs(r).max() < tol / 4:
             continue
-        A = np.stack(D, axis=1)
-        nrm = (A * A).sum(axis=0)
-        used = np.zeros(A.shape[1], dtype=bool)
+        A = np.stack(D, axis=0)                                     # [candidates, elements]: one BLAS product per pursuit step
+        nrm = np.einsum("ce,ce->c", A, A)
+        used = np.zeros(A.shape[0], dtype=bool)
         add = np.zeros_like(r)
-        for _ in range(A.shape[1]):
+        for _ in range(A.shape[0]):
             if np.abs(r).max() < tol / 4:
                 break
-            beta = (A * r[:, None]).sum(axis=0) / nrm
+            beta = (A @ r) / nrm
             rb = np.clip(np.round(beta), -1 if signed else 0, 1)
             gain = np.where((rb != 0) & ~used & (np.abs(beta - rb) < 0.25), (2 * beta * rb - rb * rb) * nrm, -np.inf)
             j = int(np.argmax(gain))
             if not np.isfinite(gain[j]) or gain[j] <= 0:
                 break
             used[j] = True
-            r = r - rb[j] * A[:, j]
-            add += rb[j] * A[:, j]
+            r = r - rb[j] * A[j]
+            add += rb[j] * A[j]
             flipped += 1
-            worst = max(worst, float(abs(beta[j] - rb[j]) * np.abs(A[:, j]).max()))
+            worst = max(worst, float(abs(beta[j] - rb[j]) * np.abs(A[j]).max()))
         add = add * scale
         o = 0
         for key, shp in zip(GRAD_KEYS, shapes):
