@@ -134,9 +134,10 @@ def _assert_grads_match_aten_port_up_to_kinks(s, o, grads_t, n_obj, tol=1e-4):
 
 
 def _assert_grads_match_oracle_up_to_kinks(s, o, n_obj, tol=2e-4, signed=False):
-    """Gradients against the numpy oracle with the ReLU kinks ACCOUNTED FOR instead of tolerated (tolerance: north_star's 1e-4
-    for the kernel + the 1e-4 tests/test_oracle_vs_golden.py allows the numpy restatement itself against the reference; the
-    reference fixtures and the ATen port are held to 1e-4 directly): the
+    """Gradients against the NUMPY oracle with the ReLU kinks ACCOUNTED FOR instead of tolerated (tolerance: north_star's 1e-4
+    for the kernel + the 1e-4 tests/test_oracle_vs_golden.py allows the numpy restatement itself against the reference - measured
+    in round 4: at 1e-4 one hidden-32 seeded shape fails for the split AND the exact-fp32 kernel alike, i.e. on the oracle's own
+    summation order; the reference fixtures and the ATen port - _assert_grads_match_aten_port_up_to_kinks - are held to 1e-4): the
     oracle lists every hidden unit whose pre-activation lies inside float32 forward rounding of 0 and the exact gradient change
     of flipping its derivative bit; the kernel's gradients must equal the oracle's plus a 0/1 combination of those changes
     (conftest.kink_aware: measured on the 5 x 300 x 14 hidden-128 case 3 flipped bits of 276 candidates take the raw
