@@ -111,6 +111,46 @@ def library_sha256():
         return None
 
 
+def observe_traffic(config, weights, timeout_s=150):
+    """HBM-side bytes per launch of the dominant kernel, OBSERVED for the library this process runs: two `rocprofv3 --kernel-trace --pmc`
+    passes (FETCH_SIZE, WRITE_SIZE - one counter per pass, as MI355X_MICROARCH.md's HBM section prescribes) over tests/tools/run_steps.py of
+    the same configuration, as subprocesses (counters cannot be sampled from inside this process); FETCH_SIZE doubled per the guide's
+    gfx950 correction.  Returns (bytes per launch, note) or (None, why not)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    tool = os.path.join(ROOT, "tests", "tools", "run_steps.py")
+    means = {}
+    work = tempfile.mkdtemp(prefix="vmap_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(work, counter)
+            r = subprocess.run([exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "p", "--",
+                                sys.executable, tool, config, "40", weights], cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"),
+                               stdin=subprocess.DEVNULL, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+            vals = []
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if "step_main" in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                        vals.append(float(row["Counter_Value"]))
+            if r.returncode != 0 or not vals:
+                return None, f"{counter} pass: rc {r.returncode}, {len(vals)} dispatches"
+            means[counter] = sum(vals) / len(vals)
+        return (2.0 * means["FETCH_SIZE"] + means["WRITE_SIZE"]) * 1024.0, \
+            (f"OBSERVED in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tests/tools/run_steps.py {config} 40 {weights} "
+             f"as subprocesses on the library this process loaded; mean per dispatch of the dominant kernel: FETCH {means['FETCH_SIZE']:.1f} KiB x 2 "
+             f"(gfx950 correction, MI355X_MICROARCH.md) + WRITE {means['WRITE_SIZE']:.1f} KiB")
+    except Exception as e:
+        return None, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
 def frame_leg(cfg, dev, ipf, obj_batch, reps=20):
     """One REAL mapping frame of the configuration (`do_bg: 1`, train.py:270-326 + :308-316): the object stack and the
     hidden-128 background model (1200 rays x 14 samples) through ``driver.HipMapper.train_frame_with_background`` - frames bound
@@ -323,6 +363,7 @@ def main():
     ap.add_argument("--pmc-file", default=None)                      # roofline.traffic from THIS file (tests/tools/pmc_summary.py output of the
                                                                      # FETCH_SIZE / WRITE_SIZE passes tests/tools/gpu_bench_with_pmc.sh ran just before,
                                                                      # over the same library) instead of the committed counter file
+    ap.add_argument("--no-pmc", action="store_true")                # do not spawn the two rocprofv3 --pmc passes that observe roofline.traffic (N = 1)
     ap.add_argument("--bg-timeout", type=float, default=float(os.environ.get("VMAP_BENCH_BG_TIMEOUT", "120")))   # watchdog of the background legs (s)
     ap.add_argument("--no-frame", action="store_true")              # skip the N = 1 `frame` leg (objects + background on two streams)
     ap.add_argument("--timed-only", action="store_true")            # skip the roofline / baseline legs (for kernel traces of the timed region)
@@ -537,6 +578,13 @@ def main():
             traffic = None
         lib_sha = library_sha256()
         traffic_observed = None
+        traffic_note = None
+        if not args.pmc_file and not args.no_pmc and world == 1:
+            t_obs, traffic_note = observe_traffic(args.config, args.weights)
+            if t_obs is not None:
+                traffic = t_obs
+            else:
+                traffic_note = "could not observe (" + traffic_note + "); "
         if args.pmc_file:
             # counters taken in the same gpurun, by the script that also launched this process (tests/tools/gpu_bench_with_pmc.sh)
             with open(args.pmc_file) as fh:
@@ -617,6 +665,16 @@ def main():
             torch.cuda.synchronize()
             x_ms = (time.perf_counter() - t1) / args.steps * 1e3
             exact = {"value": n * R / (x_ms * 1e-3), "ms_per_step": x_ms, "kernel": "step_main_h32 (v_mfma_f32_32x32x2_f32)"}
+        if traffic_note and not traffic_note.startswith("could not"):
+            traffic_source = traffic_note
+        elif traffic_observed:
+            traffic_source = ("OBSERVED in this gpurun: FETCH_SIZE / WRITE_SIZE passes (rocprofv3 --pmc, separate passes, FETCH doubled per MI355X_MICROARCH.md) over "
+                              "the library this process loaded, folded by tests/tools/pmc_summary.py: " + json.dumps(traffic_observed))
+        elif traffic is not None:
+            traffic_source = ((traffic_note or "") + "copied from the committed rocprofv3 --pmc passes of this kernel (profiles/" + pmc_file +
+                              ": separate FETCH_SIZE / WRITE_SIZE passes over tests/tools/run_steps.py, FETCH doubled per MI355X_MICROARCH.md), not observed in this run")
+        else:
+            traffic_source = traffic_note
         out = {
             "metric": "training rays/sec (all objects) per step", "value": value, "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -636,12 +694,7 @@ def main():
                                            if executed_tflops else {"instruction": "v_mfma_f32_32x32x2_f32", "peak_tflops": FP32_MFMA_PEAK_TFLOPS}),
                          "launch_plan": plan, "floor_us": floor_us, "floor_note": floor_note,
                          "traffic": traffic,
-                         "traffic_source": ("OBSERVED in this gpurun: FETCH_SIZE / WRITE_SIZE passes (rocprofv3 --pmc, separate passes, FETCH doubled per "
-                                            "MI355X_MICROARCH.md) over the library this process loaded, folded by tests/tools/pmc_summary.py: " + json.dumps(traffic_observed))
-                                           if traffic_observed else
-                                           (("copied from the committed rocprofv3 --pmc passes of this kernel (profiles/" + pmc_file +
-                                             ": separate FETCH_SIZE / WRITE_SIZE passes over tests/tools/run_steps.py, FETCH doubled per MI355X_MICROARCH.md), "
-                                             "not observed in this run - counters cannot be sampled from inside the process") if traffic is not None else None),
+                         "traffic_source": traffic_source,
                          "library_sha256": lib_sha,
                          "kernel_ms": k_ms, "kernel_ms_stream_event_pair": k_ms_pair,
                          "kernel_ms_note": "kernel_ms = average of the dispatches' own begin -> end timestamps (events attached to the launch, "
