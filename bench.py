@@ -506,7 +506,9 @@ def main():
     rccl_version = None
     if dist:
         gathered = [None] * world
-        ident = (devices[0], str(torch.cuda.get_device_properties(dev).uuid) if hasattr(torch.cuda.get_device_properties(dev), "uuid") else f"index{dev_index}")
+        pr = torch.cuda.get_device_properties(dev)
+        # a device's identity: its PCI address + UUID + index (two ranks on ONE device share all of them; two devices cannot share a PCI address)
+        ident = (devices[0], "|".join(str(getattr(pr, k, "?")) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id", "uuid")) + f"|cuda:{dev_index}")
         td.all_gather_object(gathered, ident)
         devices = [g[0] for g in gathered]
         try:
