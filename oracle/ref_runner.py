@@ -1,17 +1,19 @@
-"""TEST INFRASTRUCTURE ONLY - runs the *real* reference (kxhit/vMAP) hot path on CPU.
+"""TEST / BASELINE INFRASTRUCTURE ONLY - runs the *real* reference (kxhit/vMAP) hot path.
 
-This module imports ``model.py``, ``embedding.py``, ``render_rays.py`` and ``loss.py`` unmodified from
-``/root/reference`` (read-only, present only in the authoring container - never on the GPU box) and
-drives them exactly the way the reference does:
+This module imports ``model.py``, ``embedding.py``, ``render_rays.py`` and ``loss.py`` unmodified - from the source tree
+``/root/reference`` (read-only, present only in the authoring container) or, where that tree does not exist (the GPU box),
+from ``oracle/_ref/``: the same four files byte-compiled by ``oracle/make_ref.py`` (sourceless ``.pyc``, sha256 of every
+source recorded in ``oracle/_ref/MANIFEST.json``; no reference source is copied into this repository) - and drives them
+exactly the way the reference does:
 
 * ``utils.update_vmap``   (utils.py:30-34)  -> ``combine_state_for_ensemble`` + ``requires_grad_``
 * ``train.py:293-294``    -> ``vmap(pe_model)(...)``, ``vmap(fc_model)(...)``
 * ``train.py:303-306``    -> ``loss.step_batch_loss``
 * ``train.py:324-326``    -> ``backward()``, ``AdamW.step()``, ``zero_grad``
 
-It is used only by ``tests/golden/make_goldens.py`` to produce the committed fixtures that pin the
-oracle (``oracle/vmap_oracle.py``).  Nothing in the product, the gpu tests, ``smoke()`` or ``bench.py``
-may import it.
+Users: ``tests/golden/make_*.py`` (the committed fixtures that pin the oracle), the ``-m gpu`` test that regenerates a fixture
+on the GPU box, and ``bench.py``'s baseline legs (``ReferenceTrainer``: ``cpu_baseline`` kind "reference" and
+``gpu_reference_baseline``).  Nothing in the product package may import it.
 """
 from __future__ import annotations
 
@@ -23,19 +25,40 @@ import numpy as np
 import torch
 
 REFERENCE_ROOT = os.environ.get("VMAP_REFERENCE_ROOT", "/root/reference")
+_COMPILED = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref")
+_mods = None
+SOURCE = None          # "source tree <path>" | "compiled <path> (sha256 in MANIFEST.json)" once imported
+
+
+def reference_available() -> bool:
+    """Can the reference's modules be imported here (source tree, or the compiled files of oracle/make_ref.py)?"""
+    if os.path.isdir(REFERENCE_ROOT):
+        return True
+    from oracle import make_ref
+    return make_ref.available()
 
 
 def _import_reference():
-    if not os.path.isdir(REFERENCE_ROOT):
-        raise RuntimeError(f"reference tree not found at {REFERENCE_ROOT}")
-    sys.dont_write_bytecode = True
-    if REFERENCE_ROOT not in sys.path:
-        sys.path.insert(0, REFERENCE_ROOT)
+    global _mods, SOURCE
+    if _mods is not None:
+        return _mods
     import importlib
+    if os.path.isdir(REFERENCE_ROOT):
+        root, SOURCE = REFERENCE_ROOT, f"source tree {REFERENCE_ROOT}"
+    else:
+        from oracle import make_ref
+        if not make_ref.available():
+            raise RuntimeError(f"reference not available: no source tree at {REFERENCE_ROOT} and no compiled modules in {_COMPILED} "
+                               "(python oracle/make_ref.py builds them where the source tree exists)")
+        root, SOURCE = _COMPILED, f"compiled {_COMPILED} (byte-compiled unmodified; source sha256 in MANIFEST.json)"
+    sys.dont_write_bytecode = True
+    if root not in sys.path:
+        sys.path.insert(0, root)
     mods = {}
-    for name in ("model", "embedding", "render_rays", "loss"):
+    for name in ("model", "embedding", "render_rays", "loss"):        # loss.py does `import render_rays`: the directory is on sys.path
         mods[name] = importlib.import_module(name)
-        assert os.path.dirname(mods[name].__file__) == REFERENCE_ROOT, mods[name].__file__
+        assert os.path.dirname(os.path.abspath(mods[name].__file__)) == os.path.abspath(root), mods[name].__file__
+    _mods = mods
     return mods
 
 
@@ -56,6 +79,26 @@ def build_reference_models(fc_np, B_np, scale_np, H, dtype=torch.float32):
         fc_models.append(m.to(dtype))
         pe_models.append(pe.to(dtype))
     return fc_models, pe_models
+
+
+class ExitTrap:
+    """``render_rays.reduce_batch_loss`` ends the PROCESS on "loss explode" (render_rays.py:88-90: ``print("loss explode"); exit(-1)``).
+    Inside this context the name ``exit`` resolves, for that module only, to a recorder (a module global shadows the builtin; the
+    reference's code is untouched), so the call is counted and the function goes on to return the loss it had computed - the
+    values a caller that survives the check (ours: the device flag VMAPSTEP_FLAG_EXPLODE) must reproduce.  ``codes``: the exit codes
+    the reference asked for, in order."""
+
+    def __init__(self):
+        self.mod = _import_reference()["render_rays"]
+        self.codes = []
+
+    def __enter__(self):
+        self.mod.exit = lambda code=0: self.codes.append(code)
+        return self
+
+    def __exit__(self, *exc):
+        del self.mod.exit
+        return False
 
 
 def reference_step(fc_np, B_np, scale_np, batch, H, dtype=torch.float32, strategy="vmap",
@@ -245,3 +288,51 @@ def reference_frame(fc_np, B_np, scale_np, frame, H, rays_per_step, n_steps, dty
     out["p_B"] = pe_param[0].detach().numpy().copy()
     out["g0_B"] = first_grads[14]
     return out
+
+
+class ReferenceTrainer:
+    """The reference's vectorised training step as train.py runs it, on any torch device - the live BASELINE of bench.py:
+    ``utils.update_vmap`` (utils.py:30-34: ``combine_state_for_ensemble`` + a new AdamW param group on an optimiser built like
+    train.py:67), then per step ``vmap(pe_model)`` / ``vmap(fc_model)`` (train.py:293-294), ``loss.step_batch_loss`` (:303-306, with
+    its host-synchronising ``.any()`` checks), ``backward()``, ``AdamW.step()``, ``zero_grad(set_to_none=True)`` (:324-326).
+    The modules are the reference's own, unmodified (source tree or oracle/_ref)."""
+
+    def __init__(self, fc_np, B_np, scale_np, hidden, device="cpu", lr=1e-3, weight_decay=0.013):
+        mods = _import_reference()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            from functorch import combine_state_for_ensemble, vmap
+        self._vmap = vmap
+        self.loss_mod = mods["loss"]
+        self.device = torch.device(device)
+        fc_models, pe_models = build_reference_models(fc_np, B_np, scale_np, hidden)
+        fc_models = [m.to(self.device) for m in fc_models]
+        pe_models = [m.to(self.device) for m in pe_models]
+        self.optimiser = torch.optim.AdamW([torch.autograd.Variable(torch.tensor(0.0))], lr=lr, weight_decay=weight_decay)   # train.py:67
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            self.fc_model, self.fc_param, self.fc_buffer = combine_state_for_ensemble(fc_models)      # utils.py:31
+            self.pe_model, self.pe_param, self.pe_buffer = combine_state_for_ensemble(pe_models)
+        [p.requires_grad_() for p in self.fc_param]                                                    # utils.py:32
+        [p.requires_grad_() for p in self.pe_param]
+        self.optimiser.add_param_group({"params": self.fc_param})                                      # utils.py:33
+        self.optimiser.add_param_group({"params": self.pe_param})
+
+    def to_device(self, batch):
+        """numpy batch -> the tensors train.py:255-260 keeps on the training device"""
+        t = {k: torch.from_numpy(np.ascontiguousarray(v)).to(self.device) for k, v in batch.items()}
+        t["depth_mask"] = t["depth_mask"].bool()
+        return t
+
+    def step(self, b):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            emb = self._vmap(self.pe_model)(self.pe_param, self.pe_buffer, b["pcs"])                   # train.py:293
+            alpha, color = self._vmap(self.fc_model)(self.fc_param, self.fc_buffer, emb)               # train.py:294
+        loss, _ = self.loss_mod.step_batch_loss(alpha, color, b["gt_depth"].detach(), b["gt_rgb"].detach(), b["sem"].detach(),
+                                                b["depth_mask"].detach(), b["z"].detach())             # train.py:303-306
+        if loss.requires_grad:
+            loss.backward()                                                                            # train.py:324
+        self.optimiser.step()                                                                          # train.py:325
+        self.optimiser.zero_grad(set_to_none=True)                                                     # train.py:326
+        return loss.detach()

@@ -22,6 +22,7 @@ CASES = {
     "drop_colour":   (4, 24, 10, 32, 2.0, 34, 35, 1.0, "all_other"),
     "saturated":     (3, 24, 10, 32, 2.0, 40, 41, 4.0, None),        # |alpha| >> 17: occupancy == 1.0f
     "exact_hit":     (2, 12, 10, 32, 2.0, 42, 43, 1.0, "no_valid_surface"),
+    "explode":       (3, 24, 10, 32, 2.0, 44, 45, 4.0, "far_depth"),   # render_rays.py:88-90 fires: saturated occupancy (var -> 0: weight 1e4) x a 50 m depth error
     "h64":           (4, 32, 10, 64, 2.0, 50, 51, 1.0, None),
     "bg_h128_s14":   (1, 48, 14, 128, 5.0, 60, 61, 1.0, None),       # train.py:308-316 shapes (fewer rays)
     "imap_h256":     (1, 100, 14, 256, 10.0, 70, 71, 1.0, None),     # BASELINE configs[0]
@@ -45,6 +46,9 @@ def build_case(name):
         batch["sem"][1, :] = 2
     elif edit == "all_other":
         batch["sem"][3, :] = 0
+    elif edit == "far_depth":
+        # object 1's measured depths replaced by 50 m (its samples stay where they were): |D - d| / (sqrt(var) + 1e-4) ~ 5e5 per ray
+        batch["gt_depth"][1, :] = np.where(batch["gt_depth"][1, :] > 0, np.float32(50.0), batch["gt_depth"][1, :]).astype(np.float32)
     elif edit == "no_valid_surface":
         # every ray of object 0 is 'other object' with invalid depth: depth term has an empty mask
         batch["sem"][0, :] = 0

@@ -10,12 +10,26 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
-# Operators with an explicit plan override (tuning=...) run on the measurement build of the library: the product carries only the
-# kernel forms automatic plans launch (tests/tools/libvmapstep_ab.so = the same sources with -DVMAPSTEP_AB, built by build()).
+# The measurement build of the library (tests/tools/libvmapstep_ab.so = the same sources with -DVMAPSTEP_AB, built by build()): phase
+# stamps and the A/B kernel forms no automatic plan launches.  TEST INFRASTRUCTURE: the product package knows nothing about it.
 AB_LIBRARY = os.path.join(ROOT, "tests", "tools", "libvmapstep_ab.so")
-if os.path.exists(AB_LIBRARY):
-    from vmap_amd import step as _step
-    _step.VmapStep.ab_library = AB_LIBRARY
+
+# plan overrides merged UNDER the ``tuning`` of every operator a test builds through make_op (the "f32" leg of tests/test_gpu_parity.py)
+TEST_TUNING = {"default": None}
+
+
+def make_op(*args, tuning=None, **kw):
+    """A ``vmap_amd.step.VmapStep`` for a test: on the PRODUCT library whenever the product carries the requested kernel form
+    (every automatic plan, the exact-fp32 kernels step_main_h32 / step_main_gen, workgroups_per_object, generic_finalize, ws_flags
+    1 / 4), on the measurement build only when the product's own plan refuses the form ("measurement build only")."""
+    from vmap_amd import _lib, step
+    tuning = {**(TEST_TUNING["default"] or {}), **(tuning or {})} or None
+    try:
+        return step.VmapStep(*args, tuning=tuning, **kw)
+    except _lib.VmapStepError as e:
+        if "measurement build only" not in str(e) or not os.path.exists(AB_LIBRARY):
+            raise
+    return step.VmapStep(*args, tuning=tuning, library=AB_LIBRARY, **kw)
 
 
 def pytest_configure(config):

@@ -39,8 +39,21 @@ def main(names=None):
             rnd = lambda a: torch.from_numpy(a).to(torch.bfloat16).to(torch.float32).numpy()
             c = dict(c, fc=[rnd(a) for a in c["fc"]], B=rnd(c["B"]))
         out = {}
-        r32 = ref_runner.reference_step(c["fc"], c["B"], c["scale"], c["batch"], c["H"], torch.float32)
-        r64 = ref_runner.reference_step(c["fc"], c["B"], c["scale"], c["batch"], c["H"], torch.float64)
+        if name == "explode":
+            # the reference ENDS THE PROCESS on this input (render_rays.py:88-90): certify that, then run it again with the exit call
+            # recorded instead of obeyed (ref_runner.ExitTrap) to get the values a surviving caller must reproduce
+            try:
+                ref_runner.reference_step(c["fc"], c["B"], c["scale"], c["batch"], c["H"], torch.float32)
+                raise AssertionError("the reference did not exit on the explode case")
+            except SystemExit as e:
+                out["exit_code"] = np.array(int(e.code))
+            with ref_runner.ExitTrap() as trap:
+                r32 = ref_runner.reference_step(c["fc"], c["B"], c["scale"], c["batch"], c["H"], torch.float32)
+                out["explode_calls"] = np.array(len(trap.codes))
+                r64 = ref_runner.reference_step(c["fc"], c["B"], c["scale"], c["batch"], c["H"], torch.float64)
+        else:
+            r32 = ref_runner.reference_step(c["fc"], c["B"], c["scale"], c["batch"], c["H"], torch.float32)
+            r64 = ref_runner.reference_step(c["fc"], c["B"], c["scale"], c["batch"], c["H"], torch.float64)
         keep = ["loss", "render_depth", "render_color", "opacity", "var", "g_B"] + [f"g_fc{t}" for t in range(14)]
         for k in keep:
             out[k] = np.asarray(r32[k], dtype=np.float64 if k == "loss" else np.float32)

@@ -51,7 +51,7 @@ def test_workspace_and_error_reporting():
     # null arguments are rejected before anything touches the device
     assert lib.vmapstep_fwd_bwd(ctypes.byref(sh), None, None, None, 5.0, 10.0, None, None, None, 0, None) == -1
     with pytest.raises(_lib.VmapStepError):
-        _lib.check(-1)
+        _lib.check(-1, lib)
 
 
 def test_tuning_is_per_call_state_not_library_state():

@@ -9,14 +9,14 @@ import pytest
 import torch
 
 import cases
-from conftest import tensor_err_q, kink_aware, GRAD_KEYS, RENDER_KEYS, load_golden, relerr
+from conftest import tensor_err_q, kink_aware, GRAD_KEYS, RENDER_KEYS, load_golden, relerr, make_op, TEST_TUNING
 from oracle import vmap_oracle as vo
 from vmap_amd import _lib, layout, step, synth
 
 pytestmark = pytest.mark.gpu
 
 DEV = "cuda:0"
-TOL = {"default": (2e-5, 1e-4), "saturated": (2e-3, 2e-3)}
+TOL = {"default": (2e-5, 1e-4), "saturated": (2e-3, 2e-3), "explode": (2e-3, 2e-3)}       # 'explode' is a saturated case as well (gain 4.0)
 
 
 def _to_dev(c):
@@ -29,7 +29,7 @@ def _to_dev(c):
 
 def _run(c, fn="fwd_bwd", op=None, tuning=None, **kw):
     fc, B, sc, b = _to_dev(c)
-    op = op or step.VmapStep(c["n"], c["R"], c["S"], c["H"], device=DEV, tuning=tuning)
+    op = op or make_op(c["n"], c["R"], c["S"], c["H"], device=DEV, tuning=tuning)
     gfc = [torch.full_like(t, float("nan")) for t in fc]
     gB = torch.full_like(B, float("nan"))
     if fn == "fwd_bwd":
@@ -61,10 +61,10 @@ def _var_tol(g, base=2e-5):
 def h32_kernel(request):
     """Every test of this module runs twice: hidden 32 on the default split-bf16 kernel (step_main_s32) and on the
     exact-fp32 kernel (step_main_h32, tuning.kernel = KERNEL_H32_F32).  Other widths ignore the choice."""
-    old = step.VmapStep.default_tuning
-    step.VmapStep.default_tuning = {"kernel": _lib.KERNEL_H32_F32} if request.param == "f32" else None
+    old = TEST_TUNING["default"]
+    TEST_TUNING["default"] = {"kernel": _lib.KERNEL_H32_F32} if request.param == "f32" else None
     yield request.param
-    step.VmapStep.default_tuning = old
+    TEST_TUNING["default"] = old
 
 
 def test_native_library_is_loaded():
@@ -89,7 +89,7 @@ def test_fwd_bwd_matches_reference_fixture(name):
         assert relerr(s[k], g[k]) < gt, k
         # second, per-tensor criterion: 99.9 % of the elements within 5e-3 of |ref| + 1e-3 max|ref| (i.e. 5e-6 of the tensor's max for its smallest entries) (small-magnitude
         # entries are constrained too; the saturated case keeps its documented noise floor)
-        assert tensor_err_q(s[k], g[k]) < (2e-2 if name == "saturated" else 5e-3), k
+        assert tensor_err_q(s[k], g[k]) < (2e-2 if name in ("saturated", "explode") else 5e-3), k
     o = vo.training_step(c["fc"], c["B"], c["scale"], c["batch"], dtype=np.float32)
     assert s["flags"][:3].tolist() == [int(x) for x in o["drop"]]
     assert int(s["flags"][3]) == int(o["explode"])
@@ -116,7 +116,6 @@ def test_fwd_bwd_matches_oracle_on_seeded_shapes(n, R, S, seed):
     o = vo.training_step(fc, B, sc, batch, dtype=np.float32, kinks=True)
     for k in RENDER_KEYS + ["var"]:
         assert relerr(s[k], o[k]) < 2e-5, k
-    _assert_grads_match_oracle_up_to_kinks(s, o, n)
 
 
 def _assert_grads_match_aten_port_up_to_kinks(s, o, grads_t, n_obj, tol=1e-4):
@@ -133,19 +132,18 @@ def _assert_grads_match_aten_port_up_to_kinks(s, o, grads_t, n_obj, tol=1e-4):
         assert relerr(s[k], corr[k]) < tol, (k, flipped, cand)
 
 
-def _assert_grads_match_oracle_up_to_kinks(s, o, n_obj, tol=2e-4, signed=False):
-    """Gradients against the NUMPY oracle with the ReLU kinks ACCOUNTED FOR instead of tolerated (tolerance: north_star's 1e-4
-    for the kernel + the 1e-4 tests/test_oracle_vs_golden.py allows the numpy restatement itself against the reference - measured
-    in round 4: at 1e-4 one hidden-32 seeded shape fails for the split AND the exact-fp32 kernel alike, i.e. on the oracle's own
-    summation order; the reference fixtures and the ATen port - _assert_grads_match_aten_port_up_to_kinks - are held to 1e-4): the
-    oracle lists every hidden unit whose pre-activation lies inside float32 forward rounding of 0 and the exact gradient change
-    of flipping its derivative bit; the kernel's gradients must equal the oracle's plus a 0/1 combination of those changes
-    (conftest.kink_aware: measured on the 5 x 300 x 14 hidden-128 case 3 flipped bits of 276 candidates take the raw
-    difference from 3.5e-2 to 4e-6)."""
+def _assert_grads_match_oracle_up_to_kinks(s, o, n_obj, tol=1e-4, signed=False):
+    """Gradients against a REFERENCE FIXTURE (``o``: the fixture's gradients + the numpy oracle's kink list, ``signed``) at north_star's
+    1e-4 with the ReLU kinks ACCOUNTED FOR instead of tolerated: the oracle lists every hidden unit whose pre-activation lies inside
+    float32 forward rounding of 0 and the exact gradient change of flipping its derivative bit; the kernel's gradients must equal the
+    reference's plus a -1/0/+1 combination of those changes (conftest.kink_aware).  Round 5: the 2e-4 comparisons against the numpy
+    oracle's OWN gradients are gone - wherever they ran, the ATen port (the third-party kernels the reference itself runs) is the
+    comparator at 1e-4 (_assert_grads_match_aten_port_up_to_kinks)."""
     corr, flipped, cand, worst = kink_aware(s, o, n_obj, signed=signed, tol=tol)
     for k in GRAD_KEYS:
         assert not np.isnan(s[k]).any(), k
         assert relerr(s[k], corr[k]) < tol, (k, flipped, cand)
+    return flipped
 
 
 @pytest.mark.parametrize("H", [128, 64])
@@ -169,20 +167,16 @@ def test_hidden128_kernel_matches_oracle_on_seeded_shapes(n, R, S, seed, H):
     o = vo.training_step(fc, B, sc, batch, dtype=np.float32, kinks=True)
     for k in RENDER_KEYS + ["var"]:
         assert relerr(s[k], o[k]) < 2e-5, k
-    _assert_grads_match_oracle_up_to_kinks(s, o, n)
     _assert_grads_match_aten_port_up_to_kinks(s, o, grads_t, n)      # round 4: the ATen port at 1e-4, signed kink coefficients
     a = _run(c)                                                       # the automatic plan (product library)
     _assert_grads_match_aten_port_up_to_kinks(a, o, grads_t, n)
     e = _run(c, tuning={"kernel": _lib.KERNEL_GEN})
     w1 = _run(c, tuning={"kernel": _lib.KERNEL_WS1})              # step_main_ws: one wave per output block (single-tile rounds where they fit)
     w2 = _run(c, tuning={"kernel": _lib.KERNEL_WS1, "ws_flags": 1})    # ... two-tile rounds
-    _assert_grads_match_oracle_up_to_kinks(w1, o, n)
-    _assert_grads_match_oracle_up_to_kinks(w2, o, n)
     _assert_grads_match_aten_port_up_to_kinks(w1, o, grads_t, n)
     _assert_grads_match_aten_port_up_to_kinks(w2, o, grads_t, n)
     if H == 128:
         w3 = _run(c, tuning={"kernel": _lib.KERNEL_WS1, "ws_flags": 2})    # ... three-tile rounds (hidden 128)
-        _assert_grads_match_oracle_up_to_kinks(w3, o, n)
         _assert_grads_match_aten_port_up_to_kinks(w3, o, grads_t, n)
         for k in RENDER_KEYS:
             assert relerr(w3[k], e[k]) < 2e-5, k
@@ -215,14 +209,12 @@ def test_hidden256_kernel_matches_oracle_on_seeded_shapes(n, R, S, seed):
     assert abs(s["loss"] - o["loss"]) <= 5e-5 * abs(o["loss"])
     for k in RENDER_KEYS + ["var"]:
         assert relerr(s[k], o[k]) < 2e-5, k
-    _assert_grads_match_oracle_up_to_kinks(s, o, n)
     from oracle import vmap_oracle_torch as vt
     loss_t, rend_t, grads_t = vt.CpuTrainer(fc, B, sc).step(batch, update=False)
     assert abs(s["loss"] - float(loss_t)) <= 5e-5 * abs(float(loss_t))
     _assert_grads_match_aten_port_up_to_kinks(s, o, grads_t, n)      # round 4: the ATen port at 1e-4, signed kink coefficients
     e = _run(c, tuning={"kernel": _lib.KERNEL_GEN})
     m = _run(c, tuning={"kernel": _lib.KERNEL_WS1, "workgroups_per_object": 2})   # several rounds per workgroup
-    _assert_grads_match_oracle_up_to_kinks(m, o, n)
     _assert_grads_match_aten_port_up_to_kinks(m, o, grads_t, n)
     for k in RENDER_KEYS:
         assert relerr(s[k], e[k]) < 2e-5, k
@@ -233,6 +225,93 @@ def test_hidden256_kernel_matches_oracle_on_seeded_shapes(n, R, S, seed):
     s2 = _run(c)
     for k in GRAD_KEYS:
         assert np.array_equal(s[k], s2[k]), k                                     # bit-repeatable
+
+
+def test_explode_flag_through_every_entry_point():
+    """render_rays.py:88-90 with explode = 1 (the reference calls exit(-1) on these inputs: fixture 'explode', exit_code -1): the
+    device flag VMAPSTEP_FLAG_EXPLODE comes up - and the values the reference had computed when it gave up are reproduced - through
+    vmapstep_fwd_bwd, vmapstep_render, vmapstep_train_steps (step 0 of a frame; driver.HipMapper.check_flags turns it into an
+    exception) and the global-loss path of vmapstep_adamw_apply (the ray-sharded caller's rank-summed loss terms)."""
+    from vmap_amd import driver
+    c = cases.build_case("explode")
+    g = load_golden("explode")
+    assert int(g["exit_code"]) == -1
+    n, R, S, H = c["n"], c["R"], c["S"], c["H"]
+    # vmapstep_fwd_bwd / vmapstep_render
+    for fn in ("fwd_bwd", "render"):
+        s = _run(c, fn=fn)
+        assert s["flags"].tolist() == [0, 0, 0, 1], (fn, s["flags"])
+        assert abs(s["loss"] - float(g["loss"])) <= 2e-5 * float(g["loss"]), fn
+    # the same inputs with the far depths back in range: the flag stays down (it is the inputs, not the entry point)
+    c0 = cases.build_case("explode")
+    c0["batch"]["gt_depth"][1, :] = np.where(c0["batch"]["gt_depth"][1, :] > 0, np.float32(1.5), 0).astype(np.float32)
+    assert _run(c0)["flags"].tolist() == [0, 0, 0, 0]
+    # vmapstep_train_steps: a two-step frame whose FIRST step is the explode batch and whose second is the in-range one
+    fc, B, sc, b = _to_dev(c)
+    _, _, _, b0 = _to_dev(c0)
+    frame = {k: torch.cat([b[k], b0[k]], dim=1).contiguous() for k in b}
+    op = make_op(n, R, S, H, device=DEV, max_steps=2)
+    opt = step.FusedAdamWState(n, H, DEV, lr=1e-3, weight_decay=0.013)
+    res = op.train_steps(fc, B, sc, frame["pcs"], frame["z"], frame["gt_depth"], frame["gt_rgb"], frame["sem"], frame["depth_mask"],
+                         opt=opt, n_steps=2)
+    torch.cuda.synchronize()
+    fl = res.flags.cpu().numpy()
+    assert fl[0].tolist() == [0, 0, 0, 1] and fl[1].tolist() == [0, 0, 0, 0], fl
+    assert abs(float(res.loss[0]) - float(g["loss"])) <= 2e-5 * float(g["loss"])
+    with pytest.raises(RuntimeError, match="loss explode"):
+        driver.HipMapper.check_flags(None, res)
+    # vmapstep_adamw_apply, global-loss path: prepared step -> per-object loss terms + gradient slab -> the optimiser launch
+    # raises the flag from the (here: single-rank) summed terms
+    fc, B, sc, b = _to_dev(c)
+    P, PP = layout.param_count(H), opt.padded
+    gslab = torch.zeros(n, PP, device=DEV)
+    offs = layout.flat_offsets(H)
+    shapes = list(layout.fc_shapes(H)) + [layout.PE_B_SHAPE]
+    gviews = [gslab[:, offs[t]:offs[t] + layout.numel(shp)].view((n,) + tuple(shp)) for t, shp in enumerate(shapes)]
+    op = make_op(n, R, S, H, device=DEV, max_steps=1)
+    opt = step.FusedAdamWState(n, H, DEV, lr=1e-3, weight_decay=0.013)
+    op.prepare_frame(fc, B, b["pcs"], b["z"], b["gt_depth"], b["gt_rgb"], b["sem"], b["depth_mask"], n_steps=1)
+    terms = torch.zeros(n, 4, device=DEV)
+    r1 = op.fwd_bwd(fc, B, sc, b["pcs"], b["z"], b["gt_depth"], b["gt_rgb"], b["sem"], b["depth_mask"], grads_fc=gviews[:14],
+                    grad_B=gviews[14], prepared_step=0, loss_terms=terms)
+    loss_out = torch.zeros(1, device=DEV)
+    flags_out = torch.zeros(4, dtype=torch.int32, device=DEV)
+    op.adamw_apply(fc, B, gslab, opt, loss_terms=terms, step_index=0, loss_out=loss_out, flags_out=flags_out)
+    torch.cuda.synchronize()
+    assert r1.flags[0].cpu().tolist() == [0, 0, 0, 1]
+    assert flags_out.cpu().tolist() == [0, 0, 0, 1]
+    assert abs(float(loss_out[0]) - float(g["loss"])) <= 2e-5 * float(g["loss"])
+    assert float(terms[1, 0]) > 1e5 and float(terms[:, 0].max()) == float(terms[1, 0])      # object 1's depth term is the one that fired
+
+
+def test_reference_regenerated_on_this_box_equals_the_committed_fixture():
+    """The reference ITSELF (oracle/_ref: model / embedding / render_rays / loss byte-compiled unmodified, oracle/make_ref.py; or the
+    source tree where it exists), run on THIS box's CPU through functorch exactly like tests/golden/make_goldens.py, against the
+    committed 'tiny' and 'explode' fixtures: guards the fixtures against drifting from a future torch / another host CPU without
+    anyone noticing (torch_version is asserted; the values must agree to float32 rounding, bit-equality is reported)."""
+    from oracle import ref_runner
+    if not ref_runner.reference_available():
+        pytest.skip("neither /root/reference nor oracle/_ref (python oracle/make_ref.py) on this box")
+    g = load_golden("tiny")
+    assert str(g["torch_version"]) == torch.__version__, "fixtures were generated with another torch: regenerate them (tests/golden/make_*.py)"
+    c = cases.build_case("tiny")
+    r = ref_runner.reference_step(c["fc"], c["B"], c["scale"], c["batch"], c["H"], torch.float32)
+    keys = RENDER_KEYS + ["var"] + GRAD_KEYS
+    bit_equal = all(np.array_equal(np.asarray(r[k], np.float32), g[k]) for k in keys) and float(r["loss"]) == float(g["loss"])
+    print(f"reference ({ref_runner.SOURCE}) regenerated 'tiny': bit-identical to the committed fixture = {bit_equal}")
+    assert abs(float(r["loss"]) - float(g["loss"])) <= 2e-6 * abs(float(g["loss"]))
+    for k in keys:
+        assert relerr(r[k], g[k]) < 5e-6, k
+    # and the HIP path against what was just regenerated (not only against the stored copy)
+    s = _run(c)
+    for k in RENDER_KEYS:
+        assert relerr(s[k], r[k]) < 2e-5, k
+    for k in GRAD_KEYS:
+        assert relerr(s[k], r[k]) < 1e-4, k
+    # the reference's exit(-1) on the explode inputs happens here as well
+    ce = cases.build_case("explode")
+    with pytest.raises(SystemExit):
+        ref_runner.reference_step(ce["fc"], ce["B"], ce["scale"], ce["batch"], ce["H"], torch.float32)
 
 
 def test_render_only_equals_fwd_bwd_renders():
@@ -248,7 +327,7 @@ def test_strided_frame_slices_like_train_py():
     n, R, S, iters = 4, 24, 10, 3
     fc, B, sc = synth.make_params(n, 32, seed=11)
     frame = synth.make_batch(n, R * iters, S, seed=12)
-    op = step.VmapStep(n, R, S, 32, device=DEV)
+    op = make_op(n, R, S, 32, device=DEV)
     tfc = [torch.from_numpy(a).to(DEV) for a in fc]
     tB, tsc = torch.from_numpy(B).to(DEV), torch.from_numpy(sc).to(DEV)
     fr = {k: torch.from_numpy(v).to(DEV) for k, v in frame.items()}
@@ -287,7 +366,7 @@ def test_slab_views_as_parameters():
         views.append(v)
         gviews.append(gslab[:, offs[t]:offs[t] + sz].view((n,) + tuple(shp)))
     _, _, sc, b = _to_dev(c)
-    op = step.VmapStep(n, c["R"], c["S"], H, device=DEV)
+    op = make_op(n, c["R"], c["S"], H, device=DEV)
     op.fwd_bwd(views[:14], views[14], sc, b["pcs"], b["z"], b["gt_depth"], b["gt_rgb"], b["sem"], b["depth_mask"],
                grads_fc=gviews[:14], grad_B=gviews[14])
     torch.cuda.synchronize()
@@ -304,7 +383,7 @@ def test_workgroups_per_object_does_not_change_results(nw, weights):
     instantiations against the reference evaluated on bfloat16-rounded parameters (fixture scannet_scale_bf16)."""
     c = cases.build_case("scannet_scale")      # R=120 -> 10 ray groups per object
     g = load_golden("scannet_scale" if weights == "f32" else "scannet_scale_bf16")
-    op = step.VmapStep(c["n"], c["R"], c["S"], c["H"], device=DEV, weights=weights, tuning={"workgroups_per_object": nw})
+    op = make_op(c["n"], c["R"], c["S"], c["H"], device=DEV, weights=weights, tuning={"workgroups_per_object": nw})
     s = _run(c, op=op)
     assert abs(s["loss"] - float(g["loss"])) <= 2e-5 * abs(float(g["loss"]))
     for k in RENDER_KEYS + GRAD_KEYS:
@@ -325,7 +404,7 @@ def test_fused_adamw_equals_torch_adamw_on_same_gradients():
     """One train_steps() step == fwd_bwd gradients fed to torch.optim.AdamW (train.py:67,325)."""
     c = cases.build_case("tiny")
     fc, B, sc, b = _to_dev(c)
-    op = step.VmapStep(c["n"], c["R"], c["S"], c["H"], device=DEV)
+    op = make_op(c["n"], c["R"], c["S"], c["H"], device=DEV)
     ref_p = [t.clone().requires_grad_() for t in fc + [B]]
     opt = torch.optim.AdamW(ref_p, lr=1e-3, weight_decay=0.013)
     st = step.FusedAdamWState(c["n"], c["H"], DEV)
@@ -354,7 +433,7 @@ def test_train_steps_tracks_reference_adamw_trajectory(name):
     c = cases.build_case(name)
     g = load_golden(name)
     fc, B, sc, b = _to_dev(c)
-    op = step.VmapStep(c["n"], c["R"], c["S"], c["H"], device=DEV)
+    op = make_op(c["n"], c["R"], c["S"], c["H"], device=DEV)
     st = step.FusedAdamWState(c["n"], c["H"], DEV)
     frame = {k: torch.cat([v, v, v], dim=1).contiguous() for k, v in b.items()}      # same batch 3 times
     res = op.train_steps(fc, B, sc, frame["pcs"], frame["z"], frame["gt_depth"], frame["gt_rgb"], frame["sem"],
@@ -373,7 +452,7 @@ def test_full_size_properties_headline_config():
     """BASELINE configs[1] (20 x 120 x 10, H=32): fixture parity + size-independent properties."""
     c = cases.build_case("cfg2")
     g = load_golden("cfg2")
-    op = step.VmapStep(c["n"], c["R"], c["S"], c["H"], device=DEV)
+    op = make_op(c["n"], c["R"], c["S"], c["H"], device=DEV)
     s = _run(c, op=op)
     for k in RENDER_KEYS:
         assert relerr(s[k], g[k]) < 2e-5, k
@@ -408,7 +487,7 @@ def test_results_are_bitwise_repeatable(name):
     c = cases.build_case(name)
     fc, B, sc, b = _to_dev(c)
     # scannet_scale: 3 of 10 ray groups per workgroup -> the multi-pass kernel
-    op = step.VmapStep(c["n"], c["R"], c["S"], c["H"], device=DEV,
+    op = make_op(c["n"], c["R"], c["S"], c["H"], device=DEV,
                        tuning={"workgroups_per_object": 0 if name == "cfg2" else 3})
     ref = None
     for it in range(40):
@@ -468,7 +547,7 @@ def test_autograd_batch_loss_drives_torch_adamw_like_train_py():
     c = cases.build_case("ragged")
     fc, B, sc, b = _to_dev(c)
     params = [t.clone().requires_grad_() for t in fc] + [B.clone().requires_grad_()]
-    op = step.VmapStep(c["n"], c["R"], c["S"], c["H"], device=DEV)
+    op = make_op(c["n"], c["R"], c["S"], c["H"], device=DEV)
     optimiser = torch.optim.AdamW(params, lr=1e-3, weight_decay=0.013)
     loss = step.batch_loss(op, params[:14], params[14], sc, b["pcs"], b["z"], b["gt_depth"], b["gt_rgb"], b["sem"], b["depth_mask"])
     assert loss.requires_grad and loss.dim() == 0
@@ -488,9 +567,9 @@ def test_autograd_batch_loss_drives_torch_adamw_like_train_py():
 
 def test_unsupported_hidden_width_fails_loudly():
     with pytest.raises(_lib.VmapStepError, match="hidden=48"):
-        step.VmapStep(4, 32, 10, 48, device=DEV)
+        make_op(4, 32, 10, 48, device=DEV)
     with pytest.raises(_lib.VmapStepError, match="hidden=512"):
-        step.VmapStep(4, 32, 10, 512, device=DEV)
+        make_op(4, 32, 10, 512, device=DEV)
 
 
 @pytest.mark.parametrize("name,kernel", [("h64", "gen"), ("bg_h128_s14", "wide"), ("imap_h256", "wide"),
@@ -534,13 +613,13 @@ def test_reference_imap_batch_matches_reference_fixture(weights):
     (fixture imap_full / imap_full_bf16: loss, renders, all 15 gradient tensors).  Gradients at north_star's 1e-4; should the
     reference's run and the kernel differ on the derivative bit of kink-adjacent hidden units (67 200 points x 1024 units), the
     bits are accounted for one by one (signed coefficients, conftest.kink_aware)."""
-    if step.VmapStep.default_tuning is not None:
+    if TEST_TUNING["default"] is not None:
         pytest.skip("hidden 256: the module's hidden-32 kernel legs do not apply; run once")
     from conftest import round_bf16
     bf16 = weights == "bf16"
     c = cases.build_case("imap_full")
     g = load_golden("imap_full_bf16" if bf16 else "imap_full")
-    op = step.VmapStep(c["n"], c["R"], c["S"], c["H"], device=DEV, weights=weights)
+    op = make_op(c["n"], c["R"], c["S"], c["H"], device=DEV, weights=weights)
     plan = op.plan()
     assert plan["kernel"] == "step_main_ws<8>" and plan["single_round"] == 0 and plan["rounds_per_object"] == 2400
     s = _run(c, op=op)
@@ -566,7 +645,7 @@ def test_generic_width_multi_pass_and_train_steps():
     for k in RENDER_KEYS + GRAD_KEYS:
         assert relerr(s[k], g[k]) < 1e-4, k
     fc, B, sc, b = _to_dev(c)
-    op = step.VmapStep(c["n"], c["R"], c["S"], c["H"], device=DEV)
+    op = make_op(c["n"], c["R"], c["S"], c["H"], device=DEV)
     st = step.FusedAdamWState(c["n"], c["H"], DEV)
     frame = {k: torch.cat([v, v], dim=1).contiguous() for k, v in b.items()}
     res = op.train_steps(fc, B, sc, frame["pcs"], frame["z"], frame["gt_depth"], frame["gt_rgb"], frame["sem"],
@@ -582,7 +661,7 @@ def test_prepared_split_applies_externally_reduced_flags():
     rank's objects must drop the term here too (render_rays.py:68-73 is batch-wide)."""
     c = cases.build_case("tiny")
     fc, B, sc, b = _to_dev(c)
-    op = step.VmapStep(c["n"], c["R"], c["S"], c["H"], device=DEV)
+    op = make_op(c["n"], c["R"], c["S"], c["H"], device=DEV)
     st = step.FusedAdamWState(c["n"], c["H"], DEV, lr=0.0, weight_decay=0.0)      # lr 0: parameters stay put
     gfc = [torch.zeros_like(t) for t in fc]
     gB = torch.zeros_like(B)
@@ -653,7 +732,7 @@ def test_hidden256_frame_tracks_the_aten_port(weights):
     tfc = [torch.from_numpy(a).to(DEV) for a in fc]
     tB, tsc = torch.from_numpy(B).to(DEV), torch.from_numpy(sc).to(DEV)
     fr = {k: torch.from_numpy(v).to(DEV) for k, v in b.items()}
-    op = step.VmapStep(n, R, S, H, device=DEV, max_steps=steps, weights=weights)
+    op = make_op(n, R, S, H, device=DEV, max_steps=steps, weights=weights)
     st = step.FusedAdamWState(n, H, DEV)
     res = op.train_steps(tfc, tB, tsc, fr["pcs"], fr["z"], fr["gt_depth"], fr["gt_rgb"], fr["sem"], fr["depth_mask"], opt=st, n_steps=steps)
     torch.cuda.synchronize()
@@ -725,7 +804,7 @@ def test_bf16_weight_mode_equals_reference_on_rounded_weights(name, kernel):
     fc_r = [round_bf16(a) for a in c["fc"]]
     B_r = round_bf16(c["B"])
     loss_t, rend_t, grads_t = vt.CpuTrainer(fc_r, B_r, c["scale"]).step(c["batch"], update=False)
-    op = step.VmapStep(c["n"], c["R"], c["S"], c["H"], device=DEV, weights="bf16", tuning={"kernel": kernel} if kernel else None)
+    op = make_op(c["n"], c["R"], c["S"], c["H"], device=DEV, weights="bf16", tuning={"kernel": kernel} if kernel else None)
     s = _run(c, op=op)
     assert abs(s["loss"] - float(g["loss"])) <= 2e-5 * abs(float(g["loss"]))
     for k in RENDER_KEYS:
@@ -764,7 +843,7 @@ def test_table_driven_finalize_is_bit_identical_to_generic_finalize(name, weight
         fc, B, sc, b = _to_dev(c)
         if slab:
             _, fc, B = layout.stack_in_slab(fc, B)
-        op = step.VmapStep(c["n"], c["R"], c["S"], c["H"], device=DEV, max_steps=steps, weights=weights,
+        op = make_op(c["n"], c["R"], c["S"], c["H"], device=DEV, max_steps=steps, weights=weights,
                            tuning={"generic_finalize": generic})
         st = step.FusedAdamWState(c["n"], c["H"], DEV)
         frame = {k: torch.cat([v.roll(i, dims=1) for i in range(steps)], dim=1).contiguous() for k, v in b.items()}
@@ -824,7 +903,7 @@ def test_frame_trajectory_matches_reference_step_loop(name):
     against the reference loop run with bfloat16-rounded run-time weights over full-precision masters."""
     # bg128_frame (240 rays = 120 tiles) runs step_main_ws with single-tile rounds by default; its f32 "f32" leg of the module's
     # kernel parametrisation runs the two-tile form instead, so that both are held to the reference's own loop
-    two_tile = name.startswith("bg128") and step.VmapStep.default_tuning is not None
+    two_tile = name.startswith("bg128") and TEST_TUNING["default"] is not None
     _check_frame_trajectory(name, {"ws_flags": 1} if two_tile else None)
 
 
@@ -836,7 +915,7 @@ def test_bf16_frame_steps_teacher_forced(name):
     gradients of step i's ray slice on their bfloat16 rounding, and the kernel's loss / gradients of the same step must agree to
     2e-5 / 1e-4 (ReLU kinks accounted for, signed); then the kernel's fused AdamW advances the masters and the next step is checked
     on the new ones."""
-    if step.VmapStep.default_tuning is not None and cases.FRAME_CASES[name][3] != 32:
+    if TEST_TUNING["default"] is not None and cases.FRAME_CASES[name][3] != 32:
         pytest.skip("hidden 64 / 128: the module's hidden-32 kernel legs do not apply; run once")
     from conftest import round_bf16
     from oracle import vmap_oracle_torch as vt
@@ -846,7 +925,7 @@ def test_bf16_frame_steps_teacher_forced(name):
     B = torch.from_numpy(c["B"]).to(DEV)
     sc = torch.from_numpy(c["scale"]).to(DEV)
     fr = {k: torch.from_numpy(v).to(DEV) for k, v in c["frame"].items()}
-    op = step.VmapStep(n, R, S, H, device=DEV, max_steps=1, weights="bf16")
+    op = make_op(n, R, S, H, device=DEV, max_steps=1, weights="bf16")
     st = step.FusedAdamWState(n, H, DEV)
     keys = ("pcs", "z", "gt_depth", "gt_rgb", "sem", "depth_mask")
     for i in range(steps):
@@ -871,7 +950,7 @@ def test_background_frame_with_three_tile_rounds(name):
     """The same frame fixtures through step_main_ws<4, ., ., ., NT = 3> (tuning.ws_flags = 2; 240 rays = 40 rounds of 6 rays): the
     form a ONE-GPU background step (1200 rays) runs - forward, loss, backward, fused AdamW and the maintained W / W^T images
     over the frame's steps against the reference's own loop, float32 and bfloat16 run-time weights."""
-    if step.VmapStep.default_tuning is not None:
+    if TEST_TUNING["default"] is not None:
         pytest.skip("hidden 128: the module's hidden-32 kernel legs do not apply; run once")
     _check_frame_trajectory(name, {"ws_flags": 2})
 
@@ -885,7 +964,7 @@ def _check_frame_trajectory(name, tuning):
     B = torch.from_numpy(c["B"]).to(DEV)
     sc = torch.from_numpy(c["scale"]).to(DEV)
     fr = {k: torch.from_numpy(v).to(DEV) for k, v in c["frame"].items()}
-    op = step.VmapStep(n, R, S, H, device=DEV, max_steps=steps, weights="bf16" if bf16 else "f32", tuning=tuning)
+    op = make_op(n, R, S, H, device=DEV, max_steps=steps, weights="bf16" if bf16 else "f32", tuning=tuning)
     st = step.FusedAdamWState(n, H, DEV)
     # first-step gradients (same state): fixture parity of the strided slice [0, R)
     gfc = [torch.zeros_like(t) for t in fc]
@@ -894,6 +973,7 @@ def _check_frame_trajectory(name, tuning):
     keep = g["keep"]
     got0 = {(f"g_fc{t}" if t < 14 else "g_B"): (gfc[t] if t < 14 else gB).cpu().numpy()[keep] for t in range(15)}
     fix0 = {(f"g_fc{t}" if t < 14 else "g_B"): g[f"g0_fc{t}" if t < 14 else "g0_B"] for t in range(15)}
+    kink_bits_off_the_reference = 0
     if max(relerr(got0[k], fix0[k]) for k in GRAD_KEYS) >= 1e-4:
         # The reference's own float32 run may sit on the other side of a ReLU kink (bg128_frame_bf16: ONE hidden unit of 2.1 M moves
         # its in_layer gradient by 6e-4 against BOTH the numpy oracle and this kernel, which agree to 3e-6).  Account for it bit
@@ -903,7 +983,7 @@ def _check_frame_trajectory(name, tuning):
         sub = {k: np.ascontiguousarray(v[keep][:, :R]) for k, v in c["frame"].items()}
         o = vo.training_step([rnd(a[keep]) for a in c["fc"]], rnd(c["B"][keep]), c["scale"][keep], sub, dtype=np.float32, kinks=True)
         fix0["kink_deltas"] = o["kink_deltas"]
-        _assert_grads_match_oracle_up_to_kinks(got0, fix0, len(keep), tol=1e-4, signed=True)
+        kink_bits_off_the_reference = _assert_grads_match_oracle_up_to_kinks(got0, fix0, len(keep), tol=1e-4, signed=True)
     res = op.train_steps(fc, B, sc, fr["pcs"], fr["z"], fr["gt_depth"], fr["gt_rgb"], fr["sem"], fr["depth_mask"], opt=st,
                          n_steps=steps, ray_step=R)
     torch.cuda.synchronize()
@@ -913,11 +993,11 @@ def _check_frame_trajectory(name, tuning):
     rel = np.abs(losses - g["losses"]) / np.abs(g["losses"])
     pre = ""
     if "alt_losses" in g.files:
-        # the fixture holds both sides of a ReLU kink of step 0 (two valid float32 evaluations of the reference's loop): the kernel
-        # is on one of them
-        rel_alt = np.abs(losses - g["alt_losses"]) / np.abs(g["alt_losses"])
-        if rel_alt.max() < rel.max():
-            rel, pre = rel_alt, "alt_"
+        # the fixture holds both sides of a ReLU kink of step 0 (two valid float32 evaluations of the reference's loop).  WHICH one
+        # this kernel is on is decided by its own step-0 derivative bits (the kink accounting of the first-step gradients above:
+        # raw agreement with the reference's gradients = the reference's side, a flipped bit = the other side), not by best fit
+        if kink_bits_off_the_reference > 0:
+            rel, pre = np.abs(losses - g["alt_losses"]) / np.abs(g["alt_losses"]), "alt_"
     assert rel[0] <= 2e-5 or not bf16, rel
     assert rel[:FRAME_EARLY_STEPS.get(name, 5)].max() <= early, rel
     assert rel.max() <= late, rel
@@ -945,7 +1025,7 @@ def test_parameter_image_kept_by_finalize_equals_freshly_packed_image(weights, c
     outs = []
     for split_calls in (False, True):
         fc, B, sc, b = _to_dev(c)
-        op = step.VmapStep(c["n"], c["R"], c["S"], c["H"], device=DEV, max_steps=2, weights=weights)
+        op = make_op(c["n"], c["R"], c["S"], c["H"], device=DEV, max_steps=2, weights=weights)
         st = step.FusedAdamWState(c["n"], c["H"], DEV)
         frame = {k: torch.cat([v, v.roll(3, dims=1)], dim=1).contiguous() for k, v in b.items()}
         args = (frame["pcs"], frame["z"], frame["gt_depth"], frame["gt_rgb"], frame["sem"], frame["depth_mask"])
@@ -973,7 +1053,7 @@ def test_graph_replay_of_a_bound_frame_is_bit_identical_to_eager_calls(name, ste
     outs = []
     for graph in (False, True):
         fc, B, sc, b = _to_dev(c)
-        op = step.VmapStep(c["n"], c["R"], c["S"], c["H"], device=DEV, max_steps=steps)
+        op = make_op(c["n"], c["R"], c["S"], c["H"], device=DEV, max_steps=steps)
         st = step.FusedAdamWState(c["n"], c["H"], DEV)
         frame = {k: torch.cat([v.roll(i, dims=1) for i in range(steps)], dim=1).contiguous() for k, v in b.items()}
         bound = op.bind(fc, B, sc, frame["pcs"], frame["z"], frame["gt_depth"], frame["gt_rgb"], frame["sem"], frame["depth_mask"], opt=st,
@@ -1004,7 +1084,7 @@ def test_device_step_count_survives_mixed_host_and_device_calls():
     outs = []
     for device_steps in (False, True):
         fc, B, sc, b = _to_dev(c)
-        op = step.VmapStep(c["n"], c["R"], c["S"], c["H"], device=DEV, max_steps=4)
+        op = make_op(c["n"], c["R"], c["S"], c["H"], device=DEV, max_steps=4)
         st = step.FusedAdamWState(c["n"], c["H"], DEV)
         if device_steps:
             st.enable_device_steps()
@@ -1039,7 +1119,7 @@ def test_full_size_properties_of_the_other_baseline_configs(config, weights, tun
     fc, B, sc = synth.make_params(n, H, scale=cfg["scale"], seed=700)
     batch = synth.make_batch(n, R, S, seed=701)
     c = dict(n=n, R=R, S=S, H=H, fc=fc, B=B, scale=sc, batch=batch)
-    op = step.VmapStep(n, R, S, H, device=DEV, weights=weights, tuning=tuning)
+    op = make_op(n, R, S, H, device=DEV, weights=weights, tuning=tuning)
     s = _run(c, op=op)
     s2 = _run(c, op=op)
     for k in RENDER_KEYS + ["var"] + GRAD_KEYS:
@@ -1049,7 +1129,9 @@ def test_full_size_properties_of_the_other_baseline_configs(config, weights, tun
     assert abs(s["loss"] - o["loss"]) <= 5e-5 * abs(o["loss"])
     for k in RENDER_KEYS + ["var"]:
         assert relerr(s[k], o[k]) < 2e-5, k
-    _assert_grads_match_oracle_up_to_kinks(s, o, n)
+    from oracle import vmap_oracle_torch as vt
+    _, _, grads_t = vt.CpuTrainer(fc, B, sc, weights_bf16=weights == "bf16").step(batch, update=False)
+    _assert_grads_match_aten_port_up_to_kinks(s, o, grads_t, n)                   # the ATen port at 1e-4 (kink list from the oracle)
     if n > 1:
         perm = np.random.default_rng(0).permutation(n)
         cp = dict(c, fc=[a[perm] for a in fc], B=B[perm], scale=sc[perm], batch={k: np.ascontiguousarray(v[perm]) for k, v in batch.items()})

@@ -14,7 +14,8 @@ from oracle import vmap_oracle as vo
 # fp32-vs-fp32 noise floor between two CPU implementations (numpy vs ATen): different exp/sin and
 # summation order.  'saturated' drives occupancy to exactly 1.0f where var -> 0 and the
 # 1/(sqrt(var)+1e-4) weight amplifies rounding noise; its floor is measured, not chosen.
-F32_TOL = {"default": dict(render=2e-5, grad=1e-4), "saturated": dict(render=2e-3, grad=2e-3)}
+F32_TOL = {"default": dict(render=2e-5, grad=1e-4), "saturated": dict(render=2e-3, grad=2e-3),
+           "explode": dict(render=2e-3, grad=2e-3)}          # the explode case is saturated too (gain 4.0)
 
 
 @pytest.mark.parametrize("name", list(cases.CASES))
@@ -56,6 +57,22 @@ def test_oracle_f32_matches_reference_f32(name):
         return
     for k in GRAD_KEYS:
         assert relerr(o[k], g[k]) < tol["grad"], k
+
+
+def test_explode_fixture_records_the_reference_exit():
+    """render_rays.py:88-90: on the 'explode' inputs the unmodified reference ENDS THE PROCESS with exit(-1) (certified by the
+    generator: exit_code), exactly once per step (explode_calls: the depth term); with the call recorded instead of obeyed its
+    loss is what the oracle computes, and the oracle raises the flag on the same inputs."""
+    c = cases.build_case("explode")
+    g = load_golden("explode")
+    assert int(g["exit_code"]) == -1 and int(g["explode_calls"]) == 1
+    o = vo.training_step(c["fc"], c["B"], c["scale"], c["batch"], dtype=np.float32)
+    assert o["explode"] is True and not o["drop"].any()
+    assert float(g["loss"]) > 1e5 and abs(o["loss"] - float(g["loss"])) <= 2e-5 * float(g["loss"])
+    for name in cases.CASES:
+        if name not in ("explode", "imap_full"):
+            cc = cases.build_case(name)
+            assert vo.training_step(cc["fc"], cc["B"], cc["scale"], cc["batch"], dtype=np.float32)["explode"] is False, name
 
 
 def test_any_empty_mask_quirk_is_global():

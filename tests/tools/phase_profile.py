@@ -29,10 +29,10 @@ tB, tsc = torch.from_numpy(B).to(dev), torch.from_numpy(sc).to(dev)
 tb = {k: torch.from_numpy(v).to(dev) for k, v in batch.items()}
 from vmap_amd import _lib  # noqa: E402
 # the phase-stamp instantiations live in the measurement build of the library (tests/tools/libvmapstep_ab.so, built by build())
-step.VmapStep.ab_library = os.path.join(ROOT, "tests", "tools", "libvmapstep_ab.so")
+AB_LIBRARY = os.path.join(ROOT, "tests", "tools", "libvmapstep_ab.so")
 kern = sys.argv[2] if len(sys.argv) > 2 else "split"       # split (default kernel at hidden 32) | f32
 ws_flags = int(sys.argv[3]) if len(sys.argv) > 3 else 0      # hidden 128: tuning.ws_flags (4 = never three-tile rounds)
-op = step.VmapStep(n, R, S, H, device=dev, tuning={"kernel": _lib.KERNEL_H32_F32} if kern == "f32" else {"ws_flags": ws_flags})   # (an explicit tuning selects the measurement build)
+op = step.VmapStep(n, R, S, H, device=dev, tuning={"kernel": _lib.KERNEL_H32_F32} if kern == "f32" else {"ws_flags": ws_flags}, library=AB_LIBRARY)
 args = (tfc, tB, tsc, tb["pcs"], tb["z"], tb["gt_depth"], tb["gt_rgb"], tb["sem"], tb["depth_mask"])
 for _ in range(3):
     t = op.profile_phases(*args)

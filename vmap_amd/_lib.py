@@ -176,20 +176,23 @@ def load(path=None):
     return lib
 
 
-def describe_plan(n_obj: int, rays: int, samples: int, hidden: int, weights_bf16: bool = False, max_steps: int = 20, tuning: dict = None) -> dict:
+def describe_plan(n_obj: int, rays: int, samples: int, hidden: int, weights_bf16: bool = False, max_steps: int = 20, tuning: dict = None,
+                  library: str = None) -> dict:
     """The launch plan for a shape as a dict (kernel name, rays per round, rounds / workgroups per object, tiles per round, waves per
-    workgroup, single_round) - no device needed."""
-    lib = load()
+    workgroup, single_round) - no device needed.  ``library``: the build to ask (default: the product library)."""
+    lib = load(library)
     sh = Shape(n_obj, rays, samples, hidden, WEIGHTS_BF16 if weights_bf16 else WEIGHTS_F32)
     t = Tuning(**tuning) if tuning else None
     if t is not None:
         sh.tuning = ctypes.pointer(t)
     info = PlanInfo()
-    check(lib.vmapstep_describe_plan(ctypes.byref(sh), max_steps, ctypes.byref(info)))
+    check(lib.vmapstep_describe_plan(ctypes.byref(sh), max_steps, ctypes.byref(info)), lib)
     return {"kernel": info.kernel.decode(), **{k: int(getattr(info, k)) for k, _ in PlanInfo._fields_[1:]}}
 
 
-def check(rc: int, lib=None):
+def check(rc: int, lib):
+    """Raise on a non-zero status; the message comes from the library that made the call (each build has its own thread-local
+    last-error string)."""
     if rc != 0:
-        msg = (lib or load()).vmapstep_last_error().decode("utf-8", "replace")
+        msg = lib.vmapstep_last_error().decode("utf-8", "replace")
         raise VmapStepError(f"vmapstep error {rc}: {msg}")

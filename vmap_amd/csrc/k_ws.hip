@@ -16,7 +16,9 @@ int main_t(const vk::StepArgs& a, hipStream_t st) {
     }
 #ifndef VMAPSTEP_AB
     // three-tile rounds with several rounds per workgroup: no automatic plan launches it (the plan takes three tiles exactly when they
-    // give every workgroup ONE round) - measurement build only
+    // give every workgroup ONE round) - measurement build only.  make_plan (vmapstep.hip) refuses that PLAN for every entry point,
+    // training and render alike, before anything is launched; this guard only keeps the multi-round TRAINING instantiation out of
+    // the product binary - the forward instantiation below stays, it also serves the single-round render of the background shape
     if constexpr (NT == 3 && BWD) return fail(-2, "this kernel form ships in the measurement build only (tests/tools/libvmapstep_ab.so: phase stamps and A/B forms no automatic plan launches)");
     else
 #endif

@@ -203,7 +203,7 @@ int make_plan(const vmapstep_shape* sh, int max_steps, Plan& pl, const Layout& L
 #ifndef VMAPSTEP_AB
     // The product library carries the kernel forms automatic plans launch (+ the exact-fp32 references step_main_h32 / _gen).  Forms
     // that exist for A/B measurements only - step_main_wide<4>, step_main_ws at hidden 64, step_main_wp at hidden 128, three-tile rounds
-    // with several rounds per workgroup - and the phase-stamp instantiations live in the measurement build (tests/tools/build_ab.py).
+    // with several rounds per workgroup - and the phase-stamp instantiations live in the measurement build (tests/tools/libvmapstep_ab.so, built by __graft_entry__.build() with -DVMAPSTEP_AB).
     if (pl.wide == 1 || (pl.wide == 3 && sh->hidden == 64) || (pl.wide == 4 && sh->hidden == 128) || (pl.wide == 3 && pl.tiles == 3 && pl.NW != pl.NG))
         return fail(VMAPSTEP_ERR_UNSUPPORTED, "this kernel form ships in the measurement build only (tests/tools/libvmapstep_ab.so: phase stamps and A/B forms no automatic plan launches)");
 #endif

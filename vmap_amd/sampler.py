@@ -81,7 +81,7 @@ class FrameSampler:
         self._out, self._ws = None, None
         if self.split:
             nb = ctypes.c_size_t(0)
-            _lib.check(self.lib.vmapstep_sample_workspace_bytes(n, ctypes.byref(nb)))
+            _lib.check(self.lib.vmapstep_sample_workspace_bytes(n, ctypes.byref(nb)), self.lib)
             self._ws = torch.empty(nb.value, dtype=torch.uint8, device=self.device)
 
     def sample(self, test_randoms: Optional[dict] = None):
@@ -108,6 +108,6 @@ class FrameSampler:
                                                   self.seed, self.frame_counter, ctypes.byref(rnd) if rnd is not None else None,
                                                   self._ws.data_ptr() if self._ws is not None else None,
                                                   self._ws.numel() if self._ws is not None else 0,
-                                                  torch.cuda.current_stream(self.device).cuda_stream))
+                                                  torch.cuda.current_stream(self.device).cuda_stream), self.lib)
         self.frame_counter += 1
         return out

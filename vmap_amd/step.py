@@ -97,23 +97,15 @@ class FusedAdamWState:
 class VmapStep:
     """The fused step operator for a fixed (n_obj, rays, samples, hidden) problem shape."""
 
-    # measurement / test hook: plan overrides merged UNDER every new operator's own ``tuning`` (Python-side default only;
-    # the C library keeps no tuning state)
-    default_tuning: Optional[dict] = None
-    # test / tool hook: path of the measurement build (tests/tools/libvmapstep_ab.so: phase stamps + A/B kernel forms); None in products
-    ab_library: Optional[str] = None
-
     def __init__(self, n_obj: int, rays: int, samples: int, hidden: int, device="cuda:0", max_steps: int = 32,
-                 color_scaling: float = 5.0, opacity_scaling: float = 10.0, weights: str = "f32", tuning: Optional[dict] = None):
+                 color_scaling: float = 5.0, opacity_scaling: float = 10.0, weights: str = "f32", tuning: Optional[dict] = None,
+                 library: Optional[str] = None):
         """``tuning``: optional overrides of the automatic launch plan for measurements / A-B tests (fields of
         ``vmapstep_tuning``: workgroups_per_object, kernel, generic_finalize, ws_flags).  They belong to THIS operator (the C library
-        keeps no tuning state).  The operator may live on any GPU of the process: every C call runs on the device that owns
-        the stream it is given (``torch.cuda.current_stream(self.device)``), whatever device is current on the thread."""
-        tuning = {**(type(self).default_tuning or {}), **(tuning or {})}
-        # the product library carries the forms automatic plans launch; an operator with an explicit plan override runs on the
-        # measurement build when a test / tool registered one (VmapStep.ab_library) - otherwise on the product, which refuses
-        # forms it does not carry
-        self.lib = _lib.load(type(self).ab_library if (tuning and type(self).ab_library) else None)
+        keeps no tuning state).  ``library``: path of another build of the C ABI to run this operator on (default: the product
+        library next to this file, ``_lib.LIB_PATH``).  The operator may live on any GPU of the process: every C call runs on the
+        device that owns the stream it is given (``torch.cuda.current_stream(self.device)``), whatever device is current on the thread."""
+        self.lib = _lib.load(library)
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.VmapStepError("VmapStep runs on the GPU only (no CPU fallback)")

@@ -52,7 +52,7 @@ class Trainer:
         n = pts.shape[0]
         dev = pts.device
         nb = ctypes.c_size_t(0)
-        _lib.check(lib.vmapstep_query_workspace_bytes(self.hidden_feature_size, ctypes.byref(nb)))
+        _lib.check(lib.vmapstep_query_workspace_bytes(self.hidden_feature_size, ctypes.byref(nb)), lib)
         ws = torch.empty(nb.value + 256, dtype=torch.uint8, device=dev)
         ws_ptr = ws.data_ptr() + (-ws.data_ptr()) % 256
         pp = _lib.Params()
@@ -68,7 +68,7 @@ class Trainer:
         strides = (ctypes.c_int64 * 2)(pts.stride(0), pts.stride(1))
         _lib.check(lib.vmapstep_query_points(self.hidden_feature_size, ctypes.byref(pp), ctypes.byref(sc), 0, pts.data_ptr(), n,
                                              strides, occ.data_ptr(), col.data_ptr(), ws_ptr, nb.value,
-                                             torch.cuda.current_stream(dev).cuda_stream))
+                                             torch.cuda.current_stream(dev).cuda_stream), lib)
         return occ, col
 
 
