@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VMAPSTEP_ABI_VERSION 6
+#define VMAPSTEP_ABI_VERSION 7
 #define VMAPSTEP_NUM_FC 14 /* field-MLP tensors per object, nn.Module.parameters() order (model.py:28-49) */
 
 #define VMAPSTEP_OK 0
@@ -106,6 +106,13 @@ typedef struct vmapstep_batch {
     const float* gt_rgb;       int64_t gt_rgb_stride[3];     /* [n,R,3]    already divided by 255       */
     const uint8_t* sem;        int64_t sem_stride[2];        /* [n,R]      0 other, 1 this, 2 unknown   */
     const uint8_t* depth_mask; int64_t depth_mask_stride[2]; /* [n,R]      bool as bytes                */
+    /* ABI v7 - the sampler -> step hand-off as RAYS instead of points (second half; vmap.py:452-457): when
+     * pcs == NULL the kernels rebuild sample point s of ray r of object k as (ray_o + ray_d * z[k][r][s]) - center[k], every
+     * operation rounded on its own - the arithmetic of vmap.py:452-454 and of vmapstep_sample_frame, so the result is bit-identical
+     * to reading the points it replaces; 24 + 4 S bytes per ray instead of 16 S (64 instead of 160 at S = 10).                     */
+    const float* ray_o;        int64_t ray_o_stride[3];      /* [n,R,3]    ray origin, world frame (the keyframe's camera centre) */
+    const float* ray_d;        int64_t ray_d_stride[3];      /* [n,R,3]    ray direction, world frame                             */
+    const float* center;       int64_t center_stride;        /* [n,3]      obj_center (vmap.py:454); NULL = zeros; elements between objects */
 } vmapstep_batch;
 
 typedef struct vmapstep_outputs {
@@ -275,6 +282,16 @@ int vmapstep_sample_frame(const vmapstep_sample_cfg* cfg, const vmapstep_sample_
                           float* pcs, float* z, float* gt_depth, float* gt_rgb, uint8_t* sem, uint8_t* depth_mask,
                           uint64_t seed, uint32_t frame_counter, const vmapstep_sample_randoms* test_randoms,
                           void* workspace, size_t workspace_bytes, void* stream);
+/* ABI v7 - the same sampler handing the frame over as RAYS (second half: "or just o, dir, z = 64 B/ray instead of
+ * 160"): ray_o / ray_d [n, F*P, 3] (world-frame origin and direction of every ray, vmap.py:31-41, :507-516) and center [n, 3] (the objects'
+ * obj_center; optional) instead of the points tensor; the step kernels rebuild pcs = (ray_o + ray_d * z) - center themselves
+ * (vmapstep_batch::ray_o / ray_d / center with pcs == NULL), bit-identical to the points this call would have written.  `pcs` is optional
+ * here (non-NULL: written as well - tests).  Same pixels, samples, random numbers as vmapstep_sample_frame. */
+int vmapstep_sample_frame_rays(const vmapstep_sample_cfg* cfg, const vmapstep_sample_object* objects_device, int32_t n_obj,
+                               float* ray_o, float* ray_d, float* center, float* pcs,
+                               float* z, float* gt_depth, float* gt_rgb, uint8_t* sem, uint8_t* depth_mask,
+                               uint64_t seed, uint32_t frame_counter, const vmapstep_sample_randoms* test_randoms,
+                               void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- inference query -------------------------------------------------------------------
  * Occupancy sigmoid(alpha) and colour of ONE object's field (object `obj_index` of the stacked tensors) at `n_points`

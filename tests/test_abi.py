@@ -24,7 +24,32 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in _declared_functions():
         assert hasattr(lib, name), name
-    assert lib.vmapstep_abi_version() == 6
+    assert lib.vmapstep_abi_version() == _lib.ABI_VERSION == 7
+
+
+def test_struct_layouts_match_the_header(tmp_path):
+    """The ctypes mirrors of vmap_amd/_lib.py against include/vmapstep.h as a C compiler lays it out (gcc, C99): size of every struct
+    that crosses the ABI and the offsets of the fields ABI v7 appended to vmapstep_batch."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    structs = {"vmapstep_tuning": _lib.Tuning, "vmapstep_shape": _lib.Shape, "vmapstep_plan_info": _lib.PlanInfo, "vmapstep_tensor": _lib.Tensor,
+               "vmapstep_params": _lib.Params, "vmapstep_batch": _lib.Batch, "vmapstep_outputs": _lib.Outputs, "vmapstep_adamw": _lib.AdamW,
+               "vmapstep_sample_object": _lib.SampleObject, "vmapstep_sample_cfg": _lib.SampleCfg, "vmapstep_sample_randoms": _lib.SampleRandoms}
+    fields = ("pcs", "z", "depth_mask", "ray_o", "ray_o_stride", "ray_d", "ray_d_stride", "center", "center_stride")
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "vmapstep.h"\nint main(void) {\n'
+                   + "".join(f'  printf("{n} %zu\\n", sizeof({n}));\n' for n in structs)
+                   + "".join(f'  printf("batch.{f} %zu\\n", offsetof(vmapstep_batch, {f}));\n' for f in fields)
+                   + "  return 0;\n}\n")
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for n, c in structs.items():
+        assert int(got[n]) == ctypes.sizeof(c), n
+    for f in fields:
+        assert int(got[f"batch.{f}"]) == getattr(_lib.Batch, f).offset, f
 
 
 @pytest.mark.parametrize("H", [32, 64, 128, 256])

@@ -146,3 +146,31 @@ def test_bench_traffic_observation_degrades_without_a_gpu():
         pytest.skip("CPU-tier check")
     val, note = bench.observe_traffic("replica_room0_vmap", "f32", timeout_s=60)
     assert val is None and isinstance(note, str) and note
+
+
+def test_ray_points_container_shapes_and_slices():
+    """step.RayPoints (the sampler's hand-off as rays, ABI v7): validation, the (object, ray) slicing train.py:271-272 applies to the points
+    tensor, and the host-side reconstruction of the points (one rounding per operation: vmap.py:452-454)."""
+    import numpy as np
+    import torch
+    from vmap_amd import step
+    rng = np.random.default_rng(0)
+    o, d = torch.from_numpy(rng.standard_normal((4, 30, 3)).astype(np.float32)), torch.from_numpy(rng.standard_normal((4, 30, 3)).astype(np.float32))
+    c = torch.from_numpy(rng.standard_normal((4, 3)).astype(np.float32))
+    z = torch.from_numpy(rng.uniform(0.1, 4.0, (4, 30, 10)).astype(np.float32))
+    r = step.RayPoints(o, d, c)
+    assert r.shape[:2] == (4, 30)
+    s = r[:, 10:20]
+    assert s.shape[:2] == (4, 10) and s.origins.data_ptr() == o[:, 10:20].data_ptr() and s.centers is c or torch.equal(s.centers, c)
+    assert r[1:3].centers.shape == (2, 3)
+    p = r.points(z)
+    ref = (o.numpy()[:, :, None, :] + d.numpy()[:, :, None, :] * z.numpy()[..., None]) - c.numpy()[:, None, None, :]      # float32 numpy: same roundings
+    assert p.shape == (4, 30, 10, 3) and np.array_equal(p.numpy(), ref)
+    assert torch.equal(step.RayPoints(o, d).points(z), o.unsqueeze(2) + d.unsqueeze(2) * z.unsqueeze(-1))
+    import pytest
+    with pytest.raises(ValueError):
+        step.RayPoints(o, d[:, :5])
+    with pytest.raises(ValueError):
+        step.RayPoints(o, d, c[:2])
+    with pytest.raises(IndexError):
+        r[0]

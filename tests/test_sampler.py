@@ -151,6 +151,57 @@ def test_gpu_sampler_test_mode_equals_oracle_and_feeds_training():
     assert torch.isfinite(res.loss).all()
 
 
+@pytest.mark.gpu
+def test_gpu_sampler_ray_handoff_equals_points_and_trains_bit_identically():
+    """vmapstep_sample_frame_rays (ABI v7; SURVEY.md 8(f) row 1, second half): the same frame handed over as (origin, direction, z) +
+    object centres.  Test mode and Philox mode: z / ground truth / masks are the bytes the points form writes, the points rebuilt from
+    the rays ARE the points tensor, bit for bit, and five training steps on either form end in identical parameters."""
+    import torch
+    from vmap_amd import sampler, step, synth
+    dev = "cuda:0"
+    scenes = [sampler_cases.build_scene("obj") for _ in range(3)]
+    rng = np.random.default_rng(6)
+    for i in (1, 2):
+        scenes[i] = dict(scenes[i], center=rng.uniform(-0.3, 0.3, 3).astype(np.float32), seed=scenes[i]["seed"] + 10 * i)
+    s0 = scenes[0]
+    fx, fy, cx, cy = s0["intr"]
+    objs = [dict(rgbs=torch.from_numpy(sc["rgbs"]).to(dev), depth=torch.from_numpy(sc["depth"]).to(dev),
+                 t_wc=torch.from_numpy(sc["t_wc"]).to(dev), bbox=torch.from_numpy(sc["bbox"]).to(dev),
+                 n_keyframes=sc["K"], last2=sc["last2"], center=sc["center"]) for sc in scenes]
+    mk = lambda rays: sampler.FrameSampler(s0["W"], s0["H"], s0["F"], s0["P"], s0["n1"], s0["n2"], fx, fy, cx, cy, min_depth=s0["min_bound"],
+                                           surface_eps=EPS, stop_eps=STOP, device=dev, seed=11, rays=rays)
+    sp, sr = mk(False), mk(True)
+    sp.set_objects(objs)
+    sr.set_objects(objs)
+    rnds = [sampler_cases.draw_randoms(sc) for sc in scenes]
+    tr = {k: torch.from_numpy(np.stack([r[k] for r in rnds]).astype(np.int32 if k == "kf_ids" else np.float32)).to(dev)
+          for k in ("kf_ids", "u_w", "u_h", "u_z", "g_z")}
+    for mode in ("test", "philox"):
+        sp.frame_counter = sr.frame_counter = 4
+        a = sp.sample(test_randoms=tr if mode == "test" else None)
+        b = sr.sample(test_randoms=tr if mode == "test" else None)
+        torch.cuda.synchronize()
+        assert isinstance(b["pcs"], step.RayPoints)
+        for k in ("z", "gt_depth", "gt_rgb", "sem", "depth_mask"):
+            assert torch.equal(a[k], b[k]), (mode, k)
+        assert torch.equal(b["pcs"].points(b["z"]), a["pcs"]), mode
+        assert torch.equal(b["pcs"].centers.cpu(), torch.from_numpy(np.stack([np.broadcast_to(np.asarray(sc["center"], np.float32), (3,)) for sc in scenes])))
+    n, FP, S, iters = len(scenes), s0["F"] * s0["P"], s0["n1"] + s0["n2"], 5
+    fc, B, sc_ = synth.make_params(n, 32, seed=1)
+    finals = []
+    for fr in (a, b):
+        tfc = [torch.from_numpy(x).to(dev) for x in fc]
+        tB, tsc = torch.from_numpy(B).to(dev), torch.from_numpy(sc_).to(dev)
+        op = step.VmapStep(n, FP // iters, S, 32, device=dev, max_steps=iters)
+        res = op.train_steps(tfc, tB, tsc, fr["pcs"], fr["z"], fr["gt_depth"], fr["gt_rgb"], fr["sem"], fr["depth_mask"],
+                             opt=step.FusedAdamWState(n, 32, dev), n_steps=iters)
+        torch.cuda.synchronize()
+        assert torch.isfinite(res.loss).all()
+        finals.append([res.loss.cpu()] + [t.cpu() for t in tfc + [tB]])
+    for x, y in zip(*finals):
+        assert torch.equal(x, y)
+
+
 def _bg_frame_scene():
     """The background object's frame of the stock Replica / ScanNet configs: n_iter_per_frame * win_size_bg = 200 frame
     slots x n_samples_per_frame_bg = 120 pixels = 24000 rays, n_bins_cam2surface_bg = 5 (train.py:197, cfg.py:67-69):

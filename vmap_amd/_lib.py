@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VMAPSTEP_LIBRARY", os.path.join(_HERE, "libvmapstep.so"))   # override: measurement builds only
 
 NUM_FC = 14
-ABI_VERSION = 6
+ABI_VERSION = 7
 WEIGHTS_F32, WEIGHTS_BF16 = 0, 1
 
 
@@ -54,6 +54,10 @@ class Batch(ctypes.Structure):
         ("gt_rgb", ctypes.c_void_p), ("gt_rgb_stride", ctypes.c_int64 * 3),
         ("sem", ctypes.c_void_p), ("sem_stride", ctypes.c_int64 * 2),
         ("depth_mask", ctypes.c_void_p), ("depth_mask_stride", ctypes.c_int64 * 2),
+        # ABI v7: the hand-off as rays (pcs == NULL): point = (ray_o + ray_d * z) - center
+        ("ray_o", ctypes.c_void_p), ("ray_o_stride", ctypes.c_int64 * 3),
+        ("ray_d", ctypes.c_void_p), ("ray_d_stride", ctypes.c_int64 * 3),
+        ("center", ctypes.c_void_p), ("center_stride", ctypes.c_int64),
     ]
 
 
@@ -94,7 +98,7 @@ EXPORTS = (
     "vmapstep_profile_main_kernel", "vmapstep_profile_phases", "vmapstep_prepare", "vmapstep_train_steps_prepared",
     "vmapstep_workspace_counts_offset", "vmapstep_fwd_bwd_prepared", "vmapstep_sample_frame",
     "vmapstep_query_workspace_bytes", "vmapstep_query_points", "vmapstep_profile_train_steps", "vmapstep_adamw_apply",
-    "vmapstep_sample_workspace_bytes", "vmapstep_describe_plan",
+    "vmapstep_sample_workspace_bytes", "vmapstep_describe_plan", "vmapstep_sample_frame_rays",
 )
 
 _libs = {}
@@ -146,6 +150,11 @@ def load(path=None):
                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                           ctypes.c_uint64, ctypes.c_uint32, ctypes.POINTER(SampleRandoms), ctypes.c_void_p, ctypes.c_size_t,
                                           ctypes.c_void_p]
+    lib.vmapstep_sample_frame_rays.argtypes = [ctypes.POINTER(SampleCfg), ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
+                                               ctypes.c_void_p, ctypes.c_void_p,
+                                               ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                               ctypes.c_uint64, ctypes.c_uint32, ctypes.POINTER(SampleRandoms), ctypes.c_void_p, ctypes.c_size_t,
+                                               ctypes.c_void_p]
     lib.vmapstep_sample_workspace_bytes.argtypes = [ctypes.c_int32, ctypes.POINTER(ctypes.c_size_t)]
     lib.vmapstep_query_workspace_bytes.argtypes = [ctypes.c_int32, ctypes.POINTER(ctypes.c_size_t)]
     lib.vmapstep_query_points.argtypes = [ctypes.c_int32, ctypes.POINTER(Params), ctypes.POINTER(Tensor), ctypes.c_int32,
@@ -168,7 +177,7 @@ def load(path=None):
                "vmapstep_profile_phases", "vmapstep_prepare", "vmapstep_train_steps_prepared",
                "vmapstep_workspace_counts_offset", "vmapstep_fwd_bwd_prepared", "vmapstep_sample_frame",
                "vmapstep_query_workspace_bytes", "vmapstep_query_points", "vmapstep_profile_train_steps", "vmapstep_adamw_apply",
-               "vmapstep_sample_workspace_bytes"):
+               "vmapstep_sample_workspace_bytes", "vmapstep_sample_frame_rays"):
         getattr(lib, fn).restype = ctypes.c_int
     if lib.vmapstep_abi_version() != ABI_VERSION:
         raise VmapStepError(f"ABI mismatch: library {lib.vmapstep_abi_version()} != binding {ABI_VERSION}")

@@ -261,10 +261,11 @@ __global__ __launch_bounds__(kWG, 1) void step_main_gen(const GenArgs ga) {
     const int ray = ray0 + lray;
     float t[3] = {0.0f, 0.0f, 0.0f};
     if (valid) {
-        const float* px = a.pcs + obj * a.pcs_so + ray * a.pcs_sr + smp * a.pcs_ss;
-        t[0] = px[0] / scale;
-        t[1] = px[a.pcs_sc] / scale;
-        t[2] = px[2 * a.pcs_sc] / scale;
+        float x0, x1, x2;
+        load_point(a, obj, ray, smp, x0, x1, x2);
+        t[0] = x0 / scale;
+        t[1] = x1 / scale;
+        t[2] = x2 / scale;
     }
     float xv[16], yv[16];
     f32x16 acc;

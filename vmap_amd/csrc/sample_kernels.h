@@ -60,6 +60,10 @@ struct SampleArgs {
     unsigned seed_lo, seed_hi, frame_counter;
     SampleRandoms rnd;
     float* pcs; float* z; float* gt_depth; float* gt_rgb; unsigned char* sem; unsigned char* depth_mask;   // [n][F*P]...
+    // ABI v7 (vmapstep_sample_frame_rays): the hand-off as rays - world-frame origin and direction per ray and the objects' centres; the
+    // step kernels rebuild the points from them (load_point, step_kernels.h).  pcs may then be null (not written).
+    float* ray_o; float* ray_d;       // [n][F*P][3] or null
+    float* center_out;                // [n][3] or null
     // Split form (a workspace was given): nsplit workgroups per object, each on a contiguous slice of the object's rays.  The one
     // quantity that couples an object's rays - its maximum sampled depth (phase B) - comes from a first launch (frame_depth_max:
     // per-slice maxima joined by an order-independent integer atomic max into obj_max[k]).  nsplit = 0 / obj_max = null: one
@@ -281,15 +285,26 @@ __global__ __launch_bounds__(kWG) void frame_sample(const SampleArgs a) {
         const float ox = T[3], oy = T[7], oz = T[11];
         const long long row = (long long)k * FP + ray;
         float* pz = a.z + row * S;
-        float* pp = a.pcs + row * S * 3;
 #pragma unroll
-        for (int j = 0; j < kMaxS; ++j) {
-            if (j < S) {
-                pz[j] = zs[j];
-                pp[3 * j + 0] = (ox + wx * zs[j]) - ob.center[0];
-                pp[3 * j + 1] = (oy + wy * zs[j]) - ob.center[1];
-                pp[3 * j + 2] = (oz + wz * zs[j]) - ob.center[2];
+        for (int j = 0; j < kMaxS; ++j)
+            if (j < S) pz[j] = zs[j];
+        if (a.pcs) {
+            float* pp = a.pcs + row * S * 3;
+#pragma unroll
+            for (int j = 0; j < kMaxS; ++j) {
+                if (j < S) {
+                    pp[3 * j + 0] = (ox + wx * zs[j]) - ob.center[0];
+                    pp[3 * j + 1] = (oy + wy * zs[j]) - ob.center[1];
+                    pp[3 * j + 2] = (oz + wz * zs[j]) - ob.center[2];
+                }
             }
+        }
+        if (a.ray_o) {                                                                // the same three operations happen in the step kernel
+            float* po = a.ray_o + row * 3;
+            float* pd = a.ray_d + row * 3;
+            po[0] = ox; po[1] = oy; po[2] = oz;
+            pd[0] = wx; pd[1] = wy; pd[2] = wz;
+            if (a.center_out && ray == 0) { a.center_out[3 * k] = ob.center[0]; a.center_out[3 * k + 1] = ob.center[1]; a.center_out[3 * k + 2] = ob.center[2]; }
         }
         a.gt_depth[row] = d;
         a.gt_rgb[row * 3 + 0] = (float)(rgba & 0xFF) / 255.0f;                         // train.py:257 gt_rgb / 255.

@@ -756,10 +756,7 @@ __device__ __forceinline__ void step_main_s32_body(const StepArgs& a) {
     const int smp = valid ? pt - lray * a.S : 0;
     const int ray = ray0 + lray;
     float px3[3] = {0.0f, 0.0f, 0.0f};
-    if (valid) {
-        const float* px = a.pcs + obj * a.pcs_so + ray * a.pcs_sr + smp * a.pcs_ss;
-        px3[0] = px[0]; px3[1] = px[a.pcs_sc]; px3[2] = px[2 * a.pcs_sc];
-    }
+    if (valid) load_point(a, obj, ray, smp, px3[0], px3[1], px3[2]);
     // ---- asynchronous copy of the parameter image into LDS (issued behind the loads of the sample point, whose latency its 20 instructions cover; lands during the encoding) ----
     if (grp == wgo) {
         const char* src = gimg + wave * 1024 + lane * 16;

@@ -81,7 +81,50 @@ struct StepArgs {
     int tiles;                         // step_main_ws: 32-point tiles per round, 2 (default, also when 0) or 1 (single-tile rounds: launch plan)
     int* adam_counter;                 // device-resident optimiser step count (vmapstep_adamw::step_counter) or null: the first prep
                                        // block of a training call advances it by the previous call's steps (see prep_stats)
+    // ABI v7, pcs == nullptr: the sampler's hand-off as rays - point = (ray_o + ray_d * z) - center (vmap.py:452-454), see load_point
+    const float* ray_o; long long ro_so, ro_sr, ro_sc;
+    const float* ray_d; long long rd_so, rd_sr, rd_sc;
+    const float* center; long long ce_so;          // [n][3] or null (= zeros)
+    float* pts_buf;                                // workspace [n][R][S][3]: where step_main_wp's launcher expands a ray batch (other kernels: null)
 };
+
+// Sample point `smp` of ray `ray` of object `obj` in the object frame: read from the points tensor (train.py:272 batch_input_pcs),
+// or - pcs == nullptr, ABI v7 - rebuilt from the ray the sampler handed over, (o + d * z) - c with every operation rounded on its
+// own: the arithmetic of vmap.py:452-454 and of frame_sample (sample_kernels.h), i.e. the bits the points tensor would hold.
+__device__ __forceinline__ void load_point(const StepArgs& a, int obj, int ray, int smp, float& x0, float& x1, float& x2) {
+    if (a.pcs) {
+        const float* px = a.pcs + obj * a.pcs_so + ray * a.pcs_sr + smp * a.pcs_ss;
+        x0 = px[0]; x1 = px[a.pcs_sc]; x2 = px[2 * a.pcs_sc];
+        return;
+    }
+    {
+#pragma clang fp contract(off)
+        const float zz = a.z[obj * a.z_so + ray * a.z_sr + smp * a.z_ss];
+        const float* o = a.ray_o + obj * a.ro_so + ray * a.ro_sr;
+        const float* d = a.ray_d + obj * a.rd_so + ray * a.rd_sr;
+        float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
+        if (a.center) { const float* c = a.center + obj * a.ce_so; c0 = c[0]; c1 = c[1]; c2 = c[2]; }
+        x0 = (o[0] + d[0] * zz) - c0;
+        x1 = (o[a.ro_sc] + d[a.rd_sc] * zz) - c1;
+        x2 = (o[2 * a.ro_sc] + d[2 * a.rd_sc] * zz) - c2;
+    }
+}
+
+// rays -> points for the one kernel family that does not rebuild them in its own prologue (step_main_wp, hidden 64: two workgroups per
+// CU on 256 registers and ~230 spilled scalar registers - its prologue has nothing to spare, see HISTORY.md round 5): one thread per
+// sample point of THIS step's batch, the same load_point arithmetic, into a dense [n][R][S][3] tensor of the workspace.
+template <int = 0>
+__global__ __launch_bounds__(256) void step_rays_to_points(const StepArgs a, float* pts) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long per_obj = (long long)a.R * a.S;
+    if (i >= a.n_obj * per_obj) return;
+    const int obj = (int)(i / per_obj);
+    const int rs = (int)(i - obj * per_obj), ray = rs / a.S, smp = rs - ray * a.S;
+    float x0, x1, x2;
+    load_point(a, obj, ray, smp, x0, x1, x2);
+    float* q = pts + 3 * i;
+    q[0] = x0; q[1] = x1; q[2] = x2;
+}
 
 __device__ __forceinline__ constexpr int phi(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
@@ -1173,10 +1216,11 @@ __device__ __forceinline__ void step_main_body(const StepArgs& a) {
     const int ray = ray0 + lray;
     float t[3] = {0.0f, 0.0f, 0.0f};
     if (valid) {
-        const float* px = a.pcs + obj * a.pcs_so + ray * a.pcs_sr + smp * a.pcs_ss;
-        t[0] = px[0] / scale;              // embedding.py:83  x / self.scale
-        t[1] = px[a.pcs_sc] / scale;
-        t[2] = px[2 * a.pcs_sc] / scale;
+        float x0, x1, x2;
+        load_point(a, obj, ray, smp, x0, x1, x2);
+        t[0] = x0 / scale;                 // embedding.py:83  x / self.scale
+        t[1] = x1 / scale;
+        t[2] = x2 / scale;
     }
     float proj[kDirs];
 #pragma unroll

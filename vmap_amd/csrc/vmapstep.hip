@@ -87,7 +87,7 @@ void make_layout(int H, Layout& L) {
 struct Plan {
     int G, NG, NW;
     int tiles;         // step_main_ws: 32-point tiles per round (2; 1 = single-tile rounds when every tile gets a compute unit of its own; 3: see make_plan)
-    size_t off_stats, off_flags, off_ploss, off_imgtab, off_pgrad, off_wimg, off_scratch, total;
+    size_t off_stats, off_flags, off_ploss, off_imgtab, off_pgrad, off_wimg, off_scratch, off_pts, total;
     bool generic;      // hidden != 32: step_main_gen (global-memory activations) instead of step_main_h32
     bool split;        // hidden 32 on the bf16 matrix pipe with split operands (step_main_s32; the default at hidden 32)
     int wide;          // 0 = step_main_gen, 1 = step_main_wide<4> (hidden 128 / 256: one tile per workgroup, four waves per
@@ -225,6 +225,9 @@ int make_plan(const vmapstep_shape* sh, int max_steps, Plan& pl, const Layout& L
                                                                                  : (size_t)vk::kWsScratchMax));
     else if (pl.generic)   // register-image scratch: per wave (step_main_gen) or per workgroup (step_main_wide)
         o += align_up((size_t)sh->n_obj * nw_cap * (pl.wide == 1 ? 1 : vk::kWaves) * vk::gen_wave_blocks(GL.NB) * vk::kBlk * sizeof(float));
+    // step_main_wp takes a ray batch (ABI v7) through a points buffer its launcher fills per step: one step's [n][R][S][3] floats
+    pl.off_pts = o;
+    if (pl.wide == 4) o += align_up((size_t)sh->n_obj * sh->rays * sh->samples * 3 * sizeof(float));
     pl.off_flags = o; o += align_up((size_t)kMaxFrameSteps * 4 * sizeof(int));
     pl.off_stats = o; o += align_up((size_t)max_steps * sh->n_obj * 4 * sizeof(float));
     pl.total = o;
@@ -241,8 +244,11 @@ int check_params(const vmapstep_params* p, const char* what, bool allow_null_ent
 
 int check_batch(const vmapstep_batch* b) {
     if (!b) return fail(VMAPSTEP_ERR_ARGUMENT, "batch is null");
-    if (!b->pcs || !b->z || !b->gt_depth || !b->gt_rgb || !b->sem || !b->depth_mask)
+    if (!b->z || !b->gt_depth || !b->gt_rgb || !b->sem || !b->depth_mask)
         return fail(VMAPSTEP_ERR_ARGUMENT, "batch has a null tensor");
+    // the sample points: either the points tensor, or (ABI v7) the rays they are rebuilt from
+    if (!b->pcs && (!b->ray_o || !b->ray_d))
+        return fail(VMAPSTEP_ERR_ARGUMENT, "batch has neither pcs nor (ray_o, ray_d)");
     return VMAPSTEP_OK;
 }
 
@@ -257,8 +263,16 @@ void fill_step_args(vk::StepArgs& a, const vmapstep_shape* sh, const Plan& pl, c
     for (int t = 0; t < VMAPSTEP_NUM_FC; ++t) a.fc[t] = {params->fc[t].ptr, params->fc[t].obj_stride};
     a.pe_B = {params->pe_B.ptr, params->pe_B.obj_stride};
     a.pe_scale = {pe_scale->ptr, pe_scale->obj_stride};
-    a.pcs = b->pcs + ray0 * b->pcs_stride[1];
-    a.pcs_so = b->pcs_stride[0]; a.pcs_sr = b->pcs_stride[1]; a.pcs_ss = b->pcs_stride[2]; a.pcs_sc = b->pcs_stride[3];
+    if (b->pcs) {
+        a.pcs = b->pcs + ray0 * b->pcs_stride[1];
+        a.pcs_so = b->pcs_stride[0]; a.pcs_sr = b->pcs_stride[1]; a.pcs_ss = b->pcs_stride[2]; a.pcs_sc = b->pcs_stride[3];
+    } else {                                  // ABI v7: the rays the points are rebuilt from (load_point, step_kernels.h)
+        a.ray_o = b->ray_o + ray0 * b->ray_o_stride[1];
+        a.ro_so = b->ray_o_stride[0]; a.ro_sr = b->ray_o_stride[1]; a.ro_sc = b->ray_o_stride[2];
+        a.ray_d = b->ray_d + ray0 * b->ray_d_stride[1];
+        a.rd_so = b->ray_d_stride[0]; a.rd_sr = b->ray_d_stride[1]; a.rd_sc = b->ray_d_stride[2];
+        a.center = b->center; a.ce_so = b->center_stride;
+    }
     a.z = b->z + ray0 * b->z_stride[1];
     a.z_so = b->z_stride[0]; a.z_sr = b->z_stride[1]; a.z_ss = b->z_stride[2];
     a.gt_depth = b->gt_depth + ray0 * b->gt_depth_stride[1];
@@ -282,6 +296,7 @@ void fill_step_args(vk::StepArgs& a, const vmapstep_shape* sh, const Plan& pl, c
     a.part_grad = reinterpret_cast<float*>(ws + pl.off_pgrad);
     a.wimg = reinterpret_cast<float*>(ws + pl.off_wimg);
     a.gen_scratch = reinterpret_cast<float*>(ws + pl.off_scratch);
+    a.pts_buf = pl.wide == 4 ? reinterpret_cast<float*>(ws + pl.off_pts) : nullptr;
 }
 
 // the dominant kernel of the plan (bwd = false: the forward-only instantiation of vmapstep_render; stamps: vmapstep_profile_phases)
@@ -796,12 +811,15 @@ int vmapstep_sample_workspace_bytes(int32_t n_obj, size_t* bytes) {
     return VMAPSTEP_OK;
 }
 
-int vmapstep_sample_frame(const vmapstep_sample_cfg* cfg, const vmapstep_sample_object* objects_device, int32_t n_obj,
-                          float* pcs, float* z, float* gt_depth, float* gt_rgb, uint8_t* sem, uint8_t* depth_mask,
-                          uint64_t seed, uint32_t frame_counter, const vmapstep_sample_randoms* test_randoms,
-                          void* workspace, size_t workspace_bytes, void* stream) {
-    if (!cfg || !objects_device || !pcs || !z || !gt_depth || !gt_rgb || !sem || !depth_mask)
+static int sample_frame_impl(const vmapstep_sample_cfg* cfg, const vmapstep_sample_object* objects_device, int32_t n_obj,
+                             float* pcs, float* ray_o, float* ray_d, float* center_out,
+                             float* z, float* gt_depth, float* gt_rgb, uint8_t* sem, uint8_t* depth_mask,
+                             uint64_t seed, uint32_t frame_counter, const vmapstep_sample_randoms* test_randoms,
+                             void* workspace, size_t workspace_bytes, void* stream) {
+    if (!cfg || !objects_device || !z || !gt_depth || !gt_rgb || !sem || !depth_mask)
         return fail(VMAPSTEP_ERR_ARGUMENT, "null argument");
+    if (!pcs && !(ray_o && ray_d)) return fail(VMAPSTEP_ERR_ARGUMENT, "neither pcs nor (ray_o, ray_d) given");
+    if ((ray_o == nullptr) != (ray_d == nullptr)) return fail(VMAPSTEP_ERR_ARGUMENT, "ray_o and ray_d go together");
     const int S = cfg->n_bins_cam2surface + cfg->n_bins;
     const long long FP = (long long)cfg->frames * cfg->samples_per_frame;
     if (n_obj < 1 || cfg->frames < 1 || cfg->samples_per_frame < 1 || cfg->n_bins_cam2surface < 1 || cfg->n_bins < 1)
@@ -821,6 +839,7 @@ int vmapstep_sample_frame(const vmapstep_sample_cfg* cfg, const vmapstep_sample_
         a.rnd.u_z = test_randoms->u_z; a.rnd.g_z = test_randoms->g_z;
     }
     a.pcs = pcs; a.z = z; a.gt_depth = gt_depth; a.gt_rgb = gt_rgb; a.sem = sem; a.depth_mask = depth_mask;
+    a.ray_o = ray_o; a.ray_d = ray_d; a.center_out = center_out;
     if (workspace) {
         // split form: as many workgroups per object as fill the chip, at most one ray per thread
         if (reinterpret_cast<uintptr_t>(workspace) % sizeof(int) || workspace_bytes < (size_t)n_obj * sizeof(int))
@@ -832,6 +851,25 @@ int vmapstep_sample_frame(const vmapstep_sample_cfg* cfg, const vmapstep_sample_
     }
     VMAPSTEP_ON_STREAM_DEVICE(stream);
     return vl::sample_frame(a, n_obj, FP, static_cast<hipStream_t>(stream));
+}
+
+int vmapstep_sample_frame(const vmapstep_sample_cfg* cfg, const vmapstep_sample_object* objects_device, int32_t n_obj,
+                          float* pcs, float* z, float* gt_depth, float* gt_rgb, uint8_t* sem, uint8_t* depth_mask,
+                          uint64_t seed, uint32_t frame_counter, const vmapstep_sample_randoms* test_randoms,
+                          void* workspace, size_t workspace_bytes, void* stream) {
+    if (!pcs) return fail(VMAPSTEP_ERR_ARGUMENT, "null argument");
+    return sample_frame_impl(cfg, objects_device, n_obj, pcs, nullptr, nullptr, nullptr, z, gt_depth, gt_rgb, sem, depth_mask, seed,
+                             frame_counter, test_randoms, workspace, workspace_bytes, stream);
+}
+
+int vmapstep_sample_frame_rays(const vmapstep_sample_cfg* cfg, const vmapstep_sample_object* objects_device, int32_t n_obj,
+                               float* ray_o, float* ray_d, float* center, float* pcs,
+                               float* z, float* gt_depth, float* gt_rgb, uint8_t* sem, uint8_t* depth_mask,
+                               uint64_t seed, uint32_t frame_counter, const vmapstep_sample_randoms* test_randoms,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+    if (!ray_o || !ray_d) return fail(VMAPSTEP_ERR_ARGUMENT, "ray_o / ray_d are required");
+    return sample_frame_impl(cfg, objects_device, n_obj, pcs, ray_o, ray_d, center, z, gt_depth, gt_rgb, sem, depth_mask, seed,
+                             frame_counter, test_randoms, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

@@ -795,10 +795,7 @@ __global__ __launch_bounds__(64 * ws_waves<NB>(), 1) void step_main_ws(const WsA
         const bool valid = pt < npts;
         const int lray = valid ? pt / a.S : 0, smp = valid ? pt - lray * a.S : 0, ray = ray0 + lray;
         Pt3 q = {{0.0f, 0.0f, 0.0f}};
-        if (valid) {
-            const float* px = a.pcs + obj * a.pcs_so + ray * a.pcs_sr + smp * a.pcs_ss;
-            q.x[0] = px[0]; q.x[1] = px[a.pcs_sc]; q.x[2] = px[2 * a.pcs_sc];
-        }
+        if (valid) vk::load_point(a, obj, ray, smp, q.x[0], q.x[1], q.x[2]);
         return q;
     };
     auto encode = [&](int est, int dhalf, const Pt3& q) __attribute__((always_inline)) {

@@ -78,10 +78,11 @@ class HipMapper:
     # ---- one frame -----------------------------------------------------------------------------------------
     def train_frame(self, pcs, z, gt_depth, gt_rgb, sem, depth_mask, render: bool = False) -> step.StepResult:
         """The step loop of one frame: inputs are the stacked per-frame tensors of train.py:255-260
-        ([n, iters*R, S, 3], [n, iters*R, S], [n, iters*R], [n, iters*R, 3], u8 [n, iters*R], bool/u8 [n, iters*R])."""
+        ([n, iters*R, S, 3], [n, iters*R, S], [n, iters*R], [n, iters*R, 3], u8 [n, iters*R], bool/u8 [n, iters*R]); ``pcs`` may be a
+        ``step.RayPoints`` (the sampler's hand-off as rays, ``FrameSampler(rays=True)``)."""
         iters = self.cfg.n_iter_per_frame
         rays = pcs.shape[1] // iters
-        samples = pcs.shape[2]
+        samples = z.shape[2]                             # (pcs may be a step.RayPoints: the frame handed over as rays)
         if self._dirty or self.op is None:
             self.restack(rays, samples)                  # the object list changed: new stack, Adam restart (utils.py:33)
         elif (self.op.rays, self.op.samples) != (rays, samples):
@@ -104,7 +105,11 @@ class HipMapper:
         if render:                                   # rendered outputs are per-call tensors: the plain path
             return op.train_steps(views[:14], views[14], scale, *batch, opt=opt, n_steps=iters, ray_step=ray_step, render=True,
                                   flag_reduce=flag_reduce)
-        sig = (id(op), id(opt), ray_step) + tuple((t.data_ptr(), tuple(t.shape), tuple(t.stride()), t.dtype) for t in batch)
+        def tsig(t):
+            if isinstance(t, step.RayPoints):
+                return tuple(tsig(x) for x in (t.origins, t.dirs, t.centers) if x is not None)
+            return (t.data_ptr(), tuple(t.shape), tuple(t.stride()), t.dtype)
+        sig = (id(op), id(opt), ray_step) + tuple(tsig(t) for t in batch)
         cached = self._bound.get(key)
         if cached is None or cached[0] != sig:
             # the first frame on new buffers runs the plain path (the caller may never come back with them); the second binds
@@ -162,7 +167,9 @@ class HipMapper:
         with torch.cuda.stream(self._bg_stream):
             b = self.bg
             for t in bg_batch:
-                t.record_stream(self._bg_stream)
+                for x in ((t.origins, t.dirs, t.centers) if isinstance(t, step.RayPoints) else (t,)):
+                    if x is not None:
+                        x.record_stream(self._bg_stream)
             res_bg = self._frame_call("bg", b["op"], b["views"], b["scale"], tuple(bg_batch), b["opt"], iters, bg_batch[0].shape[1] // iters)
             join = torch.cuda.Event()
             join.record(self._bg_stream)

@@ -20,8 +20,11 @@ from . import _lib
 
 class FrameSampler:
     def __init__(self, width, height, frames, samples_per_frame, n_bins_cam2surface, n_bins, fx, fy, cx, cy,
-                 min_depth=0.0, surface_eps=0.1, stop_eps=0.05, device="cuda:0", seed=0, reuse_outputs=False, split=True):
-        """``reuse_outputs``: ``sample()`` writes into the SAME six tensors every frame (a consumer that binds its frame buffers -
+                 min_depth=0.0, surface_eps=0.1, stop_eps=0.05, device="cuda:0", seed=0, reuse_outputs=False, split=True, rays=False):
+        """``rays``: hand the frame over as RAYS (``vmapstep_sample_frame_rays``): ``sample()["pcs"]`` is then a ``step.RayPoints``
+        (origins / dirs [n, F*P, 3] + the objects' centres) instead of the [n, F*P, S, 3] points tensor - 64 instead of 160 bytes per
+        ray at S = 10; the step kernels rebuild the points bit-identically (second half; vmap.py:452-457).
+        ``reuse_outputs``: ``sample()`` writes into the SAME six tensors every frame (a consumer that binds its frame buffers -
         ``step.BoundFrame``, ``driver.HipMapper`` - then marshals them once); ``split``: many workgroups per object (a small
         workspace holds the objects' maximum depths between the two launches) instead of one."""
         self.lib = _lib.load()
@@ -34,7 +37,7 @@ class FrameSampler:
         self._table = None
         self._keep = None
         self.n_obj = 0
-        self.reuse_outputs, self.split = bool(reuse_outputs), bool(split)
+        self.reuse_outputs, self.split, self.rays = bool(reuse_outputs), bool(split), bool(rays)
         self._out, self._ws = None, None
 
     def set_objects(self, objects: Sequence[dict]):
@@ -93,7 +96,10 @@ class FrameSampler:
         n, FP, S, dev = self.n_obj, self.F * self.P, self.S, self.device
         out = self._out
         if out is None:
-            out = dict(pcs=torch.empty(n, FP, S, 3, device=dev), z=torch.empty(n, FP, S, device=dev),
+            from .step import RayPoints
+            pts = RayPoints(torch.empty(n, FP, 3, device=dev), torch.empty(n, FP, 3, device=dev), torch.empty(n, 3, device=dev)) if self.rays \
+                else torch.empty(n, FP, S, 3, device=dev)
+            out = dict(pcs=pts, z=torch.empty(n, FP, S, device=dev),
                        gt_depth=torch.empty(n, FP, device=dev), gt_rgb=torch.empty(n, FP, 3, device=dev),
                        sem=torch.empty(n, FP, dtype=torch.uint8, device=dev), depth_mask=torch.empty(n, FP, dtype=torch.uint8, device=dev))
             if self.reuse_outputs:
@@ -102,12 +108,15 @@ class FrameSampler:
         if test_randoms is not None:
             rnd = _lib.SampleRandoms(*[test_randoms[k].data_ptr() if test_randoms.get(k) is not None else None
                                        for k in ("kf_ids", "u_w", "u_h", "u_z", "g_z")])
-        _lib.check(self.lib.vmapstep_sample_frame(ctypes.byref(self.cfg), self._table.data_ptr(), n,
-                                                  out["pcs"].data_ptr(), out["z"].data_ptr(), out["gt_depth"].data_ptr(),
-                                                  out["gt_rgb"].data_ptr(), out["sem"].data_ptr(), out["depth_mask"].data_ptr(),
-                                                  self.seed, self.frame_counter, ctypes.byref(rnd) if rnd is not None else None,
-                                                  self._ws.data_ptr() if self._ws is not None else None,
-                                                  self._ws.numel() if self._ws is not None else 0,
-                                                  torch.cuda.current_stream(self.device).cuda_stream), self.lib)
+        tail = (out["z"].data_ptr(), out["gt_depth"].data_ptr(), out["gt_rgb"].data_ptr(), out["sem"].data_ptr(), out["depth_mask"].data_ptr(),
+                self.seed, self.frame_counter, ctypes.byref(rnd) if rnd is not None else None,
+                self._ws.data_ptr() if self._ws is not None else None, self._ws.numel() if self._ws is not None else 0,
+                torch.cuda.current_stream(self.device).cuda_stream)
+        if self.rays:
+            r = out["pcs"]
+            _lib.check(self.lib.vmapstep_sample_frame_rays(ctypes.byref(self.cfg), self._table.data_ptr(), n, r.origins.data_ptr(),
+                                                           r.dirs.data_ptr(), r.centers.data_ptr(), None, *tail), self.lib)
+        else:
+            _lib.check(self.lib.vmapstep_sample_frame(ctypes.byref(self.cfg), self._table.data_ptr(), n, out["pcs"].data_ptr(), *tail), self.lib)
         self.frame_counter += 1
         return out

@@ -19,6 +19,39 @@ def _obj_dense(t: torch.Tensor) -> bool:
     return t.dim() == 1 or t[0].is_contiguous()
 
 
+class RayPoints:
+    """The sample points of a batch / frame given as RAYS instead of the points tensor (ABI v7; SURVEY.md 8(f) row 1, second half):
+    ``origins`` / ``dirs`` float32 [n, R, 3] (world frame), ``centers`` float32 [n, 3] or None (= zeros).  Pass an instance wherever
+    an operator takes ``pcs``: the kernels rebuild point s of ray r as (origins + dirs * z[..., s]) - centers, every operation rounded
+    on its own (vmap.py:452-454) - bit-identical to the [n, R, S, 3] tensor it replaces, at 24 + 4 S instead of 16 S bytes per ray.
+    ``sampler.FrameSampler(..., rays=True)`` produces one per frame."""
+
+    def __init__(self, origins: torch.Tensor, dirs: torch.Tensor, centers: Optional[torch.Tensor] = None):
+        if origins.shape != dirs.shape or origins.dim() != 3 or origins.shape[-1] != 3:
+            raise ValueError(f"origins / dirs: need two [n, R, 3] tensors, got {tuple(origins.shape)} / {tuple(dirs.shape)}")
+        if centers is not None and (tuple(centers.shape) != (origins.shape[0], 3) or centers.stride(1) != 1):
+            raise ValueError(f"centers: need [n, 3] with unit inner stride, got {tuple(centers.shape)}")
+        self.origins, self.dirs, self.centers = origins, dirs, centers
+
+    @property
+    def shape(self):                   # (n, rays, ...) like the points tensor, for the callers that read pcs.shape[1]
+        return tuple(self.origins.shape[:2]) + (None, 3)
+
+    def __getitem__(self, idx):
+        """Slices along (object, ray) like ``pcs[:, i*R:(i+1)*R]`` (train.py:271-272); an object slice applies to the centres too."""
+        idx = idx if isinstance(idx, tuple) else (idx,)
+        if len(idx) > 2 or not all(isinstance(i, slice) for i in idx):
+            raise IndexError("RayPoints supports [object_slice, ray_slice]")
+        c = self.centers[idx[0]] if self.centers is not None else None
+        return RayPoints(self.origins[idx], self.dirs[idx], c)
+
+    def points(self, z: torch.Tensor) -> torch.Tensor:
+        """The [n, R, S, 3] tensor these rays stand for (host-side helper for tests / tools; eager torch ops round each operation on
+        its own like the kernels do)."""
+        p = self.origins.unsqueeze(2) + self.dirs.unsqueeze(2) * z.unsqueeze(-1)
+        return p - self.centers[:, None, None, :] if self.centers is not None else p
+
+
 class StepResult:
     """What one fused step produced (device tensors; nothing is synchronised)."""
 
@@ -149,8 +182,13 @@ class VmapStep:
 
     def _batch(self, pcs, z, gt_depth, gt_rgb, sem, depth_mask, rays_total: Optional[int] = None) -> _lib.Batch:
         n, R, S = self.n_obj, (rays_total or self.rays), self.samples
-        for name, x, shp, dt in (("pcs", pcs, (n, R, S, 3), torch.float32), ("z", z, (n, R, S), torch.float32),
-                                 ("gt_depth", gt_depth, (n, R), torch.float32), ("gt_rgb", gt_rgb, (n, R, 3), torch.float32)):
+        rays = pcs if isinstance(pcs, RayPoints) else None
+        named = [("z", z, (n, R, S), torch.float32), ("gt_depth", gt_depth, (n, R), torch.float32), ("gt_rgb", gt_rgb, (n, R, 3), torch.float32)]
+        named += [("pcs", pcs, (n, R, S, 3), torch.float32)] if rays is None else \
+                 [("origins", rays.origins, (n, R, 3), torch.float32), ("dirs", rays.dirs, (n, R, 3), torch.float32)]
+        if rays is not None and rays.centers is not None:
+            named.append(("centers", rays.centers, (n, 3), torch.float32))
+        for name, x, shp, dt in named:
             if tuple(x.shape) != shp or x.dtype != dt or x.device != self.device:
                 raise ValueError(f"{name}: need {dt} {shp} on {self.device}, got {x.dtype} {tuple(x.shape)} on {x.device}")
         if sem.dtype != torch.uint8 or tuple(sem.shape) != (n, R):
@@ -160,9 +198,18 @@ class VmapStep:
         if depth_mask.dtype != torch.uint8 or tuple(depth_mask.shape) != (n, R):
             raise ValueError(f"depth_mask: need bool/uint8 {(n, R)}")
         b = _lib.Batch()
-        b.pcs, b.z, b.gt_depth, b.gt_rgb = pcs.data_ptr(), z.data_ptr(), gt_depth.data_ptr(), gt_rgb.data_ptr()
+        b.z, b.gt_depth, b.gt_rgb = z.data_ptr(), gt_depth.data_ptr(), gt_rgb.data_ptr()
         b.sem, b.depth_mask = sem.data_ptr(), depth_mask.data_ptr()
-        b.pcs_stride[:] = pcs.stride()
+        if rays is None:
+            b.pcs = pcs.data_ptr()
+            b.pcs_stride[:] = pcs.stride()
+        else:
+            b.pcs = None
+            b.ray_o, b.ray_d = rays.origins.data_ptr(), rays.dirs.data_ptr()
+            b.ray_o_stride[:] = rays.origins.stride()
+            b.ray_d_stride[:] = rays.dirs.stride()
+            if rays.centers is not None:
+                b.center, b.center_stride = rays.centers.data_ptr(), rays.centers.stride(0)
         b.z_stride[:] = z.stride()
         b.gt_depth_stride[:] = gt_depth.stride()
         b.gt_rgb_stride[:] = gt_rgb.stride()
