@@ -217,7 +217,7 @@ def _median(xs):
     return xs[m] if len(xs) % 2 else 0.5 * (xs[m - 1] + xs[m])
 
 
-def other_config_leg(name, weights, dev, ipf, steps=40, repeats=3, warmup=20):
+def other_config_leg(name, weights, dev, ipf, steps=40, repeats=3, warmup=20, rays=False):
     """One of the OTHER BASELINE configurations (or the background step) measured like `value`: synthetic frame resident in HBM, bound
     frame calls, `steps` steps between synchronisations, median of `repeats`; the dominant kernel's own dispatch time from
     vmapstep_profile_train_steps.  Reported under `other_configs`; never part of `value`."""
@@ -228,6 +228,14 @@ def other_config_leg(name, weights, dev, ipf, steps=40, repeats=3, warmup=20):
     tfc = [torch.from_numpy(a).to(dev) for a in fc]
     tB, tsc = torch.from_numpy(B).to(dev), torch.from_numpy(sc).to(dev)
     fr = tuple(torch.from_numpy(frame[k]).to(dev) for k in ("pcs", "z", "gt_depth", "gt_rgb", "sem", "depth_mask"))
+    if rays:
+        # the frame handed over as rays (ABI v7, what sampler.FrameSampler(rays=True) emits): origin / direction per ray + object centres
+        # instead of the points tensor - 24 + 4 S instead of 16 S bytes per ray; the kernels rebuild the points bit-identically
+        rng = np.random.default_rng(7)
+        o = torch.from_numpy(rng.uniform(-1.0, 1.0, (n, R * ipf, 3)).astype(np.float32)).to(dev)
+        d = torch.from_numpy(rng.uniform(-1.0, 1.0, (n, R * ipf, 3)).astype(np.float32)).to(dev)
+        c = torch.from_numpy(rng.uniform(-0.5, 0.5, (n, 3)).astype(np.float32)).to(dev)
+        fr = (step.RayPoints(o, d, c),) + fr[1:]
     op = step.VmapStep(n, R, S, H, device=dev, max_steps=ipf, weights=weights)
     opt = step.FusedAdamWState(n, H, dev, lr=1e-3, weight_decay=0.013)
     bound = op.bind(tfc, tB, tsc, *fr, opt=opt)
@@ -249,7 +257,9 @@ def other_config_leg(name, weights, dev, ipf, steps=40, repeats=3, warmup=20):
     k_ms, _ = op.profile_train_steps(tfc, tB, tsc, *fr, opt=opt, n_steps=ipf)
     plan = op.plan()
     flops = layout.step_flops(n, R, S, H)
-    out = {"workload": f"{name}: {n} objects x 4-layer/{H}-hidden MLP, {R} rays/object, {S} samples/ray, {weights} weights, fwd+loss+bwd+fused AdamW",
+    out = {"workload": f"{name}: {n} objects x 4-layer/{H}-hidden MLP, {R} rays/object, {S} samples/ray, {weights} weights, fwd+loss+bwd+fused AdamW"
+                       + (", sample points handed over as rays (origin, direction, z: ABI v7)" if rays else ""),
+           "sample_bytes_per_ray": (24 + 4 * S + 18) if rays else (16 * S + 18),
            "ms_per_step": ms, "ms_per_step_repeats": ts, "rays_per_s": n * R / (ms * 1e-3), "kernel": plan["kernel"], "kernel_ms": k_ms,
            "frac": flops / (k_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, "frac_is": "fp32-equivalent (algorithmic FLOPs / kernel time / 157.3 TFLOP/s)",
            "plan": plan}
@@ -907,13 +917,15 @@ def main():
                 out["frame"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and args.config == "replica_room0_vmap" and args.kernel == "auto" and not args.no_other_configs:
             # the other BASELINE configurations and the background step, measured like `value` (driver-visible; never part of it)
-            legs = (("configs[0]", "imap_plumbing", "f32"), ("configs[3]", "scannet0024_vmap", "bf16"), ("configs[3]_f32_weights", "scannet0024_vmap", "f32"),
-                    ("configs[4]_per_gpu_share", "stress_rank8", "bf16"), ("configs[4]_on_one_gpu", "stress_256x64", "bf16"),
-                    ("background_step", "background", "f32"))
+            legs = (("configs[0]", "imap_plumbing", "f32", False), ("configs[3]", "scannet0024_vmap", "bf16", False),
+                    ("configs[3]_f32_weights", "scannet0024_vmap", "f32", False),
+                    ("configs[4]_per_gpu_share", "stress_rank8", "bf16", False), ("configs[4]_on_one_gpu", "stress_256x64", "bf16", False),
+                    ("background_step", "background", "f32", False),
+                    ("configs[1]_ray_handoff", "replica_room0_vmap", "f32", True), ("background_step_ray_handoff", "background", "f32", True))
             oc = {}
-            for label, cname, wts in legs:
+            for label, cname, wts, as_rays in legs:
                 try:
-                    oc[label] = other_config_leg(cname, wts, dev, ipf)
+                    oc[label] = other_config_leg(cname, wts, dev, ipf, rays=as_rays)
                 except Exception as e:
                     oc[label] = {"error": f"{type(e).__name__}: {e}"}
             out["other_configs"] = oc
