@@ -85,9 +85,16 @@ int prep_ws(const vk::StepArgs& a, int n_steps, hipStream_t st) {
 int finalize_ws(const vk::FinalizeArgs& f, const vk::FinalizeHot& h, const int* tab_wt, hipStream_t st) {
     const int grid = f.n_obj * vk::ws_finalize_blocks(f.PP) + 1;
     if (f.hidden == 256) return finalize_ws8(f, h, tab_wt, grid, st);
-    if (f.hidden == 128)
+    if (f.hidden == 128) {
+        // the narrow form where it fills the chip with one block per compute unit and the wide one does not (the background step)
+        const int narrow = f.n_obj * vk::ws_finalize_blocks(f.PP, vk::kFinQuadsNarrow);
+        if (narrow <= 256 && grid - 1 < narrow) {
+            constexpr int T = vk::kFinGroups * vk::kFinQuadsNarrow;
+            hipLaunchKernelGGL((vk::step_finalize_ws<4, vk::kFinQuadsNarrow>), dim3(narrow + 1), dim3(T), T * 4 * sizeof(float), st, f, h, tab_wt);
+            return launched("step_finalize_ws");
+        }
         hipLaunchKernelGGL(vk::step_finalize_ws<4>, dim3(grid), dim3(vk::kFinThreads), vk::kFinThreads * 4 * sizeof(float), st, f, h, tab_wt);
-    else
+    } else
         hipLaunchKernelGGL(vk::step_finalize_ws<2>, dim3(grid), dim3(vk::kFinThreads), vk::kFinThreads * 4 * sizeof(float), st, f, h, tab_wt);
     return launched("step_finalize_ws");
 }

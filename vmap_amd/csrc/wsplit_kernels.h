@@ -329,18 +329,23 @@ __device__ __forceinline__ void ws_image_store(char* img, int locw, int locwt, f
 #define VK_FIN_QUADS 128
 #endif
 constexpr int kFinGroups = VK_FIN_GROUPS, kFinQuads = VK_FIN_QUADS, kFinThreads = kFinGroups * kFinQuads;   // 8 row groups x 128 quads: 1024 threads
-__host__ __device__ inline int ws_finalize_blocks(int PP) { return (PP / 4 + kFinQuads - 1) / kFinQuads; }
+__host__ __device__ inline int ws_finalize_blocks(int PP, int fin_quads = kFinQuads) { return (PP / 4 + fin_quads - 1) / fin_quads; }
+// Narrow form: 96 quads per block (1.5 KiB per row).  Taken when it gives EVERY block a compute unit of its own where the 128-quad form does
+// not fill the chip (the one-object background step: 246 instead of 185 blocks): 0.1035 -> 0.1011 ms per step (round 5, tests/tools/finq_probe.py;
+// the kernel's time is the row reads - with the AdamW update and the image rewrite removed it does not change); otherwise slower (more
+// blocks than compute units: hidden 64 / 256 shapes +0.4 .. 0.8 %).
+constexpr int kFinQuadsNarrow = 96;
 
 // Gradients to the caller's tensors (if given), AdamW + image rewrite (if do_adam).
 // The partial gradients are NW rows of PP floats per object (one per workgroup of step_main_ws, up to 256): a block covers
 // kFinQuads consecutive quads of every row (2 KiB contiguous per row: measured 27.1 us at 64 quads, 21.0 at 128, 21.6 at 256
 // for 200 rows - the row reads want contiguity more than blocks, profiles/r03y_*), its kFinGroups row groups sum a share of the
 // rows each (loads eight deep), a fixed pairwise tree through LDS joins them - same order every run.
-template <int NB>
-__global__ __launch_bounds__(kFinThreads) void step_finalize_ws(const FinalizeArgs a, const FinalizeHot hh, const int* tab_wt) {
+template <int NB, int kFinQuads = vk::kFinQuads>
+__global__ __launch_bounds__(kFinGroups * kFinQuads) void step_finalize_ws(const FinalizeArgs a, const FinalizeHot hh, const int* tab_wt) {
     typedef int i32x4 __attribute__((ext_vector_type(4)));
     const int quads = a.PP / 4;
-    const int blocks_per_obj = ws_finalize_blocks(a.PP);
+    const int blocks_per_obj = ws_finalize_blocks(a.PP, kFinQuads);
     if (blockIdx.x == gridDim.x - 1) {
         finalize_loss(a);
         return;
