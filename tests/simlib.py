@@ -75,9 +75,11 @@ def _p(a, ty=ctypes.c_float):
 
 
 def sim_step(case_or_fc, B=None, scale=None, batch=None, G=None, bwd=True, adam=None, NW=0, xcd_affine=1, weights_bf16=0, wide=False,
-             split=False):
+             split=False, rays=None):
     """Run prep + main + finalize on the simulator. Returns dict like oracle.training_step.
-    split: hidden 32 on the split-bf16 kernels (step_prep_s32 / step_main_s32 / step_finalize_s32)."""
+    split: hidden 32 on the split-bf16 kernels (step_prep_s32 / step_main_s32 / step_finalize_s32).
+    rays: (origins [n,R,3], dirs [n,R,3], centres [n,3] or None) - the ABI v7 ray hand-off: the kernels get NO points tensor and rebuild
+    the sample points themselves (load_point, csrc/step_kernels.h)."""
     if isinstance(case_or_fc, dict):
         c = case_or_fc
         fc, B, scale, batch = c["fc"], c["B"], c["scale"], c["batch"]
@@ -113,11 +115,21 @@ def sim_step(case_or_fc, B=None, scale=None, batch=None, G=None, bwd=True, adam=
     if adam is not None:
         do_adam = 1
         p_out, m, v, step = adam["p"], adam["m"], adam["v"], adam["step"]
-    rc = lib().vmsim_step(
+    ray_keep = None
+    if rays is not None:
+        ray_keep = [np.ascontiguousarray(x, dtype=np.float32) if x is not None else None for x in rays]
+        lib().vmsim_set_rays.argtypes = [ctypes.POINTER(ctypes.c_float)] * 3
+        lib().vmsim_set_rays(_p(ray_keep[0]), _p(ray_keep[1]), _p(ray_keep[2]))
+        pcs = np.full_like(pcs, np.nan)              # must not be read
+    try:
+        rc = lib().vmsim_step(
         n, R, S, H, G, int(NW), int(xcd_affine), int(weights_bf16), arr, _p(Bc), _p(sc), _p(pcs), _p(z), _p(gd), _p(rgb),
         _p(sem, ctypes.c_uint8), _p(dm, ctypes.c_uint8), ctypes.c_float(5.0), ctypes.c_float(10.0),
         _p(grads), _p(loss), _p(dD), _p(dC), _p(dO), _p(dV), _p(flags, ctypes.c_int), int(bool(bwd)),
         do_adam, _p(p_out), _p(m), _p(v), int(step), ctypes.c_float(lr), ctypes.c_float(wd))
+    finally:
+        if rays is not None:
+            lib().vmsim_set_rays(None, None, None)
     if rc != 0:
         raise RuntimeError(f"vmsim_step failed: {rc}")
     out = dict(loss=float(loss[0]), render_depth=dD, render_color=dC, opacity=dO, var=dV, flags=flags, grads_flat=grads)

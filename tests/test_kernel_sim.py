@@ -356,3 +356,29 @@ def test_sim_ws_hidden256_matches_reference(G, nw, bf16):
     for k in GRAD_KEYS:
         assert not np.isnan(s[k]).any(), k
         assert relerr(s[k], g[k]) < 1e-4, k
+
+
+@pytest.mark.parametrize("H,wide,split,n,R,S", [(32, False, True, 3, 13, 10), (32, False, False, 2, 7, 10), (64, 4, False, 2, 9, 10), (128, 3, False, 1, 5, 14),
+                                                (256, 3, False, 1, 2, 14), (96, False, False, 1, 5, 10)])
+def test_ray_handoff_equals_points_on_the_simulator(H, wide, split, n, R, S):
+    """ABI v7 on the CPU tier: the kernels' own source, executed lane by lane, given (origin, direction, z) + centres and NO points tensor
+    (it is poisoned with NaN) - step_main_s32 / _h32 / _wp (through step_rays_to_points, like its launcher) / _ws / _ws<8> / _gen rebuild
+    (o + d z) - c with one rounding per operation and return the bits of the run on the points tensor formed the same way in numpy."""
+    from vmap_amd import synth
+    fc, B, sc = synth.make_params(n, H, seed=50 + H)
+    batch = synth.make_batch(n, R, S, seed=51 + H)
+    rng = np.random.default_rng(52 + H)
+    o = rng.uniform(-1, 1, (n, R, 3)).astype(np.float32)
+    d = rng.uniform(-1, 1, (n, R, 3)).astype(np.float32)
+    c = rng.uniform(-0.5, 0.5, (n, 3)).astype(np.float32)
+    z = batch["z"]
+    batch = dict(batch, pcs=((o[:, :, None, :] + d[:, :, None, :] * z[..., None]) - c[:, None, None, :]).astype(np.float32))   # float32 numpy: one rounding per operation
+    G = 2 if H == 256 else None                    # hidden 256: single-tile rounds (two 14-sample rays)
+    a = simlib.sim_step(fc, B, sc, batch, wide=wide, split=split, G=G)
+    b = simlib.sim_step(fc, B, sc, batch, wide=wide, split=split, rays=(o, d, c), G=G)
+    assert np.isfinite(a["loss"]) and a["loss"] == b["loss"]
+    for k in ("render_depth", "render_color", "opacity", "var", "grads_flat"):
+        assert np.array_equal(a[k], b[k]), k
+    b0 = simlib.sim_step(fc, B, sc, dict(batch, pcs=((o[:, :, None, :] + d[:, :, None, :] * z[..., None])).astype(np.float32)), wide=wide, split=split, rays=(o, d, None), G=G)
+    a0 = simlib.sim_step(fc, B, sc, dict(batch, pcs=((o[:, :, None, :] + d[:, :, None, :] * z[..., None])).astype(np.float32)), wide=wide, split=split, G=G)
+    assert np.array_equal(a0["grads_flat"], b0["grads_flat"]) and a0["loss"] == b0["loss"]          # centres omitted = zeros
