@@ -378,6 +378,36 @@ def test_ray_handoff_is_bit_identical_to_points(H, n, R, S, tuning):
                                           ctypes.byref(b), 5.0, 10.0, ctypes.byref(out), op._ws_ptr, op._ws_bytes, op._stream()), op.lib)
 
 
+def test_background_classes_take_the_frame_as_rays():
+    """parallel.SharedBackgroundHip (prepare / per-step launches + the optimiser launch) and parallel.OwnerBackgroundHip (bound frame call)
+    on a one-object frame handed over WITHOUT the object dimension as step.RayPoints (origins / dirs [R_total, 3], centre [3]): the same
+    per-step losses and the same final parameter slab, bit for bit, as on the points tensor."""
+    if TEST_TUNING["default"] is not None:
+        pytest.skip("hidden 128: the module's hidden-32 kernel legs do not apply; run once")
+    from vmap_amd import fields, parallel
+    R, S, steps, H = 60, 14, 3, 128
+    fc, B, sc, fr, rays = _ray_case(1, R, S, H, seed=1500, steps=steps)
+    flat = {k: v[0] for k, v in fr.items()}
+    ray1 = step.RayPoints(rays.origins[0], rays.dirs[0], rays.centers[0])
+    outs = []
+    for cls in (parallel.SharedBackgroundHip, parallel.OwnerBackgroundHip):
+        for pts in (flat["pcs"], ray1):
+            torch.manual_seed(3)
+            m = fields.OccupancyMap(hidden_size=H)
+            m.apply(fields.init_weights)
+            pe = fields.UniDirsEmbed(max_deg=5, scale=5.0)
+            bg = cls(m, pe, R, S, DEV, max_steps=steps)
+            args = (pts, flat["z"], flat["gt_depth"], flat["gt_rgb"], flat["sem"], flat["depth_mask"])
+            if cls is parallel.SharedBackgroundHip:
+                losses = bg.train_frame(*args, n_steps=steps).clone()
+            else:
+                losses = bg.train_frame(*args, n_steps=steps).loss[:steps].clone()
+            torch.cuda.synchronize()
+            outs.append((losses.cpu(), bg.slab.cpu().clone()))
+    for a_, b_ in ((outs[0], outs[1]), (outs[2], outs[3])):
+        assert bool(torch.isfinite(a_[0]).all()) and torch.equal(a_[0], b_[0]) and torch.equal(a_[1], b_[1])
+
+
 @pytest.mark.parametrize("H,n,R,S,weights", [(64, 32, 256, 10, "f32"), (64, 32, 256, 10, "bf16"), (256, 1, 4800, 14, "f32"), (32, 50, 120, 10, "f32")])
 def test_co_resident_waves_stay_bit_repeatable(H, n, R, S, weights):
     """Thirty launches of the forms that put TWO waves on a SIMD (step_main_wp<2>: two workgroups per CU at 480 workgroups; step_main_ws<8>:

@@ -117,7 +117,7 @@ class SharedBackgroundHip:
         flags[:, :3] = (counts[:, :, :3] == 0).any(dim=1).to(torch.int32)
         self._n_steps = n_steps
         R = self.rays_local
-        sig = (n_steps,) + tuple((x.data_ptr(), tuple(x.shape), tuple(x.stride())) for x in self._frame)
+        sig = (n_steps,) + tuple(x.signature() if hasattr(x, "signature") else (x.data_ptr(), tuple(x.shape), tuple(x.stride())) for x in self._frame)
         if getattr(self, "_sig", None) == sig:
             return                                   # the same frame buffers as last time (a sampler with fixed outputs): blocks still valid
         self._sig = sig
@@ -228,7 +228,7 @@ class OwnerBackgroundHip:
         ranks may pass None), then the slab broadcast.  Returns the owner's StepResult (loss [max_steps], flags) or None."""
         if self.is_owner:
             fr = tuple(x.unsqueeze(0) for x in (pcs, z, gt_depth, gt_rgb, sem, depth_mask))
-            sig = tuple((x.data_ptr(), tuple(x.shape), tuple(x.stride())) for x in fr)
+            sig = tuple(x.signature() if hasattr(x, "signature") else (x.data_ptr(), tuple(x.shape), tuple(x.stride())) for x in fr)
             if self._sig != sig:                     # new frame buffers: marshal once
                 self._bound = self.op.bind(self.views[:14], self.views[14], self.scale, *fr, opt=self.opt, ray_step=self.rays)
                 self._sig = sig

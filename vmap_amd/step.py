@@ -27,11 +27,18 @@ class RayPoints:
     ``sampler.FrameSampler(..., rays=True)`` produces one per frame."""
 
     def __init__(self, origins: torch.Tensor, dirs: torch.Tensor, centers: Optional[torch.Tensor] = None):
-        if origins.shape != dirs.shape or origins.dim() != 3 or origins.shape[-1] != 3:
+        one = origins.dim() == 2                        # a one-object frame without the object dimension: [R, 3] (+ centre [3]); see unsqueeze()
+        if origins.shape != dirs.shape or origins.dim() not in (2, 3) or origins.shape[-1] != 3:
             raise ValueError(f"origins / dirs: need two [n, R, 3] tensors, got {tuple(origins.shape)} / {tuple(dirs.shape)}")
-        if centers is not None and (tuple(centers.shape) != (origins.shape[0], 3) or centers.stride(1) != 1):
-            raise ValueError(f"centers: need [n, 3] with unit inner stride, got {tuple(centers.shape)}")
+        if centers is not None and (tuple(centers.shape) != ((3,) if one else (origins.shape[0], 3)) or centers.stride(-1) != 1):
+            raise ValueError(f"centers: need {'[3]' if one else '[n, 3]'} with unit inner stride, got {tuple(centers.shape)}")
         self.origins, self.dirs, self.centers = origins, dirs, centers
+
+    @classmethod
+    def __new_unchecked(cls, origins, dirs, centers):
+        r = cls.__new__(cls)
+        r.origins, r.dirs, r.centers = origins, dirs, centers
+        return r
 
     @property
     def shape(self):                   # (n, rays, ...) like the points tensor, for the callers that read pcs.shape[1]
@@ -40,10 +47,22 @@ class RayPoints:
     def __getitem__(self, idx):
         """Slices along (object, ray) like ``pcs[:, i*R:(i+1)*R]`` (train.py:271-272); an object slice applies to the centres too."""
         idx = idx if isinstance(idx, tuple) else (idx,)
-        if len(idx) > 2 or not all(isinstance(i, slice) for i in idx):
-            raise IndexError("RayPoints supports [object_slice, ray_slice]")
+        if len(idx) > 2 or not all(isinstance(i, slice) for i in idx) or self.origins.dim() != 3:
+            raise IndexError("RayPoints supports [object_slice, ray_slice] of an [n, R, 3] bundle")
         c = self.centers[idx[0]] if self.centers is not None else None
         return RayPoints(self.origins[idx], self.dirs[idx], c)
+
+    def unsqueeze(self, dim: int) -> "RayPoints":
+        """``unsqueeze(0)`` of a one-object frame given without the object dimension (origins / dirs [R, 3], centres [3] or None): what the
+        background classes of ``vmap_amd.parallel`` do to every tensor of their frame."""
+        if dim != 0:
+            raise IndexError("RayPoints.unsqueeze: only dim 0")
+        return RayPoints.__new_unchecked(self.origins.unsqueeze(0), self.dirs.unsqueeze(0),
+                                         self.centers.reshape(1, 3) if self.centers is not None else None)
+
+    def signature(self):
+        """(address, shape, strides) of the tensors: what a caller compares to see whether the frame buffers moved"""
+        return tuple((t.data_ptr(), tuple(t.shape), tuple(t.stride())) for t in (self.origins, self.dirs, self.centers) if t is not None)
 
     def points(self, z: torch.Tensor) -> torch.Tensor:
         """The [n, R, S, 3] tensor these rays stand for (host-side helper for tests / tools; eager torch ops round each operation on
