@@ -435,6 +435,29 @@ def test_co_resident_waves_stay_bit_repeatable(H, n, R, S, weights):
             assert torch.equal(x, y), (rep, i)
 
 
+@pytest.mark.parametrize("H", [32, 64, 128, 256, 96])
+def test_far_point_takes_the_library_sincos_path_on_the_device(H):
+    """One sample point 3e5 units away: 32 pi |proj| exceeds the fast sincos' range (2^20), so its whole wave takes the library sincosf for
+    octave 0 (a path ordinary scenes never reach; on the simulator it runs the HOST libm, here the device's) - loss, renders and all 15
+    gradient tensors against the ATen port at the usual bars, every kernel family."""
+    if H != 32 and TEST_TUNING["default"] is not None:
+        pytest.skip("the module's hidden-32 kernel legs do not apply; run once")
+    n, R, S = (3, 12, 10) if H != 256 else (1, 4, 14)
+    fc, B, sc = synth.make_params(n, H, seed=1700 + H)
+    batch = synth.make_batch(n, R, S, seed=1701 + H)
+    batch["pcs"][n - 1, 3, 4, :] = [3.0e5, -2.0e5, 1.0e5]
+    c = dict(n=n, R=R, S=S, H=H, fc=fc, B=B, scale=sc, batch=batch)
+    s = _run(c)
+    from oracle import vmap_oracle_torch as vt
+    loss_t, rend_t, grads_t = vt.CpuTrainer(fc, B, sc).step(batch, update=False)
+    assert abs(s["loss"] - float(loss_t)) <= 5e-5 * abs(float(loss_t))
+    for k in RENDER_KEYS:
+        assert relerr(s[k], rend_t[k].detach().numpy()) < 2e-5, k
+    if max(relerr(s[k], g.numpy()) for k, g in zip(GRAD_KEYS, grads_t)) >= 1e-4:
+        o = vo.training_step(fc, B, sc, batch, dtype=np.float32, kinks=True)
+        _assert_grads_match_aten_port_up_to_kinks(s, o, grads_t, n)
+
+
 def test_render_only_equals_fwd_bwd_renders():
     c = cases.build_case("ragged")
     a, b = _run(c), _run(c, fn="render")
