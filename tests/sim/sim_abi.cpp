@@ -62,7 +62,6 @@ extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req, int xcd
     a.pe_B = {const_cast<float*>(B), 63};
     a.pe_scale = {const_cast<float*>(scale), 1};
     a.pcs = pcs; a.pcs_so = (long long)R * S * 3; a.pcs_sr = S * 3; a.pcs_ss = 3; a.pcs_sc = 1;
-    std::vector<float> pts_buf;
     if (g_ray_o) {
         a.pcs = nullptr;
         a.ray_o = g_ray_o; a.ro_so = (long long)R * 3; a.ro_sr = 3; a.ro_sc = 1;
@@ -90,16 +89,6 @@ extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req, int xcd
         sl::prep_ws(wa);
     } else if (split) sl::prep_s32(a);
     else sl::prep_f32(a, 1 + n * (vk::gen_layout(H).imgp / 1024));
-    if (wp && !wa.s.pcs) {
-        // as the library's launcher does for this family (k_wp.hip): the step's rays expanded into a points buffer first
-        pts_buf.assign((size_t)n * R * S * 3, NAN);
-        vk::StepArgs ea = wa.s;
-        ea.z = z; ea.z_so = (long long)R * S; ea.z_sr = S; ea.z_ss = 1;
-        const long long n_pts = (long long)n * R * S;
-        sim::launch((int)((n_pts + 255) / 256), 256, 0, [&] { vk::step_rays_to_points<>(ea, pts_buf.data()); });
-        wa.s.pcs = pts_buf.data(); wa.s.pcs_so = (long long)R * S * 3; wa.s.pcs_sr = S * 3; wa.s.pcs_ss = 3; wa.s.pcs_sc = 1;
-        wa.s.ray_o = nullptr; wa.s.ray_d = nullptr; wa.s.center = nullptr;
-    }
     if (wp) sl::main_wp(wa, bwd);
     else if (ws) sl::main_ws(wa, bwd);
     else if (split) sl::main_s32(a, bwd);

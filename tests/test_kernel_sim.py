@@ -362,7 +362,7 @@ def test_sim_ws_hidden256_matches_reference(G, nw, bf16):
                                                 (256, 3, False, 1, 2, 14), (96, False, False, 1, 5, 10)])
 def test_ray_handoff_equals_points_on_the_simulator(H, wide, split, n, R, S):
     """ABI v7 on the CPU tier: the kernels' own source, executed lane by lane, given (origin, direction, z) + centres and NO points tensor
-    (it is poisoned with NaN) - step_main_s32 / _h32 / _wp (through step_rays_to_points, like its launcher) / _ws / _ws<8> / _gen rebuild
+    (it is poisoned with NaN) - step_main_s32 / _h32 / _wp / _ws / _ws<8> / _gen rebuild
     (o + d z) - c with one rounding per operation and return the bits of the run on the points tensor formed the same way in numpy."""
     from vmap_amd import synth
     fc, B, sc = synth.make_params(n, H, seed=50 + H)

@@ -30,19 +30,7 @@ int main_nb(const vk::StepArgs& a, bool bwd, bool stamps, hipStream_t st) {
 }
 }  // namespace
 
-int main_wp(const vk::StepArgs& a_in, bool bwd, bool stamps, hipStream_t st) {
-    vk::StepArgs a = a_in;
-    if (!a.pcs) {
-        // ABI v7 ray hand-off: this family reads the points tensor only - expand this step's rays into the plan's points buffer first
-        // (one small launch; 12 S bytes per ray of extra traffic in front of a step that moves ~19 KB per sample point)
-        if (!a.pts_buf) return fail(-3, "step_main_wp with a ray batch: the workspace has no points buffer");
-        const long long n_pts = (long long)a.n_obj * a.R * a.S;
-        hipLaunchKernelGGL(vk::step_rays_to_points<>, dim3((unsigned)((n_pts + 255) / 256)), dim3(256), 0, st, a, a.pts_buf);
-        if (int rc = launched("step_rays_to_points")) return rc;
-        a.pcs = a.pts_buf;
-        a.pcs_so = (long long)a.R * a.S * 3; a.pcs_sr = (long long)a.S * 3; a.pcs_ss = 3; a.pcs_sc = 1;
-        a.ray_o = nullptr; a.ray_d = nullptr; a.center = nullptr;
-    }
+int main_wp(const vk::StepArgs& a, bool bwd, bool stamps, hipStream_t st) {
 #ifdef VMAPSTEP_AB
     if (a.hidden == 128) return main_nb<4>(a, bwd, stamps, st);          // hidden 128 on step_main_wp: A/B reference of step_main_ws<4>
 #else

@@ -85,7 +85,6 @@ struct StepArgs {
     const float* ray_o; long long ro_so, ro_sr, ro_sc;
     const float* ray_d; long long rd_so, rd_sr, rd_sc;
     const float* center; long long ce_so;          // [n][3] or null (= zeros)
-    float* pts_buf;                                // workspace [n][R][S][3]: where step_main_wp's launcher expands a ray batch (other kernels: null)
 };
 
 // Sample point `smp` of ray `ray` of object `obj` in the object frame: read from the points tensor (train.py:272 batch_input_pcs),
@@ -108,22 +107,6 @@ __device__ __forceinline__ void load_point(const StepArgs& a, int obj, int ray, 
         x1 = (o[a.ro_sc] + d[a.rd_sc] * zz) - c1;
         x2 = (o[2 * a.ro_sc] + d[2 * a.rd_sc] * zz) - c2;
     }
-}
-
-// rays -> points for the one kernel family that does not rebuild them in its own prologue (step_main_wp, hidden 64: two workgroups per
-// CU on 256 registers and ~230 spilled scalar registers - its prologue has nothing to spare, see HISTORY.md round 5): one thread per
-// sample point of THIS step's batch, the same load_point arithmetic, into a dense [n][R][S][3] tensor of the workspace.
-template <int = 0>
-__global__ __launch_bounds__(256) void step_rays_to_points(const StepArgs a, float* pts) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long per_obj = (long long)a.R * a.S;
-    if (i >= a.n_obj * per_obj) return;
-    const int obj = (int)(i / per_obj);
-    const int rs = (int)(i - obj * per_obj), ray = rs / a.S, smp = rs - ray * a.S;
-    float x0, x1, x2;
-    load_point(a, obj, ray, smp, x0, x1, x2);
-    float* q = pts + 3 * i;
-    q[0] = x0; q[1] = x1; q[2] = x2;
 }
 
 __device__ __forceinline__ constexpr int phi(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }

@@ -87,7 +87,7 @@ void make_layout(int H, Layout& L) {
 struct Plan {
     int G, NG, NW;
     int tiles;         // step_main_ws: 32-point tiles per round (2; 1 = single-tile rounds when every tile gets a compute unit of its own; 3: see make_plan)
-    size_t off_stats, off_flags, off_ploss, off_imgtab, off_pgrad, off_wimg, off_scratch, off_pts, total;
+    size_t off_stats, off_flags, off_ploss, off_imgtab, off_pgrad, off_wimg, off_scratch, total;
     bool generic;      // hidden != 32: step_main_gen (global-memory activations) instead of step_main_h32
     bool split;        // hidden 32 on the bf16 matrix pipe with split operands (step_main_s32; the default at hidden 32)
     int wide;          // 0 = step_main_gen, 1 = step_main_wide<4> (hidden 128 / 256: one tile per workgroup, four waves per
@@ -225,9 +225,6 @@ int make_plan(const vmapstep_shape* sh, int max_steps, Plan& pl, const Layout& L
                                                                                  : (size_t)vk::kWsScratchMax));
     else if (pl.generic)   // register-image scratch: per wave (step_main_gen) or per workgroup (step_main_wide)
         o += align_up((size_t)sh->n_obj * nw_cap * (pl.wide == 1 ? 1 : vk::kWaves) * vk::gen_wave_blocks(GL.NB) * vk::kBlk * sizeof(float));
-    // step_main_wp takes a ray batch (ABI v7) through a points buffer its launcher fills per step: one step's [n][R][S][3] floats
-    pl.off_pts = o;
-    if (pl.wide == 4) o += align_up((size_t)sh->n_obj * sh->rays * sh->samples * 3 * sizeof(float));
     pl.off_flags = o; o += align_up((size_t)kMaxFrameSteps * 4 * sizeof(int));
     pl.off_stats = o; o += align_up((size_t)max_steps * sh->n_obj * 4 * sizeof(float));
     pl.total = o;
@@ -296,7 +293,6 @@ void fill_step_args(vk::StepArgs& a, const vmapstep_shape* sh, const Plan& pl, c
     a.part_grad = reinterpret_cast<float*>(ws + pl.off_pgrad);
     a.wimg = reinterpret_cast<float*>(ws + pl.off_wimg);
     a.gen_scratch = reinterpret_cast<float*>(ws + pl.off_scratch);
-    a.pts_buf = pl.wide == 4 ? reinterpret_cast<float*>(ws + pl.off_pts) : nullptr;
 }
 
 // the dominant kernel of the plan (bwd = false: the forward-only instantiation of vmapstep_render; stamps: vmapstep_profile_phases)

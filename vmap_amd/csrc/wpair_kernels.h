@@ -179,10 +179,7 @@ __global__ __launch_bounds__(128 * NB, 2) void step_main_wp(const WsArgs ga) {
         const bool valid = pt < npts;
         const int lray = valid ? pt / a.S : 0, smp = valid ? pt - lray * a.S : 0, ray = ray0 + lray;
         float px3[3] = {0.0f, 0.0f, 0.0f};
-        if (valid) {
-            const float* px = a.pcs + obj * a.pcs_so + ray * a.pcs_sr + smp * a.pcs_ss;
-            px3[0] = px[0]; px3[1] = px[a.pcs_sc]; px3[2] = px[2 * a.pcs_sc];
-        }
+        if (valid) load_point(a, obj, ray, smp, px3[0], px3[1], px3[2]);      // the points tensor, or (o + d z) - c of a ray batch (ABI v7)
         const float t[3] = {px3[0] / scale, px3[1] / scale, px3[2] / scale};          // embedding.py:83
         float proj[SL];
         float amax = 0.0f;
