@@ -63,7 +63,9 @@ extern "C" {
 typedef struct vmapstep_tuning {
     int32_t workgroups_per_object; /* 0 = automatic (256 / n_obj, at most one per ray group)                      */
     int32_t kernel;                /* VMAPSTEP_KERNEL_*                                                           */
-    int32_t generic_finalize;      /* 1: step_finalize instead of the table-driven step_finalize_h32 (A/B parity) */
+    int32_t generic_finalize;      /* 1: step_finalize instead of the table-driven step_finalize_h32 (A/B parity); */
+                                   /* hidden 64 / 128 / 256: step_finalize_ws always with a thread per quad and    */
+                                   /* row group, never its one-thread-per-quad form (A/B: same bits either way)    */
     int32_t ws_flags;              /* step_main_ws, measurement: bit 0 = never use single-tile rounds, bit 1 =     */
                                    /* always three-tile rounds (hidden 128), bit 2 = never three-tile rounds (A/B) */
 } vmapstep_tuning;

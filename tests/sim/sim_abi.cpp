@@ -16,6 +16,8 @@ void fc_sizes(int H, int* sz) {
 }  // namespace
 
 extern "C" int vmsim_lds_bytes() { return vk::Lds32::BYTES; }
+static int g_fin_form = 0;   // step_finalize_ws: 0 = a thread per quad and row group (what small shapes get), 1 = one thread per quad (many blocks / few rows)
+extern "C" void vmsim_set_finalize_form(int f) { g_fin_form = f; }
 static int g_wide = 0;
 extern "C" void vmsim_set_wide(int w) { g_wide = w; }
 static int g_sample_split = 0;
@@ -121,6 +123,7 @@ extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req, int xcd
         h.decay = f.decay; h.one_minus_beta1 = f.one_minus_beta1; h.beta2 = f.beta2; h.one_minus_beta2 = f.one_minus_beta2;
         h.eps = f.eps; h.step_size = f.step_size; h.bias_corr2_sqrt = f.bias_corr2_sqrt;
         f.do_adam = do_adam && p_out;
+        f.ws_grouped = g_fin_form == 0;
         sl::finalize_ws(f, h, tab_wt.data());
         return 0;
     }

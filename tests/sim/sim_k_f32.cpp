@@ -32,8 +32,16 @@ int main_f32(const vk::StepArgs& a, int wide, bool bwd, int G) {
     else     sim::launch(n * NW, vk::kWG, vk::LdsGen::bytes(GL.small_n), [&] { vk::step_main_gen<false>(ga); });
     return 0;
 }
-void finalize_generic(const vk::FinalizeArgs& f, int grid) { sim::launch(grid, vk::kWG, 2 * vk::kWG * 4, [&] { vk::step_finalize(f); }); }
-void finalize_h32(const vk::FinalizeArgs& f, const vk::FinalizeHot& h, int grid) {
-    sim::launch(grid, vk::kWG, 2 * vk::kWG * 4, [&] { vk::step_finalize_h32(f, h); });
+void finalize_generic(const vk::FinalizeArgs& f_in, int grid) {
+    vk::FinalizeArgs f = f_in;
+    const size_t lds = vk::loss_lds_bytes(f.n_obj, f.NW);
+    f.loss_stage = vk::loss_stage_cap(lds);
+    sim::launch(grid, vk::kWG, (int)lds, [&] { vk::step_finalize(f); });
+}
+void finalize_h32(const vk::FinalizeArgs& f_in, const vk::FinalizeHot& h, int grid) {
+    vk::FinalizeArgs f = f_in;
+    const size_t lds = vk::loss_lds_bytes(f.n_obj, f.NW);
+    f.loss_stage = vk::loss_stage_cap(lds);
+    sim::launch(grid, vk::kWG, (int)lds, [&] { vk::step_finalize_h32(f, h); });
 }
 }  // namespace sl

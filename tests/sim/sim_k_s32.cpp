@@ -17,7 +17,10 @@ void main_s32(const vk::StepArgs& a, bool bwd) {
         if (!bwd)          sim::launch(grid, vk::kWG, lb, [&] { vk::step_main_s32<false, false, false, true>(a); });
     }
 }
-void finalize_s32(const vk::FinalizeArgs& f, const vk::FinalizeHot& h, int grid) {
-    sim::launch(grid, vk::kWG, 2 * vk::kWG * 4, [&] { vk::step_finalize_s32(f, h); });
+void finalize_s32(const vk::FinalizeArgs& f_in, const vk::FinalizeHot& h, int grid) {
+    vk::FinalizeArgs f = f_in;
+    const size_t lds = vk::loss_lds_bytes(f.n_obj, f.NW);
+    f.loss_stage = vk::loss_stage_cap(lds);
+    sim::launch(grid, vk::kWG, (int)lds, [&] { vk::step_finalize_s32(f, h); });
 }
 }  // namespace sl

@@ -61,9 +61,19 @@ void main_ws_t(const vk::WsArgs& wa, bool bwd) {
     }
 }
 }  // namespace
-void finalize_ws(const vk::FinalizeArgs& f, const vk::FinalizeHot& h, const int* tab_wt) {
+void finalize_ws(const vk::FinalizeArgs& f_in, const vk::FinalizeHot& h, const int* tab_wt) {
+    vk::FinalizeArgs f = f_in;
+    f.loss_stage = vk::loss_stage_cap(vk::kFinThreads * 16);
     const int grid = f.n_obj * vk::ws_finalize_blocks(f.PP) + 1;
     if (f.hidden == 256) return finalize_ws8(f, h, tab_wt, grid);
+    if (!f.ws_grouped) {            // the form the library's launcher picks for many blocks / few rows (here: on request)
+        constexpr int Q = vk::kFinQuadsWide;
+        const int lds = vk::kFinGroups * Q * 16, gw = f.n_obj * vk::ws_finalize_blocks(f.PP, Q) + 1;
+        f.loss_stage = vk::loss_stage_cap(lds);
+        if (f.hidden == 128) sim::launch(gw, Q, lds, [&] { vk::step_finalize_ws<4, Q, 1>(f, h, tab_wt); });
+        else sim::launch(gw, Q, lds, [&] { vk::step_finalize_ws<2, Q, 1>(f, h, tab_wt); });
+        return;
+    }
     if (f.hidden == 128) sim::launch(grid, vk::kFinThreads, vk::kFinThreads * 16, [&] { vk::step_finalize_ws<4>(f, h, tab_wt); });
     else sim::launch(grid, vk::kFinThreads, vk::kFinThreads * 16, [&] { vk::step_finalize_ws<2>(f, h, tab_wt); });
 }

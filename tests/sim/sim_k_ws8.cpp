@@ -19,7 +19,15 @@ void main_ws8(const vk::WsArgs& wa, bool bwd) {
         else sim::launch(grid, LD::NTH, lb, [&] { vk::step_main_ws<8, false, true, false, 1, false>(wa); });
     }
 }
-void finalize_ws8(const vk::FinalizeArgs& f, const vk::FinalizeHot& h, const int* tab_wt, int grid) {
+void finalize_ws8(const vk::FinalizeArgs& f_in, const vk::FinalizeHot& h, const int* tab_wt, int grid) {
+    vk::FinalizeArgs f = f_in;
+    if (!f.ws_grouped) {
+        constexpr int Q = vk::kFinQuadsWide;
+        const int lds = vk::kFinGroups * Q * 16;
+        f.loss_stage = vk::loss_stage_cap(lds);
+        sim::launch(f.n_obj * vk::ws_finalize_blocks(f.PP, Q) + 1, Q, lds, [&] { vk::step_finalize_ws<8, Q, 1>(f, h, tab_wt); });
+        return;
+    }
     sim::launch(grid, vk::kFinThreads, vk::kFinThreads * 16, [&] { vk::step_finalize_ws<8>(f, h, tab_wt); });
 }
 }  // namespace sl

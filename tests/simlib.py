@@ -75,7 +75,7 @@ def _p(a, ty=ctypes.c_float):
 
 
 def sim_step(case_or_fc, B=None, scale=None, batch=None, G=None, bwd=True, adam=None, NW=0, xcd_affine=1, weights_bf16=0, wide=False,
-             split=False, rays=None):
+             split=False, rays=None, finalize_form=0):
     """Run prep + main + finalize on the simulator. Returns dict like oracle.training_step.
     split: hidden 32 on the split-bf16 kernels (step_prep_s32 / step_main_s32 / step_finalize_s32).
     rays: (origins [n,R,3], dirs [n,R,3], centres [n,3] or None) - the ABI v7 ray hand-off: the kernels get NO points tensor and rebuild
@@ -90,6 +90,7 @@ def sim_step(case_or_fc, B=None, scale=None, batch=None, G=None, bwd=True, adam=
     if G is None:
         G = max(1, (32 if wide in (True, 1) else 64 if wide in (3, 4) else 128) // S)
     lib().vmsim_set_split(int(bool(split)))      # 0 exact fp32 (step_main_h32), 1 step_main_s32
+    lib().vmsim_set_finalize_form(int(finalize_form))   # step_finalize_ws: 0 a thread per quad and row group, 1 one thread per quad (the library's choice for many blocks / few rows)
     lib().vmsim_set_wide(int(wide))       # 0 general kernel, 1 / True step_main_wide<4>, 3 step_main_ws, 4 step_main_wp (hidden 64 / 128)
     fc_c = [np.ascontiguousarray(a, dtype=np.float32) for a in fc]
     sizes = [a[0].size for a in fc_c]

@@ -1006,6 +1006,41 @@ def test_table_driven_finalize_is_bit_identical_to_generic_finalize(name, weight
     assert torch.equal(a["m"], b_["m"]) and torch.equal(a["v"], b_["v"])
 
 
+@pytest.mark.parametrize("H,n,R,S,weights", [(64, 24, 40, 10, "bf16"), (64, 12, 64, 10, "f32"), (128, 16, 24, 14, "f32"), (256, 2, 16, 14, "f32")])
+def test_ws_finalize_one_thread_per_quad_is_bit_identical_to_the_grouped_form(H, n, R, S, weights):
+    """Shapes with many finalize blocks and few gradient rows per object (>= 512 blocks, <= 16 rows: the launcher's rule, as at configs[4]):
+    step_finalize_ws runs with ONE thread per quad that walks all eight row groups; tuning.generic_finalize = 1 forces the form with a
+    thread per quad and row group (what few-block shapes like the background step get).  Same ordered sums: two 5-step frames agree bit
+    for bit in losses, parameters and both moments.  (Round 5: at 256 objects x 2 rows the grouped form left seven of eight threads
+    without a row and ran at 1.35 TB/s.)"""
+    if TEST_TUNING["default"] is not None:
+        pytest.skip("the module's hidden-32 kernel legs do not apply; run once")
+    fc0, B0, sc0 = synth.make_params(n, H, seed=2100 + H)
+    steps = 5
+    fr0 = synth.make_batch(n, R * steps, S, seed=2101 + H)
+    outs = []
+    for grouped in (1, 0):
+        fc = [torch.from_numpy(a).to(DEV) for a in fc0]
+        B, sc = torch.from_numpy(B0).to(DEV), torch.from_numpy(sc0).to(DEV)
+        fr = {k: torch.from_numpy(v).to(DEV) for k, v in fr0.items()}
+        op = make_op(n, R, S, H, device=DEV, max_steps=steps, weights=weights, tuning={"generic_finalize": grouped})
+        plan = op.plan()
+        assert plan["workgroups_per_object"] <= 16, plan
+        st = step.FusedAdamWState(n, H, DEV)
+        losses = []
+        for _ in range(2):
+            res = op.train_steps(fc, B, sc, fr["pcs"], fr["z"], fr["gt_depth"], fr["gt_rgb"], fr["sem"], fr["depth_mask"], opt=st, n_steps=steps)
+            losses.append(res.loss.clone())
+        torch.cuda.synchronize()
+        outs.append(dict(p=[t.clone() for t in fc + [B]], m=st.exp_avg.clone(), v=st.exp_avg_sq.clone(), losses=torch.stack(losses)))
+    a, b_ = outs
+    assert bool(torch.isfinite(a["losses"]).all())
+    assert torch.equal(a["losses"], b_["losses"])
+    for x, y in zip(a["p"], b_["p"]):
+        assert torch.equal(x, y)
+    assert torch.equal(a["m"], b_["m"]) and torch.equal(a["v"], b_["v"])
+
+
 FRAME_TOL = {   # (relative loss tolerance for steps < 5, for later steps, q99 / median of |final parameter - reference|)
     # Measured per step (tests/tools/frame_drift.py, profiles/r03n_frame_drift.json): over the 20 steps of the headline frame the
     # default kernel stays within 2.3e-5 of the reference's loop (the exact-fp32 kernel within 3.1e-6; the reference's own float32

@@ -271,6 +271,28 @@ def test_sim_ws_fused_adamw_matches_oracle_update():
     assert relerr(state["v"][:, :P], v_ref) < 1e-6
 
 
+@pytest.mark.parametrize("name,kw", [("h64", dict(wide=4, NW=2)), ("h64", dict(wide=4, NW=1)), ("bg_h128_s14", dict(wide=3, NW=3)),
+                                     ("bg_h128_s14", dict(wide=4, NW=5)), ("imap_h256", dict(wide=3, G=2))])
+def test_sim_ws_finalize_forms_give_the_same_bits(name, kw):
+    """step_finalize_ws with a thread per quad AND row group (few blocks, many rows) and with one thread per quad walking all eight row
+    groups (what the library launches for many blocks / few rows - 256 objects x 2 rows): the same ordered sums, so the same gradients,
+    loss and AdamW update, bit for bit (also with fewer rows than row groups: empty groups contribute exact zeros)."""
+    c = cases.build_case(name)
+    n = c["n"]
+    flat = np.concatenate([a.reshape(n, -1) for a in c["fc"]] + [c["B"].reshape(n, -1)], axis=1).astype(np.float32)
+    PP = (flat.shape[1] + 63) // 64 * 64
+    out = []
+    for form in (0, 1):
+        state = dict(p=flat.copy(), m=np.zeros((n, PP), np.float32), v=np.zeros((n, PP), np.float32), step=1)
+        s = simlib.sim_step(c, adam=state, finalize_form=form, **kw)
+        out.append((s, state))
+    (s0, st0), (s1, st1) = out
+    assert s0["loss"] == s1["loss"]
+    assert np.array_equal(s0["grads_flat"], s1["grads_flat"])
+    for k in ("p", "m", "v"):
+        assert np.array_equal(st0[k], st1[k]), k
+
+
 @pytest.mark.parametrize("name,kw", [("ragged", dict(split=True, NW=2, G=5)), ("ragged", dict(split=True, NW=1)),
                                      ("h64", dict(wide=4, NW=2)), ("h64", dict(wide=3, NW=2)), ("bg_h128_s14", dict(wide=3, NW=3))])
 def test_sim_bf16_weights_in_the_multi_pass_and_multi_round_forms(name, kw):

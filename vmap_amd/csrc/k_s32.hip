@@ -37,7 +37,10 @@ int prep_s32(const vk::StepArgs& a, int n_steps, hipStream_t st) {
 }
 
 int finalize_s32(const vk::FinalizeArgs& f, const vk::FinalizeHot& h, int grid, hipStream_t st) {
-    hipLaunchKernelGGL(vk::step_finalize_s32<>, dim3(grid), dim3(vk::kWG), 2 * vk::kWG * sizeof(float), st, f, h);
+    vk::FinalizeArgs g = f;
+    const size_t lds = vk::loss_lds_bytes(f.n_obj, f.NW);
+    g.loss_stage = vk::loss_stage_cap(lds);
+    hipLaunchKernelGGL(vk::step_finalize_s32<>, dim3(grid), dim3(vk::kWG), lds, st, g, h);
     return launched("step_finalize_s32");
 }
 

@@ -82,14 +82,31 @@ int prep_ws(const vk::StepArgs& a, int n_steps, hipStream_t st) {
     return launched("step_prep_ws");
 }
 
-int finalize_ws(const vk::FinalizeArgs& f, const vk::FinalizeHot& h, const int* tab_wt, hipStream_t st) {
+// many blocks, few rows per object: the form in which one thread per quad walks all row groups (see step_finalize_ws)
+static bool finalize_one_thread_per_quad(const vk::FinalizeArgs& f) {
+    return !f.ws_grouped && f.NW <= 16 && (long long)f.n_obj * vk::ws_finalize_blocks(f.PP) >= 512;
+}
+template <int NB>
+static int finalize_wide(vk::FinalizeArgs f, const vk::FinalizeHot& h, const int* tab_wt, hipStream_t st) {
+    constexpr int Q = vk::kFinQuadsWide;
+    const size_t lds = (size_t)vk::kFinGroups * Q * 4 * sizeof(float);
+    f.loss_stage = vk::loss_stage_cap(lds);
+    hipLaunchKernelGGL((vk::step_finalize_ws<NB, Q, 1>), dim3(f.n_obj * vk::ws_finalize_blocks(f.PP, Q) + 1), dim3(Q), lds, st, f, h, tab_wt);
+    return launched("step_finalize_ws");
+}
+
+int finalize_ws(const vk::FinalizeArgs& f_in, const vk::FinalizeHot& h, const int* tab_wt, hipStream_t st) {
+    vk::FinalizeArgs f = f_in;
+    f.loss_stage = vk::loss_stage_cap(vk::kFinThreads * 4 * sizeof(float));       // the row blocks' LDS doubles as the loss block's staging area
     const int grid = f.n_obj * vk::ws_finalize_blocks(f.PP) + 1;
     if (f.hidden == 256) return finalize_ws8(f, h, tab_wt, grid, st);
+    if (finalize_one_thread_per_quad(f)) return f.hidden == 128 ? finalize_wide<4>(f, h, tab_wt, st) : finalize_wide<2>(f, h, tab_wt, st);
     if (f.hidden == 128) {
         // the narrow form where it fills the chip with one block per compute unit and the wide one does not (the background step)
         const int narrow = f.n_obj * vk::ws_finalize_blocks(f.PP, vk::kFinQuadsNarrow);
         if (narrow <= 256 && grid - 1 < narrow) {
             constexpr int T = vk::kFinGroups * vk::kFinQuadsNarrow;
+            f.loss_stage = vk::loss_stage_cap(T * 4 * sizeof(float));
             hipLaunchKernelGGL((vk::step_finalize_ws<4, vk::kFinQuadsNarrow>), dim3(narrow + 1), dim3(T), T * 4 * sizeof(float), st, f, h, tab_wt);
             return launched("step_finalize_ws");
         }

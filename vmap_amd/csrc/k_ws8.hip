@@ -33,8 +33,16 @@ int prep_ws8(const vk::WsArgs& ga, int n_steps, hipStream_t st) {
     return launched("step_prep_ws<8>");
 }
 
-int finalize_ws8(const vk::FinalizeArgs& f, const vk::FinalizeHot& h, const int* tab_wt, int grid, hipStream_t st) {
-    hipLaunchKernelGGL(vk::step_finalize_ws<8>, dim3(grid), dim3(vk::kFinThreads), vk::kFinThreads * 4 * sizeof(float), st, f, h, tab_wt);
+int finalize_ws8(const vk::FinalizeArgs& f_in, const vk::FinalizeHot& h, const int* tab_wt, int grid, hipStream_t st) {
+    if (!f_in.ws_grouped && f_in.NW <= 16 && grid - 1 >= 512) {      // many blocks, few rows: one thread per quad walks all row groups (as finalize_ws does)
+        vk::FinalizeArgs f = f_in;
+        constexpr int Q = vk::kFinQuadsWide;
+        const size_t lds = (size_t)vk::kFinGroups * Q * 4 * sizeof(float);
+        f.loss_stage = vk::loss_stage_cap(lds);
+        hipLaunchKernelGGL((vk::step_finalize_ws<8, Q, 1>), dim3(f.n_obj * vk::ws_finalize_blocks(f.PP, Q) + 1), dim3(Q), lds, st, f, h, tab_wt);
+        return launched("step_finalize_ws<8>");
+    }
+    hipLaunchKernelGGL(vk::step_finalize_ws<8>, dim3(grid), dim3(vk::kFinThreads), vk::kFinThreads * 4 * sizeof(float), st, f_in, h, tab_wt);   // f.loss_stage: set by finalize_ws
     return launched("step_finalize_ws<8>");
 }
 

@@ -965,7 +965,20 @@ struct FinalizeArgs {
     // ... or, for graph replay, the two step-dependent ones from a host-built table indexed by the device-resident step count:
     // adam_tab[2 t] = lr / (1 - beta1^(t+1)), adam_tab[2 t + 1] = sqrt(1 - beta2^(t+1)), t = adam_cnt[0] + adam_i (clamped)
     const float* adam_tab; const int* adam_cnt; int adam_i, adam_len;
+    int ws_grouped;                    // launcher hint (tuning.generic_finalize on the step_main_ws / _wp path): step_finalize_ws always with a
+                                       // thread per quad AND row group, never the one-thread-per-quad form the launcher picks for many blocks / few rows
+    int loss_stage;                    // loss partials (16 B each) the launch's LDS has room for behind the loss block's reduction scratch
+                                       // (set by the launcher, loss_stage_cap); 0: the loss block reads them from memory one by one
 };
+// LDS of a finalize launch as the loss block sees it: kWG floats + kWG ints of reduction scratch, then the staging area of the partials
+constexpr int kLossRedBytes = 2 * kWG * 4;
+constexpr int kLossStageMax = 1024;    // what the 256-thread finalize kernels make room for (16 KB)
+__host__ __device__ inline int loss_stage_cap(size_t lds_bytes) { return lds_bytes > (size_t)kLossRedBytes ? (int)((lds_bytes - kLossRedBytes) / 16) : 0; }
+// LDS bytes of a 256-thread finalize launch (step_finalize, _h32, _s32) and the capacity to put into FinalizeArgs::loss_stage
+__host__ __device__ inline size_t loss_lds_bytes(int n_obj, int NW) {
+    const long long total = (long long)n_obj * NW;
+    return (size_t)kLossRedBytes + (total <= kLossStageMax ? (size_t)total * 16 : 0);
+}
 // the two step-dependent AdamW constants of this launch (wave-uniform scalar loads in table mode)
 template <class Consts>
 __device__ __forceinline__ void adam_step_consts(const FinalizeArgs& f, const Consts& c, float& step_size, float& bias_corr2_sqrt) {
@@ -1067,13 +1080,26 @@ __device__ __forceinline__ void finalize_loss(const FinalizeArgs& a) {
     if (!a.loss_out) return;           // optimiser-only call (vmapstep_adamw_apply): no loss partials to reduce (uniform exit)
     float* red = wv::lds_base();       // kWG floats + kWG ints
     int* redi = reinterpret_cast<int*>(red + kWG);
+    // The partials are summed in workgroup order by ONE thread per object (the order is part of the result).  Read from memory in that
+    // loop they are NW dependent round trips - 200 for the one-object background step: the loss block, not the row reads, bounded that
+    // launch (round 5: ~23 us against 14 for the rows).  So the whole block first copies them to LDS, one round trip, same order after.
+    const int total = a.n_obj * a.NW;
+    const bool staged = total <= a.loss_stage;
+    wv::f32x4* stage = reinterpret_cast<wv::f32x4*>(redi + kWG);
+    if (staged) {
+        for (int i = threadIdx.x; i < total; i += blockDim.x) stage[i] = *reinterpret_cast<const wv::f32x4*>(a.part_loss + 4ll * i);
+        __syncthreads();
+    }
     float loss = 0.0f;
     int explode = 0;
     const bool act = threadIdx.x < kWG;  // blocks wider than kWG threads (step_finalize_ws): the extra waves only take part in the barriers
     for (int k = act ? (int)threadIdx.x : a.n_obj; k < a.n_obj; k += kWG) {
         float ld = 0.0f, lc = 0.0f, lo = 0.0f;
         for (int q = 0; q < a.NW; ++q) {
-            const float* pl = a.part_loss + ((long long)k * a.NW + q) * 4;
+            const long long i = (long long)k * a.NW + q;
+            wv::f32x4 pl;
+            if (staged) pl = stage[i];
+            else pl = *reinterpret_cast<const wv::f32x4*>(a.part_loss + i * 4);
             ld += pl[0]; lc += pl[1]; lo += pl[2];
         }
         explode |= (ld > 100000.0f) || (lc > 100000.0f) || (lo > 100000.0f);   // render_rays.py:88

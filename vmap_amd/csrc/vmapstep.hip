@@ -373,6 +373,7 @@ int launch_finalize(const vk::StepArgs& a, const Layout& L, const vmapstep_param
     if (a.wide >= 3 && have_grad) {
         // step_main_ws / _wp: one finalize for gradients to the caller and / or AdamW; it is the only writer of the two weight images
         fill_hot(h, f, a, L, params);
+        f.ws_grouped = generic_finalize ? 1 : 0;
         return vl::finalize_ws(f, h, a.tab_wt, st);
     }
     if (a.split && f.do_adam) {

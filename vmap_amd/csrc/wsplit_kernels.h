@@ -341,8 +341,14 @@ constexpr int kFinQuadsNarrow = 96;
 // kFinQuads consecutive quads of every row (2 KiB contiguous per row: measured 27.1 us at 64 quads, 21.0 at 128, 21.6 at 256
 // for 200 rows - the row reads want contiguity more than blocks, profiles/r03y_*), its kFinGroups row groups sum a share of the
 // rows each (loads eight deep), a fixed pairwise tree through LDS joins them - same order every run.
-template <int NB, int kFinQuads = vk::kFinQuads>
-__global__ __launch_bounds__(kFinGroups * kFinQuads) void step_finalize_ws(const FinalizeArgs a, const FinalizeHot hh, const int* tab_wt) {
+// PG = the row groups that have threads of their own (kFinGroups: one thread per quad and group - few blocks, many rows: the background
+// step; 1: one thread per quad sums all kFinGroups groups one after the other, in the same order and into the same LDS slots - many
+// blocks, few rows: with 256 objects x 2 rows seven of eight threads had nothing to read and the update ran on an eighth of the block,
+// 1.35 TB/s; round 5).  The result does not depend on PG.
+constexpr int kFinQuadsWide = 256;     // quads per block of the PG = 1 form (a 256-thread block: finalize_loss needs kWG threads)
+template <int NB, int kFinQuads = vk::kFinQuads, int PG = kFinGroups>
+__global__ __launch_bounds__(PG * kFinQuads) void step_finalize_ws(const FinalizeArgs a, const FinalizeHot hh, const int* tab_wt) {
+    static_assert(kFinGroups % PG == 0 && PG * kFinQuads >= kWG, "row groups per thread; the loss block reduces over kWG threads");
     typedef int i32x4 __attribute__((ext_vector_type(4)));
     const int quads = a.PP / 4;
     const int blocks_per_obj = ws_finalize_blocks(a.PP, kFinQuads);
@@ -355,21 +361,78 @@ __global__ __launch_bounds__(kFinGroups * kFinQuads) void step_finalize_ws(const
     const int q = min(part * kFinQuads + ql, quads - 1);
     const bool live = part * kFinQuads + ql < quads && 4 * q < a.P;
     wv::f32x4* red = reinterpret_cast<wv::f32x4*>(wv::lds_base());      // [kFinGroups][kFinQuads]
+    // The update's own operands (moments, parameters, image positions) are requested by the threads that will apply it BEFORE the row
+    // reads: behind the join they were a second, fully exposed memory round trip on 96 of the block's 768 threads (round 5: the row
+    // reads alone take 14.3 us of this kernel's 20-24, tests/tools/fin_layout_probe.hip).
+    const bool tail = rg == 0 && live;
+    const long long s = (long long)obj * hh.PP + 4 * q;
+    int ten[4] = {0, 0, 0, 0}, off[4] = {0, 0, 0, 0};
+    if (tail) {                        // (the other seven row groups' threads have no use for the tensor lookup)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = min(4 * q + e, a.P - 1);
+            int t = 0;
+#pragma unroll
+            for (int k = 1; k <= kNFc; ++k) t += i >= a.offs[k];
+            ten[e] = t; off[e] = i - a.offs[t];
+        }
+    }
+    wv::f32x4 m4 = {0.0f, 0.0f, 0.0f, 0.0f}, v4 = m4;
+    i32x4 iw = {0, 0, 0, 0}, it = iw;
+    float* pp[4] = {nullptr, nullptr, nullptr, nullptr};
+    float pv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (tail && a.do_adam) {
+        m4 = *reinterpret_cast<const wv::f32x4*>(hh.m + s);
+        v4 = *reinterpret_cast<const wv::f32x4*>(hh.v + s);
+        iw = *reinterpret_cast<const i32x4*>(hh.img_tab + 4 * q);
+        it = *reinterpret_cast<const i32x4*>(tab_wt + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            pp[e] = a.param[ten[e]].p + obj * a.param[ten[e]].stride + off[e];
+            pv[e] = *pp[e];
+        }
+    }
     {
         const wv::f32x4* pg = reinterpret_cast<const wv::f32x4*>(hh.part_grad + (long long)obj * hh.NW * hh.PP + 4 * q);
         const long long qs = hh.PP / 4;
-        const int per = (hh.NW + kFinGroups - 1) / kFinGroups, u_begin = min(hh.NW, rg * per), u_end = min(hh.NW, u_begin + per);
+        const int per = (hh.NW + kFinGroups - 1) / kFinGroups;
         wv::f32x4 g = {0.0f, 0.0f, 0.0f, 0.0f};
-        int u0 = u_begin;
-        for (; u0 + 8 <= u_end; u0 += 8) {
-            wv::f32x4 t[8];
+        if constexpr (PG == kFinGroups) {
+            const int u_begin = min(hh.NW, rg * per), u_end = min(hh.NW, u_begin + per);
+            int u0 = u_begin;
+            for (; u0 + 8 <= u_end; u0 += 8) {
+                wv::f32x4 t[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) t[u] = VK_FIN_LOAD(pg + (u0 + u) * qs);
+                for (int u = 0; u < 8; ++u) t[u] = VK_FIN_LOAD(pg + (u0 + u) * qs);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) g += t[u];
+                for (int u = 0; u < 8; ++u) g += t[u];
+            }
+            for (; u0 < u_end; ++u0) g += VK_FIN_LOAD(pg + u0 * qs);
+            red[rg * kFinQuads + ql] = g;
+        } else {
+            // this thread's kFinGroups / PG row groups one after the other: a running sum that is handed to the group's slot and
+            // restarted at every group boundary (= what the group's own thread would have computed), loads eight deep across boundaries
+            constexpr int VPT = kFinGroups / PG;
+            const int vg0 = rg * VPT;
+#pragma unroll
+            for (int j = 0; j < VPT; ++j) red[(vg0 + j) * kFinQuads + ql] = g;
+            const int u_begin = min(hh.NW, vg0 * per), u_end = min(hh.NW, (vg0 + VPT) * per);
+            int vg = vg0, left = per;
+            auto take = [&](const wv::f32x4& t) __attribute__((always_inline)) {
+                g += t;
+                if (--left == 0) { red[vg * kFinQuads + ql] = g; g = wv::f32x4{0.0f, 0.0f, 0.0f, 0.0f}; ++vg; left = per; }
+            };
+            int u0 = u_begin;
+            for (; u0 + 8 <= u_end; u0 += 8) {
+                wv::f32x4 t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = VK_FIN_LOAD(pg + (u0 + u) * qs);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) take(t[u]);
+            }
+            for (; u0 < u_end; ++u0) take(VK_FIN_LOAD(pg + u0 * qs));
+            if (left != per) red[vg * kFinQuads + ql] = g;
         }
-        for (; u0 < u_end; ++u0) g += VK_FIN_LOAD(pg + u0 * qs);
-        red[rg * kFinQuads + ql] = g;
     }
     __syncthreads();
     if (rg != 0 || !live) return;
@@ -382,16 +445,6 @@ __global__ __launch_bounds__(kFinGroups * kFinQuads) void step_finalize_ws(const
 #pragma unroll
         for (int i = 0; i < kFinGroups; i += 2 * w) jn[i] = jn[i] + jn[i + w];
     const wv::f32x4 g = jn[0];
-    const long long s = (long long)obj * hh.PP + 4 * q;
-    int ten[4], off[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int i = min(4 * q + e, a.P - 1);
-        int t = 0;
-#pragma unroll
-        for (int k = 1; k <= kNFc; ++k) t += i >= a.offs[k];
-        ten[e] = t; off[e] = i - a.offs[t];
-    }
     // the caller's gradient tensors (fwd_bwd, the last step of a frame call, the shared background's step)
 #pragma unroll
     for (int e = 0; e < 4; ++e)
@@ -399,16 +452,6 @@ __global__ __launch_bounds__(kFinGroups * kFinQuads) void step_finalize_ws(const
     if (!a.do_adam) return;
     float ss, bc;
     adam_step_consts(a, hh, ss, bc);
-    wv::f32x4 m4 = *reinterpret_cast<const wv::f32x4*>(hh.m + s);
-    wv::f32x4 v4 = *reinterpret_cast<const wv::f32x4*>(hh.v + s);
-    const i32x4 iw = *reinterpret_cast<const i32x4*>(hh.img_tab + 4 * q);
-    const i32x4 it = *reinterpret_cast<const i32x4*>(tab_wt + 4 * q);
-    float* pp[4]; float pv[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        pp[e] = a.param[ten[e]].p + obj * a.param[ten[e]].stride + off[e];
-        pv[e] = *pp[e];
-    }
     char* image = reinterpret_cast<char*>(hh.wimg) + (long long)obj * ImgWs<NB>::BYTES;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
