@@ -47,6 +47,30 @@ __global__ __launch_bounds__(kGroups * kQuads) void reader(const f4* rows, f4* o
     out[blockIdx.x * kQuads + ql] = s;
 }
 
+// the hidden-32 finalize's shape: 20 objects x 12 blocks of 256 threads, one thread per quad, 10 rows of 2848 quads per object, + the
+// update's own traffic (moments and parameters read and written back) - what is the floor of such a launch?
+constexpr int sObj = 20, sNW = 10, sPPq = 2848, sBpo = 12;
+template <bool UPDATE>
+__global__ __launch_bounds__(256) void reader_s32(const f4* rows, f4* m, f4* v, f4* p) {
+    const int obj = blockIdx.x / sBpo, q = (blockIdx.x % sBpo) * 256 + threadIdx.x;
+    if (q >= sPPq) return;
+    const f4* pg = rows + (long long)obj * sNW * sPPq + q;
+    const long long s = (long long)obj * sPPq + q;
+    f4 m4, v4, p4;
+    if (UPDATE) { m4 = m[s]; v4 = v[s]; p4 = p[s]; }
+    f4 t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = pg[u * (long long)sPPq];
+    f4 g = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int u = 0; u < 8; ++u) g += t[u];
+    g += pg[8ll * sPPq];
+    g += pg[9ll * sPPq];
+    if (UPDATE) { m4 = m4 * 0.9f + g * 0.1f; v4 = v4 * 0.999f + g * g * 0.001f; p4 = p4 - m4 * 1e-3f; m[s] = m4; v[s] = v4; p[s] = p4; }
+    else p[s] = g;
+}
+__global__ void empty_kernel() {}
+
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 template <class K>
 static float run(K k, const char* name, f4* rows, f4* out, int reps, int wmode = 0) {
@@ -66,7 +90,39 @@ static float run(K k, const char* name, f4* rows, f4* out, int reps, int wmode =
     printf("{\"layout\": \"%s\", \"mean_us\": %.2f, \"min_us\": %.2f, \"TB_per_s_at_mean\": %.2f}\n", name, 1e3 * tot / reps, 1e3 * best, bytes / (tot / reps * 1e-3) / 1e12);
     return tot / reps;
 }
+template <class K>
+static void run_s32(K k, const char* name, f4* rows, f4* m, f4* v, f4* p, int reps) {
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float tot = 0.0f, best = 1e9f;
+    for (int r = 0; r < reps + 3; ++r) {
+        writer<<<512, 1024>>>(rows, (float)r);
+        CK(hipEventRecord(e0));
+        k<<<sObj * sBpo, 256>>>(rows, m, v, p);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        if (r >= 3) { tot += ms; best = ms < best ? ms : best; }
+    }
+    printf("{\"layout\": \"%s\", \"mean_us\": %.2f, \"min_us\": %.2f}\n", name, 1e3 * tot / reps, 1e3 * best);
+}
 int main() {
+    {
+        f4 *rows, *m, *v, *p;
+        CK(hipMalloc(&rows, (size_t)kNW * kPPq * 16)); CK(hipMalloc(&m, (size_t)sObj * sPPq * 16)); CK(hipMalloc(&v, (size_t)sObj * sPPq * 16)); CK(hipMalloc(&p, (size_t)sObj * sPPq * 16));
+        for (int pass = 0; pass < 2; ++pass) {
+            run_s32(reader_s32<false>, "hidden-32 shape: ten row reads + one store per quad", rows, m, v, p, 200);
+            run_s32(reader_s32<true>, "hidden-32 shape: + moments and parameters read and written", rows, m, v, p, 200);
+        }
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        float tot = 0.0f;
+        for (int r = 0; r < 203; ++r) {
+            writer<<<512, 1024>>>(rows, (float)r);
+            CK(hipEventRecord(e0)); empty_kernel<<<1, 64>>>(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (r >= 3) tot += ms;
+        }
+        printf("{\"layout\": \"an empty kernel between the same two events\", \"mean_us\": %.2f}\n", 1e3 * tot / 200);
+        CK(hipFree(rows)); CK(hipFree(m)); CK(hipFree(v)); CK(hipFree(p));
+    }
     f4 *rows, *out;
     CK(hipMalloc(&rows, (size_t)kNW * kPPq * 16)); CK(hipMalloc(&out, (size_t)kPPq * 16));
     for (int pass = 0; pass < 2; ++pass) {
