@@ -9,6 +9,7 @@ namespace wv {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 
 // v_mfma_f32_32x32x2_f32 lane maps (cdna_hip_programming.md section 3):
 //   A[i][k]: lane = 32*k + i;  B[k][j]: lane = 32*k + j;  D[i][j]: lane = j + 32*((i>>2)&1), reg = (i&3) + 4*(i>>3)

@@ -239,17 +239,29 @@ __device__ __forceinline__ void finalize_quad_s32(const FinalizeArgs& f, const F
     wv::f32x4 v4 = *reinterpret_cast<const wv::f32x4*>(a.v + s);
     const i32x4 img = *reinterpret_cast<const i32x4*>(a.img_tab + 4 * q);
     float* pp[4]; float pv[4];
+    int tq[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int i = min(4 * q + e, Flat32::P - 1);
         if (SLAB) {
             pp[e] = a.slab + obj * a.slab_stride + i;
+            tq[e] = 0;
         } else {
-            int t, o;
-            flat32_tensor_of(i, t, o);
-            pp[e] = f.param[t].p + obj * f.param[t].stride + o;
+            int o;
+            flat32_tensor_of(i, tq[e], o);
+            pp[e] = f.param[tq[e]].p + obj * f.param[tq[e]].stride + o;
         }
-        pv[e] = *pp[e];
+    }
+    // a quad that lies inside ONE parameter tensor (all but the few that straddle two) is one 16-byte access at a 4-byte boundary
+    // instead of four 4-byte ones, in and out
+    const bool pvec = 4 * q + 3 < Flat32::P && tq[0] == tq[3];
+    if (pvec) {
+        const wv::f32x4 p4 = *reinterpret_cast<const wv::f32x4u*>(pp[0]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pv[e] = p4[e];
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pv[e] = *pp[e];
     }
     wv::f32x4 g = {0.0f, 0.0f, 0.0f, 0.0f};
     {
@@ -275,10 +287,12 @@ __device__ __forceinline__ void finalize_quad_s32(const FinalizeArgs& f, const F
         if (4 * q + e < Flat32::P) {
             float p = pv[e], m = m4[e], v = v4[e];
             adamw_elem(a, ss, bc, g[e], p, m, v);
-            *pp[e] = p; m4[e] = m; v4[e] = v;
+            if (!pvec) *pp[e] = p;
+            pv[e] = p; m4[e] = m; v4[e] = v;
             split_image_store(image, img[e], p, a.weights_bf16);
         }
     }
+    if (pvec) *reinterpret_cast<wv::f32x4u*>(pp[0]) = wv::f32x4{pv[0], pv[1], pv[2], pv[3]};
     *reinterpret_cast<wv::f32x4*>(a.m + s) = m4;
     *reinterpret_cast<wv::f32x4*>(a.v + s) = v4;
 }

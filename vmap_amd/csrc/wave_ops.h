@@ -15,6 +15,7 @@ namespace wv {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // four floats at any 4-byte boundary (global_load / store_dwordx4: gfx950 runs in unaligned access mode)
 
 // D = A(32x2) * B(2x32) + C, exact fp32 (bitwise an fmaf chain over k), 64 cycles per SIMD.
 //   a: lane l supplies A[i = l & 31][k = l >> 5]

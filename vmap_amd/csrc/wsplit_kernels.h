@@ -381,15 +381,21 @@ __global__ __launch_bounds__(PG * kFinQuads) void step_finalize_ws(const Finaliz
     i32x4 iw = {0, 0, 0, 0}, it = iw;
     float* pp[4] = {nullptr, nullptr, nullptr, nullptr};
     float pv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const bool pvec = 4 * q + 3 < a.P && ten[0] == ten[3];
     if (tail && a.do_adam) {
         m4 = *reinterpret_cast<const wv::f32x4*>(hh.m + s);
         v4 = *reinterpret_cast<const wv::f32x4*>(hh.v + s);
         iw = *reinterpret_cast<const i32x4*>(hh.img_tab + 4 * q);
         it = *reinterpret_cast<const i32x4*>(tab_wt + 4 * q);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            pp[e] = a.param[ten[e]].p + obj * a.param[ten[e]].stride + off[e];
-            pv[e] = *pp[e];
+        for (int e = 0; e < 4; ++e) pp[e] = a.param[ten[e]].p + obj * a.param[ten[e]].stride + off[e];
+        if (pvec) {                    // a quad inside ONE parameter tensor: one 16-byte access at a 4-byte boundary, in and out
+            const wv::f32x4 p4 = *reinterpret_cast<const wv::f32x4u*>(pp[0]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pv[e] = p4[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pv[e] = *pp[e];
         }
     }
     {
@@ -458,10 +464,12 @@ __global__ __launch_bounds__(PG * kFinQuads) void step_finalize_ws(const Finaliz
         if (4 * q + e < a.P) {
             float p = pv[e], m = m4[e], v = v4[e];
             adamw_elem(hh, ss, bc, g[e], p, m, v);
-            *pp[e] = p; m4[e] = m; v4[e] = v;
+            if (!pvec) *pp[e] = p;
+            pv[e] = p; m4[e] = m; v4[e] = v;
             ws_image_store<NB>(image, iw[e], it[e], p, hh.weights_bf16);
         }
     }
+    if (pvec) *reinterpret_cast<wv::f32x4u*>(pp[0]) = wv::f32x4{pv[0], pv[1], pv[2], pv[3]};
     *reinterpret_cast<wv::f32x4*>(hh.m + s) = m4;
     *reinterpret_cast<wv::f32x4*>(hh.v + s) = v4;
 }
