@@ -435,6 +435,27 @@ def test_co_resident_waves_stay_bit_repeatable(H, n, R, S, weights):
             assert torch.equal(x, y), (rep, i)
 
 
+def test_loss_block_reads_its_partials_from_memory_when_they_do_not_fit_the_staging_area():
+    """The finalize kernels' loss workgroup copies the n_obj x NW loss partials to LDS before one thread per object sums them in order
+    (FinalizeArgs::loss_stage); with more partials than the launch's LDS has room for (1024 at hidden 32) it reads them from memory as
+    it did before round 5.  600 objects x 2 workgroups: loss, per-object terms and gradients against the ATen port."""
+    n, R, S, H = 600, 24, 10, 32
+    fc, B, sc = synth.make_params(n, H, seed=2300)
+    batch = synth.make_batch(n, R, S, seed=2301)
+    c = dict(n=n, R=R, S=S, H=H, fc=fc, B=B, scale=sc, batch=batch)
+    op = make_op(n, R, S, H, device=DEV, tuning={"workgroups_per_object": 2})
+    assert op.plan()["workgroups_per_object"] == 2
+    s = _run(c, op=op)
+    from oracle import vmap_oracle_torch as vt
+    loss_t, rend_t, grads_t = vt.CpuTrainer(fc, B, sc).step(batch, update=False)
+    assert abs(s["loss"] - float(loss_t)) <= 2e-5 * abs(float(loss_t))
+    for k in RENDER_KEYS:
+        assert relerr(s[k], rend_t[k].detach().numpy()) < 2e-5, k
+    if max(relerr(s[k], g.numpy()) for k, g in zip(GRAD_KEYS, grads_t)) >= 1e-4:
+        o = vo.training_step(fc, B, sc, batch, dtype=np.float32, kinks=True)
+        _assert_grads_match_aten_port_up_to_kinks(s, o, grads_t, n)
+
+
 @pytest.mark.parametrize("H", [32, 64, 128, 256, 96])
 def test_far_point_takes_the_library_sincos_path_on_the_device(H):
     """One sample point 3e5 units away: 32 pi |proj| exceeds the fast sincos' range (2^20), so its whole wave takes the library sincosf for
