@@ -64,11 +64,12 @@ void main_ws_t(const vk::WsArgs& wa, bool bwd) {
 void finalize_ws(const vk::FinalizeArgs& f_in, const vk::FinalizeHot& h, const int* tab_wt) {
     vk::FinalizeArgs f = f_in;
     f.loss_stage = vk::loss_stage_cap(vk::kFinThreads * 16);
-    const int grid = f.n_obj * vk::ws_finalize_blocks(f.PP) + 1;
+    f.xcd_affine = f.n_obj >= 8 ? 1 : 0;          // as the library's launcher
+    const int grid = vk::ws_finalize_grid(f.n_obj, f.PP, vk::kFinQuads, f.xcd_affine);
     if (f.hidden == 256) return finalize_ws8(f, h, tab_wt, grid);
     if (!f.ws_grouped) {            // the form the library's launcher picks for many blocks / few rows (here: on request)
         constexpr int Q = vk::kFinQuadsWide;
-        const int lds = vk::kFinGroups * Q * 16, gw = f.n_obj * vk::ws_finalize_blocks(f.PP, Q) + 1;
+        const int lds = vk::kFinGroups * Q * 16, gw = vk::ws_finalize_grid(f.n_obj, f.PP, Q, f.xcd_affine);
         f.loss_stage = vk::loss_stage_cap(lds);
         if (f.hidden == 128) sim::launch(gw, Q, lds, [&] { vk::step_finalize_ws<4, Q, 1>(f, h, tab_wt); });
         else sim::launch(gw, Q, lds, [&] { vk::step_finalize_ws<2, Q, 1>(f, h, tab_wt); });

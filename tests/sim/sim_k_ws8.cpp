@@ -25,7 +25,7 @@ void finalize_ws8(const vk::FinalizeArgs& f_in, const vk::FinalizeHot& h, const 
         constexpr int Q = vk::kFinQuadsWide;
         const int lds = vk::kFinGroups * Q * 16;
         f.loss_stage = vk::loss_stage_cap(lds);
-        sim::launch(f.n_obj * vk::ws_finalize_blocks(f.PP, Q) + 1, Q, lds, [&] { vk::step_finalize_ws<8, Q, 1>(f, h, tab_wt); });
+        sim::launch(vk::ws_finalize_grid(f.n_obj, f.PP, Q, f.xcd_affine), Q, lds, [&] { vk::step_finalize_ws<8, Q, 1>(f, h, tab_wt); });
         return;
     }
     sim::launch(grid, vk::kFinThreads, vk::kFinThreads * 16, [&] { vk::step_finalize_ws<8>(f, h, tab_wt); });

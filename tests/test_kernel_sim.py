@@ -293,6 +293,25 @@ def test_sim_ws_finalize_forms_give_the_same_bits(name, kw):
         assert np.array_equal(st0[k], st1[k]), k
 
 
+def test_sim_ws_finalize_xcd_affine_block_map_with_nine_objects():
+    """From eight objects on step_finalize_ws deals its blocks to the objects in groups of eight (block b -> object 8 * group + b % 8: all blocks
+    of an object on one XCD; a ninth object leaves seven of the second group's eight slots empty).  Both thread forms, against the ATen port."""
+    from oracle import vmap_oracle_torch as vt
+    from vmap_amd import synth
+    n, R, S, H = 9, 6, 10, 64
+    fc, B, sc = synth.make_params(n, H, seed=91)
+    batch = synth.make_batch(n, R, S, seed=92)
+    loss_t, rend_t, grads_t = vt.CpuTrainer(fc, B, sc).step(batch, update=False)
+    ref = np.concatenate([g.numpy().reshape(n, -1) for g in grads_t], axis=1)
+    outs = []
+    for form in (0, 1):
+        s = simlib.sim_step(fc, B, sc, batch, wide=4, NW=1, finalize_form=form)
+        assert abs(s["loss"] - float(loss_t)) <= 2e-5 * abs(float(loss_t))
+        assert relerr(s["grads_flat"][:, :ref.shape[1]], ref) < 1e-4
+        outs.append(s)
+    assert outs[0]["loss"] == outs[1]["loss"] and np.array_equal(outs[0]["grads_flat"], outs[1]["grads_flat"])
+
+
 @pytest.mark.parametrize("name,kw", [("ragged", dict(split=True, NW=2, G=5)), ("ragged", dict(split=True, NW=1)),
                                      ("h64", dict(wide=4, NW=2)), ("h64", dict(wide=3, NW=2)), ("bg_h128_s14", dict(wide=3, NW=3))])
 def test_sim_bf16_weights_in_the_multi_pass_and_multi_round_forms(name, kw):

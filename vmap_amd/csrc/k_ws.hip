@@ -91,20 +91,21 @@ static int finalize_wide(vk::FinalizeArgs f, const vk::FinalizeHot& h, const int
     constexpr int Q = vk::kFinQuadsWide;
     const size_t lds = (size_t)vk::kFinGroups * Q * 4 * sizeof(float);
     f.loss_stage = vk::loss_stage_cap(lds);
-    hipLaunchKernelGGL((vk::step_finalize_ws<NB, Q, 1>), dim3(f.n_obj * vk::ws_finalize_blocks(f.PP, Q) + 1), dim3(Q), lds, st, f, h, tab_wt);
+    hipLaunchKernelGGL((vk::step_finalize_ws<NB, Q, 1>), dim3(vk::ws_finalize_grid(f.n_obj, f.PP, Q, f.xcd_affine)), dim3(Q), lds, st, f, h, tab_wt);
     return launched("step_finalize_ws");
 }
 
 int finalize_ws(const vk::FinalizeArgs& f_in, const vk::FinalizeHot& h, const int* tab_wt, hipStream_t st) {
     vk::FinalizeArgs f = f_in;
     f.loss_stage = vk::loss_stage_cap(vk::kFinThreads * 4 * sizeof(float));       // the row blocks' LDS doubles as the loss block's staging area
-    const int grid = f.n_obj * vk::ws_finalize_blocks(f.PP) + 1;
+    f.xcd_affine = f.n_obj >= 8 ? 1 : 0;                                          // an object's blocks on one XCD (see ws_finalize_grid)
+    const int grid = vk::ws_finalize_grid(f.n_obj, f.PP, vk::kFinQuads, f.xcd_affine);
     if (f.hidden == 256) return finalize_ws8(f, h, tab_wt, grid, st);
     if (finalize_one_thread_per_quad(f)) return f.hidden == 128 ? finalize_wide<4>(f, h, tab_wt, st) : finalize_wide<2>(f, h, tab_wt, st);
     if (f.hidden == 128) {
         // the narrow form where it fills the chip with one block per compute unit and the wide one does not (the background step)
         const int narrow = f.n_obj * vk::ws_finalize_blocks(f.PP, vk::kFinQuadsNarrow);
-        if (narrow <= 256 && grid - 1 < narrow) {
+        if (!f.xcd_affine && narrow <= 256 && grid - 1 < narrow) {
             constexpr int T = vk::kFinGroups * vk::kFinQuadsNarrow;
             f.loss_stage = vk::loss_stage_cap(T * 4 * sizeof(float));
             hipLaunchKernelGGL((vk::step_finalize_ws<4, vk::kFinQuadsNarrow>), dim3(narrow + 1), dim3(T), T * 4 * sizeof(float), st, f, h, tab_wt);

@@ -39,7 +39,7 @@ int finalize_ws8(const vk::FinalizeArgs& f_in, const vk::FinalizeHot& h, const i
         constexpr int Q = vk::kFinQuadsWide;
         const size_t lds = (size_t)vk::kFinGroups * Q * 4 * sizeof(float);
         f.loss_stage = vk::loss_stage_cap(lds);
-        hipLaunchKernelGGL((vk::step_finalize_ws<8, Q, 1>), dim3(f.n_obj * vk::ws_finalize_blocks(f.PP, Q) + 1), dim3(Q), lds, st, f, h, tab_wt);
+        hipLaunchKernelGGL((vk::step_finalize_ws<8, Q, 1>), dim3(vk::ws_finalize_grid(f.n_obj, f.PP, Q, f.xcd_affine)), dim3(Q), lds, st, f, h, tab_wt);
         return launched("step_finalize_ws<8>");
     }
     hipLaunchKernelGGL(vk::step_finalize_ws<8>, dim3(grid), dim3(vk::kFinThreads), vk::kFinThreads * 4 * sizeof(float), st, f_in, h, tab_wt);   // f.loss_stage: set by finalize_ws

@@ -330,6 +330,13 @@ __device__ __forceinline__ void ws_image_store(char* img, int locw, int locwt, f
 #endif
 constexpr int kFinGroups = VK_FIN_GROUPS, kFinQuads = VK_FIN_QUADS, kFinThreads = kFinGroups * kFinQuads;   // 8 row groups x 128 quads: 1024 threads
 __host__ __device__ inline int ws_finalize_blocks(int PP, int fin_quads = kFinQuads) { return (PP / 4 + fin_quads - 1) / fin_quads; }
+// Launch grid of step_finalize_ws (+ 1: the loss block).  With FinalizeArgs::xcd_affine the blocks of ONE object all run on one XCD (block b
+// runs on XCD b % 8: objects are dealt to the XCDs in groups of eight): the update's scattered 2-byte image stores of an object then meet
+// in ONE L2 and leave it as whole lines, instead of as byte-masked fragments of the same lines from eight L2s that are not coherent with
+// each other.  Worth it from eight objects on (launcher's choice).
+__host__ __device__ inline int ws_finalize_grid(int n_obj, int PP, int fin_quads, int xcd_affine) {
+    return (xcd_affine ? 8 * ((n_obj + 7) / 8) : n_obj) * ws_finalize_blocks(PP, fin_quads) + 1;
+}
 // Narrow form: 96 quads per block (1.5 KiB per row).  Taken when it gives EVERY block a compute unit of its own where the 128-quad form does
 // not fill the chip (the one-object background step: 246 instead of 185 blocks): 0.1035 -> 0.1011 ms per step (round 5, tests/tools/finq_probe.py;
 // the kernel's time is the row reads - with the AdamW update and the image rewrite removed it does not change); otherwise slower (more
@@ -356,7 +363,16 @@ __global__ __launch_bounds__(PG * kFinQuads) void step_finalize_ws(const Finaliz
         finalize_loss(a);
         return;
     }
-    const int obj = blockIdx.x / blocks_per_obj, part = blockIdx.x - obj * blocks_per_obj;
+    int obj, part;
+    if (a.xcd_affine) {
+        const int slot = blockIdx.x >> 3, og = slot / blocks_per_obj;
+        obj = og * 8 + (blockIdx.x & 7);
+        part = slot - og * blocks_per_obj;
+        if (obj >= a.n_obj) return;
+    } else {
+        obj = blockIdx.x / blocks_per_obj;
+        part = blockIdx.x - obj * blocks_per_obj;
+    }
     const int ql = threadIdx.x % kFinQuads, rg = threadIdx.x / kFinQuads;
     const int q = min(part * kFinQuads + ql, quads - 1);
     const bool live = part * kFinQuads + ql < quads && 4 * q < a.P;
