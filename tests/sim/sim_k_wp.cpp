@@ -2,8 +2,10 @@
 #include "sim_launch.h"
 
 namespace sl {
-void main_wp(const vk::WsArgs& wa, bool bwd) {
-    const int grid = wa.s.n_obj * wa.s.NW;
+void main_wp(const vk::WsArgs& wa_in, bool bwd) {
+    vk::WsArgs wa = wa_in;
+    wa.s.xcd_affine = wa.s.n_obj >= 8 ? 1 : 0;             // as the library's launcher (k_wp.hip)
+    const int grid = (wa.s.xcd_affine ? 8 * ((wa.s.n_obj + 7) / 8) : wa.s.n_obj) * wa.s.NW;
     if (wa.s.hidden == 128) {
         const int lb = vk::LdsWp<4>::LDS_BYTES;
         if (wa.s.weights_bf16) {

@@ -93,19 +93,31 @@ __global__ __launch_bounds__(128 * NB, 2) void step_main_wp(const WsArgs ga) {
     const GenLayout L = gen_layout(H);
     char* lds = reinterpret_cast<char*>(wv::lds_base());
     const int tid_k = threadIdx.x;
-    const int obj = blockIdx.x / a.NW, wgo = blockIdx.x - obj * a.NW;
+    // xcd_affine (the launcher's choice, from eight objects on): an object's workgroups all on ONE XCD (block b runs on XCD b % 8), so the
+    // object's weight images are fetched into one L2 instead of into as many as it has workgroups
+    int obj, wgo;
+    if (a.xcd_affine) {
+        const int slot = blockIdx.x >> 3, og = slot / a.NW;
+        obj = og * 8 + (blockIdx.x & 7);
+        wgo = slot - og * a.NW;
+        if (obj >= a.n_obj) return;
+    } else {
+        obj = blockIdx.x / a.NW;
+        wgo = blockIdx.x - obj * a.NW;
+    }
+    const int wg_index = obj * a.NW + wgo;               // this workgroup's row / scratch / stamp slot (the block index without the map)
     const char* gimg = reinterpret_cast<const char*>(a.wimg) + (long long)obj * I::BYTES;
     const float* SM = reinterpret_cast<const float*>(gimg + I::SMALL_OFF);
     float* loss_cells = reinterpret_cast<float*>(lds + LD::LOSS);
     if (tid_k < kWaves * 4) loss_cells[tid_k] = 0.0f;
-    float* out_k = a.part_grad + ((long long)(obj * a.NW + wgo)) * a.PP;
+    float* out_k = a.part_grad + (long long)wg_index * a.PP;
     float* cb = reinterpret_cast<float*>(lds + LD::CBO);
     float* hp = reinterpret_cast<float*>(lds + LD::HP);
     float* hx = reinterpret_cast<float*>(lds + LD::HX);
     const float scale = a.pe_scale.p[obj * a.pe_scale.stride];
     const float* Bg = SM + I::PE_B;
-    char* wgs_k = ga.scratch + (long long)blockIdx.x * LD::WG_SCRATCH;
-    unsigned* tmark = STAMPS && a.timing ? a.timing + ((long long)blockIdx.x * kWaves + ((tid_k >> 6) & 3)) * kMarks : nullptr;
+    char* wgs_k = ga.scratch + (long long)wg_index * LD::WG_SCRATCH;
+    unsigned* tmark = STAMPS && a.timing ? a.timing + ((long long)wg_index * kWaves + ((tid_k >> 6) & 3)) * kMarks : nullptr;
 #define WP_MARK(i) do { if constexpr (STAMPS) { if (tmark && first && tid_k < 256 && (tid_k & 63) == 0) tmark[i] = wv::clock32(); } } while (0)
 
     for (int grp = wgo; grp < a.NG; grp += a.NW) {
