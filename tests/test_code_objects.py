@@ -60,3 +60,9 @@ def test_shipped_code_objects_hold_no_affected_instruction(lib, tmp_path):
         assert not bad, (name, bad[:5])
     assert packed > 1000          # the listing really is this library's device code (it is full of packed instructions)
     shutil.rmtree(tmp_path / "dis", ignore_errors=True)
+
+
+@pytest.mark.gpu
+def test_the_library_this_gpu_box_loads_holds_no_affected_instruction(tmp_path):
+    """The same lint on the GPU box (the .so travels there prebuilt): what the parity tests next to this one run is the rewritten code."""
+    test_shipped_code_objects_hold_no_affected_instruction(LIBS[0], tmp_path)
