@@ -524,6 +524,77 @@ def emit(out):
     print(json.dumps(out), flush=True)
 
 
+def multi_rank_region_costs(td, dev, run, barrier, ipf, rays_per_step, flags, reduce_flags, frames=10, repeats=3):
+    """N > 1 only.  (i) the cost of the two collectives a timed region of ONE frame call contains besides the work - the frame's
+    flag all-reduce (4 x steps int32, MAX) and a barrier - each measured alone, back to back on the current stream; (ii) the objects'
+    rate over `frames` frame calls per repeat between barriers (MAX over ranks), where those fixed costs are < 1 % of the region."""
+    cur = torch.cuda.current_stream(dev)
+    K = 50
+    for _ in range(5):
+        reduce_flags(flags)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(cur)
+    for _ in range(K):
+        reduce_flags(flags)
+    e1.record(cur)
+    torch.cuda.synchronize()
+    flag_us = e0.elapsed_time(e1) / K * 1e3
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        td.barrier()
+    torch.cuda.synchronize()
+    barrier_us = (time.perf_counter() - t0) / 20 * 1e6
+    ts = []
+    for _ in range(repeats):
+        barrier()
+        t0 = time.perf_counter()
+        run(frames * ipf)
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+        barrier()
+    t = torch.tensor(ts + [flag_us, barrier_us], dtype=torch.float64, device=dev)
+    td.all_reduce(t, op=td.ReduceOp.MAX)
+    t = [float(x) for x in t.tolist()]
+    el = _median(t[:repeats])
+    return {"flag_allreduce_alone_us_per_frame": t[repeats], "barrier_alone_us": t[repeats + 1],
+            "ten_frame_region": {"frames_per_repeat": frames, "steps_per_repeat": frames * ipf, "ms_per_step": el / (frames * ipf) * 1e3,
+                                 "value": rays_per_step / (el / (frames * ipf)),
+                                 "ms_per_step_repeats": [x / (frames * ipf) * 1e3 for x in t[:repeats]]},
+            "note": "MAX over ranks; `value` of the line is the contract's region (exactly --steps steps); these figures show how much of it "
+                    "is the frame's one collective and how the rate reads when the region is ten frame calls long"}
+
+
+def launch_ranks(n_gpus, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment (WORLD_SIZE unset): start the N ranks HERE - one process per
+    GPU through torch.distributed.run (the same command line the module docstring shows, rendezvous on 127.0.0.1 and a free port),
+    wait for them and hand their exit status on.  Rank 0's JSON line goes straight to this process's stdout.  Refuses (exit status 2,
+    message on stderr) when the box has fewer than N devices instead of reporting a number for fewer ranks - except for the gloo dry
+    run of the multi-rank plumbing (VMAP_BENCH_BACKEND=gloo), where ranks knowingly share devices."""
+    import socket
+    import subprocess
+    backend = os.environ.get("VMAP_BENCH_BACKEND", "nccl")
+    try:
+        have = torch.cuda.device_count()
+    except Exception:
+        have = 0
+    if have < 1 or (backend == "nccl" and have < n_gpus):
+        print(f"bench.py --gpus {n_gpus}: this box exposes {have} GPU(s); a scaling run is one rank per GPU over RCCL - refusing to "
+              f"run fewer ranks and report them as {n_gpus}" + ("" if have < 1 else " (VMAP_BENCH_BACKEND=gloo runs a dry run of the "
+              "multi-rank plumbing with ranks sharing devices; its timings mean nothing)"), file=sys.stderr, flush=True)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n_gpus) // n_gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    print(f"[bench.py] launching {n_gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env, stdin=subprocess.DEVNULL).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -562,6 +633,12 @@ def main():
     ap.add_argument("--no-precision", action="store_true")          # skip the `precision` leg (measured errors of the two hidden-32 kernels)
     ap.add_argument("--pmc-timeout", type=float, default=60.0)      # per rocprofv3 --pmc pass of the traffic observation (it runs LAST, under a watchdog)
     args = ap.parse_args()
+
+    if args.gpus < 1:
+        raise SystemExit(f"bench.py: --gpus {args.gpus}")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: no launcher set the rank environment up, so this process becomes the launcher
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -660,18 +737,32 @@ def main():
     run(args.warmup)
     # the timed region: EXACTLY args.steps steps between barrier + synchronize on both sides - measured args.repeats times back to
     # back (nothing else in between), MAX over ranks per repeat; the line reports the MEDIAN repeat (+ min / max / all)
-    own_times = []
+    # Every rank's clock stops when ITS device has drained (torch.cuda.synchronize()), the closing barrier follows; the line takes
+    # the MAX over ranks = the moment the last rank finished, counted from the common start.  (Stopping the clock behind the closing
+    # barrier instead adds one RCCL barrier to a region that is ONE frame call at the driver's K = 20 - that figure is reported next
+    # to it as `incl_closing_barrier`.)
+    own_times, own_times_b = [], []
     for _ in range(max(1, args.repeats)):
         barrier()
         t0 = time.perf_counter()
         run(args.steps)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
         barrier()
-        own_times.append(time.perf_counter() - t0)
-    times = list(own_times)
+        own_times.append(t1 - t0)
+        own_times_b.append(time.perf_counter() - t0)
+    times, times_b = list(own_times), list(own_times_b)
     if dist:
-        t = torch.tensor(own_times, dtype=torch.float64, device=dev)
+        t = torch.tensor(own_times + own_times_b, dtype=torch.float64, device=dev)
         td.all_reduce(t, op=td.ReduceOp.MAX)
-        times = [float(x) for x in t.tolist()]
+        t = [float(x) for x in t.tolist()]
+        times, times_b = t[:len(own_times)], t[len(own_times):]
+    # N > 1: what the region's collectives cost on their own, and the same measurement over TEN frame calls per repeat (a barrier is
+    # then < 1 % of the region): reported beside `value`, which stays EXACTLY --steps steps per the contract
+    region = None
+    if dist:
+        region = multi_rank_region_costs(td, dev, run, barrier, ipf, n * R * world,
+                                         flags=torch.zeros(ipf, 4, dtype=torch.int32, device=dev), reduce_flags=flag_reduce)
     elapsed = _median(times)
     elapsed_own = _median(own_times)
     ms_per_step = elapsed / args.steps * 1e3
@@ -679,7 +770,8 @@ def main():
     value = rays_per_step / (elapsed / args.steps)
     repeats_info = {"n": len(times), "ms_per_step": [x / args.steps * 1e3 for x in times], "ms_per_step_min": min(times) / args.steps * 1e3,
                     "ms_per_step_max": max(times) / args.steps * 1e3, "reported": "median",
-                    "each": f"{args.steps} steps between barrier + torch.cuda.synchronize(), MAX over ranks"}
+                    "each": f"{args.steps} steps: barrier + torch.cuda.synchronize(), clock, the steps, torch.cuda.synchronize(), clock, barrier; MAX over ranks",
+                    "ms_per_step_incl_closing_barrier": _median(times_b) / args.steps * 1e3}
 
     # every rank's own clock around the timed region (the line reports MAX over ranks as ms_per_step, per the contract)
     per_rank_ms = [ms_per_step]
@@ -909,7 +1001,7 @@ def main():
             "preheat": {"ms": args.preheat_ms, "steps": preheat_steps, "timed": False},
             "with_background": with_bg,
             "world": {"world_size": world, "devices": devices, "rccl": rccl_version, "backend": backend if dist else None,
-                      "ms_per_step_per_rank": per_rank_ms},
+                      "ms_per_step_per_rank": per_rank_ms, "region_costs": region},
             "frame": None,
             "frame_call": ("marshalled per call" if bound is None else
                            "bound (arguments marshalled once), replayed as a hipGraph per frame (device-resident optimiser step count)" if bound.graph

@@ -261,3 +261,43 @@ def test_bench_runs_with_two_ranks_on_one_gpu(tmp_path):
     assert wb["owner_computes"]["beside_objects_ms_per_step"] > 0
     assert len(j["world"]["ms_per_step_per_rank"]) == 2 and max(j["world"]["ms_per_step_per_rank"]) <= j["ms_per_step"] * 1.0001
     assert j["world"]["world_size"] == 2 and len(j["world"]["devices"]) == 2 and j["world"]["backend"] == "gloo"
+
+
+def test_plain_bench_gpus_2_starts_its_own_ranks(tmp_path):
+    """plain `python bench.py --gpus 2` - no torch.distributed.run around it, no rank environment - must start
+    its two ranks itself and print ONE line with n_gpus == 2 (gloo dry-run backend: both ranks share the box's one device), with the
+    region's collective costs and the ten-frame region beside `value`."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VMAP_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR", "GROUP_RANK", "LOCAL_WORLD_SIZE", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--preheat-ms", "30",
+           "--profile-reps", "20", "--no-background"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 20 and j["scaling"] == "weak" and j["value"] > 0
+    assert j["world"]["world_size"] == 2 and len(j["world"]["devices"]) == 2 and len(j["world"]["ms_per_step_per_rank"]) == 2
+    rc = j["world"]["region_costs"]
+    assert rc["flag_allreduce_alone_us_per_frame"] > 0 and rc["barrier_alone_us"] > 0
+    assert rc["ten_frame_region"]["steps_per_repeat"] == 200 and rc["ten_frame_region"]["value"] > 0
+    assert j["repeats"]["ms_per_step_incl_closing_barrier"] >= j["ms_per_step"]
+
+
+def test_plain_bench_refuses_more_ranks_than_devices():
+    """... and over RCCL it refuses loudly (exit status 2, a message) when the box has fewer devices than --gpus, instead of running
+    one rank and printing n_gpus 1 (what round 5's file did)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    want = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "VMAP_BENCH_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(want), "--steps", "20", "--warmup", "5"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2, (r.returncode, r.stderr[-1000:])
+    assert "refusing" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]

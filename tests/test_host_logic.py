@@ -174,3 +174,19 @@ def test_ray_points_container_shapes_and_slices():
         step.RayPoints(o, d, c[:2])
     with pytest.raises(IndexError):
         r[0]
+
+
+def test_plain_bench_gpus_n_refuses_without_devices():
+    """`python bench.py --gpus 2` without a launcher environment becomes its own launcher (bench.launch_ranks); on a box with fewer
+    devices than ranks (this container: none) it must leave with status 2 and say why - never run fewer ranks under the label N."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("box has two devices: the launch itself is covered by the GPU tier")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "VMAP_BENCH_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2, (r.returncode, r.stderr[-1000:])
+    assert "refusing" in r.stderr and "{" not in r.stdout
