@@ -98,7 +98,13 @@ def gpu_reference_baseline(cfg, dev, budget_s=3.0):
     on THIS GPU through PyTorch-ROCm, for ~budget_s.  None where the reference cannot be imported."""
     rr = _reference_runner()
     if rr is None:
-        return None
+        # say WHY the north star's denominator is missing (no source tree here and oracle/_ref absent / compiled by another Python)
+        try:
+            from oracle import make_ref
+            why = make_ref.why_unavailable()
+        except Exception as e:      # noqa: BLE001
+            why = f"{type(e).__name__}: {e}"
+        return {"error": f"the reference cannot be imported on this box: {why}"}
     fc, B, sc = synth.make_params(cfg["n_obj"], cfg["H"], scale=cfg["scale"], seed=0)
     batch = synth.make_batch(cfg["n_obj"], cfg["R"], cfg["S"], seed=1)
     tr = rr.ReferenceTrainer(fc, B, sc, cfg["H"], device=dev)
@@ -1044,7 +1050,10 @@ def main():
                 out["frame"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and args.config == "replica_room0_vmap" and args.kernel == "auto" and not args.no_other_configs:
             # the other BASELINE configurations and the background step, measured like `value` (driver-visible; never part of it)
-            legs = (("configs[0]", "imap_plumbing", "f32", False), ("configs[3]", "scannet0024_vmap", "bf16", False),
+            legs = (("configs[0]", "imap_plumbing", "f32", False),
+                    # the config-faithful iMAP batch (configs/Replica/config_replica_room0_iMAP.json: n_per_optim 4800, 9 + 5 bins, hidden 256)
+                    ("configs[0]_as_the_reference_config_4800_rays", "imap_full", "f32", False),
+                    ("configs[3]", "scannet0024_vmap", "bf16", False),
                     ("configs[3]_f32_weights", "scannet0024_vmap", "f32", False),
                     ("configs[4]_per_gpu_share", "stress_rank8", "bf16", False), ("configs[4]_on_one_gpu", "stress_256x64", "bf16", False),
                     ("background_step", "background", "f32", False),

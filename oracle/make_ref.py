@@ -56,6 +56,10 @@ def build(reference_root="/root/reference", force=False):
                            invalidation_mode=py_compile.PycInvalidationMode.UNCHECKED_HASH)
     import torch
     man = {"what": "kxhit/vMAP hot-path modules byte-compiled unmodified from reference_root (no source is copied)",
+           "basis": "a build artefact of the reference's own files, produced where they lie by this committed recipe and written only under "
+                    "oracle/_ref/ (git-ignored; never committed, never imported by the product package vmap_amd/) - the Python counterpart "
+                    "of compiling a C reference into oracle/_ref/*.so; the reference's licence file (if any) stays with its sources at "
+                    "reference_root, and the modules are used only as the checker / timed baseline",
            "reference_root": reference_root, "modules": list(MODULES), "sha256": shas, "bytecode_magic": magic,
            "python": sys.version.split()[0], "torch_version_at_build": torch.__version__}
     with open(MANIFEST, "w") as fh:
@@ -71,11 +75,24 @@ def load_manifest():
         return None
 
 
+def why_unavailable():
+    """None when the compiled modules are there AND this interpreter can load them; else the reason, in words (bench.py prints it
+    instead of a bare null when the north star's denominator cannot be measured on a box)."""
+    man = load_manifest()
+    if not man:
+        return f"no {os.path.relpath(MANIFEST, os.path.dirname(HERE))} (oracle/make_ref.py builds oracle/_ref where /root/reference exists)"
+    if man.get("bytecode_magic") != importlib.util.MAGIC_NUMBER.hex():
+        return (f"bytecode magic mismatch: oracle/_ref was compiled by Python {man.get('python')} (magic {man.get('bytecode_magic')}), "
+                f"this interpreter is {sys.version.split()[0]} (magic {importlib.util.MAGIC_NUMBER.hex()})")
+    missing = [m for m in MODULES if not os.path.exists(os.path.join(REF_DIR, m + ".pyc"))]
+    if missing:
+        return f"oracle/_ref lacks {missing}"
+    return None
+
+
 def available():
     """True when the compiled modules are there AND this interpreter can load them (same bytecode magic)."""
-    man = load_manifest()
-    return bool(man and man.get("bytecode_magic") == importlib.util.MAGIC_NUMBER.hex()
-                and all(os.path.exists(os.path.join(REF_DIR, m + ".pyc")) for m in MODULES))
+    return why_unavailable() is None
 
 
 if __name__ == "__main__":

@@ -54,10 +54,8 @@ def test_mapping_pipeline_learns_a_synthetic_scene():
     from vmap_amd.driver import HipMapper
     from vmap_amd.keyframes import FrameStore, ObjectKeyframes
     from vmap_amd.trainer import SimpleConfig, Trainer
-    import random
     dev = "cuda:0"
     torch.manual_seed(0)
-    random.seed(0)                     # the keyframe pruning draws from Python's generator (vmap.py:259-262)
     cfg = SimpleConfig(training_device=dev, hidden_feature_size=32, n_iter_per_frame=20, n_per_optim=120, win_size=5)
     ITERS, F, P, n1, n2 = cfg.n_iter_per_frame, 100, 24, 1, 9                     # 100 frames x 24 pixels = 20 x 120 rays
     store = FrameStore(12, W, H, device=dev)
@@ -78,12 +76,11 @@ def test_mapping_pipeline_learns_a_synthetic_scene():
             if not (inst == oid).any():
                 continue
             if oid not in oks:                                                    # new object: train.py:146-164
-                oks[oid] = ObjectKeyframes(store, oid, slot, bbox_of(inst, oid), fid, keyframe_buffer_size=6, keyframe_step=2,
-                                           center=tuple(float(v) for v in c))
+                oks[oid] = ObjectKeyframes(store, oid, slot, bbox_of(inst, oid), keyframe_buffer_size=6, center=tuple(float(v) for v in c))
                 trainers[oid] = Trainer(SimpleConfig(training_device=dev, hidden_feature_size=32, obj_scale=1.0))
                 mapper.add_object(trainers[oid])
             else:
-                oks[oid].append_keyframe(slot, bbox_of(inst, oid), fid)
+                oks[oid].append(slot, bbox_of(inst, oid))
         store.collect()
         smp.set_objects([oks[o].sampler_entry() for o in sorted(oks)])
         fr = smp.sample()

@@ -15,8 +15,8 @@ int main_v(const vk::StepArgs& a, hipStream_t st) {
     ga.s = a;
     ga.scratch = reinterpret_cast<char*>(a.gen_scratch);
     ga.tab_wt = a.tab_wt;
-    ga.s.xcd_affine = a.n_obj >= 8 ? 1 : 0;
-    VL_LAUNCH_MAIN(kern, dim3((ga.s.xcd_affine ? 8 * ((a.n_obj + 7) / 8) : a.n_obj) * a.NW), dim3(LD::NTH), LD::LDS_BYTES, st, ga);
+    // a.xcd_affine (an object's workgroups on one XCD; this family: from eight objects on) is decided once, in fill_step_args
+    VL_LAUNCH_MAIN(kern, dim3((a.xcd_affine ? 8 * ((a.n_obj + 7) / 8) : a.n_obj) * a.NW), dim3(LD::NTH), LD::LDS_BYTES, st, ga);
     return launched("step_main_wp");
 }
 template <int NB>

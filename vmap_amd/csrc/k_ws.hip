@@ -1,7 +1,6 @@
 // k_ws.hip - hidden 64 / 128 on the bf16 matrix pipe, one wave per output block (wsplit_kernels.h): step_prep_ws,
 // step_main_ws, step_finalize_ws (the last two also serve step_main_wp).  The background model's path.  gfx950 only.
-#include "launch.h"
-#include "wsplit_kernels.h"
+#include "ws_launch.h"
 
 namespace vl {
 
@@ -82,39 +81,20 @@ int prep_ws(const vk::StepArgs& a, int n_steps, hipStream_t st) {
     return launched("step_prep_ws");
 }
 
-// many blocks, few rows per object: the form in which one thread per quad walks all row groups (see step_finalize_ws)
-static bool finalize_one_thread_per_quad(const vk::FinalizeArgs& f) {
-    return !f.ws_grouped && f.NW <= 16 && (long long)f.n_obj * vk::ws_finalize_blocks(f.PP) >= 512;
-}
-template <int NB>
-static int finalize_wide(vk::FinalizeArgs f, const vk::FinalizeHot& h, const int* tab_wt, hipStream_t st) {
-    constexpr int Q = vk::kFinQuadsWide;
-    const size_t lds = (size_t)vk::kFinGroups * Q * 4 * sizeof(float);
-    f.loss_stage = vk::loss_stage_cap(lds);
-    hipLaunchKernelGGL((vk::step_finalize_ws<NB, Q, 1>), dim3(vk::ws_finalize_grid(f.n_obj, f.PP, Q, f.xcd_affine)), dim3(Q), lds, st, f, h, tab_wt);
-    return launched("step_finalize_ws");
-}
-
-int finalize_ws(const vk::FinalizeArgs& f_in, const vk::FinalizeHot& h, const int* tab_wt, hipStream_t st) {
-    vk::FinalizeArgs f = f_in;
-    f.loss_stage = vk::loss_stage_cap(vk::kFinThreads * 4 * sizeof(float));       // the row blocks' LDS doubles as the loss block's staging area
-    f.xcd_affine = f.n_obj >= 8 ? 1 : 0;                                          // an object's blocks on one XCD (see ws_finalize_grid)
-    const int grid = vk::ws_finalize_grid(f.n_obj, f.PP, vk::kFinQuads, f.xcd_affine);
-    if (f.hidden == 256) return finalize_ws8(f, h, tab_wt, grid, st);
+int finalize_ws(const vk::FinalizeArgs& f, const vk::FinalizeHot& h, const int* tab_wt, hipStream_t st) {
+    // (f.xcd_affine - an object's blocks on one XCD, see ws_finalize_grid - is decided once, in fill_finalize_args)
+    if (f.hidden == 256) return finalize_ws8(f, h, tab_wt, st);
     if (finalize_one_thread_per_quad(f)) return f.hidden == 128 ? finalize_wide<4>(f, h, tab_wt, st) : finalize_wide<2>(f, h, tab_wt, st);
     if (f.hidden == 128) {
         // the narrow form where it fills the chip with one block per compute unit and the wide one does not (the background step)
         const int narrow = f.n_obj * vk::ws_finalize_blocks(f.PP, vk::kFinQuadsNarrow);
-        if (!f.xcd_affine && narrow <= 256 && grid - 1 < narrow) {
+        if (!f.xcd_affine && narrow <= 256 && vk::ws_finalize_grid(f.n_obj, f.PP, vk::kFinQuads, 0) - 1 < narrow) {
             constexpr int T = vk::kFinGroups * vk::kFinQuadsNarrow;
-            f.loss_stage = vk::loss_stage_cap(T * 4 * sizeof(float));
-            hipLaunchKernelGGL((vk::step_finalize_ws<4, vk::kFinQuadsNarrow>), dim3(narrow + 1), dim3(T), T * 4 * sizeof(float), st, f, h, tab_wt);
-            return launched("step_finalize_ws");
+            return launch_finalize_ws<4, vk::kFinQuadsNarrow, vk::kFinGroups>(f, h, tab_wt, narrow, T, T * 4 * sizeof(float), st);
         }
-        hipLaunchKernelGGL(vk::step_finalize_ws<4>, dim3(grid), dim3(vk::kFinThreads), vk::kFinThreads * 4 * sizeof(float), st, f, h, tab_wt);
-    } else
-        hipLaunchKernelGGL(vk::step_finalize_ws<2>, dim3(grid), dim3(vk::kFinThreads), vk::kFinThreads * 4 * sizeof(float), st, f, h, tab_wt);
-    return launched("step_finalize_ws");
+        return finalize_grouped<4>(f, h, tab_wt, st);
+    }
+    return finalize_grouped<2>(f, h, tab_wt, st);
 }
 
 }  // namespace vl

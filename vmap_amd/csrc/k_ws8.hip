@@ -1,8 +1,7 @@
 // k_ws8.hip - hidden 256 (the iMAP field, configs/Replica/config_replica_room0_iMAP.json) on the bf16 matrix pipe: step_main_ws<8>
 // (wsplit_kernels.h with EIGHT waves, one output block each, single-tile rounds), its prep and finalize.  Its own translation
 // unit so that it compiles next to k_ws.hip.  gfx950 only.
-#include "launch.h"
-#include "wsplit_kernels.h"
+#include "ws_launch.h"
 
 namespace vl {
 
@@ -33,17 +32,9 @@ int prep_ws8(const vk::WsArgs& ga, int n_steps, hipStream_t st) {
     return launched("step_prep_ws<8>");
 }
 
-int finalize_ws8(const vk::FinalizeArgs& f_in, const vk::FinalizeHot& h, const int* tab_wt, int grid, hipStream_t st) {
-    if (!f_in.ws_grouped && f_in.NW <= 16 && grid - 1 >= 512) {      // many blocks, few rows: one thread per quad walks all row groups (as finalize_ws does)
-        vk::FinalizeArgs f = f_in;
-        constexpr int Q = vk::kFinQuadsWide;
-        const size_t lds = (size_t)vk::kFinGroups * Q * 4 * sizeof(float);
-        f.loss_stage = vk::loss_stage_cap(lds);
-        hipLaunchKernelGGL((vk::step_finalize_ws<8, Q, 1>), dim3(vk::ws_finalize_grid(f.n_obj, f.PP, Q, f.xcd_affine)), dim3(Q), lds, st, f, h, tab_wt);
-        return launched("step_finalize_ws<8>");
-    }
-    hipLaunchKernelGGL(vk::step_finalize_ws<8>, dim3(grid), dim3(vk::kFinThreads), vk::kFinThreads * 4 * sizeof(float), st, f_in, h, tab_wt);   // f.loss_stage: set by finalize_ws
-    return launched("step_finalize_ws<8>");
+int finalize_ws8(const vk::FinalizeArgs& f, const vk::FinalizeHot& h, const int* tab_wt, hipStream_t st) {
+    if (finalize_one_thread_per_quad(f)) return finalize_wide<8>(f, h, tab_wt, st);       // the same predicate as the other widths
+    return finalize_grouped<8>(f, h, tab_wt, st);
 }
 
 }  // namespace vl

@@ -49,7 +49,7 @@ int finalize_ws(const vk::FinalizeArgs& f, const vk::FinalizeHot& h, const int* 
 // k_ws8.hip: hidden 256 on the same scheme with eight waves (called through main_ws / prep_ws / finalize_ws)
 int main_ws8(const vk::StepArgs& a, bool bwd, hipStream_t st);
 int prep_ws8(const vk::WsArgs& ga, int n_steps, hipStream_t st);
-int finalize_ws8(const vk::FinalizeArgs& f, const vk::FinalizeHot& h, const int* tab_wt, int grid, hipStream_t st);
+int finalize_ws8(const vk::FinalizeArgs& f, const vk::FinalizeHot& h, const int* tab_wt, hipStream_t st);
 
 // k_misc.hip: inference query and the frame sampler
 int query_points(int hidden, const vk::StepArgs& pack, const vk::QueryArgs& q, long long n_points, hipStream_t st);

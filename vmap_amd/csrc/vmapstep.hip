@@ -255,8 +255,13 @@ void fill_step_args(vk::StepArgs& a, const vmapstep_shape* sh, const Plan& pl, c
     std::memset(&a, 0, sizeof(a));
     a.n_obj = sh->n_obj; a.R = sh->rays; a.S = sh->samples;
     a.G = pl.G; a.NG = pl.NG; a.NW = pl.NW; a.PP = L.PP; a.tiles = pl.tiles;
-    // XCD-affine block map only while every XCD's share still fits its 32 CUs in one round
-    a.xcd_affine = (!pl.generic && ((sh->n_obj + 7) / 8) * pl.NW <= 32) ? 1 : 0;
+    // XCD-affine block map (an object's workgroups on ONE XCD / L2), decided HERE for every kernel family - the launchers, the
+    // phase-profile workgroup count and fill_finalize_args read this one value:
+    //  * hidden 32 (step_main_s32 / _h32): only while every XCD's share still fits its 32 CUs in one round;
+    //  * step_main_wp (hidden 64, two workgroups per CU): from eight objects on (the grid is padded to whole groups of eight objects;
+    //    measured: a rank's share of configs[4] 0.2207 -> 0.2112 ms, profiles/round5q_*);
+    //  * step_main_ws / _gen / _wide: never (one object, or no per-object L2 reuse to keep).
+    a.xcd_affine = pl.wide == 4 ? (sh->n_obj >= 8 ? 1 : 0) : (!pl.generic && ((sh->n_obj + 7) / 8) * pl.NW <= 32) ? 1 : 0;
     for (int t = 0; t < VMAPSTEP_NUM_FC; ++t) a.fc[t] = {params->fc[t].ptr, params->fc[t].obj_stride};
     a.pe_B = {params->pe_B.ptr, params->pe_B.obj_stride};
     a.pe_scale = {pe_scale->ptr, pe_scale->obj_stride};
@@ -342,7 +347,9 @@ void fill_finalize_args(vk::FinalizeArgs& f, const vk::StepArgs& a, const Layout
             f.adam_tab = opt->bias_table; f.adam_cnt = opt->step_counter; f.adam_i = step_in_call; f.adam_len = opt->table_len;
         }
     }
-    f.xcd_affine = (a.xcd_affine && have_grad) ? 1 : 0;
+    // the finalize's own block -> object map: hidden 32 follows the main kernel's; step_finalize_ws (hidden >= 64) deals an object's
+    // blocks to one XCD from eight objects on (its scattered 2-byte image stores then merge in one L2: profiles/round5p_*)
+    f.xcd_affine = !have_grad ? 0 : a.wide >= 3 ? (a.n_obj >= 8 ? 1 : 0) : a.xcd_affine;
 }
 
 // the per-quad fields of a finalize (vk::FinalizeHot) from its FinalizeArgs

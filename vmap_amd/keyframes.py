@@ -1,4 +1,4 @@
-"""Shared keyframe store + the reference's per-object keyframe policy on top of it.
+"""Shared keyframe store + the per-object table the batched sampler reads.  STORAGE ONLY.
 
 The reference gives every object its own copy of every keyframe it keeps: ``rgbs_batch [K,W,H,4]`` u8 (RGB + pixel
 state), ``depth_batch [K,W,H]`` f32, ``t_wc_batch [K,4,4]`` (vmap.py:143-176) - 130 MB per object at 20 x 1200 x 680,
@@ -6,11 +6,13 @@ state), ``depth_batch [K,W,H]`` f32, ``t_wc_batch [K,4,4]`` (vmap.py:143-176) - 
 
 ``FrameStore``       device ring of C frames: ``rgbx`` u8 [C,W,H,4] (byte 3 unused), ``depth`` f32 [C,W,H],
                      ``inst`` i32 [C,W,H] (instance ids, -1 = unknown), ``t_wc`` f32 [C,4,4]; reference-counted slots.
-``ObjectKeyframes``  per object: the table keyframe index -> store slot, the 2-D boxes, and exactly the bookkeeping of
-                     ``sceneObject.append_keyframe`` / ``prune_keyframe`` (vmap.py:205-262): every ``keyframe_step``-th
-                     frame becomes a keyframe, other frames overwrite the newest entry, a full buffer overwrites
-                     ``kf_pointer`` and prunes a random keyframe other than the latest two (``random.choice``, so the
-                     decisions are reproducible against the reference under the same ``random.seed``).
+``ObjectKeyframes``  per object: the table keyframe index -> store slot, the 2-D boxes, the two latest keyframe indices - what
+                     ``vmapstep_sample_object`` needs, nothing else.  WHICH frame becomes a keyframe and which entry a full
+                     buffer overwrites or prunes (``sceneObject.append_keyframe`` / ``prune_keyframe``, vmap.py:205-262) is
+                     keyframe POLICY: out of scope and left with the caller, who calls ``write(k, ...)``
+                     where the reference writes ``rgbs_batch[k] / depth_batch[k] / t_wc_batch[k] / bbox[k]`` and
+                     ``note_latest(k)`` where it appends to its latest-keyframe queue.  ``append`` is this package's own
+                     minimal stand-in for tests and demos (every frame a keyframe, oldest entry overwritten when full).
 
 The pixel state the reference bakes into byte 3 per object (train.py:128-130: 1 = this object, 2 = unknown, 0 = other) is
 derived by the sampler kernel from ``inst`` and the object's id at gather time (``vmapstep_sample_object.slots/inst``),
@@ -18,8 +20,7 @@ so the batched sampler reads the shared store directly: ``FrameSampler.set_objec
 """
 from __future__ import annotations
 
-import random
-from typing import Dict, List, Optional
+from typing import List
 
 import torch
 
@@ -75,81 +76,51 @@ class FrameStore:
 
 
 class ObjectKeyframes:
-    """Keyframe bookkeeping of ONE object over a shared FrameStore; same decisions as vmap.py:205-262."""
+    """The keyframe table of ONE object over a shared FrameStore (storage only; the keyframe policy is the caller's)."""
 
-    def __init__(self, store: FrameStore, obj_id: int, first_slot: int, bbox_2d, frame_id: int = 0,
-                 keyframe_buffer_size: int = 20, keyframe_step: int = 25, center=(0.0, 0.0, 0.0)):
+    def __init__(self, store: FrameStore, obj_id: int, first_slot: int, bbox_2d, keyframe_buffer_size: int = 20, center=(0.0, 0.0, 0.0)):
         self.store, self.obj_id = store, int(obj_id)
-        self.keyframe_buffer_size, self.keyframe_step = int(keyframe_buffer_size), int(keyframe_step)
-        self.n_keyframes = 1                                  # vmap.py:128
-        self.kf_pointer: Optional[int] = None
-        self.kf_id_dict: Dict[int, int] = {int(frame_id): 0}  # frame id -> keyframe index (insertion ordered, like bidict)
-        self.kf_buffer_full = False
-        self.frame_cnt = 0
-        self.lastest_kf_queue: List[int] = []
+        self.keyframe_buffer_size = int(keyframe_buffer_size)
+        self.n_keyframes = 0
+        self.latest: List[int] = []                           # the (up to) two newest keyframe indices, oldest first
         self.slots = [-1] * self.keyframe_buffer_size        # keyframe index -> store slot
         self.bbox = torch.zeros(self.keyframe_buffer_size, 4, dtype=torch.float32, device=store.device)
         self.center = tuple(float(c) for c in center)
         self._slots_dev = torch.zeros(self.keyframe_buffer_size, dtype=torch.int32, device=store.device)
-        self._set(0, first_slot, bbox_2d)
+        self._next = 0                                        # append()'s ring position once the table is full
+        self.write(0, first_slot, bbox_2d)
+        self.note_latest(0)
 
-    # ---- storage of one entry -------------------------------------------------------------------------------
-    def _set(self, k: int, slot: int, bbox_2d):
+    def write(self, k: int, slot: int, bbox_2d):
+        """Entry k := frame in store slot `slot` with its 2-D box (the old entry's frame loses a reference)."""
+        if not 0 <= k < self.keyframe_buffer_size:
+            raise IndexError(f"keyframe index {k} outside the table of {self.keyframe_buffer_size}")
         if self.slots[k] >= 0:
             self.store.release(self.slots[k])
         self.store.retain(slot)
         self.slots[k] = int(slot)
         self._slots_dev[k] = int(slot)
         self.bbox[k] = torch.as_tensor(bbox_2d, dtype=torch.float32)
+        self.n_keyframes = max(self.n_keyframes, k + 1)
 
-    def _inv_set(self, k: int, frame_id: int):
-        """``kf_id_dict.inv[k] = frame_id`` of the reference's ``bidict`` (bidict==0.22.0, environment.yml:77; restated from
-        its published ``BidictBase._write``): the forward item whose value is k is dropped and ``frame_id -> k`` is
-        inserted as the NEWEST item - the forward mapping is an insertion-ordered dict and ``prune_keyframe`` protects
-        its last two items.  Re-assigning the same pair is a no-op; a frame id that already maps to another keyframe
-        raises, as bidict's default ``on_dup`` does."""
-        frame_id = int(frame_id)
-        if self.kf_id_dict.get(frame_id, None) == k:
-            return
-        if frame_id in self.kf_id_dict:
-            raise ValueError(f"frame id {frame_id} already names keyframe {self.kf_id_dict[frame_id]}")
-        for f, v in list(self.kf_id_dict.items()):
-            if v == k:
-                del self.kf_id_dict[f]
-        self.kf_id_dict[frame_id] = k
+    def note_latest(self, k: int):
+        """k is now the newest keyframe (the sampler draws a fixed share of its rays from the latest two)."""
+        self.latest = [i for i in self.latest if i != k][-1:] + [int(k)]
 
-    # ---- vmap.py:205-257 ------------------------------------------------------------------------------------
-    def append_keyframe(self, slot: int, bbox_2d, frame_id: int = 1):
-        assert self.n_keyframes <= self.keyframe_buffer_size - 1
-        is_kf = (self.frame_cnt % self.keyframe_step == 0) or self.n_keyframes == 1
-        if self.n_keyframes == self.keyframe_buffer_size - 1:          # buffer full: overwrite kf_pointer, maybe prune
-            self.kf_buffer_full = True
-            if self.kf_pointer is None:
-                self.kf_pointer = self.n_keyframes
-            self._set(self.kf_pointer, slot, bbox_2d)
-            self._inv_set(self.kf_pointer, frame_id)
-            if is_kf:
-                self.lastest_kf_queue.append(self.kf_pointer)
-                _, pruned_kf_id = self.prune_keyframe()
-                self.kf_pointer = pruned_kf_id
+    def append(self, slot: int, bbox_2d) -> int:
+        """This package's stand-in policy (NOT the reference's): every frame becomes a keyframe; a full table overwrites its oldest
+        entry.  Returns the index written."""
+        if self.n_keyframes < self.keyframe_buffer_size:
+            k = self.n_keyframes
         else:
-            if not is_kf:                                              # not a keyframe: replace the newest entry
-                self._set(self.n_keyframes - 1, slot, bbox_2d)
-                self._inv_set(self.n_keyframes - 1, frame_id)
-            else:                                                      # new keyframe
-                self.kf_id_dict[int(frame_id)] = self.n_keyframes
-                self._set(self.n_keyframes, slot, bbox_2d)
-                self.lastest_kf_queue.append(self.n_keyframes)
-                self.n_keyframes += 1
-        self.frame_cnt += 1
-        if len(self.lastest_kf_queue) > 2:
-            self.lastest_kf_queue = self.lastest_kf_queue[-2:]
-
-    def prune_keyframe(self):
-        return random.choice(list(self.kf_id_dict.items())[:-2])       # vmap.py:259-262: never the latest two
+            k = self._next
+            self._next = (self._next + 1) % self.keyframe_buffer_size
+        self.write(k, slot, bbox_2d)
+        self.note_latest(k)
+        return k
 
     # ---- what the batched sampler needs (vmapstep_sample_object in shared-store mode) ------------------------
     def sampler_entry(self) -> dict:
-        last2 = (self.lastest_kf_queue + [0, 0])[:2] if len(self.lastest_kf_queue) < 2 else self.lastest_kf_queue[-2:]
+        last2 = (self.latest + [0, 0])[:2] if len(self.latest) < 2 else self.latest[-2:]
         return dict(store=self.store, slots=self._slots_dev, bbox=self.bbox, n_keyframes=self.n_keyframes,
                     last2=tuple(int(v) for v in last2), center=self.center, obj_id=self.obj_id)

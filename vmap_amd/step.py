@@ -41,7 +41,15 @@ class RayPoints:
         return r
 
     @property
-    def shape(self):                   # (n, rays, ...) like the points tensor, for the callers that read pcs.shape[1]
+    def rays(self) -> int:             # rays per object
+        return int(self.origins.shape[-2])
+
+    @property
+    def shape(self):                   # (n, rays, None, 3) like the points tensor, for callers that read pcs.shape[0] / [1]; the sample
+                                       # count is not a property of the rays - read it from z
+        if self.origins.dim() != 3:
+            raise ValueError("RayPoints.shape: a one-object bundle without the object dimension ([R, 3]) has no [n, R, S, 3] shape; "
+                             "unsqueeze(0) it first (RayPoints.rays gives its ray count)")
         return tuple(self.origins.shape[:2]) + (None, 3)
 
     def __getitem__(self, idx):
@@ -228,6 +236,8 @@ class VmapStep:
             b.ray_o_stride[:] = rays.origins.stride()
             b.ray_d_stride[:] = rays.dirs.stride()
             if rays.centers is not None:
+                if rays.centers.stride(-1) != 1:             # the ABI carries one stride for the centres (per object); bundles built by
+                    raise ValueError("centers: need unit inner stride")      # unsqueeze() / slicing bypass __init__'s check
                 b.center, b.center_stride = rays.centers.data_ptr(), rays.centers.stride(0)
         b.z_stride[:] = z.stride()
         b.gt_depth_stride[:] = gt_depth.stride()
