@@ -110,7 +110,8 @@ def test_mapping_pipeline_learns_a_synthetic_scene():
         occ_fr, _ = tr.eval_points(front)
         print("object", oid, "occupancy behind the surface", occ_sh.tolist(), "in front", occ_fr.tolist())
         assert float(occ_fr.max()) < 0.2 and float(occ_sh.min()) > 0.5, (oid, occ_sh.tolist(), occ_fr.tolist())
-    # the keyframe policy ran into its buffer limit and the shared store holds each frame once
-    assert any(ok.kf_buffer_full for ok in oks.values())
+    # the tables ran into their limit (16 frames, 6 entries: the stand-in policy overwrote old entries) and the shared store holds
+    # each kept frame once
+    assert any(ok.n_keyframes == ok.keyframe_buffer_size for ok in oks.values())
     live = sum(r > 0 for r in store.refs)
     assert live <= store.capacity and live < 16, live          # 16 frames came in; only the kept ones are stored, once

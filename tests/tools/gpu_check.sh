@@ -1,0 +1,16 @@
+# the usual check of a kernel change: GPU tier, the headline kernel back to back, the driver's command (no baselines)
+set -x
+T=${1:-chk}
+mkdir -p gpurun_out/$T
+export TMPDIR=/tmp
+O=$PWD/gpurun_out/$T
+timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -8 > $O/pytest_gpu_tail.txt; cat $O/pytest_gpu_tail.txt
+timeout 300 python tests/tools/abl_probe.py replica_room0_vmap f32 2>&1 | grep "^{" | tee $O/probe.jsonl
+timeout 300 python tests/tools/abl_probe.py scannet0024_vmap bf16 2>&1 | grep "^{" | tee -a $O/probe.jsonl
+timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-gpu-baseline --no-other-configs --no-pmc --no-frame > $O/bench_20_5.json 2> $O/bench_20_5.err; echo rc=$?
+python - <<PY
+import json
+j = json.loads([l for l in open("gpurun_out/$T/bench_20_5.json").read().splitlines() if l.startswith("{")][-1])
+print("value %.2f M ms/step %.5f kernel_ms %.5f frac %.3f" % (j["value"]/1e6, j["ms_per_step"], j["roofline"]["kernel_ms"], j["roofline"]["frac"]), j.get("precision"), j.get("value_exact_fp32_kernel"))
+PY
+true

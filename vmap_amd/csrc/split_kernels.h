@@ -32,7 +32,19 @@
 #pragma once
 #include "step_kernels.h"
 
+// Measurement builds only (tests/tools/build_variant.py ... -DVS_ABL=<mask>; results WRONG on purpose - the product never defines it):
+// bit 3: only the staging / finishing of the blocks is skipped (the products stay);
+// bit 2: only the P->F transposes of the weight-gradient operands are skipped (tile_put / tile_get);
+// bit 0: the backward without its weight-gradient products (no matrix instructions in mm_dw_il, no P->F transposes, no staging /
+// finishing of blocks) = the d-prop critical chain alone; bit 1: without the backward's workgroup barriers.
+#ifndef VS_ABL
+#define VS_ABL 0
+#endif
+#if VS_ABL & 2
+#define VS_BWD_BARRIER() do { } while (0)
+#else
 #define VS_BWD_BARRIER() __syncthreads()
+#endif
 
 namespace vk {
 
@@ -446,6 +458,7 @@ __device__ __forceinline__ void dprop_mm(f32x16& acc, const unsigned (&w)[16], c
 template <int NQ>
 __device__ __forceinline__ void tile_put(char* tile, const unsigned* h, const unsigned* m, int p31, int hi) {
     using I = Img32s;
+    if (VS_ABL & 5) return;
     wv::wave_lds_fence();   // earlier reads of this tile are ordered before the overwrite
     char* row = tile + p31 * I::TPIT + hi * 8;
 #pragma unroll
@@ -459,6 +472,7 @@ __device__ __forceinline__ void tile_put(char* tile, const unsigned* h, const un
 // of step s <-> point 16 s + 8 hi + t
 __device__ __forceinline__ void tile_get(unsigned (&f)[16], const char* tile, const TrLane& L) {
     using I = Img32s;
+    if (VS_ABL & 5) { for (int i = 0; i < 16; ++i) f[i] = 0x3F803F80u + (unsigned)((size_t)tile & 0xFFu); return; }
     const char* base = tile + (8 * L.hi + L.jj) * I::TPIT + (16 * L.half + 4 * L.q) * 2;
 #pragma unroll
     for (int pl = 0; pl < 2; ++pl)
@@ -470,6 +484,44 @@ __device__ __forceinline__ void tile_get(unsigned (&f)[16], const char* tile, co
                 f[pl * 8 + s * 4 + u * 2] = v[0];
                 f[pl * 8 + s * 4 + u * 2 + 1] = v[1];
             }
+}
+// ---- P-form -> F-form ON THE MATRIX PIPE (round 6).  The weight-gradient products contract over POINTS, so both operands must hold
+// 8 consecutive points per lane (lane = feature): a lane <-> register transpose of the P-form planes.  Through LDS (tile_put + tile_get:
+// 8 ds_write_b64 + 16 ds_read_b64_tr_b16 per block and wave, four waves at once) that cost 3.2 us of the kernel's 23.2 (measurement
+// builds, profiles/round6_ablation_step_main_s32.jsonl).  Here the plane itself is the A operand (lane = point i, k = feature) of a
+// product with a SELECTOR B[k][n] = (feature(k) == n): D[i][n] = X[i][n] exactly (bf16 x 1.0, zeros), and D comes back in the
+// accumulator map - lane = n = feature, register r <-> point (r & 3) + 8 (r >> 2) + 4 hi - which IS an F-form: registers 8 s .. 8 s + 7
+// are the eight k of 16-deep step s.  Both operands of a weight-gradient product are built this way, so their point <-> k maps agree.
+// 2 matrix instructions + 8 v_cvt_pk_bf16_f32 per plane, no LDS.
+struct SelOps { u32x4 s0, s1; };
+// lane (n = p31, hi'): element t of step s is 1.0 iff hidden_k(s, hi', t) == n
+__device__ __forceinline__ SelOps sel_ops(int p31, int hi) {
+    const int q = p31 & 15, t = (q & 3) + 4 * (q >> 3);
+    const bool mine = ((q >> 2) & 1) == hi;
+    const unsigned one = (t & 1) ? 0x3F800000u : 0x00003F80u;
+    u32x4 w = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = (mine && (t >> 1) == j) ? one : 0u;
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    return SelOps{p31 < 16 ? w : z, p31 < 16 ? z : w};
+}
+// NQ = 4: a whole 32-feature block (8 dwords per plane); NQ = 2: its first 16-deep step only (features 16..31 of the result are zero)
+template <int NQ>
+__device__ __forceinline__ void toF_mm(unsigned (&f)[16], const unsigned* h, const unsigned* m, const SelOps& S) {
+    f32x16 th, tm;
+    zero_acc(th);
+    zero_acc(tm);
+    th = wv::mfma_bf16(u32x4{h[0], h[1], h[2], h[3]}, S.s0, th);
+    tm = wv::mfma_bf16(u32x4{m[0], m[1], m[2], m[3]}, S.s0, tm);
+    if (NQ == 4) {
+        th = wv::mfma_bf16(u32x4{h[4], h[5], h[6], h[7]}, S.s1, th);
+        tm = wv::mfma_bf16(u32x4{m[4], m[5], m[6], m[7]}, S.s1, tm);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        f[j] = wv::pack_bf16(th[2 * j], th[2 * j + 1]);
+        f[8 + j] = wv::pack_bf16(tm[2 * j], tm[2 * j + 1]);
+    }
 }
 // weight gradient: acc[j][k] += sum_p dY[p][j] X[p][k], both operands in F-form planes: hi.mid + mid.hi + hi.hi
 __device__ __forceinline__ void dw_mm_s(f32x16& acc, const unsigned (&dyF)[16], const unsigned (&xF)[16]) {
@@ -543,6 +595,7 @@ __device__ __forceinline__ void store_quarter_map(float* out_w, float* out_b, co
 template <int KIND, int K, bool MULTI>
 __device__ __forceinline__ void finish_block_s(float (&qp)[4], const float* stage, float* out_w, float* out_b, int blk, int ncols,
                                                int wave, int p31, int hi) {
+    if (VS_ABL & 9) return;
     int col; bool bias;
     col_target<KIND>(blk, p31, col, bias);
     if (MULTI) {
@@ -584,7 +637,8 @@ __device__ __forceinline__ void mm_dw_il(f32x16& acc, f32x16& accb, const unsign
     wv::sched_fence();
 #pragma unroll
     for (int i = 0; i < (DB ? 10 : 6); ++i) {
-        if (i < 6) {
+        if (VS_ABL & 1) {
+        } else if (i < 6) {
             const int s = i / 3, k = i % 3;
             const u32x4 ah = u32x4{dyF[4 * s], dyF[4 * s + 1], dyF[4 * s + 2], dyF[4 * s + 3]};
             const u32x4 am = u32x4{dyF[8 + 4 * s], dyF[8 + 4 * s + 1], dyF[8 + 4 * s + 2], dyF[8 + 4 * s + 3]};
@@ -617,6 +671,7 @@ struct FinState { wv::f32x4 t0, t1, t2, t3; };
 template <int KIND, int K, bool MULTI>
 __device__ __forceinline__ void fin_chunk(int j, FinState& st, float (&qp)[4], const float* stage, float* out_w, float* out_b, int blk,
                                           int ncols, int wave, int p31, int hi) {
+    if (VS_ABL & 9) return;
     if (j == 0) {
         const float* rd = stage + p31 * Lds32::TP + 8 * wave + 4 * hi;
         st.t0 = *reinterpret_cast<const wv::f32x4*>(rd);
@@ -701,6 +756,17 @@ __device__ __forceinline__ void octave_sincos(float a0, float (&s)[6], float (&c
         s[f] = t * c[f - 1];
         c[f] = fmaf(-t, s[f - 1], 1.0f);
     }
+}
+
+__device__ __forceinline__ void stage_put_s(float* stage, const f32x16& acc, int wave, int p31, int hi) {
+    if (!(VS_ABL & 9)) stage_put(stage, acc, wave, p31, hi);
+    else if (VS_ABL & 8) {                      // the products stay: their result is "used" (no instruction)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[r]));
+    }
+}
+__device__ __forceinline__ void stage_get_s(float (&q)[4], const float* stage, int wave, int p31, int hi) {
+    if (!(VS_ABL & 9)) stage_get(q, stage, wave, p31, hi);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -972,32 +1038,27 @@ __device__ __forceinline__ void step_main_s32_body(const StepArgs& a) {
         if (i == 0) fin_chunk<KIND, K, MULTI>(0, fs, qacc[QI], STG, OW, OB, BLK, NC, wave, p31, hi);                          \
         if (i == NA - 3) fin_chunk<KIND, K, MULTI>(1, fs, qacc[QI], STG, OW, OB, BLK, NC, wave, p31, hi);                     \
     }
-    tile_put<4>(scrD, dch, dcm, p31, hi);
-    tile_put<4>(scrX, h4h, h4m, p31, hi);
+    const SelOps SEL = sel_ops(p31, hi);
     wt_get<I::PIT_C, W3>(wA, W + I::O_C, 0, TL);
-    tile_get(dF, scrD, TL);                                       // F(d hc): the delta of units 0..2
-    tile_get(xA, scrX, TL);                                       // F(h4)
-    tile_put<4>(scrX, e2h, e2m, p31, hi);                         // x of unit 1
+    toF_mm<4>(dF, dch, dcm, SEL);                                 // F(d hc): the delta of units 0..2
+    toF_mm<4>(xA, h4h, h4m, SEL);                                 // F(h4)
     wt_get<I::PIT_C, W3>(wB, W + I::O_C, 2, TL);
     // unit 0: colour layer x h4;  d h4 = W_a d raw + W_c[:, :H]^T d hc
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc2[r] = SM[I::W_A + phi(r, hi)] * d_raw;
     mm_dprop_il<W3>(acc2, wA, dch, dcm, nothing);
-    tile_get(xB, scrX, TL);                                       // F(second-group slots 0..15)
+    toF_mm<4>(xB, e2h, e2m, SEL);                                 // F(second-group slots 0..15)
     zero_acc(acc);
     mm_dw_il<false>(acc, accb, dF, xA, [&](int i) {
 #pragma unroll
         for (int j = i * 8 / 6; j < (i + 1) * 8 / 6; ++j) mask_split_pair(j, acc2, h4h, d4h, d4m, acc[0]);
     });
-    tile_put<2>(scrX, e2h + 8, e2m + 8, p31, hi);                 // x of unit 2 (half a block)
     wt_get<I::PIT_C, W3>(wA, W + I::O_C, 4, TL);
-    tile_put<4>(scrD, d4h, d4m, p31, hi);                         // delta of unit 3 (F(d hc) stays in dF for units 1, 2)
     VS_BWD_BARRIER();
     // unit 1: x = second-group slots 0..15
     zero_acc(acc2);
-    mm_dprop_il<W3>(acc2, wB, dch, dcm, [&](int i) { if (i == NA - 1) stage_put(stg0, acc, wave, p31, hi); });       // block 0
-    tile_get(xA, scrX, TL);                                       // F(second-group slots 16..23)
-    tile_put<4>(scrX, h3h, h3m, p31, hi);                         // x of unit 3
+    mm_dprop_il<W3>(acc2, wB, dch, dcm, [&](int i) { if (i == NA - 1) stage_put_s(stg0, acc, wave, p31, hi); });       // block 0
+    toF_mm<2>(xA, e2h + 8, e2m + 8, SEL);                         // F(second-group slots 16..23): half a block
     wt_get<I::PIT_M, W3>(wB, W + I::O_M2, 0, TL);
     zero_acc(acc);
     mm_dw_il<false>(acc, accb, dF, xB, [&](int i) {
@@ -1011,10 +1072,9 @@ __device__ __forceinline__ void step_main_s32_body(const StepArgs& a) {
     zero_acc(acc2);
     {
         auto fin = VS_FIN(0, H + kEmb2, 0, stg0, out + F::W_C, nullptr, 0, 32);
-        mm_dprop_il<W3>(acc2, wA, dch, dcm, [&](int i) { fin(i); if (i == NA - 1) stage_put(stg1, acc, wave, p31, hi); });   // block 1
+        mm_dprop_il<W3>(acc2, wA, dch, dcm, [&](int i) { fin(i); if (i == NA - 1) stage_put_s(stg1, acc, wave, p31, hi); });   // block 1
     }
-    tile_get(xB, scrX, TL);                                       // F(h3)
-    tile_put<4>(scrX, h2h, h2m, p31, hi);                         // x of unit 4
+    toF_mm<4>(xB, h3h, h3m, SEL);                                 // F(h3)
     wt_get<I::PIT_CAT, W3>(wA, W + I::O_CAT, 0, TL);
     zero_acc(acc);
     mm_dw_il<false>(acc, accb, dF, xA, [&](int i) {
@@ -1023,17 +1083,16 @@ __device__ __forceinline__ void step_main_s32_body(const StepArgs& a) {
             for (int r = 2 * i; r < 2 * i + 2; ++r) dproj[8 + (r >> 1)] += wv::after(acc2[r], acc[0]) * cfac[8 + (r >> 1)][4 + (r & 1)];   // slots 16..21: directions 8..10
         }
     });
-    tile_get(dF, scrD, TL);                                       // F(d4)
+    toF_mm<4>(dF, d4h, d4m, SEL);                                 // F(d4) (F(d hc) was the delta of units 0..2)
     VS_BWD_BARRIER();
     VS_MARK(7);
     // unit 3: mid2, delta = d4, x = h3
     zero_acc(acc2);
     {
         auto fin = VS_FIN(2, H + kEmb2, 1, stg1, out + F::W_C + H, out + F::B_C, 0, kEmb2);
-        mm_dprop_il<W3>(acc2, wB, d4h, d4m, [&](int i) { fin(i); if (i == NA - 1) stage_put(stg0, acc, wave, p31, hi); });   // block 2
+        mm_dprop_il<W3>(acc2, wB, d4h, d4m, [&](int i) { fin(i); if (i == NA - 1) stage_put_s(stg0, acc, wave, p31, hi); });   // block 2
     }
-    tile_get(xA, scrX, TL);                                       // F(h2)
-    tile_put<4>(scrX, h1h, h1m, p31, hi);                         // x of unit 5
+    toF_mm<4>(xA, h2h, h2m, SEL);                                 // F(h2)
     wt_get<I::PIT_M, W3>(wB, W + I::O_M1, 0, TL);
     zero_acc(acc);
     zero_acc(accb);
@@ -1045,35 +1104,32 @@ __device__ __forceinline__ void step_main_s32_body(const StepArgs& a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) Gv[I::B_M2 + phi(r, hi)] += accb[r];
     }
-    tile_put<4>(scrD, d3h, d3m, p31, hi);
-    tile_get(dF3, scrD, TL);                                      // F(d3): kept for the three first-group blocks
+    toF_mm<4>(dF3, d3h, d3m, SEL);                                // F(d3): kept for the three first-group blocks
     VS_BWD_BARRIER();
     VS_MARK(8);
     // unit 4: cat_layer, delta = d3, x = h2
     zero_acc(acc2);
     {
         auto fin = VS_FIN(2, H + kEmb2, 2, stg0, out + F::W_C + H, out + F::B_C, 1, kEmb2);
-        mm_dprop_il<W3>(acc2, wA, d3h, d3m, [&](int i) { fin(i); if (i == NA - 1) stage_put(stg1, acc, wave, p31, hi); });   // block 3
+        mm_dprop_il<W3>(acc2, wA, d3h, d3m, [&](int i) { fin(i); if (i == NA - 1) stage_put_s(stg1, acc, wave, p31, hi); });   // block 3
     }
-    tile_get(xB, scrX, TL);                                       // F(h1)
-    tile_put<4>(scrX, e1h, e1m, p31, hi);                         // x of units 6, 7
+    toF_mm<4>(xB, h1h, h1m, SEL);                                 // F(h1)
     wt_get<I::PIT_CAT, W3>(wA, W + I::O_CAT, 2, TL);
     zero_acc(acc);
     mm_dw_il<false>(acc, accb, dF3, xA, [&](int i) {
 #pragma unroll
         for (int j = i * 8 / 6; j < (i + 1) * 8 / 6; ++j) mask_split_pair(j, acc2, h2h, d2h, d2m, acc[0]);
     });
-    tile_put<4>(scrD, d2h, d2m, p31, hi);
-    tile_get(dF, scrD, TL);                                       // F(d2)
+    toF_mm<4>(dF, d2h, d2m, SEL);                                 // F(d2)
     VS_BWD_BARRIER();
     VS_MARK(9);
     // unit 5: mid1, delta = d2, x = h1
     zero_acc(acc2);
     {
         auto fin = VS_FIN(0, H, 3, stg1, out + F::W_M2, nullptr, 0, 32);
-        mm_dprop_il<W3>(acc2, wB, d2h, d2m, [&](int i) { fin(i); if (i == NA - 1) stage_put(stg0, acc, wave, p31, hi); });   // block 4
+        mm_dprop_il<W3>(acc2, wB, d2h, d2m, [&](int i) { fin(i); if (i == NA - 1) stage_put_s(stg0, acc, wave, p31, hi); });   // block 4
     }
-    tile_get(xA, scrX, TL);                                       // F(first-group block 0)
+    toF_mm<4>(xA, e1h, e1m, SEL);                                 // F(first-group block 0)
     wt_get<I::PIT_IN, W3>(wB, W + I::O_IN, 0, TL);
     zero_acc(acc);
     zero_acc(accb);
@@ -1085,8 +1141,7 @@ __device__ __forceinline__ void step_main_s32_body(const StepArgs& a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) Gv[I::B_M1 + phi(r, hi)] += accb[r];
     }
-    tile_put<4>(scrD, d1h, d1m, p31, hi);
-    tile_get(dF1, scrD, TL);                                      // F(d1): kept for the three in_layer blocks
+    toF_mm<4>(dF1, d1h, d1m, SEL);                                // F(d1): kept for the three in_layer blocks
     VS_BWD_BARRIER();
     VS_MARK(10);
     // units 6..11: the three first-group blocks feed cat_layer (delta d3, weights wA) and in_layer (delta d1, weights wB);
@@ -1100,15 +1155,14 @@ __device__ __forceinline__ void step_main_s32_body(const StepArgs& a) {
         zero_acc(de);
         if (blk == 0) {
             auto fin = VS_FIN(0, H + kEmb1, 4, stg0, out + F::W_CAT, nullptr, 0, 32);
-            mm_dprop_il<W3>(de, wA, d3h, d3m, [&](int i) { fin(i); if (i == NA - 1) stage_put(stg1, acc, wave, p31, hi); });   // block 5
+            mm_dprop_il<W3>(de, wA, d3h, d3m, [&](int i) { fin(i); if (i == NA - 1) stage_put_s(stg1, acc, wave, p31, hi); });   // block 5
         } else {
             auto fin = VS_FIN(1, H + kEmb1, 6 + blk - 1, stg0, out + F::W_CAT + H, out + F::B_CAT, blk - 1, kEmb1);
-            mm_dprop_il<W3>(de, wA, d3h, d3m, [&](int i) { fin(i); if (i == NA - 1) stage_put(stg1, acc, wave, p31, hi); });   // block 9 + blk - 1
+            mm_dprop_il<W3>(de, wA, d3h, d3m, [&](int i) { fin(i); if (i == NA - 1) stage_put_s(stg1, acc, wave, p31, hi); });   // block 9 + blk - 1
         }
         if (blk < 2) {
-            tile_put<4>(scrX, e1h + 8 * (blk + 1), e1m + 8 * (blk + 1), p31, hi);
             wt_get<I::PIT_CAT, W3>(wA, W + I::O_CAT, 2 + 2 * (blk + 1), TL);
-            tile_get(xn, scrX, TL);
+            toF_mm<4>(xn, e1h + 8 * (blk + 1), e1m + 8 * (blk + 1), SEL);
         }
         zero_acc(acc);
         mm_dw_il<false>(acc, accb, dF3, xc, nothing);
@@ -1116,10 +1170,10 @@ __device__ __forceinline__ void step_main_s32_body(const StepArgs& a) {
         // in_layer x block: finishes the mid1 block (blk 0) or the previous round's in block; stages this round's cat block
         if (blk == 0) {
             auto fin = VS_FIN(0, H, 5, stg1, out + F::W_M1, nullptr, 0, 32);
-            mm_dprop_il<W3>(de, wB, d1h, d1m, [&](int i) { fin(i); if (i == NA - 1) stage_put(stg0, acc, wave, p31, hi); });   // block 6 + blk
+            mm_dprop_il<W3>(de, wB, d1h, d1m, [&](int i) { fin(i); if (i == NA - 1) stage_put_s(stg0, acc, wave, p31, hi); });   // block 6 + blk
         } else {
             auto fin = VS_FIN(1, kEmb1, 9 + blk - 1, stg1, out + F::W_IN, out + F::B_IN, blk - 1, kEmb1);
-            mm_dprop_il<W3>(de, wB, d1h, d1m, [&](int i) { fin(i); if (i == NA - 1) stage_put(stg0, acc, wave, p31, hi); });   // block 6 + blk
+            mm_dprop_il<W3>(de, wB, d1h, d1m, [&](int i) { fin(i); if (i == NA - 1) stage_put_s(stg0, acc, wave, p31, hi); });   // block 6 + blk
         }
         if (blk < 2) wt_get<I::PIT_IN, W3>(wB, W + I::O_IN, 2 * (blk + 1), TL);
         zero_acc(acc);
@@ -1145,21 +1199,20 @@ __device__ __forceinline__ void step_main_s32_body(const StepArgs& a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) dpP[r] = r < 11 ? dproj[r] : 0.0f;          // row phi(r, hi) <-> direction hi ? 11 + r : r
         split_planes<16, 2>(dpP, dph, dpm, xl_unused);
-        tile_put<4>(scrD, dph, dpm, p31, hi);
-        tile_get(dF, scrD, TL);
+        toF_mm<4>(dF, dph, dpm, SEL);
         // finish the last cat block (staged in stg0), stage the last in block
         fin_chunk<1, H + kEmb1, MULTI>(0, fs, qacc[8], stg0, out + F::W_CAT + H, out + F::B_CAT, 2, kEmb1, wave, p31, hi);
-        stage_put(stg1, acc, wave, p31, hi);                      // block 11
+        stage_put_s(stg1, acc, wave, p31, hi);                      // block 11
         fin_chunk<1, H + kEmb1, MULTI>(1, fs, qacc[8], stg0, out + F::W_CAT + H, out + F::B_CAT, 2, kEmb1, wave, p31, hi);
         zero_acc(acc);
         mm_dw_il<false>(acc, accb, dF, xA, nothing);
         VS_BWD_BARRIER();
         finish_block_s<1, kEmb1, MULTI>(qacc[11], stg1, out + F::W_IN, out + F::B_IN, 2, kEmb1, wave, p31, hi);
-        stage_put(stg0, acc, wave, p31, hi);
+        stage_put_s(stg0, acc, wave, p31, hi);
         VS_BWD_BARRIER();
         float q[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (MULTI) stage_get(qacc[12], stg0, wave, p31, hi);
-        else stage_get(q, stg0, wave, p31, hi);
+        if (MULTI) stage_get_s(qacc[12], stg0, wave, p31, hi);
+        else stage_get_s(q, stg0, wave, p31, hi);
         if (!MULTI && p31 >= 24 && p31 < 27) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
