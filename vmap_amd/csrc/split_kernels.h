@@ -33,6 +33,7 @@
 #include "step_kernels.h"
 
 // Measurement builds only (tests/tools/build_variant.py ... -DVS_ABL=<mask>; results WRONG on purpose - the product never defines it):
+// bit 4: only the partial-gradient global stores are skipped; bit 5: the finishing (staged reads, sums, stores) is skipped, the staging writes stay;
 // bit 3: only the staging / finishing of the blocks is skipped (the products stay);
 // bit 2: only the P->F transposes of the weight-gradient operands are skipped (tile_put / tile_get);
 // bit 0: the backward without its weight-gradient products (no matrix instructions in mm_dw_il, no P->F transposes, no staging /
@@ -72,16 +73,20 @@ struct Img32s {
     static constexpr int TILE = 32 * Lds32::TP * 4;          // 4608: one float32 32x32 exchange tile = two bf16 planes [32][72 B]
     static constexpr int TPL = TILE / 2;                     // one bf16 plane of a transpose tile
     static constexpr int TPIT = 72;                          // bytes per point row of a bf16 transpose plane (8 x odd)
-    static constexpr int STG = P_LO;                         // staging tiles OVERLAY the lo planes (dead once the forward is done)
-    static constexpr int STG_BYTES = 2 * kWaves * TILE;
-    static constexpr int SCR = STG + STG_BYTES;              // per-wave transpose tiles: kWaves x 2
+    // Round 6: the weight-gradient operands are transposed on the matrix pipe (toF_mm), so the per-wave tiles only carry the two
+    // float32 head transposes (written at the end of the forward, read at the start of the backward) - the staging tiles of the
+    // backward's cross-wave sums ALIAS them (first staged in unit 1, behind unit 0's barrier) instead of overlaying the lo planes:
+    // the whole image stays valid to the end of the pass (no lo-plane re-copy in multi-pass launches), 36 KB less LDS.
+    static constexpr int SCR = BYTES;                        // per-wave float32 transpose tiles: kWaves x 2
+    static constexpr int STG = SCR;                          // staging tiles: the same bytes, later in the pass
+    static constexpr int STG_BYTES = 2 * kWaves * TILE, kWavesTiles = kWaves * 2 * TILE;
     static constexpr int VEC = SCR + kWaves * 2 * TILE;      // per-wave small-vector gradient accumulators
     static constexpr int CB = VEC + kWaves * SMALL_N * 4;
     static constexpr int LOSS = CB + kMaxPts * 8 * 4;
     static constexpr int LDS_BYTES = LOSS + kWaves * 4 * 4;
 };
 static_assert(Img32s::PLANE == 26112 && Img32s::BYTES == 81920, "image size");
-static_assert(Img32s::STG + Img32s::STG_BYTES >= Img32s::BYTES, "the staging overlay must end behind the image");
+static_assert(Img32s::STG >= Img32s::BYTES && Img32s::STG_BYTES == Img32s::kWavesTiles, "staging tiles = the transpose tiles' bytes, behind the image");
 static_assert(Img32s::LDS_BYTES <= 160 * 1024, "LDS budget");
 static_assert(Img32s::PLANE % 16 == 0 && Img32s::SMALL % 16 == 0 && Img32s::P_LO % 16 == 0, "16-byte planes");
 
@@ -577,7 +582,11 @@ __device__ __forceinline__ void col_target(int blk, int k, int& col, bool& bias)
     col = c >= 0 ? c : -1;
 }
 // this wave's quarter (rows 8 wave + 4 hi + i) of a reduced block -> the workgroup's partial gradients
+#if VS_ABL & 16
+#define VS_PARTIAL_STORE(v, p) asm volatile("" ::"v"(v), "v"(p))
+#else
 #define VS_PARTIAL_STORE(v, p) __builtin_nontemporal_store((v), (p))
+#endif
 template <int K>
 __device__ __forceinline__ void store_quarter_map(float* out_w, float* out_b, const float (&q)[4], int col, bool bias, int ncols,
                                                   int wave, int hi) {
@@ -595,7 +604,7 @@ __device__ __forceinline__ void store_quarter_map(float* out_w, float* out_b, co
 template <int KIND, int K, bool MULTI>
 __device__ __forceinline__ void finish_block_s(float (&qp)[4], const float* stage, float* out_w, float* out_b, int blk, int ncols,
                                                int wave, int p31, int hi) {
-    if (VS_ABL & 9) return;
+    if (VS_ABL & (9 | 32)) return;
     int col; bool bias;
     col_target<KIND>(blk, p31, col, bias);
     if (MULTI) {
@@ -671,7 +680,7 @@ struct FinState { wv::f32x4 t0, t1, t2, t3; };
 template <int KIND, int K, bool MULTI>
 __device__ __forceinline__ void fin_chunk(int j, FinState& st, float (&qp)[4], const float* stage, float* out_w, float* out_b, int blk,
                                           int ncols, int wave, int p31, int hi) {
-    if (VS_ABL & 9) return;
+    if (VS_ABL & (9 | 32)) return;
     if (j == 0) {
         const float* rd = stage + p31 * Lds32::TP + 8 * wave + 4 * hi;
         st.t0 = *reinterpret_cast<const wv::f32x4*>(rd);
@@ -843,14 +852,6 @@ __device__ __forceinline__ void step_main_s32_body(const StepArgs& a) {
 #pragma unroll
         for (int c = 0; c < I::ROUNDS; ++c)
             wv::glds16(reinterpret_cast<const float*>(src + c * 4096), reinterpret_cast<float*>(lds + c * 4096 + wave * 1024));
-    } else if (W3) {
-        // later passes: the lo planes were overwritten by the staging tiles of the previous pass (26 chunks of 1 KiB; the
-        // last one runs 512 bytes into the image's zero tail / the dead staging area)
-        const char* src = gimg + I::P_LO + wave * 1024 + lane * 16;
-#pragma unroll
-        for (int c = 0; c < (I::PLANE + 4095) / 4096; ++c)
-            if (4 * c + wave < (I::PLANE + 1023) / 1024)
-                wv::glds16(reinterpret_cast<const float*>(src + c * 4096), reinterpret_cast<float*>(lds + I::P_LO + c * 4096 + wave * 1024));
     }
     const float t[3] = {px3[0] / scale, px3[1] / scale, px3[2] / scale};          // embedding.py:83  x / self.scale (0 for padding lanes)
     // this lane's directions: hi = 0 -> 0..10, hi = 1 -> 11..20 (+ one dummy)

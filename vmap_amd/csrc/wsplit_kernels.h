@@ -661,11 +661,18 @@ __device__ __forceinline__ void acts_load_plane(unsigned (&h)[8], const char* ub
         h[4 * s] = v[0]; h[4 * s + 1] = v[1]; h[4 * s + 2] = v[2]; h[4 * s + 3] = v[3];
     }
 }
-// P-form planes (hi, mid) -> F-form registers through the wave's transpose tile
+// P-form planes (hi, mid) -> F-form registers.  Round 6: on the matrix pipe (toF_mm, split_kernels.h: the plane times a selector
+// operand comes back transposed in the accumulator map; 4 matrix instructions + 16 conversions, no LDS round trip) instead of through
+// the wave's transpose tile (VS_TOF_LDS: the old form, for A/B builds).  Every F-form of a round - the deltas a wave keeps in registers,
+// the layer-input images it publishes to the other waves - comes from this one function, so their point <-> k maps agree.
 template <int NQ>
 __device__ __forceinline__ void to_F(unsigned (&f)[16], char* tile, const unsigned* h, const unsigned* m, int p31, int hi, const TrLane& TL) {
+#ifdef VS_TOF_LDS
     tile_put<NQ>(tile, h, m, p31, hi);
     tile_get(f, tile, TL);
+#else
+    toF_mm<NQ>(f, h, m, sel_ops(p31, hi));
+#endif
 }
 // F-form registers <-> a 4 KiB image [4][64 lanes][16 B] (img already holds the lane offset)
 __device__ __forceinline__ void put_F(char* img, const unsigned (&f)[16]) {
