@@ -294,8 +294,10 @@ def precision_leg(dev):
     keys = ("pcs", "z", "gt_depth", "gt_rgb", "sem", "depth_mask")
     fr = tuple(torch.from_numpy(c["frame"][k]).to(dev) for k in keys)
     out = {"fixture": "tests/golden/cfg2_frame20.npz (the reference's own step loop, train.py:270-326, 20 steps x 20 objects x 120 rays)",
-           "error_is": "max over the 20 steps of |loss - ref| / |ref|; max over the 15 tensors of max|g - ref| / max|ref| for step 0"}
-    for label, tuning in (("default_split_bf16_6fwd_3bwd", None), ("exact_fp32_kernel", {"kernel": _lib.KERNEL_H32_F32})):
+           "error_is": "max over the 20 steps of |loss - ref| / |ref|; max over the 15 tensors of max|g - ref| / max|ref| for step 0; the same for "
+                       "the single-step fixture tests/golden/cfg2.npz (same shape, the reference's own step on other seeds)"}
+    for label, tuning in (("default_split_bf16_6fwd_3bwd", None), ("split_bf16_6fwd_6bwd", {"kernel": _lib.KERNEL_S32_BWD6}),
+                          ("exact_fp32_kernel", {"kernel": _lib.KERNEL_H32_F32})):
         fc = [torch.from_numpy(a).to(dev) for a in c["fc"]]
         B, sc = torch.from_numpy(c["B"]).to(dev), torch.from_numpy(c["scale"]).to(dev)
         op = step.VmapStep(n, R, S, H, device=dev, max_steps=steps, tuning=tuning)
@@ -310,6 +312,20 @@ def precision_leg(dev):
         losses = res.loss.cpu().numpy().astype(np.float64)
         out[label] = {"loss_rel_err_max_over_steps": float((np.abs(losses - g["losses"]) / np.abs(g["losses"])).max()),
                       "grad_rel_err_step0_max_over_tensors": gerr}
+        # the same kernels on the single-step fixture of the same shape (tests/golden/cfg2.npz): no ReLU unit of it sits inside the
+        # forward's rounding, so this figure shows the BACKWARD's arithmetic (the frame's step 0 above holds one such unit for the
+        # bf16-pipe forward - 1.7e-5 on one tensor whatever the backward does; the tests account for it unit by unit, conftest.kink_aware)
+        c1, g1 = cases.build_case("cfg2"), np.load(os.path.join(ROOT, "tests", "golden", "cfg2.npz"))
+        fc1 = [torch.from_numpy(a).to(dev) for a in c1["fc"]]
+        B1, sc1 = torch.from_numpy(c1["B"]).to(dev), torch.from_numpy(c1["scale"]).to(dev)
+        b1 = tuple(torch.from_numpy(c1["batch"][k]).to(dev) for k in keys)
+        op1 = step.VmapStep(c1["n"], c1["R"], c1["S"], c1["H"], device=dev, tuning=tuning)
+        gfc1, gB1 = [torch.zeros_like(t) for t in fc1], torch.zeros_like(B1)
+        op1.fwd_bwd(fc1, B1, sc1, *b1, grads_fc=gfc1, grad_B=gB1)
+        errs = [float(np.abs((gfc1[t] if t < 14 else gB1).cpu().numpy().astype(np.float64) - g1[f"g_fc{t}" if t < 14 else "g_B"]).max()
+                      / (np.abs(g1[f"g_fc{t}" if t < 14 else "g_B"]).max() + 1e-30)) for t in range(15)]
+        out[label]["grad_rel_err_single_step_fixture_max_over_tensors"] = max(errs)
+        out[label]["grad_rel_err_single_step_fixture_median_over_tensors"] = float(np.median(errs))
     if "forloop_losses" in g.files:
         out["reference_vmap_vs_its_own_forloop_path"] = {"loss_rel_err_max_over_steps": float((np.abs(g["forloop_losses"] - g["losses"]) / np.abs(g["losses"])).max())}
     return out
@@ -500,11 +516,12 @@ def summarise(out):
     s["repeats_ms_per_step"] = [r3(x) for x in (out.get("repeats") or {}).get("ms_per_step", [])]
     s["kernel_ms"], s["frac"] = r3(out["roofline"].get("kernel_ms")), r3(out["roofline"].get("frac"))
     s["exact_fp32_kernel_rays_per_s"] = r3((out.get("value_exact_fp32_kernel") or {}).get("value"))
+    s["six_product_backward_rays_per_s"] = r3((out.get("value_fp32_equivalent_backward") or {}).get("value"))
     s["reference_on_this_gpu_rays_per_s"], s["reference_on_this_gpu_ms_per_step"], s["vs_reference_on_this_gpu"] = r3(g.get("value")), r3(g.get("ms_per_step")), r3(g.get("speedup"))
     s["aten_port_on_this_gpu_rays_per_s"] = r3(p.get("value"))
     s["reference_on_host_cpu_rays_per_s"], s["host_threads"], s["cpu_baseline_kind"] = r3(c.get("value")), c.get("cores"), c.get("kind")
     pr = out.get("precision") or {}
-    s["precision_loss_err_grad_err"] = {k: [r3(v.get("loss_rel_err_max_over_steps")), r3(v.get("grad_rel_err_step0_max_over_tensors"))]
+    s["precision_loss_err_grad_err_frame_step0_grad_err_single_step_fixture"] = {k: [r3(v.get("loss_rel_err_max_over_steps")), r3(v.get("grad_rel_err_step0_max_over_tensors")), r3(v.get("grad_rel_err_single_step_fixture_max_over_tensors"))]
                                         for k, v in pr.items() if isinstance(v, dict) and "loss_rel_err_max_over_steps" in v}
     s["other_configs_ms_per_step_rays_per_s_frac"] = {k: ([r3(v.get("ms_per_step")), r3(v.get("rays_per_s")), r3(v.get("frac"))] if "error" not in v else v["error"][:60])
                                                       for k, v in (out.get("other_configs") or {}).items()}
@@ -946,7 +963,7 @@ def main():
         fb_ms = (time.perf_counter() - t1) / 100 * 1e3
         # the same workload on the exact-fp32 matrix instruction (step_main_h32: every product an fp32 FMA; the A/B reference of the
         # default kernel's split-bf16 operands), timed like `value`: the number to quote if the backward's ~2^-16 operands are not wanted
-        exact = None
+        exact, bwd6 = None, None
         if split and world == 1:
             from vmap_amd import _lib as _l
             op_x = step.VmapStep(n, R, S, H, device=dev, max_steps=ipf, weights=args.weights, tuning={"kernel": _l.KERNEL_H32_F32})
@@ -965,6 +982,29 @@ def main():
             torch.cuda.synchronize()
             x_ms = (time.perf_counter() - t1) / args.steps * 1e3
             exact = {"value": n * R / (x_ms * 1e-3), "ms_per_step": x_ms, "kernel": "step_main_h32 (v_mfma_f32_32x32x2_f32)"}
+            # ... and on the default kernel with the SIX-product backward (tuning.kernel = VMAPSTEP_KERNEL_S32_BWD6: hi.lo + lo.hi + mid.mid on
+            # top of the three, ~2^-24 like the forward): the float32-equivalent form of the bf16-pipe kernel, timed the same way
+            if args.weights == "f32":
+                op_6 = step.VmapStep(n, R, S, H, device=dev, max_steps=ipf, weights=args.weights, tuning={"kernel": _l.KERNEL_S32_BWD6})
+                opt_6 = step.FusedAdamWState(n, H, dev, lr=1e-3, weight_decay=0.013)
+                b6 = op_6.bind([t.clone() for t in tfc], tB.clone(), tsc, *fargs, opt=opt_6)
+                for _ in range(max(1, args.warmup // ipf)):
+                    b6.train_steps(ipf)
+                ts6 = []
+                for _ in range(max(1, args.repeats)):
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    done = 0
+                    while done < args.steps:
+                        k = min(ipf, args.steps - done)
+                        b6.train_steps(k)
+                        done += k
+                    torch.cuda.synchronize()
+                    ts6.append((time.perf_counter() - t1) / args.steps * 1e3)
+                k6_ms, _ = op_6.profile_train_steps([t.clone() for t in tfc], tB.clone(), tsc, *fargs, opt=opt_6, n_steps=ipf)
+                bwd6 = {"value": n * R / (_median(ts6) * 1e-3), "ms_per_step": _median(ts6), "ms_per_step_repeats": ts6, "kernel_ms": k6_ms,
+                        "frac": flops / (k6_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                        "kernel": "step_main_s32<bwd6> (bf16 matrix pipe, split operands: 6 products forward AND backward, ~2^-24 both ways)"}
         if traffic_observed:
             traffic_source = ("OBSERVED in this gpurun: FETCH_SIZE / WRITE_SIZE passes (rocprofv3 --pmc, separate passes, FETCH doubled per MI355X_MICROARCH.md) over "
                               "the library this process loaded, folded by tests/tools/pmc_summary.py: " + json.dumps(traffic_observed))
@@ -1003,6 +1043,7 @@ def main():
                          "hbm_achieved_GBs": abytes / (k_ms * 1e-3) / 1e9,
                          "hbm_frac": abytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "value_exact_fp32_kernel": exact,
+            "value_fp32_equivalent_backward": bwd6,
             "fwd_bwd_only": {"ms_per_step_host_launched": fb_ms, "rays_per_s": n * R / (fb_ms * 1e-3)},
             "preheat": {"ms": args.preheat_ms, "steps": preheat_steps, "timed": False},
             "with_background": with_bg,

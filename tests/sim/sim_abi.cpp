@@ -26,7 +26,7 @@ extern "C" void vmsim_set_sample_split(int nsplit) { g_sample_split = nsplit; } 
 static const float* g_ray_o = nullptr; static const float* g_ray_d = nullptr; static const float* g_ray_c = nullptr;
 extern "C" void vmsim_set_rays(const float* o, const float* d, const float* c) { g_ray_o = o; g_ray_d = d; g_ray_c = c; }
 static int g_split = 0;
-extern "C" void vmsim_set_split(int on) { g_split = on; }   // hidden 32: 1 = step_main_s32 (split-bf16 matrix pipe) instead of step_main_h32   
+extern "C" void vmsim_set_split(int on) { g_split = on; }   // hidden 32: 1 = step_main_s32 (split-bf16 matrix pipe) instead of step_main_h32; 2 = ... with the six-product backward   
 
 // fc[t]: [n][size_t] contiguous; grads: flat slab [n][P] in natural order (14 field tensors then B).
 extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req, int xcd_affine, int weights_bf16,
@@ -93,7 +93,7 @@ extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req, int xcd
     else sl::prep_f32(a, 1 + n * (vk::gen_layout(H).imgp / 1024));
     if (wp) sl::main_wp(wa, bwd);
     else if (ws) sl::main_ws(wa, bwd);
-    else if (split) sl::main_s32(a, bwd);
+    else if (split) { a.bwd6 = (g_split == 2 && bwd && !weights_bf16) ? 1 : 0; sl::main_s32(a, bwd); }
     else if (int rc = sl::main_f32(a, g_wide, bwd, G)) return rc;
 
     vk::FinalizeArgs f{};

@@ -11,6 +11,9 @@ void main_s32(const vk::StepArgs& a, bool bwd) {
         if (bwd && multi)  sim::launch(grid, vk::kWG, lb, [&] { vk::step_main_s32<true, true, false, false>(a); });
         if (bwd && !multi) sim::launch(grid, vk::kWG, lb, [&] { vk::step_main_s32<true, false, false, false>(a); });
         if (!bwd)          sim::launch(grid, vk::kWG, lb, [&] { vk::step_main_s32<false, false, false, false>(a); });
+    } else if (bwd && a.bwd6) {               // the six-product backward (tuning.kernel = VMAPSTEP_KERNEL_S32_BWD6)
+        if (multi)  sim::launch(grid, vk::kWG, lb, [&] { vk::step_main_s32<true, true, false, true, true>(a); });
+        else        sim::launch(grid, vk::kWG, lb, [&] { vk::step_main_s32<true, false, false, true, true>(a); });
     } else {
         if (bwd && multi)  sim::launch(grid, vk::kWG, lb, [&] { vk::step_main_s32<true, true, false, true>(a); });
         if (bwd && !multi) sim::launch(grid, vk::kWG, lb, [&] { vk::step_main_s32<true, false, false, true>(a); });

@@ -89,7 +89,7 @@ def sim_step(case_or_fc, B=None, scale=None, batch=None, G=None, bwd=True, adam=
     H = fc[2].shape[-1]
     if G is None:
         G = max(1, (32 if wide in (True, 1) else 64 if wide in (3, 4) else 128) // S)
-    lib().vmsim_set_split(int(bool(split)))      # 0 exact fp32 (step_main_h32), 1 step_main_s32
+    lib().vmsim_set_split(int(split))      # 0 exact fp32 (step_main_h32), 1 step_main_s32, 2 step_main_s32 with the six-product backward
     lib().vmsim_set_finalize_form(int(finalize_form))   # step_finalize_ws: 0 a thread per quad and row group, 1 one thread per quad (the library's choice for many blocks / few rows)
     lib().vmsim_set_wide(int(wide))       # 0 general kernel, 1 / True step_main_wide<4>, 3 step_main_ws, 4 step_main_wp (hidden 64 / 128)
     fc_c = [np.ascontiguousarray(a, dtype=np.float32) for a in fc]

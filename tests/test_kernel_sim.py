@@ -203,9 +203,30 @@ def test_sim_split_kernel_matches_reference(name):
     assert s["flags"][:3].tolist() == [int(x) for x in o["drop"]]
 
 
+@pytest.mark.parametrize("name,kw", [("tiny", {}), ("ragged", {}), ("ragged", dict(NW=2, G=5)), ("exact_hit", {})])
+def test_sim_split_six_product_backward(name, kw):
+    """tuning.kernel = VMAPSTEP_KERNEL_S32_BWD6: hi.lo + lo.hi + mid.mid on top of the default's three products in the d-prop and
+    weight-gradient chains (lo planes of deltas, layer inputs and W^T carried through the backward).  Same fixtures and bars - and,
+    measured against the oracle evaluated in float64 on the same float32 inputs, gradients several times closer than the default's."""
+    c = cases.build_case(name)
+    g = load_golden(name)
+    s6 = simlib.sim_step(c, split=2, **kw)
+    s3 = simlib.sim_step(c, split=1, **kw)
+    assert s6["loss"] == s3["loss"]                       # the forward is the same code
+    for k in RENDER_KEYS:
+        assert np.array_equal(s6[k], s3[k]), k
+    for k in GRAD_KEYS:
+        assert relerr(s6[k], g[k]) < 1e-4, k
+    o = vo.training_step(c["fc"], c["B"], c["scale"], c["batch"], dtype=np.float64)
+    e6 = max(relerr(s6[k], o[k]) for k in GRAD_KEYS)
+    e3 = max(relerr(s3[k], o[k]) for k in GRAD_KEYS)
+    print(name, kw, "max gradient error vs the float64 oracle: six products %.2e, three %.2e" % (e6, e3))
+    assert e6 <= e3 * 1.05
+
+
 @pytest.mark.parametrize("nw,G", [(1, None), (2, 5), (3, 7)])
 def test_sim_split_pass_loop_and_group_sizes(nw, G):
-    """Several passes per workgroup: the lo planes are re-copied per pass (the staging tiles overlay them)."""
+    """Several passes per workgroup (the image stays valid across passes: the staging tiles alias the idle transpose tiles)."""
     c = cases.build_case("ragged")
     g = load_golden("ragged")
     s = simlib.sim_step(c, NW=nw, G=G, split=True)

@@ -6,9 +6,9 @@
 namespace vl {
 
 namespace {
-template <bool BWD, bool MULTI, bool STAMPS, bool W3>
+template <bool BWD, bool MULTI, bool STAMPS, bool W3, bool B6 = false>
 int main_v(const vk::StepArgs& a, hipStream_t st) {
-    auto kern = vk::step_main_s32<BWD, MULTI, STAMPS, W3>;
+    auto kern = vk::step_main_s32<BWD, MULTI, STAMPS, W3, B6>;
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), vk::Img32s::LDS_BYTES, "step_main_s32")) return rc;
     const int grid = a.xcd_affine ? 8 * ((a.n_obj + 7) / 8) * a.NW : a.n_obj * a.NW;
     VL_LAUNCH_MAIN(kern, dim3(grid), dim3(vk::kWG), vk::Img32s::LDS_BYTES, st, a);
@@ -18,6 +18,9 @@ template <bool BWD, bool STAMPS>
 int main_bs(const vk::StepArgs& a, hipStream_t st) {
     const bool multi = a.NW < a.NG;
     if (a.weights_bf16) return multi ? main_v<BWD, true, STAMPS, false>(a, st) : main_v<BWD, false, STAMPS, false>(a, st);
+    if constexpr (BWD && !STAMPS) {          // the six-product backward (tuning.kernel = VMAPSTEP_KERNEL_S32_BWD6): training instantiations only
+        if (a.bwd6) return multi ? main_v<true, true, false, true, true>(a, st) : main_v<true, false, false, true, true>(a, st);
+    }
     return multi ? main_v<BWD, true, STAMPS, true>(a, st) : main_v<BWD, false, STAMPS, true>(a, st);
 }
 }  // namespace

@@ -429,36 +429,22 @@ __device__ __forceinline__ TrLane tr_lane(int lane) { return TrLane{(lane >> 4) 
 // A operand of a d-prop chain: W^T for the 32 input columns that start at 16-deep step `step0` of matrix rows at `wmat`
 // (hi plane, row pitch PIT): w[pl * 8 + s * 4 + u * 2 + {0, 1}], pl = 0 hi / 1 mid plane, s = 16-deep step over the 32
 // OUTPUT rows j, u = which four of the lane's eight j: element t = 4 u + jj' <-> j = 16 s + 8 u + 4 hi + jj'.
-template <int PIT, bool W3>
-__device__ __forceinline__ void wt_get(unsigned (&w)[16], const char* wmat, int step0, const TrLane& L) {
+// NP = planes fetched (1: bf16 weights; 2: hi, mid; 3: + lo for the six-product backward): w[pl * 8 + ...]
+template <int PIT, int NP>
+__device__ __forceinline__ void wt_get(unsigned (&w)[24], const char* wmat, int step0, const TrLane& L) {
     using I = Img32s;
     const char* base = wmat + (4 * L.hi + L.jj) * PIT + (step0 + L.half) * 32 + ((L.q & 1) * 8 + (L.q >> 1) * 4) * 2;
 #pragma unroll
-    for (int pl = 0; pl < (W3 ? 2 : 1); ++pl)
+    for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const u32x2 v = wv::lds_tr16(base + (pl ? I::P_MID : I::P_HI) + (16 * s + 8 * u) * PIT);
+                const u32x2 v = wv::lds_tr16(base + (pl == 0 ? I::P_HI : pl == 1 ? I::P_MID : I::P_LO) + (16 * s + 8 * u) * PIT);
                 w[pl * 8 + s * 4 + u * 2] = v[0];
                 w[pl * 8 + s * 4 + u * 2 + 1] = v[1];
             }
 }
-// d-prop: acc += W^T . dY with dY = dh + dm (P-form planes): hi.mid + mid.hi + hi.hi
-template <bool W3>
-__device__ __forceinline__ void dprop_mm(f32x16& acc, const unsigned (&w)[16], const unsigned (&dh)[8], const unsigned (&dm)[8]) {
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        const u32x4 wh = u32x4{w[4 * s], w[4 * s + 1], w[4 * s + 2], w[4 * s + 3]};
-        acc = wv::mfma_bf16(wh, opnd(dm, s), acc);
-        if (W3) {
-            const u32x4 wm = u32x4{w[8 + 4 * s], w[8 + 4 * s + 1], w[8 + 4 * s + 2], w[8 + 4 * s + 3]};
-            acc = wv::mfma_bf16(wm, opnd(dh, s), acc);
-        }
-        acc = wv::mfma_bf16(wh, opnd(dh, s), acc);
-    }
-}
-
 // P-form planes (hi, mid; NQ quads of four features per lane) -> wave-private transpose tile [plane][point][feature]
 template <int NQ>
 __device__ __forceinline__ void tile_put(char* tile, const unsigned* h, const unsigned* m, int p31, int hi) {
@@ -512,21 +498,25 @@ __device__ __forceinline__ SelOps sel_ops(int p31, int hi) {
 }
 // NQ = 4: a whole 32-feature block (8 dwords per plane); NQ = 2: its first 16-deep step only (features 16..31 of the result are zero)
 template <int NQ>
-__device__ __forceinline__ void toF_mm(unsigned (&f)[16], const unsigned* h, const unsigned* m, const SelOps& S) {
-    f32x16 th, tm;
-    zero_acc(th);
-    zero_acc(tm);
-    th = wv::mfma_bf16(u32x4{h[0], h[1], h[2], h[3]}, S.s0, th);
-    tm = wv::mfma_bf16(u32x4{m[0], m[1], m[2], m[3]}, S.s0, tm);
-    if (NQ == 4) {
-        th = wv::mfma_bf16(u32x4{h[4], h[5], h[6], h[7]}, S.s1, th);
-        tm = wv::mfma_bf16(u32x4{m[4], m[5], m[6], m[7]}, S.s1, tm);
-    }
+__device__ __forceinline__ void toF_plane(unsigned* f, const unsigned* h, const SelOps& S) {
+    f32x16 t;
+    zero_acc(t);
+    t = wv::mfma_bf16(u32x4{h[0], h[1], h[2], h[3]}, S.s0, t);
+    if (NQ == 4) t = wv::mfma_bf16(u32x4{h[4], h[5], h[6], h[7]}, S.s1, t);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        f[j] = wv::pack_bf16(th[2 * j], th[2 * j + 1]);
-        f[8 + j] = wv::pack_bf16(tm[2 * j], tm[2 * j + 1]);
-    }
+    for (int j = 0; j < 8; ++j) f[j] = wv::pack_bf16(t[2 * j], t[2 * j + 1]);
+}
+template <int NQ>
+__device__ __forceinline__ void toF_mm(unsigned (&f)[16], const unsigned* h, const unsigned* m, const SelOps& S) {
+    toF_plane<NQ>(f, h, S);
+    toF_plane<NQ>(f + 8, m, S);
+}
+// the same for NPL planes into f[pl * 8 + ...] (NPL = 3: the six-product backward also carries the lo plane)
+template <int NQ, int NPL>
+__device__ __forceinline__ void toF_mm3(unsigned (&f)[24], const unsigned* h, const unsigned* m, const unsigned* l, const SelOps& S) {
+    toF_plane<NQ>(f, h, S);
+    toF_plane<NQ>(f + 8, m, S);
+    if (NPL == 3) toF_plane<NQ>(f + 16, l, S);
 }
 // weight gradient: acc[j][k] += sum_p dY[p][j] X[p][k], both operands in F-form planes: hi.mid + mid.hi + hi.hi
 __device__ __forceinline__ void dw_mm_s(f32x16& acc, const unsigned (&dyF)[16], const unsigned (&xF)[16]) {
@@ -621,43 +611,59 @@ __device__ __forceinline__ void finish_block_s(float (&qp)[4], const float* stag
 // for the pipe blocks everything behind it, so independent VALU work hides behind matrix instructions only when the two are
 // interleaved in the instruction stream (<= 6 VALU per bf16 matrix instruction are free: profiles/r02a_bf16_probe.jsonl).
 // Every helper takes a callable vc(i) that is invoked right after matrix instruction i, between scheduling fences. ----
-template <bool W3, class VC>
-__device__ __forceinline__ void mm_dprop_il(f32x16& acc, const unsigned (&w)[16], const unsigned (&dh)[8], const unsigned (&dm)[8], VC&& vc) {
-    constexpr int PS = W3 ? 3 : 2;
+// MODE 0: bf16 weights (one weight plane x delta hi, mid); 1: float32 weights, three products (hi.mid + mid.hi + hi.hi, ~2^-16);
+// 2: float32 weights, SIX products (+ hi.lo + lo.hi + mid.mid, ~2^-24: the float32-equivalent backward, tuning.bwd_products = 6)
+constexpr int kDpropPS(int mode) { return mode == 0 ? 2 : mode == 1 ? 3 : 6; }
+constexpr int kDpropMM(int mode) { return 2 * kDpropPS(mode); }
+template <int MODE, class VC>
+__device__ __forceinline__ void mm_dprop_il(f32x16& acc, const unsigned (&w)[24], const unsigned (&dh)[8], const unsigned (&dm)[8], const unsigned (&dl)[8], VC&& vc) {
+    constexpr int PS = kDpropPS(MODE);
     wv::sched_fence();
 #pragma unroll
     for (int i = 0; i < 2 * PS; ++i) {
         const int s = i / PS, k = i % PS;
         const u32x4 wh = u32x4{w[4 * s], w[4 * s + 1], w[4 * s + 2], w[4 * s + 3]};
         const u32x4 wm = u32x4{w[8 + 4 * s], w[8 + 4 * s + 1], w[8 + 4 * s + 2], w[8 + 4 * s + 3]};
-        if (k == 0) acc = wv::mfma_bf16(wh, opnd(dm, s), acc);
-        else if (W3 && k == 1) acc = wv::mfma_bf16(wm, opnd(dh, s), acc);
+        const u32x4 wl = u32x4{w[16 + 4 * s], w[16 + 4 * s + 1], w[16 + 4 * s + 2], w[16 + 4 * s + 3]};
+        if (MODE == 2) {                               // smallest terms first
+            acc = k == 0 ? wv::mfma_bf16(wh, opnd(dl, s), acc) : k == 1 ? wv::mfma_bf16(wl, opnd(dh, s), acc) : k == 2 ? wv::mfma_bf16(wm, opnd(dm, s), acc)
+                : k == 3 ? wv::mfma_bf16(wh, opnd(dm, s), acc) : k == 4 ? wv::mfma_bf16(wm, opnd(dh, s), acc) : wv::mfma_bf16(wh, opnd(dh, s), acc);
+        } else if (k == 0) acc = wv::mfma_bf16(wh, opnd(dm, s), acc);
+        else if (MODE == 1 && k == 1) acc = wv::mfma_bf16(wm, opnd(dh, s), acc);
         else acc = wv::mfma_bf16(wh, opnd(dh, s), acc);
         wv::sched_fence();
         vc(i);
         wv::sched_fence();
     }
 }
-constexpr int kDpropMM(bool w3) { return w3 ? 6 : 4; }
 // weight-gradient chain (6 matrix instructions), optionally followed by the 4 of the ones-column bias gradient (DB)
-template <bool DB, class VC>
-__device__ __forceinline__ void mm_dw_il(f32x16& acc, f32x16& accb, const unsigned (&dyF)[16], const unsigned (&xF)[16], VC&& vc) {
+// B6: six products per 16-deep step (+ hi.lo + lo.hi + mid.mid) and the lo plane in the bias sums
+constexpr int kDwMM(bool b6) { return b6 ? 12 : 6; }
+constexpr int kDwDbMM(bool b6) { return b6 ? 18 : 10; }
+template <bool DB, bool B6, class VC>
+__device__ __forceinline__ void mm_dw_il(f32x16& acc, f32x16& accb, const unsigned (&dyF)[24], const unsigned (&xF)[24], VC&& vc) {
     const u32x4 ones = u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+    constexpr int PS = B6 ? 6 : 3, NDW = 2 * PS, PB = B6 ? 3 : 2;
     wv::sched_fence();
 #pragma unroll
-    for (int i = 0; i < (DB ? 10 : 6); ++i) {
+    for (int i = 0; i < (DB ? NDW + 2 * PB : NDW); ++i) {
         if (VS_ABL & 1) {
-        } else if (i < 6) {
-            const int s = i / 3, k = i % 3;
+        } else if (i < NDW) {
+            const int s = i / PS, k = i % PS;
             const u32x4 ah = u32x4{dyF[4 * s], dyF[4 * s + 1], dyF[4 * s + 2], dyF[4 * s + 3]};
             const u32x4 am = u32x4{dyF[8 + 4 * s], dyF[8 + 4 * s + 1], dyF[8 + 4 * s + 2], dyF[8 + 4 * s + 3]};
+            const u32x4 al = u32x4{dyF[16 + 4 * s], dyF[16 + 4 * s + 1], dyF[16 + 4 * s + 2], dyF[16 + 4 * s + 3]};
             const u32x4 bh = u32x4{xF[4 * s], xF[4 * s + 1], xF[4 * s + 2], xF[4 * s + 3]};
             const u32x4 bm = u32x4{xF[8 + 4 * s], xF[8 + 4 * s + 1], xF[8 + 4 * s + 2], xF[8 + 4 * s + 3]};
-            acc = k == 0 ? wv::mfma_bf16(ah, bm, acc) : k == 1 ? wv::mfma_bf16(am, bh, acc) : wv::mfma_bf16(ah, bh, acc);
+            const u32x4 bl = u32x4{xF[16 + 4 * s], xF[16 + 4 * s + 1], xF[16 + 4 * s + 2], xF[16 + 4 * s + 3]};
+            if (B6) {                                  // smallest terms first
+                acc = k == 0 ? wv::mfma_bf16(ah, bl, acc) : k == 1 ? wv::mfma_bf16(al, bh, acc) : k == 2 ? wv::mfma_bf16(am, bm, acc)
+                    : k == 3 ? wv::mfma_bf16(ah, bm, acc) : k == 4 ? wv::mfma_bf16(am, bh, acc) : wv::mfma_bf16(ah, bh, acc);
+            } else
+                acc = k == 0 ? wv::mfma_bf16(ah, bm, acc) : k == 1 ? wv::mfma_bf16(am, bh, acc) : wv::mfma_bf16(ah, bh, acc);
         } else {
-            const int s = (i - 6) / 2, k = (i - 6) % 2;
-            const u32x4 a = k == 0 ? u32x4{dyF[8 + 4 * s], dyF[8 + 4 * s + 1], dyF[8 + 4 * s + 2], dyF[8 + 4 * s + 3]}
-                                   : u32x4{dyF[4 * s], dyF[4 * s + 1], dyF[4 * s + 2], dyF[4 * s + 3]};
+            const int s = (i - NDW) / PB, k = (i - NDW) % PB, pl = PB - 1 - k;      // lo (B6), mid, hi
+            const u32x4 a = u32x4{dyF[8 * pl + 4 * s], dyF[8 * pl + 4 * s + 1], dyF[8 * pl + 4 * s + 2], dyF[8 * pl + 4 * s + 3]};
             accb = wv::mfma_bf16(a, ones, accb);
         }
         wv::sched_fence();
@@ -666,14 +672,18 @@ __device__ __forceinline__ void mm_dw_il(f32x16& acc, f32x16& accb, const unsign
     }
 }
 // ReLU mask + two-plane split of register pair j of a d-prop result (the VALU work of a hidden unit, one chunk per pair)
-__device__ __forceinline__ void mask_split_pair(int j, const f32x16& v, const unsigned (&hh)[8], unsigned (&dh)[8], unsigned (&dm)[8], float dep) {
+template <int NPD = 2>
+__device__ __forceinline__ void mask_split_pair(int j, const f32x16& v, const unsigned (&hh)[8], unsigned (&dh)[8], unsigned (&dm)[8], unsigned (&dl)[8], float dep) {
     const unsigned u = wv::opaque_u(hh[j]);
     const float va = wv::after(v[2 * j], dep);           // (the tie sits outside the select: inside it the select becomes a branch)
     const float a = (u & 0xFFFFu) != 0u ? va : 0.0f;
     const float b = u > 0xFFFFu ? v[2 * j + 1] : 0.0f;
     const unsigned ph = wv::pack_bf16(a, b);
     dh[j] = ph;
-    dm[j] = wv::pack_bf16(a - bf_lo(ph), b - bf_hi(ph));
+    const float ra = a - bf_lo(ph), rb = b - bf_hi(ph);
+    const unsigned pm = wv::pack_bf16(ra, rb);
+    dm[j] = pm;
+    if (NPD == 3) dl[j] = wv::pack_bf16(ra - bf_lo(pm), rb - bf_hi(pm));
 }
 // finishing a staged block in two chunks: 0 = the four 16-byte reads of this wave's quarter, 1 = sum + store (or keep, MULTI)
 struct FinState { wv::f32x4 t0, t1, t2, t3; };
@@ -781,8 +791,9 @@ __device__ __forceinline__ void stage_get_s(float (&q)[4], const float* stage, i
 // ---------------------------------------------------------------------------------------------------------
 // step_main_s32<BWD, MULTI, STAMPS, W3>:  W3 = float32 weights as three planes (false: bf16 weights, one plane)
 // ---------------------------------------------------------------------------------------------------------
-template <bool BWD, bool MULTI, bool STAMPS, bool W3>
+template <bool BWD, bool MULTI, bool STAMPS, bool W3, bool B6 = false>
 __device__ __forceinline__ void step_main_s32_body(const StepArgs& a) {
+    static_assert(!B6 || (W3 && BWD), "six-product backward: float32 weights, training instantiations");
     using I = Img32s;
     using F = Flat32;
     constexpr int H = 32;
@@ -903,14 +914,13 @@ __device__ __forceinline__ void step_main_s32_body(const StepArgs& a) {
     wv::sched_fence();
 
     // ---- field MLP forward (model.py:59-83) ----
-    unsigned h1h[8], h1m[8], h2h[8], h2m[8], h3h[8], h3m[8], h4h[8], h4m[8];
+    unsigned h1h[8], h1m[8], h1l[8], h2h[8], h2m[8], h2l[8], h3h[8], h3m[8], h3l[8], h4h[8], h4m[8], h4l[8];   // (the lo planes live on only in the six-product backward)
     float h4[16], hc[16];
     f32x16 acc;
     {
         // The layer-to-layer chain (matrix chain -> ReLU -> split into planes -> next matrix chain) would leave the matrix pipe
         // idle while the ~100 VALU instructions of a split run; the encoding halves of cat_layer and color_linear do not
         // depend on any hidden layer, so their 54 matrix instructions are interleaved with the four splits (gap_fill).
-        unsigned xl[8];
         float hf[16];
         f32x16 accE, accC;
         const char* w = W + I::O_IN + p31 * I::PIT_IN + 16 * hi;
@@ -919,19 +929,19 @@ __device__ __forceinline__ void step_main_s32_body(const StepArgs& a) {
         zero_acc(acc);                                            // the bias rides in the column of the constant-1 slot
         fwd_chain<W3, 6>(acc, w, e1h, e1m, e1l);
         zero_acc(accE);
-        gap_fill<W3, 3>(accE, wcat + 32 * 2, e1h, e1m, e1l, acc, hf, h1h, h1m, xl);                 // :59 in_layer -> h1 | :63 x[:emb1] half, steps 0..2
+        gap_fill<W3, 3>(accE, wcat + 32 * 2, e1h, e1m, e1l, acc, hf, h1h, h1m, h1l);                 // :59 in_layer -> h1 | :63 x[:emb1] half, steps 0..2
         w = W + I::O_M1 + p31 * I::PIT_M + 16 * hi;
         load_bias(acc, SM + I::B_M1, hi);
-        fwd_chain<W3, 2>(acc, w, h1h, h1m, xl);
-        gap_fill<W3, 3>(accE, wcat + 32 * 5, e1h + 12, e1m + 12, e1l + 12, acc, hf, h2h, h2m, xl);  // :60 mid1 -> h2 | steps 3..5
-        fwd_chain<W3, 2>(accE, wcat, h2h, h2m, xl);                                                  // :63 cat((fc2, x[:emb1]))
+        fwd_chain<W3, 2>(acc, w, h1h, h1m, h1l);
+        gap_fill<W3, 3>(accE, wcat + 32 * 5, e1h + 12, e1m + 12, e1l + 12, acc, hf, h2h, h2m, h2l);  // :60 mid1 -> h2 | steps 3..5
+        fwd_chain<W3, 2>(accE, wcat, h2h, h2m, h2l);                                                  // :63 cat((fc2, x[:emb1]))
         zero_acc(accC);
-        gap_fill<W3, 2>(accC, wc + 32 * 2, e2h, e2m, e2l, accE, hf, h3h, h3m, xl);                  // :64 cat_layer -> h3 | :81 x[emb1:] half, steps 0, 1
+        gap_fill<W3, 2>(accC, wc + 32 * 2, e2h, e2m, e2l, accE, hf, h3h, h3m, h3l);                  // :64 cat_layer -> h3 | :81 x[emb1:] half, steps 0, 1
         w = W + I::O_M2 + p31 * I::PIT_M + 16 * hi;
         load_bias(acc, SM + I::B_M2, hi);
-        fwd_chain<W3, 2>(acc, w, h3h, h3m, xl);
-        gap_fill<W3, 1>(accC, wc + 32 * 4, e2h + 8, e2m + 8, e2l + 8, acc, h4, h4h, h4m, xl);       // :67 mid2 -> h4 | step 2
-        fwd_chain<W3, 2>(accC, wc, h4h, h4m, xl);                                                    // :81 cat((fc4, x[emb1:]))
+        fwd_chain<W3, 2>(acc, w, h3h, h3m, h3l);
+        gap_fill<W3, 1>(accC, wc + 32 * 4, e2h + 8, e2m + 8, e2l + 8, acc, h4, h4h, h4m, h4l);       // :67 mid2 -> h4 | step 2
+        fwd_chain<W3, 2>(accC, wc, h4h, h4m, h4l);                                                    // :81 cat((fc4, x[emb1:]))
         relu_to(hc, accC);                                        // :81 color_linear
     }
     VS_MARK(3);
@@ -978,11 +988,12 @@ __device__ __forceinline__ void step_main_s32_body(const StepArgs& a) {
         const float* row = cb + pt * 8;          // pt < kMaxPts always; padding rows hold zeros
         d_raw = row[0]; d_c0 = row[1]; d_c1 = row[2]; d_c2 = row[3];
     }
-    unsigned dF[16];
+    constexpr int DM = !W3 ? 0 : B6 ? 2 : 1, NA = kDpropMM(DM), NPW = !W3 ? 1 : B6 ? 3 : 2, NPB = B6 ? 3 : 2, NDW = kDwMM(B6), NDB = kDwDbMM(B6);
+    unsigned dF[24];
     float dproj[11];
 #pragma unroll
     for (int i = 0; i < 11; ++i) dproj[i] = 0.0f;
-    unsigned dch[8], dcm[8], d4h[8], d4m[8], xl_unused[8];
+    unsigned dch[8], dcm[8], dcl[8], d4h[8], d4m[8], d4l[8];
     {
         // heads: out_alpha / out_color weight + bias gradients (lane = hidden feature), float32 as in step_main_h32
         float h4F[16], hcF[16];
@@ -1019,7 +1030,7 @@ __device__ __forceinline__ void step_main_s32_body(const StepArgs& a) {
             const float v = SM[I::W_OC + j] * d_c0 + SM[I::W_OC + H + j] * d_c1 + SM[I::W_OC + 2 * H + j] * d_c2;
             dcp[r] = wv::opaque(hc[r]) > 0.0f ? v : 0.0f;
         }
-        split_planes<16, 2>(dcp, dch, dcm, xl_unused);
+        split_planes<16, NPB>(dcp, dch, dcm, dcl);
     }
     // ---- 13 units, one 32x32 weight-gradient block each.  Per unit two matrix chains, each with VALU work interleaved by
     // hand (one wave per SIMD issues in order):
@@ -1030,9 +1041,8 @@ __device__ __forceinline__ void step_main_s32_body(const StepArgs& a) {
     // (xA / xB; the tile is refilled as soon as its previous content has been read); a new delta is transposed behind B. ----
     f32x16 acc2, accb;
     FinState fs;
-    unsigned wA[16], wB[16], xA[16], xB[16];
-    unsigned d3h[8], d3m[8], d2h[8], d2m[8], d1h[8], d1m[8], dF3[16], dF1[16];
-    constexpr int NA = kDpropMM(W3);
+    unsigned wA[24], wB[24], xA[24], xB[24];
+    unsigned d3h[8], d3m[8], d3l[8], d2h[8], d2m[8], d2l[8], d1h[8], d1m[8], d1l[8], dF3[24], dF1[24];
     const auto nothing = [](int) {};
 #define VS_FIN(KIND, K, QI, STG, OW, OB, BLK, NC)                                                                             \
     [&](int i) {                                                                                                              \
@@ -1040,29 +1050,29 @@ __device__ __forceinline__ void step_main_s32_body(const StepArgs& a) {
         if (i == NA - 3) fin_chunk<KIND, K, MULTI>(1, fs, qacc[QI], STG, OW, OB, BLK, NC, wave, p31, hi);                     \
     }
     const SelOps SEL = sel_ops(p31, hi);
-    wt_get<I::PIT_C, W3>(wA, W + I::O_C, 0, TL);
-    toF_mm<4>(dF, dch, dcm, SEL);                                 // F(d hc): the delta of units 0..2
-    toF_mm<4>(xA, h4h, h4m, SEL);                                 // F(h4)
-    wt_get<I::PIT_C, W3>(wB, W + I::O_C, 2, TL);
+    wt_get<I::PIT_C, NPW>(wA, W + I::O_C, 0, TL);
+    toF_mm3<4, NPB>(dF, dch, dcm, dcl, SEL);                                 // F(d hc): the delta of units 0..2
+    toF_mm3<4, NPB>(xA, h4h, h4m, h4l, SEL);                                 // F(h4)
+    wt_get<I::PIT_C, NPW>(wB, W + I::O_C, 2, TL);
     // unit 0: colour layer x h4;  d h4 = W_a d raw + W_c[:, :H]^T d hc
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc2[r] = SM[I::W_A + phi(r, hi)] * d_raw;
-    mm_dprop_il<W3>(acc2, wA, dch, dcm, nothing);
-    toF_mm<4>(xB, e2h, e2m, SEL);                                 // F(second-group slots 0..15)
+    mm_dprop_il<DM>(acc2, wA, dch, dcm, dcl, nothing);
+    toF_mm3<4, NPB>(xB, e2h, e2m, e2l, SEL);                                 // F(second-group slots 0..15)
     zero_acc(acc);
-    mm_dw_il<false>(acc, accb, dF, xA, [&](int i) {
+    mm_dw_il<false, B6>(acc, accb, dF, xA, [&](int i) {
 #pragma unroll
-        for (int j = i * 8 / 6; j < (i + 1) * 8 / 6; ++j) mask_split_pair(j, acc2, h4h, d4h, d4m, acc[0]);
+        for (int j = i * 8 / NDW; j < (i + 1) * 8 / NDW; ++j) mask_split_pair<NPB>(j, acc2, h4h, d4h, d4m, d4l, acc[0]);
     });
-    wt_get<I::PIT_C, W3>(wA, W + I::O_C, 4, TL);
+    wt_get<I::PIT_C, NPW>(wA, W + I::O_C, 4, TL);
     VS_BWD_BARRIER();
     // unit 1: x = second-group slots 0..15
     zero_acc(acc2);
-    mm_dprop_il<W3>(acc2, wB, dch, dcm, [&](int i) { if (i == NA - 1) stage_put_s(stg0, acc, wave, p31, hi); });       // block 0
-    toF_mm<2>(xA, e2h + 8, e2m + 8, SEL);                         // F(second-group slots 16..23): half a block
-    wt_get<I::PIT_M, W3>(wB, W + I::O_M2, 0, TL);
+    mm_dprop_il<DM>(acc2, wB, dch, dcm, dcl, [&](int i) { if (i == NA - 1) stage_put_s(stg0, acc, wave, p31, hi); });       // block 0
+    toF_mm3<2, NPB>(xA, e2h + 8, e2m + 8, e2l + 8, SEL);                         // F(second-group slots 16..23): half a block
+    wt_get<I::PIT_M, NPW>(wB, W + I::O_M2, 0, TL);
     zero_acc(acc);
-    mm_dw_il<false>(acc, accb, dF, xB, [&](int i) {
+    mm_dw_il<false, B6>(acc, accb, dF, xB, [&](int i) {
         if (i < 4) {
 #pragma unroll
             for (int r = 4 * i; r < 4 * i + 4; ++r) dproj[r >> 1] += wv::after(acc2[r], acc[0]) * cfac[r >> 1][4 + (r & 1)];     // slot R = r: direction r >> 1, octave 4 + (r & 1)
@@ -1073,76 +1083,76 @@ __device__ __forceinline__ void step_main_s32_body(const StepArgs& a) {
     zero_acc(acc2);
     {
         auto fin = VS_FIN(0, H + kEmb2, 0, stg0, out + F::W_C, nullptr, 0, 32);
-        mm_dprop_il<W3>(acc2, wA, dch, dcm, [&](int i) { fin(i); if (i == NA - 1) stage_put_s(stg1, acc, wave, p31, hi); });   // block 1
+        mm_dprop_il<DM>(acc2, wA, dch, dcm, dcl, [&](int i) { fin(i); if (i == NA - 1) stage_put_s(stg1, acc, wave, p31, hi); });   // block 1
     }
-    toF_mm<4>(xB, h3h, h3m, SEL);                                 // F(h3)
-    wt_get<I::PIT_CAT, W3>(wA, W + I::O_CAT, 0, TL);
+    toF_mm3<4, NPB>(xB, h3h, h3m, h3l, SEL);                                 // F(h3)
+    wt_get<I::PIT_CAT, NPW>(wA, W + I::O_CAT, 0, TL);
     zero_acc(acc);
-    mm_dw_il<false>(acc, accb, dF, xA, [&](int i) {
+    mm_dw_il<false, B6>(acc, accb, dF, xA, [&](int i) {
         if (i < 3) {
 #pragma unroll
             for (int r = 2 * i; r < 2 * i + 2; ++r) dproj[8 + (r >> 1)] += wv::after(acc2[r], acc[0]) * cfac[8 + (r >> 1)][4 + (r & 1)];   // slots 16..21: directions 8..10
         }
     });
-    toF_mm<4>(dF, d4h, d4m, SEL);                                 // F(d4) (F(d hc) was the delta of units 0..2)
+    toF_mm3<4, NPB>(dF, d4h, d4m, d4l, SEL);                                 // F(d4) (F(d hc) was the delta of units 0..2)
     VS_BWD_BARRIER();
     VS_MARK(7);
     // unit 3: mid2, delta = d4, x = h3
     zero_acc(acc2);
     {
         auto fin = VS_FIN(2, H + kEmb2, 1, stg1, out + F::W_C + H, out + F::B_C, 0, kEmb2);
-        mm_dprop_il<W3>(acc2, wB, d4h, d4m, [&](int i) { fin(i); if (i == NA - 1) stage_put_s(stg0, acc, wave, p31, hi); });   // block 2
+        mm_dprop_il<DM>(acc2, wB, d4h, d4m, d4l, [&](int i) { fin(i); if (i == NA - 1) stage_put_s(stg0, acc, wave, p31, hi); });   // block 2
     }
-    toF_mm<4>(xA, h2h, h2m, SEL);                                 // F(h2)
-    wt_get<I::PIT_M, W3>(wB, W + I::O_M1, 0, TL);
+    toF_mm3<4, NPB>(xA, h2h, h2m, h2l, SEL);                                 // F(h2)
+    wt_get<I::PIT_M, NPW>(wB, W + I::O_M1, 0, TL);
     zero_acc(acc);
     zero_acc(accb);
-    mm_dw_il<true>(acc, accb, dF, xB, [&](int i) {
+    mm_dw_il<true, B6>(acc, accb, dF, xB, [&](int i) {
 #pragma unroll
-        for (int j = i * 8 / 10; j < (i + 1) * 8 / 10; ++j) mask_split_pair(j, acc2, h3h, d3h, d3m, i < 6 ? acc[0] : accb[0]);
+        for (int j = i * 8 / NDB; j < (i + 1) * 8 / NDB; ++j) mask_split_pair<NPB>(j, acc2, h3h, d3h, d3m, d3l, i < NDW ? acc[0] : accb[0]);
     });
     if (p31 == 0) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) Gv[I::B_M2 + phi(r, hi)] += accb[r];
     }
-    toF_mm<4>(dF3, d3h, d3m, SEL);                                // F(d3): kept for the three first-group blocks
+    toF_mm3<4, NPB>(dF3, d3h, d3m, d3l, SEL);                                // F(d3): kept for the three first-group blocks
     VS_BWD_BARRIER();
     VS_MARK(8);
     // unit 4: cat_layer, delta = d3, x = h2
     zero_acc(acc2);
     {
         auto fin = VS_FIN(2, H + kEmb2, 2, stg0, out + F::W_C + H, out + F::B_C, 1, kEmb2);
-        mm_dprop_il<W3>(acc2, wA, d3h, d3m, [&](int i) { fin(i); if (i == NA - 1) stage_put_s(stg1, acc, wave, p31, hi); });   // block 3
+        mm_dprop_il<DM>(acc2, wA, d3h, d3m, d3l, [&](int i) { fin(i); if (i == NA - 1) stage_put_s(stg1, acc, wave, p31, hi); });   // block 3
     }
-    toF_mm<4>(xB, h1h, h1m, SEL);                                 // F(h1)
-    wt_get<I::PIT_CAT, W3>(wA, W + I::O_CAT, 2, TL);
+    toF_mm3<4, NPB>(xB, h1h, h1m, h1l, SEL);                                 // F(h1)
+    wt_get<I::PIT_CAT, NPW>(wA, W + I::O_CAT, 2, TL);
     zero_acc(acc);
-    mm_dw_il<false>(acc, accb, dF3, xA, [&](int i) {
+    mm_dw_il<false, B6>(acc, accb, dF3, xA, [&](int i) {
 #pragma unroll
-        for (int j = i * 8 / 6; j < (i + 1) * 8 / 6; ++j) mask_split_pair(j, acc2, h2h, d2h, d2m, acc[0]);
+        for (int j = i * 8 / NDW; j < (i + 1) * 8 / NDW; ++j) mask_split_pair<NPB>(j, acc2, h2h, d2h, d2m, d2l, acc[0]);
     });
-    toF_mm<4>(dF, d2h, d2m, SEL);                                 // F(d2)
+    toF_mm3<4, NPB>(dF, d2h, d2m, d2l, SEL);                                 // F(d2)
     VS_BWD_BARRIER();
     VS_MARK(9);
     // unit 5: mid1, delta = d2, x = h1
     zero_acc(acc2);
     {
         auto fin = VS_FIN(0, H, 3, stg1, out + F::W_M2, nullptr, 0, 32);
-        mm_dprop_il<W3>(acc2, wB, d2h, d2m, [&](int i) { fin(i); if (i == NA - 1) stage_put_s(stg0, acc, wave, p31, hi); });   // block 4
+        mm_dprop_il<DM>(acc2, wB, d2h, d2m, d2l, [&](int i) { fin(i); if (i == NA - 1) stage_put_s(stg0, acc, wave, p31, hi); });   // block 4
     }
-    toF_mm<4>(xA, e1h, e1m, SEL);                                 // F(first-group block 0)
-    wt_get<I::PIT_IN, W3>(wB, W + I::O_IN, 0, TL);
+    toF_mm3<4, NPB>(xA, e1h, e1m, e1l, SEL);                                 // F(first-group block 0)
+    wt_get<I::PIT_IN, NPW>(wB, W + I::O_IN, 0, TL);
     zero_acc(acc);
     zero_acc(accb);
-    mm_dw_il<true>(acc, accb, dF, xB, [&](int i) {
+    mm_dw_il<true, B6>(acc, accb, dF, xB, [&](int i) {
 #pragma unroll
-        for (int j = i * 8 / 10; j < (i + 1) * 8 / 10; ++j) mask_split_pair(j, acc2, h1h, d1h, d1m, i < 6 ? acc[0] : accb[0]);
+        for (int j = i * 8 / NDB; j < (i + 1) * 8 / NDB; ++j) mask_split_pair<NPB>(j, acc2, h1h, d1h, d1m, d1l, i < NDW ? acc[0] : accb[0]);
     });
     if (p31 == 0) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) Gv[I::B_M1 + phi(r, hi)] += accb[r];
     }
-    toF_mm<4>(dF1, d1h, d1m, SEL);                                // F(d1): kept for the three in_layer blocks
+    toF_mm3<4, NPB>(dF1, d1h, d1m, d1l, SEL);                                // F(d1): kept for the three in_layer blocks
     VS_BWD_BARRIER();
     VS_MARK(10);
     // units 6..11: the three first-group blocks feed cat_layer (delta d3, weights wA) and in_layer (delta d1, weights wB);
@@ -1150,35 +1160,35 @@ __device__ __forceinline__ void step_main_s32_body(const StepArgs& a) {
     f32x16 de;
 #pragma unroll
     for (int blk = 0; blk < 3; ++blk) {
-        unsigned (&xc)[16] = (blk & 1) ? xB : xA;
-        unsigned (&xn)[16] = (blk & 1) ? xA : xB;
+        unsigned (&xc)[24] = (blk & 1) ? xB : xA;
+        unsigned (&xn)[24] = (blk & 1) ? xA : xB;
         // cat_layer x block: finishes block 4 (blk 0) or the cat block of the previous round; stages the last in / mid1 block
         zero_acc(de);
         if (blk == 0) {
             auto fin = VS_FIN(0, H + kEmb1, 4, stg0, out + F::W_CAT, nullptr, 0, 32);
-            mm_dprop_il<W3>(de, wA, d3h, d3m, [&](int i) { fin(i); if (i == NA - 1) stage_put_s(stg1, acc, wave, p31, hi); });   // block 5
+            mm_dprop_il<DM>(de, wA, d3h, d3m, d3l, [&](int i) { fin(i); if (i == NA - 1) stage_put_s(stg1, acc, wave, p31, hi); });   // block 5
         } else {
             auto fin = VS_FIN(1, H + kEmb1, 6 + blk - 1, stg0, out + F::W_CAT + H, out + F::B_CAT, blk - 1, kEmb1);
-            mm_dprop_il<W3>(de, wA, d3h, d3m, [&](int i) { fin(i); if (i == NA - 1) stage_put_s(stg1, acc, wave, p31, hi); });   // block 9 + blk - 1
+            mm_dprop_il<DM>(de, wA, d3h, d3m, d3l, [&](int i) { fin(i); if (i == NA - 1) stage_put_s(stg1, acc, wave, p31, hi); });   // block 9 + blk - 1
         }
         if (blk < 2) {
-            wt_get<I::PIT_CAT, W3>(wA, W + I::O_CAT, 2 + 2 * (blk + 1), TL);
-            toF_mm<4>(xn, e1h + 8 * (blk + 1), e1m + 8 * (blk + 1), SEL);
+            wt_get<I::PIT_CAT, NPW>(wA, W + I::O_CAT, 2 + 2 * (blk + 1), TL);
+            toF_mm3<4, NPB>(xn, e1h + 8 * (blk + 1), e1m + 8 * (blk + 1), e1l + 8 * (blk + 1), SEL);
         }
         zero_acc(acc);
-        mm_dw_il<false>(acc, accb, dF3, xc, nothing);
+        mm_dw_il<false, B6>(acc, accb, dF3, xc, nothing);
         VS_BWD_BARRIER();
         // in_layer x block: finishes the mid1 block (blk 0) or the previous round's in block; stages this round's cat block
         if (blk == 0) {
             auto fin = VS_FIN(0, H, 5, stg1, out + F::W_M1, nullptr, 0, 32);
-            mm_dprop_il<W3>(de, wB, d1h, d1m, [&](int i) { fin(i); if (i == NA - 1) stage_put_s(stg0, acc, wave, p31, hi); });   // block 6 + blk
+            mm_dprop_il<DM>(de, wB, d1h, d1m, d1l, [&](int i) { fin(i); if (i == NA - 1) stage_put_s(stg0, acc, wave, p31, hi); });   // block 6 + blk
         } else {
             auto fin = VS_FIN(1, kEmb1, 9 + blk - 1, stg1, out + F::W_IN, out + F::B_IN, blk - 1, kEmb1);
-            mm_dprop_il<W3>(de, wB, d1h, d1m, [&](int i) { fin(i); if (i == NA - 1) stage_put_s(stg0, acc, wave, p31, hi); });   // block 6 + blk
+            mm_dprop_il<DM>(de, wB, d1h, d1m, d1l, [&](int i) { fin(i); if (i == NA - 1) stage_put_s(stg0, acc, wave, p31, hi); });   // block 6 + blk
         }
-        if (blk < 2) wt_get<I::PIT_IN, W3>(wB, W + I::O_IN, 2 * (blk + 1), TL);
+        if (blk < 2) wt_get<I::PIT_IN, NPW>(wB, W + I::O_IN, 2 * (blk + 1), TL);
         zero_acc(acc);
-        mm_dw_il<false>(acc, accb, dF1, xc, [&](int i) {
+        mm_dw_il<false, B6>(acc, accb, dF1, xc, [&](int i) {
             // d(first-group slot R = 16 blk + r) -> direction R >> 2, octave R & 3 (slots 44..47: xyz / one / padding: no gradient)
             if (i < 4) {
 #pragma unroll
@@ -1196,17 +1206,17 @@ __device__ __forceinline__ void step_main_s32_body(const StepArgs& a) {
     //      = features 24..26 of the last first-group block, whose F-form is still in xA ----
     {
         float dpP[16];
-        unsigned dph[8], dpm[8];
+        unsigned dph[8], dpm[8], dpl[8];
 #pragma unroll
         for (int r = 0; r < 16; ++r) dpP[r] = r < 11 ? dproj[r] : 0.0f;          // row phi(r, hi) <-> direction hi ? 11 + r : r
-        split_planes<16, 2>(dpP, dph, dpm, xl_unused);
-        toF_mm<4>(dF, dph, dpm, SEL);
+        split_planes<16, NPB>(dpP, dph, dpm, dpl);
+        toF_mm3<4, NPB>(dF, dph, dpm, dpl, SEL);
         // finish the last cat block (staged in stg0), stage the last in block
         fin_chunk<1, H + kEmb1, MULTI>(0, fs, qacc[8], stg0, out + F::W_CAT + H, out + F::B_CAT, 2, kEmb1, wave, p31, hi);
         stage_put_s(stg1, acc, wave, p31, hi);                      // block 11
         fin_chunk<1, H + kEmb1, MULTI>(1, fs, qacc[8], stg0, out + F::W_CAT + H, out + F::B_CAT, 2, kEmb1, wave, p31, hi);
         zero_acc(acc);
-        mm_dw_il<false>(acc, accb, dF, xA, nothing);
+        mm_dw_il<false, B6>(acc, accb, dF, xA, nothing);
         VS_BWD_BARRIER();
         finish_block_s<1, kEmb1, MULTI>(qacc[11], stg1, out + F::W_IN, out + F::B_IN, 2, kEmb1, wave, p31, hi);
         stage_put_s(stg0, acc, wave, p31, hi);
@@ -1281,9 +1291,9 @@ __device__ __forceinline__ void step_main_s32_body(const StepArgs& a) {
 #undef VS_MARK
 }
 
-template <bool BWD, bool MULTI, bool STAMPS, bool W3>
+template <bool BWD, bool MULTI, bool STAMPS, bool W3, bool B6 = false>
 __global__ __launch_bounds__(kWG, 1) void step_main_s32(const StepArgs a) {
-    step_main_s32_body<BWD, MULTI, STAMPS, W3>(a);
+    step_main_s32_body<BWD, MULTI, STAMPS, W3, B6>(a);
 }
 
 }  // namespace vk

@@ -74,6 +74,7 @@ struct StepArgs {
     int weights_bf16;                  // 1: the parameter image holds the masters rounded to bfloat16 (RNE)
     int wide;                          // 1: step_main_wide (tile per workgroup, G*S <= 32) instead of step_main_gen; 3: step_main_ws (wsplit_kernels.h)
     int* img_tab;                      // step_prep: [PP] flat parameter -> image position table (or null)
+    int bwd6;                          // 1: step_main_s32 with the six-product (float32-equivalent) backward (tuning.kernel = VMAPSTEP_KERNEL_S32_BWD6)
     int split;                         // 1: hidden 32 on the split-bf16 kernels (split_kernels.h); wimg is then the byte image of Img32s
     float* gen_scratch;                // step_main_gen / step_main_wide: per-wave (per-workgroup) register-image scratch (workspace)
                                        // step_main_ws (wide == 3): per-workgroup cos factors of the encoding

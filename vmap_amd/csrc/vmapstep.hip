@@ -90,6 +90,7 @@ struct Plan {
     size_t off_stats, off_flags, off_ploss, off_imgtab, off_pgrad, off_wimg, off_scratch, total;
     bool generic;      // hidden != 32: step_main_gen (global-memory activations) instead of step_main_h32
     bool split;        // hidden 32 on the bf16 matrix pipe with split operands (step_main_s32; the default at hidden 32)
+    bool bwd6;         // ... with the six-product backward (VMAPSTEP_KERNEL_S32_BWD6)
     int wide;          // 0 = step_main_gen, 1 = step_main_wide<4> (hidden 128 / 256: one tile per workgroup, four waves per
                        // tile), 3 = step_main_ws, 4 = step_main_wp (hidden 64 / 128, bf16 matrix pipe)
 };
@@ -143,8 +144,11 @@ int make_plan(const vmapstep_shape* sh, int max_steps, Plan& pl, const Layout& L
     pl.wide = 0;
     const vmapstep_tuning& tun = tuning_of(sh);
     const int force = tun.kernel;
-    if (force < VMAPSTEP_KERNEL_AUTO || force > VMAPSTEP_KERNEL_WP) return fail(VMAPSTEP_ERR_ARGUMENT, "tuning.kernel=%d", force);
+    if (force < VMAPSTEP_KERNEL_AUTO || force > VMAPSTEP_KERNEL_S32_BWD6) return fail(VMAPSTEP_ERR_ARGUMENT, "tuning.kernel=%d", force);
     pl.split = !pl.generic && force != VMAPSTEP_KERNEL_H32_F32;
+    pl.bwd6 = force == VMAPSTEP_KERNEL_S32_BWD6;
+    if (pl.bwd6 && (pl.generic || sh->weight_dtype != VMAPSTEP_WEIGHTS_F32))
+        return fail(VMAPSTEP_ERR_UNSUPPORTED, "VMAPSTEP_KERNEL_S32_BWD6: hidden 32 with float32 weights");
     if (pl.generic && sh->hidden % 128 == 0 && force != VMAPSTEP_KERNEL_GEN) {
         if (sh->samples <= vk::kWideTile) {
             const int gw = std::min(vk::kWideTile / sh->samples, sh->rays);
@@ -290,6 +294,7 @@ void fill_step_args(vk::StepArgs& a, const vmapstep_shape* sh, const Plan& pl, c
     a.weights_bf16 = sh->weight_dtype == VMAPSTEP_WEIGHTS_BF16 ? 1 : 0;
     a.wide = pl.wide;
     a.split = pl.split ? 1 : 0;
+    a.bwd6 = pl.bwd6 ? 1 : 0;
     a.stats = reinterpret_cast<float*>(ws + pl.off_stats);
     a.flags = reinterpret_cast<int*>(ws + pl.off_flags);
     a.part_loss = reinterpret_cast<float*>(ws + pl.off_ploss);
@@ -450,7 +455,7 @@ int vmapstep_describe_plan(const vmapstep_shape* shape, int32_t max_steps, vmaps
     if (rc) return rc;
     std::memset(info, 0, sizeof(*info));
     const int nb = shape->hidden / 32;
-    if (pl.split) std::snprintf(info->kernel, sizeof(info->kernel), "step_main_s32");
+    if (pl.split) std::snprintf(info->kernel, sizeof(info->kernel), pl.bwd6 ? "step_main_s32<bwd6>" : "step_main_s32");
     else if (!pl.generic) std::snprintf(info->kernel, sizeof(info->kernel), "step_main_h32");
     else if (pl.wide == 3) std::snprintf(info->kernel, sizeof(info->kernel), "step_main_ws<%d>", nb);
     else if (pl.wide == 4) std::snprintf(info->kernel, sizeof(info->kernel), "step_main_wp<%d>", nb);
