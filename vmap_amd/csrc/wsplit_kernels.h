@@ -491,6 +491,13 @@ __global__ __launch_bounds__(PG * kFinQuads) void step_finalize_ws(const Finaliz
 }
 
 // ---- device helpers of step_main_ws -----------------------------------------------------------------------------------
+// Measurement builds only (tests/tools/build_variant.py ... -DVS_ABLW=<mask>; results WRONG on purpose - the product never defines it):
+// bit 0: the partial-gradient row stores are skipped (the products stay); bit 1: no weight-gradient products either; bit 2: the
+// activation planes do not travel through the workgroup's scratch (stores skipped, loads replaced by constants); bit 3: no d-prop
+// matrix chains; bit 4: no forward matrix chains; bit 5 / 6: only the scratch stores / only the scratch loads of bit 2
+#ifndef VS_ABLW
+#define VS_ABLW 0
+#endif
 #define WS_WSTEP(s) (s)
 // block_io of a layer for a runtime (wave-uniform) mode; A / B: the hidden-block / encoding-block form, M = the mode
 #define WS_IO3(mode, is_a, A, B)                                                              \
@@ -563,6 +570,7 @@ __device__ __forceinline__ void wpre_load(WPre& p, const char* wa, const char* w
 template <bool W3, int NA, int NB2, bool XAG = false, int NT = 2, int NACC>
 __device__ __forceinline__ void fwd_run(f32x16 (&acc)[NACC], const WPre& pre, const char* wa, const char* xa, int xsta,
                                         const char* wb, const char* xb, int xstb, unsigned voff) {
+    if (VS_ABLW & 16) return;
     constexpr int NST = NA + NB2;
     WOp w[3];
     XOp xo[2];
@@ -617,6 +625,7 @@ __device__ __forceinline__ void bop_mm(f32x16 (&acc)[NA], const TOp& w, const DO
 }
 template <bool W3, int NST, int NT = 2, int NA>
 __device__ __forceinline__ void bwd_run(f32x16 (&acc)[NA], const TPre& pre, const char* gwt, unsigned voff, const char* d, int dst) {
+    if (VS_ABLW & 8) return;
     TOp w[4];
     DOp dd[2];
     w[0] = pre.w[0]; w[1] = pre.w[1]; w[2] = pre.w[2];
@@ -645,6 +654,7 @@ __device__ __forceinline__ void put_image(char* img, const unsigned (&h)[8], con
 // ((layer * 2 + st) * 2 + plane) * 2 + step
 template <int TT = 2, int CH = 4096>
 __device__ __forceinline__ void acts_store(char* ubase, unsigned voff, int layer, int st, const unsigned (&h)[8], const unsigned (&m)[8]) {
+    if (VS_ABLW & (4 | 32)) return;
     char* q = ubase + (layer * TT + st) * 4 * CH;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -654,6 +664,7 @@ __device__ __forceinline__ void acts_store(char* ubase, unsigned voff, int layer
 }
 template <int TT = 2, int CH = 4096>
 __device__ __forceinline__ void acts_load_plane(unsigned (&h)[8], const char* ubase, unsigned voff, int layer, int st, int plane) {
+    if (VS_ABLW & (4 | 64)) { for (int i = 0; i < 8; ++i) h[i] = 0x3F803F80u + (voff & 0xFu) + layer; return; }
     const char* q = ubase + ((layer * TT + st) * 2 + plane) * 2 * CH;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -703,6 +714,7 @@ __device__ __forceinline__ void put_F_g(char* ubase, unsigned voff, const unsign
 template <int NT = 2, int ND>
 __device__ __forceinline__ void dw_mm_pair(f32x16& acc, const unsigned (&dF)[ND][16], const FImg& x) {
     zero_acc(acc);
+    if (VS_ABLW & 2) return;
 #pragma unroll
     for (int st = 0; st < NT; ++st)
 #pragma unroll
@@ -732,6 +744,11 @@ __device__ __forceinline__ void db_pair(f32x16& acc, const unsigned (&dF)[ND][16
 // MODE 0: store (a workgroup's first round); 1: read the values of the earlier rounds into old; 2: store old + acc.
 template <int K, int MODE>
 __device__ __forceinline__ void rows_io(float* ubase, unsigned voff, const f32x16& acc, float (&old)[16]) {
+    if (VS_ABLW & 3) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { asm volatile("" ::"v"(acc[r])); old[r] = 0.0f; }
+        return;
+    }
     float* q = ubase + voff;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -758,7 +775,10 @@ __device__ __forceinline__ void block_io(float* out_w, float* out_b, const f32x1
     if (col >= 0 && col < ncols) rows_io<K, MODE>(out_w, (unsigned)(col + 4 * hi * K), acc, old);
     else if (bias) rows_io<1, MODE>(out_b, (unsigned)(4 * hi), acc, old);
 }
-__device__ __forceinline__ void store_one(float* q, float v, bool first) { *q = first ? v : *q + v; }
+__device__ __forceinline__ void store_one(float* q, float v, bool first) {
+    if (VS_ABLW & 3) { asm volatile("" ::"v"(v)); return; }
+    *q = first ? v : *q + v;
+}
 // ReLU mask from the packed hi plane: d[r] = h[r] > 0 ? v[r] : 0
 __device__ __forceinline__ void mask_by(float (&d)[16], const f32x16& v, const unsigned (&hh)[8]) {
 #pragma unroll
@@ -948,6 +968,16 @@ __global__ __launch_bounds__(64 * ws_waves<NB>(), 1) void step_main_ws(const WsA
     char* act_own = lds + LD::ACT + wave * 2 * I::XCH + lo16;             // this wave's block of the layer-input images (tile 0)
     f32x16 acc[kWsT];
     float hpart[kWsT][4];                                                // the heads' partial sums of this wave's block (hi = 0 lanes)
+    // Round 6: the hi / mid planes of layers 1 .. 4 (h2, h3, h4, hc: ReLU masks and weight-gradient operands of the backward) STAY IN
+    // REGISTERS from the epilogue to the backward instead of travelling through the workgroup's L2-side scratch; only layer 0 (h1,
+    // needed last) still does.  Measured (profiles/round6_ablation_step_main_ws.jsonl): the scratch round trip of all five layers cost
+    // ~9 of the background step's 80 us; the three-tile single-round form has the registers (406 -> 482 of 512, no scratch memory; all
+    // five: 512 + a 100-byte spill): 80.5 -> 76.2 us (float32 weights), 70.9 -> 65.8 us (bf16).  Hidden 256 (eight waves, 256 registers): none kept.
+#ifndef VS_KEEP_LAYERS
+#define VS_KEEP_LAYERS (NB == 4 ? 4 : 0)
+#endif
+    constexpr int NKEEP = VS_KEEP_LAYERS, KEEP0 = 5 - NKEEP;              // layers KEEP0 .. 4 are kept
+    unsigned keep_h[NKEEP > 0 ? NKEEP : 1][kWsT][8], keep_m[NKEEP > 0 ? NKEEP : 1][kWsT][8];
     // epilogue of a layer: ReLU, the heads' partial sums, split into planes; planes -> the next layer's input images (lo
     // included) and, hi / mid, -> the scratch (backward)
     auto epilogue = [&](int layer) {
@@ -982,7 +1012,12 @@ __global__ __launch_bounds__(64 * ws_waves<NB>(), 1) void step_main_ws(const WsA
             }
             split_planes<16, 3>(hf, ph, pm, pl);
             if (layer < 4) put_image<3, I::XCH>(act_own + st * LD::ACT_ST, ph, pm, pl);
-            if (BWD) acts_store<LD::TT, LD::CHUNK>(acts, tid16, layer, st, ph, pm);
+            if (BWD) {
+                if (layer >= KEEP0) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { keep_h[layer - KEEP0 < 0 ? 0 : layer - KEEP0][st][i] = ph[i]; keep_m[layer - KEEP0 < 0 ? 0 : layer - KEEP0][st][i] = pm[i]; }
+                } else acts_store<LD::TT, LD::CHUNK>(acts, tid16, layer, st, ph, pm);
+            }
         }
     };
     auto wchunk = [&](int base, int ks, int s) { return gW + ((long long)(base + wave * ks + s)) * I::XCH; };     // wave-uniform
@@ -1074,6 +1109,13 @@ __global__ __launch_bounds__(64 * ws_waves<NB>(), 1) void step_main_ws(const WsA
     // ---- backward ----
     unsigned ah[kWsT][8], am[kWsT][8];                                         // planes of an activation block coming back from the scratch
     auto fetch = [&](int layer) {
+        if (layer >= KEEP0) {
+#pragma unroll
+            for (int st = 0; st < NT; ++st)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { ah[st][i] = keep_h[layer - KEEP0 < 0 ? 0 : layer - KEEP0][st][i]; am[st][i] = keep_m[layer - KEEP0 < 0 ? 0 : layer - KEEP0][st][i]; }
+            return;
+        }
 #pragma unroll
         for (int st = 0; st < NT; ++st) { acts_load_plane<LD::TT, LD::CHUNK>(ah[st], acts, tid16, layer, st, 0); acts_load_plane<LD::TT, LD::CHUNK>(am[st], acts, tid16, layer, st, 1); }
         wv::sched_fence();
