@@ -974,7 +974,7 @@ __global__ __launch_bounds__(64 * ws_waves<NB>(), 1) void step_main_ws(const WsA
     // ~9 of the background step's 80 us; the three-tile single-round form has the registers (406 -> 482 of 512, no scratch memory; all
     // five: 512 + a 100-byte spill): 80.5 -> 76.2 us (float32 weights), 70.9 -> 65.8 us (bf16).  Hidden 256 (eight waves, 256 registers): none kept.
 #ifndef VS_KEEP_LAYERS
-#define VS_KEEP_LAYERS (NB == 4 ? 4 : 0)
+#define VS_KEEP_LAYERS (NB == 4 ? (W3 ? 4 : 5) : 0)       // bf16 weights: all five fit (504 registers, no spill)
 #endif
     constexpr int NKEEP = VS_KEEP_LAYERS, KEEP0 = 5 - NKEEP;              // layers KEEP0 .. 4 are kept
     unsigned keep_h[NKEEP > 0 ? NKEEP : 1][kWsT][8], keep_m[NKEEP > 0 ? NKEEP : 1][kWsT][8];
