@@ -148,6 +148,13 @@ inline float row_sum16(float x) {       // same butterfly order as the device DP
     return x;
 }
 
+inline float half_sum32_hi_row(float x) {   // row sums, then rows 1 / 3 add the sum of rows 0 / 2 (own row's sum first, as the device does)
+    const int l = sim::lane_id();
+    x = row_sum16(x);
+    const float t = shfl(x, (l & ~31) + 15);
+    return (l & 16) ? x + t : x;
+}
+
 inline bool wave_any(bool pred) {
     const int w = sim::wave_id(), l = sim::lane_id();
     sim::g_block->xa[w][l] = pred ? 1.0f : 0.0f;

@@ -69,6 +69,8 @@ struct Img32s {
     static constexpr int ELEMS = PLANE / 2;                                          // bf16 elements per plane
     // small float32 vectors (index in floats from SMALL)
     static constexpr int B_M1 = 0, B_M2 = 32, W_A = 64, W_OC = 96, B_A = 192, B_OC = 196, PE_B = 200, SMALL_N = 208;
+    // per-wave gradient accumulators (LDS region VEC): the SMALL_N slots above + the B_layer.weight partials [half][3 i + j] (round 6)
+    static constexpr int G_PEB = SMALL_N, VEC_N = SMALL_N + 66 + 6;
     // ---- LDS map of step_main_s32 (bytes) ----
     static constexpr int TILE = 32 * Lds32::TP * 4;          // 4608: one float32 32x32 exchange tile = two bf16 planes [32][72 B]
     static constexpr int TPL = TILE / 2;                     // one bf16 plane of a transpose tile
@@ -81,7 +83,7 @@ struct Img32s {
     static constexpr int STG = SCR;                          // staging tiles: the same bytes, later in the pass
     static constexpr int STG_BYTES = 2 * kWaves * TILE, kWavesTiles = kWaves * 2 * TILE;
     static constexpr int VEC = SCR + kWaves * 2 * TILE;      // per-wave small-vector gradient accumulators
-    static constexpr int CB = VEC + kWaves * SMALL_N * 4;
+    static constexpr int CB = VEC + kWaves * VEC_N * 4;
     static constexpr int LOSS = CB + kMaxPts * 8 * 4;
     static constexpr int LDS_BYTES = LOSS + kWaves * 4 * 4;
 };
@@ -801,7 +803,7 @@ __device__ __forceinline__ void step_main_s32_body(const StepArgs& a) {
     const char* W = lds;                                       // the image
     const float* SM = reinterpret_cast<const float*>(lds + I::SMALL);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p31 = lane & 31, hi = lane >> 5;
-    float* Gv = reinterpret_cast<float*>(lds + I::VEC) + wave * I::SMALL_N;      // this wave's private small-vector gradients
+    float* Gv = reinterpret_cast<float*>(lds + I::VEC) + wave * I::VEC_N;        // this wave's private small-vector gradients
     int obj, wgo;
     if (a.xcd_affine) {
         const int slot = blockIdx.x >> 3;
@@ -817,14 +819,14 @@ __device__ __forceinline__ void step_main_s32_body(const StepArgs& a) {
 #define VS_MARK(i) do { if constexpr (STAMPS) { if (tmark && lane == 0) tmark[i] = wv::clock32(); } } while (0)
     VS_MARK(0);
     if (BWD) {
-        for (int i = tid; i < kWaves * I::SMALL_N; i += kWG) reinterpret_cast<float*>(lds + I::VEC)[i] = 0.0f;
+        for (int i = tid; i < kWaves * I::VEC_N; i += kWG) reinterpret_cast<float*>(lds + I::VEC)[i] = 0.0f;
     }
     float* loss_cells = reinterpret_cast<float*>(lds + I::LOSS);
     if (tid < kWaves * 4) loss_cells[tid] = 0.0f;
     float* out = a.part_grad + ((long long)(obj * a.NW + wgo)) * a.PP;   // this workgroup's partial gradients
-    float qacc[13][4];      // MULTI only: this wave's quarter of every reduced weight-gradient block
+    float qacc[12][4];      // MULTI only: this wave's quarter of every reduced weight-gradient block
 #pragma unroll
-    for (int b = 0; b < 13; ++b) {
+    for (int b = 0; b < 12; ++b) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) qacc[b][i] = 0.0f;
     }
@@ -1202,35 +1204,35 @@ __device__ __forceinline__ void step_main_s32_body(const StepArgs& a) {
     }
     VS_MARK(11);
     VS_MARK(12);
-    // ---- unit 12: B_layer.weight gradient: dB[d][j] = sum_points dproj[d] * t[j]; t = slots 44..46 of the hi = 0 lanes
-    //      = features 24..26 of the last first-group block, whose F-form is still in xA ----
+    // ---- unit 12: B_layer.weight gradient dB[d][j] = sum_points dproj[d] * t[j] (embedding.py:84) - 21 x 3 numbers.  Round 6: float32
+    //      VALU products + a DPP reduction over the wave's 32 points into the wave's private accumulators (summed over the waves
+    //      with the other small vectors behind the pass loop) instead of a 32 x 32 matrix block through split / transpose /
+    //      products / staging and two workgroup barriers (3.9 k of the pass's 50 k clocks, profiles/round6a_phase_clocks_*): one
+    //      barrier, no matrix instruction, and the exact float32 products of step_main_h32 ----
     {
-        float dpP[16];
-        unsigned dph[8], dpm[8], dpl[8];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dpP[r] = r < 11 ? dproj[r] : 0.0f;          // row phi(r, hi) <-> direction hi ? 11 + r : r
-        split_planes<16, NPB>(dpP, dph, dpm, dpl);
-        toF_mm3<4, NPB>(dF, dph, dpm, dpl, SEL);
         // finish the last cat block (staged in stg0), stage the last in block
         fin_chunk<1, H + kEmb1, MULTI>(0, fs, qacc[8], stg0, out + F::W_CAT + H, out + F::B_CAT, 2, kEmb1, wave, p31, hi);
         stage_put_s(stg1, acc, wave, p31, hi);                      // block 11
         fin_chunk<1, H + kEmb1, MULTI>(1, fs, qacc[8], stg0, out + F::W_CAT + H, out + F::B_CAT, 2, kEmb1, wave, p31, hi);
-        zero_acc(acc);
-        mm_dw_il<false, B6>(acc, accb, dF, xA, nothing);
-        VS_BWD_BARRIER();
-        finish_block_s<1, kEmb1, MULTI>(qacc[11], stg1, out + F::W_IN, out + F::B_IN, 2, kEmb1, wave, p31, hi);
-        stage_put_s(stg0, acc, wave, p31, hi);
-        VS_BWD_BARRIER();
-        float q[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (MULTI) stage_get_s(qacc[12], stg0, wave, p31, hi);
-        else stage_get_s(q, stg0, wave, p31, hi);
-        if (!MULTI && p31 >= 24 && p31 < 27) {
+        float keep[3] = {0.0f, 0.0f, 0.0f};                         // value v = 3 i + j lives on lane (lane & 15) == (v & 15) of the half's second row, slot v >> 4
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = i + 4 * wave, d = hi ? 11 + r : r;          // row 8 wave + 4 hi + i = phi(r, hi)
-                if (r < (hi ? 10 : 11)) out[F::PE_B + 3 * d + (p31 - 24)] = q[i];
+        for (int i = 0; i < 11; ++i) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int v = 3 * i + j;
+                const float sum = wv::half_sum32_hi_row(dproj[i] * t[j]);      // this lane's direction: hi ? 11 + i : i (the eleventh of the hi = 1 half is a dummy: dproj = 0)
+                keep[v >> 4] = (lane & 15) == (v & 15) ? sum : keep[v >> 4];
             }
         }
+        if (lane & 16) {
+#pragma unroll
+            for (int sl = 0; sl < 3; ++sl) {
+                const int v = 16 * sl + (lane & 15);
+                if (v < 33) Gv[I::G_PEB + 36 * hi + v] += keep[sl];
+            }
+        }
+        VS_BWD_BARRIER();
+        finish_block_s<1, kEmb1, MULTI>(qacc[11], stg1, out + F::W_IN, out + F::B_IN, 2, kEmb1, wave, p31, hi);
     }
 #undef VS_FIN
     VS_MARK(13);
@@ -1266,19 +1268,16 @@ __device__ __forceinline__ void step_main_s32_body(const StepArgs& a) {
             store_quarter_map<H + kEmb1>(out + F::W_CAT + H, out + F::B_CAT, qacc[6 + blk], col, bias, kEmb1, wave, hi);
             store_quarter_map<kEmb1>(out + F::W_IN, out + F::B_IN, qacc[9 + blk], col, bias, kEmb1, wave, hi);
         }
-        if (p31 >= 24 && p31 < 27) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = i + 4 * wave, d = hi ? 11 + r : r;
-                if (r < (hi ? 10 : 11)) out[F::PE_B + 3 * d + (p31 - 24)] = qacc[12][i];
-            }
-        }
     }
-    // small vectors: sum of the four waves' private accumulators (biases of mid1 / mid2, the heads)
-    for (int sv = tid; sv < I::SMALL_N; sv += kWG) {
+    // small vectors: sum of the four waves' private accumulators (biases of mid1 / mid2, the heads, B_layer.weight)
+    for (int sv = tid; sv < I::VEC_N; sv += kWG) {
         const float* v = reinterpret_cast<const float*>(lds + I::VEC) + sv;
-        const float g = (v[0] + v[I::SMALL_N]) + (v[2 * I::SMALL_N] + v[3 * I::SMALL_N]);
+        const float g = (v[0] + v[I::VEC_N]) + (v[2 * I::VEC_N] + v[3 * I::VEC_N]);
         int o = -1;
+        if (sv >= I::G_PEB) {                                        // [half][3 i + j]: direction half ? 11 + i : i
+            const int x = sv - I::G_PEB, hf = x >= 36 ? 1 : 0, vv = x - 36 * hf, i = vv / 3;
+            if (vv < 33 && i < (hf ? 10 : 11)) o = F::PE_B + 3 * (hf ? 11 + i : i) + (vv - 3 * i);
+        } else
         if (sv < I::B_M2) o = F::B_M1 + (sv - I::B_M1);
         else if (sv < I::W_A) o = F::B_M2 + (sv - I::B_M2);
         else if (sv < I::W_OC) o = F::W_A + (sv - I::W_A);

@@ -88,6 +88,14 @@ __device__ __forceinline__ float row_sum16(float x) {
     return x;
 }
 
+// sum of x over the 32 lanes of this lane's HALF of the wave (lanes with the same lane >> 5), valid on the lanes of the half's second
+// 16-lane row (lane & 16): the row sums, then DPP row_bcast:15 (lane 15 of rows 0 / 2 -> every lane of rows 1 / 3; a GFX9 control)
+__device__ __forceinline__ float half_sum32_hi_row(float x) {
+    x = row_sum16(x);
+    const float t = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), 0x142, 0xA, 0xF, false));
+    return x + t;
+}
+
 // value of x held by lane `src` (0..63) of this wave
 __device__ __forceinline__ float shfl(float x, int src) { return __shfl(x, src & 63); }
 
