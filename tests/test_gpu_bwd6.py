@@ -86,3 +86,20 @@ def test_six_product_backward_is_refused_where_it_does_not_exist():
         step.VmapStep(4, 16, 10, 32, device=DEV, weights="bf16", tuning=B6)
     with pytest.raises(_lib.VmapStepError, match="hidden 32"):
         step.VmapStep(1, 16, 14, 128, device=DEV, tuning=B6)
+
+
+def test_mapper_takes_the_kernel_choice():
+    """driver.HipMapper(tuning=...) hands the choice to the object stack's operator ("Precision choices")."""
+    from vmap_amd.driver import HipMapper
+    from vmap_amd.trainer import SimpleConfig, Trainer
+    torch.manual_seed(5)
+    n, R, S, steps = 3, 24, 10, 4
+    m = HipMapper(SimpleConfig(training_device=DEV, n_iter_per_frame=steps), device=DEV, tuning=B6)
+    for _ in range(n):
+        m.add_object(Trainer(SimpleConfig(training_device=DEV, hidden_feature_size=32, obj_scale=2.0)))
+    fr = synth.make_batch(n, R * steps, S, seed=9)
+    batch = tuple(torch.from_numpy(fr[k]).to(DEV) for k in ("pcs", "z", "gt_depth", "gt_rgb", "sem", "depth_mask"))
+    res = m.train_frame(*batch)
+    torch.cuda.synchronize()
+    assert m.op.plan()["kernel"] == "step_main_s32<bwd6>"
+    assert torch.isfinite(res.loss[:steps]).all()

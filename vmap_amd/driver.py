@@ -23,8 +23,12 @@ from . import layout, step
 
 
 class HipMapper:
-    def __init__(self, cfg, device=None, group_reduce=None):
+    def __init__(self, cfg, device=None, group_reduce=None, tuning=None):
+        """``tuning``: passed to the OBJECT stack's ``step.VmapStep`` (e.g. ``{"kernel": _lib.KERNEL_S32_BWD6}`` for the six-product,
+        float32-equivalent backward of the hidden-32 kernel, or ``KERNEL_H32_F32`` for the exact-fp32 matrix instruction); the
+        background model's operator always takes the automatic plan."""
         self.cfg = cfg
+        self.tuning = tuning
         self.device = torch.device(device or cfg.training_device)
         self.trainers: List = []
         self._dirty = False
@@ -70,7 +74,7 @@ class HipMapper:
             self.scale = torch.stack([tr.pe.scale.detach().to(self.device).reshape(()) for tr in self.trainers]).contiguous()
         self.slab, self.views = slab, views
         self.opt = step.FusedAdamWState(n, H, self.device, lr=self.cfg.learning_rate, weight_decay=self.cfg.weight_decay)
-        self.op = step.VmapStep(n, rays, samples, H, device=self.device, max_steps=self.cfg.n_iter_per_frame)
+        self.op = step.VmapStep(n, rays, samples, H, device=self.device, max_steps=self.cfg.n_iter_per_frame, tuning=self.tuning)
         self._dirty = False
         self._bound.pop("obj", None)
         self._seen.pop("obj", None)
@@ -89,7 +93,7 @@ class HipMapper:
             # only the batch shape changed: a new operator (workspace sized for the shape); slab, views and the optimiser state
             # stay - the reference restarts the moments only when update_vmap re-stacks the object list
             self.op = step.VmapStep(len(self.trainers), rays, samples, self.trainers[0].hidden_feature_size, device=self.device,
-                                    max_steps=self.cfg.n_iter_per_frame)
+                                    max_steps=self.cfg.n_iter_per_frame, tuning=self.tuning)
             self._bound.pop("obj", None)
             self._seen.pop("obj", None)
         res = self._frame_call("obj", self.op, self.views, self.scale, (pcs, z, gt_depth, gt_rgb, sem, depth_mask), self.opt, iters, rays,
