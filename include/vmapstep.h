@@ -57,7 +57,8 @@ extern "C" {
 #define VMAPSTEP_KERNEL_H32_F32 4 /* hidden 32: step_main_h32 on the exact-fp32 matrix instruction instead of the default
                                      step_main_s32 (bf16 matrix pipe, split operands, float32-equivalent forward)      */
 #define VMAPSTEP_KERNEL_WS1 5     /* hidden 64 / 128: step_main_ws (one wave per output block; the default at hidden 128)            */
-#define VMAPSTEP_KERNEL_S32_BWD6 7 /* hidden 32, float32 weights: step_main_s32 with the SIX-product backward (hi.lo + lo.hi + mid.mid on top of
+#define VMAPSTEP_KERNEL_S32_BWD6 8 /* (7 was a measurement prototype of ABI v4 and stays invalid)
+                                    * hidden 32, float32 weights: step_main_s32 with the SIX-product backward (hi.lo + lo.hi + mid.mid on top of
                                     * the default's three: the backward is then float32-equivalent, ~2^-24, like the forward; ~+15 % kernel time).
                                     * The reference is float32 end to end (train.py:64-66): this is the strictly comparable form of the default kernel */
 #define VMAPSTEP_KERNEL_WP 6      /* hidden 64 / 128: step_main_wp (two waves per block, partial sums exchanged through LDS; the

@@ -16,7 +16,7 @@ ABI_VERSION = 7
 WEIGHTS_F32, WEIGHTS_BF16 = 0, 1
 
 
-KERNEL_AUTO, KERNEL_GEN, KERNEL_WIDE4, KERNEL_H32_F32, KERNEL_WS1, KERNEL_WP, KERNEL_S32_BWD6 = 0, 1, 2, 4, 5, 6, 7
+KERNEL_AUTO, KERNEL_GEN, KERNEL_WIDE4, KERNEL_H32_F32, KERNEL_WS1, KERNEL_WP, KERNEL_S32_BWD6 = 0, 1, 2, 4, 5, 6, 8
 
 
 class Tuning(ctypes.Structure):

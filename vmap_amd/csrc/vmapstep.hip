@@ -144,7 +144,7 @@ int make_plan(const vmapstep_shape* sh, int max_steps, Plan& pl, const Layout& L
     pl.wide = 0;
     const vmapstep_tuning& tun = tuning_of(sh);
     const int force = tun.kernel;
-    if (force < VMAPSTEP_KERNEL_AUTO || force > VMAPSTEP_KERNEL_S32_BWD6) return fail(VMAPSTEP_ERR_ARGUMENT, "tuning.kernel=%d", force);
+    if (force < VMAPSTEP_KERNEL_AUTO || (force > VMAPSTEP_KERNEL_WP && force != VMAPSTEP_KERNEL_S32_BWD6)) return fail(VMAPSTEP_ERR_ARGUMENT, "tuning.kernel=%d", force);
     pl.split = !pl.generic && force != VMAPSTEP_KERNEL_H32_F32;
     pl.bwd6 = force == VMAPSTEP_KERNEL_S32_BWD6;
     if (pl.bwd6 && (pl.generic || sh->weight_dtype != VMAPSTEP_WEIGHTS_F32))
