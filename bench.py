@@ -881,14 +881,14 @@ def main():
         try:
             # the committed counter file of the kernel this run used
             if args.config == "replica_room0_vmap" and split:
-                pmc_file, key = "round4a_pmc_counters_step_main_s32.json", "hbm_traffic_bytes_per_launch_step_main"
+                pmc_file, key = "round6b_pmc_counters_step_main_s32.json", "hbm_traffic_bytes_per_launch_step_main"
             elif args.config == "replica_room0_vmap":
                 pmc_file, key = "r01m_pmc_counters.json", "hbm_traffic_bytes_per_launch_step_main"
             elif args.config == "imap_plumbing" and ws8 and args.weights == "f32":
                 pmc_file, key = "r04p_pmc_counters_imap_ws8.json", "hbm_traffic_bytes_per_launch_step_main_ws"
             elif args.config == "background" and args.kernel == "auto" and args.weights == "f32":
                 # three-tile rounds (the automatic plan): r04g; the round-2 plan (--ws-flags 4): r03q
-                pmc_file, key = ("r04g_pmc_counters_background_ws.json" if ws_nt == 3 else "r03q_pmc_counters_background_ws.json"), "hbm_traffic_bytes_per_launch_step_main_ws"
+                pmc_file, key = ("round6b_pmc_counters_background_ws.json" if ws_nt == 3 else "r03q_pmc_counters_background_ws.json"), "hbm_traffic_bytes_per_launch_step_main_ws"
             if pmc_file:
                 with open(os.path.join(ROOT, "profiles", pmc_file)) as fh:
                     traffic = json.load(fh)["_notes"][key]
@@ -909,7 +909,7 @@ def main():
         # what the matrix pipe actually executes (bf16 kernels): instructions per 32-point tile / 64-point round x tiles x 32x32x16 x 2 FLOP
         executed_tflops, mm_per_launch = None, None
         if split:
-            per_tile = 288 if args.weights == "f32" else 195
+            per_tile = 344 if args.weights == "f32" else 251      # 275.2 k matrix instructions per launch / 800 working waves (round6b counters); bf16 weights: 93 fewer
             mm_per_launch = n * ((R + (128 // S) - 1) // (128 // S)) * 4 * per_tile
         elif ws8 and args.weights == "f32":
             # 975 matrix instructions per wave and single-tile round (profiles/r04p_pmc_counters_imap_ws8.json), eight waves per round
@@ -919,7 +919,7 @@ def main():
             mm_per_launch = n * plan["rounds_per_object"] * 2 * mfma_per_tile(H, args.weights == "f32")
         elif wsk and H == 128:
             gq = (32 * ws_nt) // S
-            mm_per_launch = n * ((R + gq - 1) // gq) * 4 * (1185 if args.weights == "f32" else 807) * ws_nt // 2
+            mm_per_launch = n * ((R + gq - 1) // gq) * 4 * (1285 if args.weights == "f32" else 907) * ws_nt // 2      # 1927 per wave and three-tile round (round6b counters)
         if mm_per_launch:
             executed_tflops = mm_per_launch * 32768 / (k_ms * 1e-3) / 1e12
         # Floor of THIS formulation at hidden 32 (one 32-point tile per wave, one wave per SIMD): a SIMD's time is the SUM of its matrix
@@ -927,8 +927,8 @@ def main():
         # them): 296 matrix instructions x 32 clocks + 3838 vector instructions x 4.8 clocks = 27.9 k clocks at 2.4 GHz.
         floor_us, floor_note = None, None
         if split and args.weights == "f32":
-            floor_us = (296 * 32 + 3838 * 4.8) / 2400.0
-            floor_note = ("sum of one tile's matrix (296 x 32 clk) and vector (3838 x 4.8 clk) issue time on its SIMD at 2.4 GHz: the part of "
+            floor_us = (354 * 32 + 4505 * 4.8) / 2400.0
+            floor_note = ("sum of one tile's matrix (354 x 32 clk) and vector (4505 x 4.8 clk; profiles/round6b_pmc_counters_step_main_s32.json) issue time on its SIMD at 2.4 GHz: the part of "
                           "kernel_ms no schedule of this tiling can remove; kernel_ms - floor_us = waits, barriers, issue stalls, launch ramp")
         if ws8 and args.weights == "f32":
             rounds_per_wg = -(-plan["rounds_per_object"] // plan["workgroups_per_object"])
@@ -941,10 +941,10 @@ def main():
             nt = ws_nt
             rounds_per_wg = -(-plan["rounds_per_object"] // plan["workgroups_per_object"])
             if nt == 3:
-                # the three-tile single-round form, counted afresh (profiles/r04g_pmc_counters_background_ws.json): 1778 matrix +
-                # 7535 vector instructions per wave and 96-point round
-                floor_us = rounds_per_wg * (1778 * 32 + 7535 * 4.8) / 2400.0
-                floor_note = (f"{rounds_per_wg} round(s) per workgroup x (1778 matrix x 32 clk + 7535 vector x 4.8 clk per wave and 96-point round, hardware "
+                # the three-tile single-round form, counted afresh in round 6 (profiles/round6b_pmc_counters_background_ws.json): 1927 matrix
+                # (on-pipe transposes included) + 8477 vector instructions per wave and 96-point round
+                floor_us = rounds_per_wg * (1927 * 32 + 8477 * 4.8) / 2400.0
+                floor_note = (f"{rounds_per_wg} round(s) per workgroup x (1927 matrix x 32 clk + 8477 vector x 4.8 clk per wave and 96-point round, hardware "
                               "counters of this kernel form) at 2.4 GHz: issue time only; the round's LDS and vector-memory phases run in between, not "
                               "underneath (DESIGN 3.1f)")
             else:
