@@ -33,7 +33,7 @@
 #include "step_kernels.h"
 
 // Measurement builds only (tests/tools/build_variant.py ... -DVS_ABL=<mask>; results WRONG on purpose - the product never defines it):
-// bit 4: only the partial-gradient global stores are skipped; bit 5: the finishing (staged reads, sums, stores) is skipped, the staging writes stay;
+// bit 7: step_finalize_s32 does not rewrite the parameter image; bit 4: only the partial-gradient global stores are skipped; bit 5: the finishing (staged reads, sums, stores) is skipped, the staging writes stay;
 // bit 3: only the staging / finishing of the blocks is skipped (the products stay);
 // bit 2: only the P->F transposes of the weight-gradient operands are skipped (tile_put / tile_get);
 // bit 0: the backward without its weight-gradient products (no matrix instructions in mm_dw_il, no P->F transposes, no staging /
@@ -308,7 +308,7 @@ __device__ __forceinline__ void finalize_quad_s32(const FinalizeArgs& f, const F
             adamw_elem(a, ss, bc, g[e], p, m, v);
             if (!pvec) *pp[e] = p;
             pv[e] = p; m4[e] = m; v4[e] = v;
-            split_image_store(image, img[e], p, a.weights_bf16);
+            if (!(VS_ABL & 128)) split_image_store(image, img[e], p, a.weights_bf16);      // (bit 7: the finalize leaves the image alone - what its rewrite costs the NEXT main kernel)
         }
     }
     if (pvec) *reinterpret_cast<wv::f32x4u*>(pp[0]) = wv::f32x4{pv[0], pv[1], pv[2], pv[3]};
@@ -576,6 +576,8 @@ __device__ __forceinline__ void col_target(int blk, int k, int& col, bool& bias)
 // this wave's quarter (rows 8 wave + 4 hi + i) of a reduced block -> the workgroup's partial gradients
 #if VS_ABL & 16
 #define VS_PARTIAL_STORE(v, p) asm volatile("" ::"v"(v), "v"(p))
+#elif defined(VS_PARTIAL_PLAIN)          /* A/B: the rows as ordinary stores */
+#define VS_PARTIAL_STORE(v, p) (*(p) = (v))
 #else
 #define VS_PARTIAL_STORE(v, p) __builtin_nontemporal_store((v), (p))
 #endif
