@@ -167,6 +167,9 @@ def compile_unit(hipcc, flags, include_dir, src, obj, log=None):
                                 or the hand-driven assemble / link / bundle steps fail under a hipcc whose driver changed): the object's
                                 device code is then disassembled and linted.
     Raises only if all three leave the form in the object."""
+    # hipcc derives a unit's CUID (a suffix of internal symbol names shared by its device and host halves) from the source file's
+    # PATH: pin it to the unit's name so that the library's bytes do not depend on where the repository is checked out
+    flags = list(flags) + ["-cuid=vmapstep_" + os.path.splitext(os.path.basename(src))[0]]
     rec = {"unit": os.path.basename(src), "flags": list(flags)}
     why = None
     try:
