@@ -1048,7 +1048,10 @@ def main():
             "preheat": {"ms": args.preheat_ms, "steps": preheat_steps, "timed": False},
             "with_background": with_bg,
             "world": {"world_size": world, "devices": devices, "rccl": rccl_version, "backend": backend if dist else None,
-                      "ms_per_step_per_rank": per_rank_ms, "region_costs": region},
+                      "ms_per_step_per_rank": per_rank_ms, "region_costs": region,
+                      "weak_scaling_prediction": ("objects shard with no collective on the step path; per frame ONE all_reduce(MAX) of 4 x steps int32 (a ring of "
+                                                  "latency-bound hops: 20-40 us at 8 ranks = 3-6 % of a 0.6 ms frame of 20 steps) => >= 7.5x at 8 GPUs expected against the "
+                                                  "north star's >= 6x (DESIGN.md section 4); measured cost of that collective and of a barrier: region_costs") if world > 1 else None},
             "frame": None,
             "frame_call": ("marshalled per call" if bound is None else
                            "bound (arguments marshalled once), replayed as a hipGraph per frame (device-resident optimiser step count)" if bound.graph
