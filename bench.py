@@ -1,8 +1,10 @@
 """bench.py - training rays/sec of the fused per-object step on MI355X (BASELINE.json metric).
 
     python bench.py --gpus 1 --steps 200 --warmup 20
+    python bench.py --gpus N --steps K --warmup W            (no launcher around it: starts its own N ranks, one per GPU, RCCL;
+                                                              exit status 2 if the box has fewer than N devices)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W                (joins the launcher's ranks)
 
 A "step" = one pass of the hot path over one synthetic batch already resident in HBM: encoding + field MLP
 forward + compositing + loss + backward + fused AdamW for every object (train.py:293-326 without the data
@@ -17,7 +19,8 @@ one real collective (ONE all-reduce of [gradients | loss terms] per step over RC
 Rank 0 prints ONE JSON line with the contract fields plus
   roofline     - the dominant kernel against the matrix peaks (fp32-equivalent and the executed bf16 pipe), timed live with the
                  dispatch's own begin / end events
-  cpu_baseline - the PyTorch-CPU port of the oracle timed on this host's cores (reported, not a target)
+  cpu_baseline - the reference's own step (oracle/_ref) timed on this host's cores (reported, not a target)
+  value_fp32_equivalent_backward / value_exact_fp32_kernel / precision - the precision / throughput curve of the hidden-32 kernels
 """
 from __future__ import annotations
 
