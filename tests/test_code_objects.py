@@ -126,3 +126,15 @@ def test_manifest_describes_the_libraries_in_the_tree():
             assert man[key]["sha256"] == hashlib.sha256(open(lib, "rb").read()).hexdigest(), key
         assert all(u["mode"] in ("rewrite", "rewrite+no-slp", "plain+no-slp") for u in man[key]["units"].values()), man[key]["units"]
     assert set(man["product"]["units"]) >= {"vmapstep", "k_s32", "k_ws", "k_wp", "k_f32", "k_ws8", "k_misc"}
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc on this box")
+@pytest.mark.parametrize("unit,defs", [("k_s32", ["-DVS_ABL=255", "-DVS_PARTIAL_PLAIN"]), ("k_ws", ["-DVS_ABLW=127", "-DVS_TOF_LDS", "-DVS_KEEP_LAYERS=2"]),
+                                       ("k_wp", ["-DVS_ABLW=127"])])
+def test_measurement_switches_still_compile(unit, defs):
+    """The ablation switches (VS_ABL / VS_ABLW / VS_KEEP_LAYERS / VS_TOF_LDS: tests/tools/build_variant.py + abl_probe.py)
+    live in the kernel sources behind macros the product never defines; keep them compiling (front end only: a second)."""
+    import subprocess
+    r = subprocess.run([HIPCC] + FLAGS + ["--cuda-device-only", "-fsyntax-only"] + defs + ["-I", os.path.join(ROOT, "vmap_amd", "csrc"),
+                       os.path.join(ROOT, "vmap_amd", "csrc", unit + ".hip")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
