@@ -818,7 +818,7 @@ def main():
             except Exception:
                 pass
             print(json.dumps({"value": value, "ms_per_step": ms_per_step, "steps": args.steps, "warmup": args.warmup,
-                              "preheat_ms": args.preheat_ms, "timed_only": True}), flush=True)
+                              "preheat_ms": args.preheat_ms, "timed_only": True, "repeats": repeats_info}), flush=True)
         return
     # who took part (so that a scaling run can show its N ranks): device of every rank + the RCCL version torch links
     devices = [torch.cuda.get_device_name(dev) + f" (cuda:{dev_index})"]

@@ -48,18 +48,20 @@ extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req, int xcd
     const int NG = (R + G - 1) / G;
     const int NW = NW_req > 0 && NW_req < NG ? NW_req : NG;
 
-    std::vector<float> stats(n * 4, NAN), part_grad((size_t)n * NW * PP, NAN), part_loss((size_t)n * NW * 4, NAN);
     std::vector<int> fl(4, -1);
     const vk::GenLayout GL = vk::gen_layout(H);
     const bool split = g_split && H == 32;
     const bool wp = g_wide == 4 && (H == 128 || H == 64);    // step_main_wp (two waves per output block)
     const bool ws = ((g_wide == 3 || g_wide == 4) && (H == 128 || H == 64)) || (g_wide == 3 && H == 256);    // step_main_ws / _wp (split-bf16 matrix pipe, hidden 128 / 64; _ws also 256)
+    const int PR = ws ? vk::ws_row_floats(H) : PP;          // floats per row of partial gradients (step_main_ws / _wp: block-native rows)
+    std::vector<float> stats(n * 4, NAN), part_grad((size_t)n * NW * PR, NAN), part_loss((size_t)n * NW * 4, NAN);
+    std::vector<int> row_tab(PR, -7);
     if (ws && G * S > (H == 256 ? 32 : g_wide == 3 && H == 128 ? 96 : vk::ImgWs<4>::kPts)) return -3;   // step_main_ws at hidden 128: up to three 32-point tiles per round
     std::vector<float> wimg((size_t)n * (split ? vk::Img32s::BYTES / 4 : ws ? (H == 256 ? vk::ImgWs<8>::BYTES : H == 128 ? vk::ImgWs<4>::BYTES : vk::ImgWs<2>::BYTES) / 4 : GL.imgp), NAN);
 
     vk::StepArgs a{};
     a.tiles = g_wide == 3 ? (G * S <= 32 ? 1 : G * S <= 64 ? 2 : 3) : 2;   // step_main_ws: the fewest 32-point tiles that hold the caller's ray groups
-    a.n_obj = n; a.R = R; a.S = S; a.G = G; a.NG = NG; a.NW = NW; a.PP = PP; a.prep_steps = 1; a.prep_ray_step = 0; a.xcd_affine = (xcd_affine && H == 32) ? 1 : 0; a.hidden = H; a.weights_bf16 = weights_bf16;
+    a.n_obj = n; a.R = R; a.S = S; a.G = G; a.NG = NG; a.NW = NW; a.PP = PP; a.PR = PR; a.row_tab = ws ? row_tab.data() : nullptr; a.prep_steps = 1; a.prep_ray_step = 0; a.xcd_affine = (xcd_affine && H == 32) ? 1 : 0; a.hidden = H; a.weights_bf16 = weights_bf16;
     for (int t = 0; t < 14; ++t) a.fc[t] = {const_cast<float*>(fc[t]), sz[t]};
     a.pe_B = {const_cast<float*>(B), 63};
     a.pe_scale = {const_cast<float*>(scale), 1};
@@ -98,6 +100,7 @@ extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req, int xcd
 
     vk::FinalizeArgs f{};
     f.n_obj = n; f.NW = NW; f.PP = PP; f.P = P; f.hidden = H; f.weights_bf16 = weights_bf16;
+    f.PR = PR; f.row_tab = a.row_tab;
     for (int t = 0; t < 16; ++t) f.offs[t] = offs[t];
     for (int t = 0; t < 15; ++t) {
         f.grad[t] = {grads ? grads + offs[t] : nullptr, P};
@@ -119,7 +122,7 @@ extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req, int xcd
         // one finalize for the gradients the tests look at and / or the AdamW update (as the library launches it)
         vk::FinalizeHot h{};
         h.m = f.m; h.v = f.v; h.part_grad = f.part_grad; h.wimg = f.wimg; h.img_tab = img_tab.data();
-        h.NW = f.NW; h.PP = f.PP; h.weights_bf16 = f.weights_bf16;
+        h.NW = f.NW; h.PP = f.PP; h.PR = f.PR; h.weights_bf16 = f.weights_bf16;
         h.decay = f.decay; h.one_minus_beta1 = f.one_minus_beta1; h.beta2 = f.beta2; h.one_minus_beta2 = f.one_minus_beta2;
         h.eps = f.eps; h.step_size = f.step_size; h.bias_corr2_sqrt = f.bias_corr2_sqrt;
         f.do_adam = do_adam && p_out;
@@ -139,7 +142,7 @@ extern "C" int vmsim_step(int n, int R, int S, int H, int G, int NW_req, int xcd
         vk::FinalizeHot h{};
         h.m = f.m; h.v = f.v; h.part_grad = f.part_grad; h.wimg = f.wimg; h.img_tab = img_tab.data();
         h.slab = p_out; h.slab_stride = P;
-        h.NW = f.NW; h.PP = f.PP; h.weights_bf16 = f.weights_bf16;
+        h.NW = f.NW; h.PP = f.PP; h.PR = f.PR; h.weights_bf16 = f.weights_bf16;
         h.decay = f.decay; h.one_minus_beta1 = f.one_minus_beta1; h.beta2 = f.beta2; h.one_minus_beta2 = f.one_minus_beta2;
         h.eps = f.eps; h.step_size = f.step_size; h.bias_corr2_sqrt = f.bias_corr2_sqrt;
         if (split) sl::finalize_s32(f, h, n * bpo + 1);

@@ -5,8 +5,8 @@ namespace sl {
 void prep_ws(const vk::WsArgs& wa) {
     const int n = wa.s.n_obj;
     if (wa.s.hidden == 256) return prep_ws8(wa);
-    if (wa.s.hidden == 128) sim::launch(wa.s.prep_steps + n * vk::ws_pack_blocks<4>(), vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep_ws<4>(wa); });
-    else sim::launch(wa.s.prep_steps + n * vk::ws_pack_blocks<2>(), vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep_ws<2>(wa); });
+    if (wa.s.hidden == 128) sim::launch(vk::ws_prep_grid<4>(wa.s.prep_steps, n), vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep_ws<4>(wa); });
+    else sim::launch(vk::ws_prep_grid<2>(wa.s.prep_steps, n), vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep_ws<2>(wa); });
 }
 namespace {
 template <int NT>
@@ -65,11 +65,11 @@ void finalize_ws(const vk::FinalizeArgs& f_in, const vk::FinalizeHot& h, const i
     vk::FinalizeArgs f = f_in;
     f.loss_stage = vk::loss_stage_cap(vk::kFinThreads * 16);
     f.xcd_affine = f.n_obj >= 8 ? 1 : 0;          // as the library's launcher
-    const int grid = vk::ws_finalize_grid(f.n_obj, f.PP, vk::kFinQuads, f.xcd_affine);
+    const int grid = vk::ws_finalize_grid(f.n_obj, f.PR, vk::kFinQuads, f.xcd_affine);
     if (f.hidden == 256) return finalize_ws8(f, h, tab_wt, grid);
     if (!f.ws_grouped) {            // the form the library's launcher picks for many blocks / few rows (here: on request)
         constexpr int Q = vk::kFinQuadsWide;
-        const int lds = vk::kFinGroups * Q * 16, gw = vk::ws_finalize_grid(f.n_obj, f.PP, Q, f.xcd_affine);
+        const int lds = vk::kFinGroups * Q * 16, gw = vk::ws_finalize_grid(f.n_obj, f.PR, Q, f.xcd_affine);
         f.loss_stage = vk::loss_stage_cap(lds);
         if (f.hidden == 128) sim::launch(gw, Q, lds, [&] { vk::step_finalize_ws<4, Q, 1>(f, h, tab_wt); });
         else sim::launch(gw, Q, lds, [&] { vk::step_finalize_ws<2, Q, 1>(f, h, tab_wt); });

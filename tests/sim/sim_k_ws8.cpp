@@ -3,7 +3,7 @@
 
 namespace sl {
 void prep_ws8(const vk::WsArgs& wa) {
-    sim::launch(wa.s.prep_steps + wa.s.n_obj * vk::ws_pack_blocks<8>(), vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep_ws<8>(wa); });
+    sim::launch(vk::ws_prep_grid<8>(wa.s.prep_steps, wa.s.n_obj), vk::kWG, 3 * vk::kWG * 4, [&] { vk::step_prep_ws<8>(wa); });
 }
 void main_ws8(const vk::WsArgs& wa, bool bwd) {
     using LD = vk::LdsWs<8, 1>;
@@ -25,7 +25,7 @@ void finalize_ws8(const vk::FinalizeArgs& f_in, const vk::FinalizeHot& h, const 
         constexpr int Q = vk::kFinQuadsWide;
         const int lds = vk::kFinGroups * Q * 16;
         f.loss_stage = vk::loss_stage_cap(lds);
-        sim::launch(vk::ws_finalize_grid(f.n_obj, f.PP, Q, f.xcd_affine), Q, lds, [&] { vk::step_finalize_ws<8, Q, 1>(f, h, tab_wt); });
+        sim::launch(vk::ws_finalize_grid(f.n_obj, f.PR, Q, f.xcd_affine), Q, lds, [&] { vk::step_finalize_ws<8, Q, 1>(f, h, tab_wt); });
         return;
     }
     sim::launch(grid, vk::kFinThreads, vk::kFinThreads * 16, [&] { vk::step_finalize_ws<8>(f, h, tab_wt); });

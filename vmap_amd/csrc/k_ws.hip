@@ -75,9 +75,9 @@ int prep_ws(const vk::StepArgs& a, int n_steps, hipStream_t st) {
     if (e != hipSuccess) return fail(-4, "hipMemsetAsync(tab_wt): %s", hipGetErrorString(e));
     if (a.hidden == 256) return prep_ws8(ga, n_steps, st);
     if (a.hidden == 128)
-        hipLaunchKernelGGL(vk::step_prep_ws<4>, dim3(n_steps + a.n_obj * vk::ws_pack_blocks<4>()), dim3(vk::kWG), 3 * vk::kWG * sizeof(int), st, ga);
+        hipLaunchKernelGGL(vk::step_prep_ws<4>, dim3(vk::ws_prep_grid<4>(n_steps, a.n_obj)), dim3(vk::kWG), 3 * vk::kWG * sizeof(int), st, ga);
     else
-        hipLaunchKernelGGL(vk::step_prep_ws<2>, dim3(n_steps + a.n_obj * vk::ws_pack_blocks<2>()), dim3(vk::kWG), 3 * vk::kWG * sizeof(int), st, ga);
+        hipLaunchKernelGGL(vk::step_prep_ws<2>, dim3(vk::ws_prep_grid<2>(n_steps, a.n_obj)), dim3(vk::kWG), 3 * vk::kWG * sizeof(int), st, ga);
     return launched("step_prep_ws");
 }
 
@@ -87,8 +87,8 @@ int finalize_ws(const vk::FinalizeArgs& f, const vk::FinalizeHot& h, const int* 
     if (finalize_one_thread_per_quad(f)) return f.hidden == 128 ? finalize_wide<4>(f, h, tab_wt, st) : finalize_wide<2>(f, h, tab_wt, st);
     if (f.hidden == 128) {
         // the narrow form where it fills the chip with one block per compute unit and the wide one does not (the background step)
-        const int narrow = f.n_obj * vk::ws_finalize_blocks(f.PP, vk::kFinQuadsNarrow);
-        if (!f.xcd_affine && narrow <= 256 && vk::ws_finalize_grid(f.n_obj, f.PP, vk::kFinQuads, 0) - 1 < narrow) {
+        const int narrow = f.n_obj * vk::ws_finalize_blocks(f.PR, vk::kFinQuadsNarrow);
+        if (!f.xcd_affine && narrow <= 256 && vk::ws_finalize_grid(f.n_obj, f.PR, vk::kFinQuads, 0) - 1 < narrow) {
             constexpr int T = vk::kFinGroups * vk::kFinQuadsNarrow;
             return launch_finalize_ws<4, vk::kFinQuadsNarrow, vk::kFinGroups>(f, h, tab_wt, narrow, T, T * 4 * sizeof(float), st);
         }

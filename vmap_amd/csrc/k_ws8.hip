@@ -28,7 +28,7 @@ int main_ws8(const vk::StepArgs& a, bool bwd, hipStream_t st) {
 }
 
 int prep_ws8(const vk::WsArgs& ga, int n_steps, hipStream_t st) {
-    hipLaunchKernelGGL(vk::step_prep_ws<8>, dim3(n_steps + ga.s.n_obj * vk::ws_pack_blocks<8>()), dim3(vk::kWG), 3 * vk::kWG * sizeof(int), st, ga);
+    hipLaunchKernelGGL(vk::step_prep_ws<8>, dim3(vk::ws_prep_grid<8>(n_steps, ga.s.n_obj)), dim3(vk::kWG), 3 * vk::kWG * sizeof(int), st, ga);
     return launched("step_prep_ws<8>");
 }
 

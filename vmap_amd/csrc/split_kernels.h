@@ -563,7 +563,7 @@ __device__ __forceinline__ void relu_mask(float (&d)[16], const f32x16& v, const
 // 1: first-group encoding block blk (0..2), 2: second-group block blk (0..1).  col = column inside the tensor row (after
 // the hidden part) or -1; bias = the column is the layer's bias gradient.
 template <int KIND>
-__device__ __forceinline__ void col_target(int blk, int k, int& col, bool& bias) {
+__host__ __device__ __forceinline__ void col_target(int blk, int k, int& col, bool& bias) {
     bias = false;
     if (KIND == 0) { col = k; return; }
     const int hs = (k >> 2) & 1, r = (k & 3) + 4 * (k >> 3), R = 16 * blk + r;

@@ -86,6 +86,9 @@ struct StepArgs {
     const float* ray_o; long long ro_so, ro_sr, ro_sc;
     const float* ray_d; long long rd_so, rd_sr, rd_sc;
     const float* center; long long ce_so;          // [n][3] or null (= zeros)
+    // the workgroups' rows of partial gradients: PR floats each (= PP: the parameters' flat order; step_main_ws / _wp: RowWs<NB>::PR,
+    // block-native order, with row_tab [PR] = the flat parameter behind every row element or -1, written by step_prep_ws)
+    int PR; int* row_tab;
 };
 
 // Sample point `smp` of ray `ray` of object `obj` in the object frame: read from the points tensor (train.py:272 batch_input_pcs),
@@ -970,6 +973,7 @@ struct FinalizeArgs {
                                        // thread per quad AND row group, never the one-thread-per-quad form the launcher picks for many blocks / few rows
     int loss_stage;                    // loss partials (16 B each) the launch's LDS has room for behind the loss block's reduction scratch
                                        // (set by the launcher, loss_stage_cap); 0: the loss block reads them from memory one by one
+    int PR; const int* row_tab;        // floats per row of part_grad; step_finalize_ws: row element -> flat parameter (or -1), null = the rows are in flat order
 };
 // LDS of a finalize launch as the loss block sees it: kWG floats + kWG ints of reduction scratch, then the staging area of the partials
 constexpr int kLossRedBytes = 2 * kWG * 4;
@@ -1137,6 +1141,7 @@ struct FinalizeHot {
                                        // (flat parameter i of object k at slab[k * slab_stride + i]): no per-element lookup
     int NW, PP, weights_bf16;
     float decay, one_minus_beta1, beta2, one_minus_beta2, eps, step_size, bias_corr2_sqrt;
+    int PR;                            // floats per row of part_grad (step_finalize_ws; = PP elsewhere)
 };
 // tensor index and offset inside it of flat parameter i (hidden 32, compile-time offsets)
 __device__ __forceinline__ void flat32_tensor_of(int i, int& t, int& o) {

@@ -91,6 +91,7 @@ struct Plan {
     bool generic;      // hidden != 32: step_main_gen (global-memory activations) instead of step_main_h32
     bool split;        // hidden 32 on the bf16 matrix pipe with split operands (step_main_s32; the default at hidden 32)
     bool bwd6;         // ... with the six-product backward (VMAPSTEP_KERNEL_S32_BWD6)
+    int PR;            // floats per row of partial gradients: PP (flat order), or RowWs<NB>::PR (step_main_ws / _wp: block-native rows + a row table)
     int wide;          // 0 = step_main_gen, 1 = step_main_wide<4> (hidden 128 / 256: one tile per workgroup, four waves per
                        // tile), 3 = step_main_ws, 4 = step_main_wp (hidden 64 / 128, bf16 matrix pipe)
 };
@@ -219,8 +220,10 @@ int make_plan(const vmapstep_shape* sh, int max_steps, Plan& pl, const Layout& L
     if (max_steps > kMaxFrameSteps) return fail(VMAPSTEP_ERR_UNSUPPORTED, "steps per call %d > %d", max_steps, kMaxFrameSteps);
     size_t o = 0;
     pl.off_ploss = o; o += align_up((size_t)sh->n_obj * nw_cap * 4 * sizeof(float));
-    pl.off_imgtab = o; o += pl.wide >= 3 ? 2 * align_up((size_t)L.PP * sizeof(int)) : pl.generic ? 0 : align_up((size_t)L.PP * sizeof(int));
-    pl.off_pgrad = o; o += align_up((size_t)sh->n_obj * nw_cap * L.PP * sizeof(float));
+    pl.PR = pl.wide >= 3 ? vk::ws_row_floats(sh->hidden) : L.PP;
+    // tables: flat parameter -> image position [PP] (+ step_main_ws / _wp: -> W^T image position [PP], row element -> flat parameter [PR])
+    pl.off_imgtab = o; o += pl.wide >= 3 ? 2 * align_up((size_t)L.PP * sizeof(int)) + align_up((size_t)pl.PR * sizeof(int)) : pl.generic ? 0 : align_up((size_t)L.PP * sizeof(int));
+    pl.off_pgrad = o; o += align_up((size_t)sh->n_obj * nw_cap * pl.PR * sizeof(float));
     const vk::GenLayout GL = vk::gen_layout(sh->hidden);
     pl.off_wimg = o; o += align_up(pl.split ? (size_t)sh->n_obj * vk::Img32s::BYTES : pl.wide >= 3 ? (size_t)sh->n_obj * (sh->hidden == 256 ? vk::ImgWs<8>::BYTES : sh->hidden == 128 ? vk::ImgWs<4>::BYTES : vk::ImgWs<2>::BYTES)
                                                                                    : (size_t)sh->n_obj * GL.imgp * sizeof(float));
@@ -300,6 +303,8 @@ void fill_step_args(vk::StepArgs& a, const vmapstep_shape* sh, const Plan& pl, c
     a.part_loss = reinterpret_cast<float*>(ws + pl.off_ploss);
     a.img_tab = (!pl.generic || pl.wide >= 3) ? reinterpret_cast<int*>(ws + pl.off_imgtab) : nullptr;   // also read by step_finalize_h32
     a.tab_wt = pl.wide >= 3 ? reinterpret_cast<int*>(ws + pl.off_imgtab + align_up((size_t)L.PP * sizeof(int))) : nullptr;
+    a.PR = pl.PR;
+    a.row_tab = pl.wide >= 3 ? reinterpret_cast<int*>(ws + pl.off_imgtab + 2 * align_up((size_t)L.PP * sizeof(int))) : nullptr;
     a.part_grad = reinterpret_cast<float*>(ws + pl.off_pgrad);
     a.wimg = reinterpret_cast<float*>(ws + pl.off_wimg);
     a.gen_scratch = reinterpret_cast<float*>(ws + pl.off_scratch);
@@ -324,6 +329,7 @@ void fill_finalize_args(vk::FinalizeArgs& f, const vk::StepArgs& a, const Layout
                         float* loss_out, int* flags_out, float* terms_out, int step_in_call) {
     std::memset(&f, 0, sizeof(f));
     f.n_obj = a.n_obj; f.NW = a.NW; f.PP = L.PP; f.P = L.P; f.hidden = a.hidden; f.weights_bf16 = a.weights_bf16;
+    f.PR = a.PR; f.row_tab = a.row_tab;
     for (int t = 0; t < 16; ++t) f.offs[t] = L.offs[t];
     for (int t = 0; t < 15; ++t) {
         const vmapstep_tensor* pt = t < 14 ? &params->fc[t] : &params->pe_B;
@@ -361,7 +367,7 @@ void fill_finalize_args(vk::FinalizeArgs& f, const vk::StepArgs& a, const Layout
 void fill_hot(vk::FinalizeHot& h, const vk::FinalizeArgs& f, const vk::StepArgs& a, const Layout& L, const vmapstep_params* params) {
     std::memset(&h, 0, sizeof(h));
     h.m = f.m; h.v = f.v; h.part_grad = f.part_grad; h.wimg = f.wimg; h.img_tab = a.img_tab;
-    h.NW = f.NW; h.PP = f.PP; h.weights_bf16 = f.weights_bf16;
+    h.NW = f.NW; h.PP = f.PP; h.PR = f.PR; h.weights_bf16 = f.weights_bf16;
     h.decay = f.decay; h.one_minus_beta1 = f.one_minus_beta1; h.beta2 = f.beta2; h.one_minus_beta2 = f.one_minus_beta2;
     h.eps = f.eps; h.step_size = f.step_size; h.bias_corr2_sqrt = f.bias_corr2_sqrt;
     // parameters that are views of one [n, >= P] slab in flat order (vmap_amd.driver allocates them so): one base
@@ -545,6 +551,7 @@ int vmapstep_adamw_apply(const vmapstep_shape* shape, const vmapstep_params* par
     std::memset(&a, 0, sizeof(a));
     char* ws = static_cast<char*>(workspace);
     a.n_obj = shape->n_obj; a.NW = 1; a.PP = L.PP; a.hidden = shape->hidden;
+    a.PR = L.PP; a.row_tab = nullptr;            // the caller's slab is in flat order
     a.weights_bf16 = shape->weight_dtype == VMAPSTEP_WEIGHTS_BF16 ? 1 : 0;
     a.split = pl.split ? 1 : 0;
     a.xcd_affine = 0;

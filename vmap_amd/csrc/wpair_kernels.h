@@ -110,7 +110,7 @@ __global__ __launch_bounds__(128 * NB, 2) void step_main_wp(const WsArgs ga) {
     const float* SM = reinterpret_cast<const float*>(gimg + I::SMALL_OFF);
     float* loss_cells = reinterpret_cast<float*>(lds + LD::LOSS);
     if (tid_k < kWaves * 4) loss_cells[tid_k] = 0.0f;
-    float* out_k = a.part_grad + (long long)wg_index * a.PP;
+    float* out_k = a.part_grad + (long long)wg_index * a.PR;
     float* cb = reinterpret_cast<float*>(lds + LD::CBO);
     float* hp = reinterpret_cast<float*>(lds + LD::HP);
     float* hx = reinterpret_cast<float*>(lds + LD::HX);
@@ -399,11 +399,9 @@ __global__ __launch_bounds__(128 * NB, 2) void step_main_wp(const WsArgs ga) {
     for (int st = 0; st < 2; ++st)
 #pragma unroll
         for (int i = 0; i < 11; ++i) dproj[st][i] = 0.0f;
-    float* outW_c = out + L.f[10] + (long long)32 * ob * (H + kEmb2);
-    float* outW_m2 = out + L.f[6] + (long long)32 * ob * H;
-    float* outW_cat = out + L.f[4] + (long long)32 * ob * (H + kEmb1);
-    float* outW_m1 = out + L.f[2] + (long long)32 * ob * H;
-    float* outW_in = out + L.f[0] + (long long)32 * ob * kEmb1;
+    using RW = RowWs<NB>;
+    float* outR = out + RW::slot(0, ob, 0);                           // this output block's slots of the workgroup's row
+    const unsigned lane4 = 4u * (unsigned)lane;
     char* dlt_own = lds + LD::DLT + kh * LD::DLT_ST + ob * 2 * I::DCH + lo16;
     const char* dlt_partner = lds + LD::DLT + (1 - kh) * LD::DLT_ST + ob * 2 * I::DCH + lo16;
     const char* dltx = lds + LD::DLT + lo16;
@@ -538,15 +536,15 @@ __global__ __launch_bounds__(128 * NB, 2) void step_main_wp(const WsArgs ga) {
     tpre_load<W3>(tp, hidden_ptr(I::CT_C), vlo16);
     __syncthreads();
     if (kh == 0 && hi == 0) {
-        store_one(out + L.f[8] + 32 * ob + p31, ga4[0] + cell[0 * 64], first);
-        store_one(out + L.f[12] + 0 * H + 32 * ob + p31, gc4[1] + cell[1 * 64], first);
-        store_one(out + L.f[12] + 1 * H + 32 * ob + p31, gc4[2] + cell[2 * 64], first);
-        store_one(out + L.f[12] + 2 * H + 32 * ob + p31, gc4[3] + cell[3 * 64], first);
+        store_one(out + RW::W_A + 32 * ob + p31, ga4[0] + cell[0 * 64], first);
+        store_one(out + RW::W_OC + 0 * H + 32 * ob + p31, gc4[1] + cell[1 * 64], first);
+        store_one(out + RW::W_OC + 1 * H + 32 * ob + p31, gc4[2] + cell[2 * 64], first);
+        store_one(out + RW::W_OC + 2 * H + 32 * ob + p31, gc4[3] + cell[3 * 64], first);
         if (ob == 0 && lane == 0) {
-            store_one(out + L.f[9], gb4[0] + cell[4 * 64], first);
-            store_one(out + L.f[13] + 0, gb4[1] + cell[5 * 64], first);
-            store_one(out + L.f[13] + 1, gb4[2] + cell[6 * 64], first);
-            store_one(out + L.f[13] + 2, gb4[3] + cell[7 * 64], first);
+            store_one(out + RW::B_A, gb4[0] + cell[4 * 64], first);
+            store_one(out + RW::B_OC + 0, gb4[1] + cell[5 * 64], first);
+            store_one(out + RW::B_OC + 1, gb4[2] + cell[6 * 64], first);
+            store_one(out + RW::B_OC + 2, gb4[3] + cell[7 * 64], first);
         }
     }
     WP_MARK(9);
@@ -555,8 +553,7 @@ __global__ __launch_bounds__(128 * NB, 2) void step_main_wp(const WsArgs ga) {
     dw_layer_half<NB + 2>(dF, first, kh,
         [&](FImg& x, int kb) { if (kb < NB) xload_hidden(x, kb); else fimg_load_g(x, efo + (3 + kb - NB) * 4096, efs, vlo16); },
         [&](int mode, int kb, const f32x16& v, float (&old)[16]) {
-            WS_IO3(mode, kb < NB, (block_io<0, H + kEmb2, M>(outW_c + 32 * kb, nullptr, v, old, 0, 32, p31, hi)),
-                   (block_io<2, H + kEmb2, M>(outW_c + H, out + L.f[11] + 32 * ob, v, old, kb - NB, kEmb2, p31, hi)));
+            WS_IO(mode, (slot_io<M>(outR + RW::slot(RW::S_C, 0, kb), lane4, v, old)));
         });
     if (wave == EW2) dprop_enc(I::CT_C + (NB + 0) * JS, 2, 0);
     if (wave == EW3) dprop_enc(I::CT_C + (NB + 1) * JS, 2, 1);
@@ -572,9 +569,9 @@ __global__ __launch_bounds__(128 * NB, 2) void step_main_wp(const WsArgs ga) {
     // mid2
     partner_dF();
     dw_layer_half<NB>(dF, first, kh, xload_hidden, [&](int mode, int kb, const f32x16& v, float (&old)[16]) {
-        WS_IO3(mode, true, (block_io<0, H, M>(outW_m2 + 32 * kb, nullptr, v, old, 0, 32, p31, hi)), (void)0);
+        WS_IO(mode, (slot_io<M>(outR + RW::slot(RW::S_M2, 0, kb), lane4, v, old)));
     });
-    if (kh == 1) bias_rows(out + L.f[7]);
+    if (kh == 1) bias_rows(out + RW::B_M2);
     dprop_hidden(I::CT_M2, false);
     tpre_load<W3>(tp, hidden_ptr(I::CT_CAT), vlo16);
     __syncthreads();
@@ -589,8 +586,7 @@ __global__ __launch_bounds__(128 * NB, 2) void step_main_wp(const WsArgs ga) {
     dw_layer_half<NB + 3>(dF, first, kh,
         [&](FImg& x, int kb) { if (kb < NB) xload_hidden(x, kb); else fimg_load_g(x, efo + (kb - NB) * 4096, efs, vlo16); },
         [&](int mode, int kb, const f32x16& v, float (&old)[16]) {
-            WS_IO3(mode, kb < NB, (block_io<0, H + kEmb1, M>(outW_cat + 32 * kb, nullptr, v, old, 0, 32, p31, hi)),
-                   (block_io<1, H + kEmb1, M>(outW_cat + H, out + L.f[5] + 32 * ob, v, old, kb - NB, kEmb1, p31, hi)));
+            WS_IO(mode, (slot_io<M>(outR + RW::slot(RW::S_CAT, 0, kb), lane4, v, old)));
         });
     if (wave == EW1) dprop_enc(I::CT_CAT + (NB + 0) * JS, 1, 0);
     if (wave == EW2) dprop_enc(I::CT_CAT + (NB + 1) * JS, 1, 1);
@@ -606,9 +602,9 @@ __global__ __launch_bounds__(128 * NB, 2) void step_main_wp(const WsArgs ga) {
     // mid1
     partner_dF();
     dw_layer_half<NB>(dF, first, kh, xload_hidden, [&](int mode, int kb, const f32x16& v, float (&old)[16]) {
-        WS_IO3(mode, true, (block_io<0, H, M>(outW_m1 + 32 * kb, nullptr, v, old, 0, 32, p31, hi)), (void)0);
+        WS_IO(mode, (slot_io<M>(outR + RW::slot(RW::S_M1, 0, kb), lane4, v, old)));
     });
-    if (kh == 1) bias_rows(out + L.f[3]);
+    if (kh == 1) bias_rows(out + RW::B_M1);
     dprop_hidden(I::CT_M1, false);
     __syncthreads();
     finish_delta(pbh);                                                   // delta 4 = d h1
@@ -619,7 +615,7 @@ __global__ __launch_bounds__(128 * NB, 2) void step_main_wp(const WsArgs ga) {
     partner_dF();
     dw_layer_half<3>(dF, first, kh, [&](FImg& x, int kb) { fimg_load_g(x, efo + kb * 4096, efs, vlo16); },
                      [&](int mode, int kb, const f32x16& v, float (&old)[16]) {
-                         WS_IO3(mode, true, (block_io<1, kEmb1, M>(outW_in, out + L.f[1] + 32 * ob, v, old, kb, kEmb1, p31, hi)), (void)0);
+                         WS_IO(mode, (slot_io<M>(outR + RW::slot(RW::S_IN, 0, kb), lane4, v, old)));
                      });
     if (wave == EW1) dprop_enc(I::CT_IN + 0 * JS, 1, 0);
     if (wave == EW2) dprop_enc(I::CT_IN + 1 * JS, 1, 1);
@@ -660,7 +656,7 @@ __global__ __launch_bounds__(128 * NB, 2) void step_main_wp(const WsArgs ga) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int d = hi ? 11 + r : r;                          // row phi(r, hi) <-> direction
-                    if (r < (hi ? 10 : 11)) store_one(out + L.f[14] + 3 * d + (p31 - 24), accB[r], first);
+                    if (r < (hi ? 10 : 11)) store_one(out + RW::PE_B + 3 * d + (p31 - 24), accB[r], first);
                 }
             }
         }

@@ -9,7 +9,7 @@ namespace vl {
 
 // many blocks, few rows per object: the form in which one thread per quad walks all row groups (see step_finalize_ws)
 inline bool finalize_one_thread_per_quad(const vk::FinalizeArgs& f) {
-    return !f.ws_grouped && f.NW <= 16 && (long long)f.n_obj * vk::ws_finalize_blocks(f.PP) >= 512;
+    return !f.ws_grouped && f.NW <= 16 && (long long)f.n_obj * vk::ws_finalize_blocks(f.PR) >= 512;
 }
 
 // step_finalize_ws<NB, Q, PG> on `blocks` row blocks (+ 1: the loss block) of `threads` threads with `lds` bytes
@@ -23,12 +23,12 @@ inline int launch_finalize_ws(vk::FinalizeArgs f, const vk::FinalizeHot& h, cons
 template <int NB>
 inline int finalize_wide(const vk::FinalizeArgs& f, const vk::FinalizeHot& h, const int* tab_wt, hipStream_t st) {
     constexpr int Q = vk::kFinQuadsWide;
-    return launch_finalize_ws<NB, Q, 1>(f, h, tab_wt, vk::ws_finalize_grid(f.n_obj, f.PP, Q, f.xcd_affine) - 1, Q, (size_t)vk::kFinGroups * Q * 4 * sizeof(float), st);
+    return launch_finalize_ws<NB, Q, 1>(f, h, tab_wt, vk::ws_finalize_grid(f.n_obj, f.PR, Q, f.xcd_affine) - 1, Q, (size_t)vk::kFinGroups * Q * 4 * sizeof(float), st);
 }
 // the grouped form, kFinQuads quads per block
 template <int NB>
 inline int finalize_grouped(const vk::FinalizeArgs& f, const vk::FinalizeHot& h, const int* tab_wt, hipStream_t st) {
-    return launch_finalize_ws<NB, vk::kFinQuads, vk::kFinGroups>(f, h, tab_wt, vk::ws_finalize_grid(f.n_obj, f.PP, vk::kFinQuads, f.xcd_affine) - 1, vk::kFinThreads,
+    return launch_finalize_ws<NB, vk::kFinQuads, vk::kFinGroups>(f, h, tab_wt, vk::ws_finalize_grid(f.n_obj, f.PR, vk::kFinQuads, f.xcd_affine) - 1, vk::kFinThreads,
                                                     vk::kFinThreads * 4 * sizeof(float), st);
 }
 

@@ -219,9 +219,68 @@ __host__ __device__ inline bool ws_small_source(int i, int& t, int& o) {
     return o < 63;
 }
 
+// ---- the workgroup's row of partial gradients, BLOCK-NATIVE (round 6) ------------------------------------------------------
+// A wave's 32 x 32 weight-gradient block leaves the matrix pipe with 16 values per lane (lane = column, register r <-> row phi(r, hi)).
+// Stored in the parameters' flat order that is sixteen 4-byte stores per lane, each a 128-byte run; stored AS IT STANDS - register
+// group g of lane l at float g * 256 + l * 4 of the block's 4 KiB slot - it is four 16-byte stores that cover 1 KiB each without a
+// gap (measured with a deliberately wrong layout first: step_main_ws<4> 73.1 -> 67.6 us on the background step,
+// profiles/round6d_*).  So the row is a sequence of block slots - per output block ob the blocks of color_linear, mid2, cat_layer,
+// mid1, in_layer in the order the backward produces them - followed by the small vectors; step_finalize_ws walks the ROW and finds
+// every element's parameter through a table (row position -> flat parameter, -1 for the padding columns of the encoding blocks)
+// that step_prep_ws writes.  The sums, their order and the update do not change: only where a number waits in between.
+template <int NB>
+struct RowWs {
+    static constexpr int H = 32 * NB;
+    static constexpr int NKB_C = NB + 2, NKB_M2 = NB, NKB_CAT = NB + 3, NKB_M1 = NB, NKB_IN = 3;
+    static constexpr int S_C = 0, S_M2 = S_C + NKB_C, S_CAT = S_M2 + NKB_M2, S_M1 = S_CAT + NKB_CAT, S_IN = S_M1 + NKB_M1, PER_OB = S_IN + NKB_IN;
+    static constexpr int BLOCKS = NB * PER_OB;
+    // the small vectors behind the blocks (floats): mid1 bias, mid2 bias, out_alpha weight, out_color weight [3][H], out_alpha bias, out_color bias, B_layer
+    static constexpr int SMALL = BLOCKS * 1024;
+    static constexpr int B_M1 = SMALL, B_M2 = B_M1 + H, W_A = B_M2 + H, W_OC = W_A + H, B_A = W_OC + 3 * H, B_OC = B_A + 1, PE_B = B_OC + 3, END = PE_B + 63;
+    static constexpr int PR = (END + 63) / 64 * 64;                        // floats per row
+    __host__ __device__ static constexpr int slot(int layer0, int ob, int kb) { return (ob * PER_OB + layer0 + kb) * 1024; }
+};
+__host__ __device__ inline int ws_row_floats(int hidden) { return hidden == 256 ? RowWs<8>::PR : hidden == 128 ? RowWs<4>::PR : RowWs<2>::PR; }
+// element r of a row -> (tensor t, offset o); false = padding
+template <int NB>
+__host__ __device__ inline bool ws_row_source(int r, int& t, int& o) {
+    using RW = RowWs<NB>;
+    constexpr int H = RW::H;
+    if (r >= RW::SMALL) {
+        if (r < RW::B_M2) { t = 3; o = r - RW::B_M1; return true; }
+        if (r < RW::W_A) { t = 7; o = r - RW::B_M2; return true; }
+        if (r < RW::W_OC) { t = 8; o = r - RW::W_A; return true; }
+        if (r < RW::B_A) { t = 12; o = r - RW::W_OC; return true; }
+        if (r < RW::B_OC) { t = 9; o = 0; return true; }
+        if (r < RW::PE_B) { t = 13; o = r - RW::B_OC; return true; }
+        if (r < RW::END) { t = 14; o = r - RW::PE_B; return true; }
+        return false;
+    }
+    const int sl = r >> 10, w = r & 1023, g = w >> 8, lane = (w >> 2) & 63, j = w & 3, p31 = lane & 31, hi = lane >> 5;
+    const int ob = sl / RW::PER_OB, ls = sl - ob * RW::PER_OB;
+    const int row = 32 * ob + 8 * g + 4 * hi + j;                          // = 32 ob + phi(4 g + j, hi)
+    int tw, tb, K, kb, nh, kind, ncols;                                     // weight / bias tensor, its row length, block, hidden blocks, encoding kind
+    if (ls < RW::S_M2) { tw = 10; tb = 11; K = H + kEmb2; kb = ls - RW::S_C; nh = NB; kind = 2; ncols = kEmb2; }
+    else if (ls < RW::S_CAT) { tw = 6; tb = -1; K = H; kb = ls - RW::S_M2; nh = NB; kind = 0; ncols = 0; }
+    else if (ls < RW::S_M1) { tw = 4; tb = 5; K = H + kEmb1; kb = ls - RW::S_CAT; nh = NB; kind = 1; ncols = kEmb1; }
+    else if (ls < RW::S_IN) { tw = 2; tb = -1; K = H; kb = ls - RW::S_M1; nh = NB; kind = 0; ncols = 0; }
+    else { tw = 0; tb = 1; K = kEmb1; kb = ls - RW::S_IN; nh = 0; kind = 1; ncols = kEmb1; }
+    if (kb < nh) { t = tw; o = row * K + 32 * kb + p31; return true; }
+    int col; bool bias;
+    if (kind == 1) col_target<1>(kb - nh, p31, col, bias); else col_target<2>(kb - nh, p31, col, bias);
+    if (col >= 0 && col < ncols) { t = tw; o = row * K + (K - ncols) + col; return true; }
+    if (bias) { t = tb; o = row; return true; }
+    return false;
+}
+
 // ---- step_prep_ws: mask statistics (blocks [0, prep_steps)) + image build (one thread per 4 plane elements) -------------
 template <int NB>
 __host__ __device__ constexpr int ws_pack_blocks() { return (ImgWs<NB>::W_ELEMS / 4 + ImgWs<NB>::WT_ELEMS / 4 + 256 + kWG - 1) / kWG; }
+template <int NB>
+__host__ __device__ constexpr int ws_rowtab_blocks() { return (RowWs<NB>::PR / 4 + kWG - 1) / kWG; }
+// grid of step_prep_ws<NB>: the steps' mask statistics, every object's image, the row table
+template <int NB>
+__host__ __device__ constexpr int ws_prep_grid(int n_steps, int n_obj) { return n_steps + n_obj * ws_pack_blocks<NB>() + ws_rowtab_blocks<NB>(); }
 
 template <int NB>
 __global__ __launch_bounds__(kWG) void step_prep_ws(const WsArgs ga) {
@@ -235,6 +294,20 @@ __global__ __launch_bounds__(kWG) void step_prep_ws(const WsArgs ga) {
     const int b = blockIdx.x - a.prep_steps;
     const int per = ws_pack_blocks<NB>();
     const int k = b / per;
+    if (k >= a.n_obj) {                                  // the last ws_rowtab_blocks<NB>() blocks: row element -> flat parameter
+        const int rq = (b - a.n_obj * per) * kWG + threadIdx.x;
+        if (a.row_tab && rq < RowWs<NB>::PR / 4) {
+            typedef int i32x4 __attribute__((ext_vector_type(4)));
+            i32x4 f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int t, o;
+                f[e] = ws_row_source<NB>(4 * rq + e, t, o) ? L.f[t] + o : -1;
+            }
+            *reinterpret_cast<i32x4*>(a.row_tab + 4 * rq) = f;
+        }
+        return;
+    }
     const int q = (b - k * per) * kWG + threadIdx.x;
     char* img = reinterpret_cast<char*>(a.wimg) + (long long)k * I::BYTES;
     auto fetch = [&](int t, int o) { return t < kNFc ? a.fc[t].p[k * a.fc[t].stride + o] : a.pe_B.p[k * a.pe_B.stride + o]; };
@@ -357,8 +430,9 @@ template <int NB, int kFinQuads = vk::kFinQuads, int PG = kFinGroups>
 __global__ __launch_bounds__(PG * kFinQuads) void step_finalize_ws(const FinalizeArgs a, const FinalizeHot hh, const int* tab_wt) {
     static_assert(kFinGroups % PG == 0 && PG * kFinQuads >= kWG, "row groups per thread; the loss block reduces over kWG threads");
     typedef int i32x4 __attribute__((ext_vector_type(4)));
-    const int quads = a.PP / 4;
-    const int blocks_per_obj = ws_finalize_blocks(a.PP, kFinQuads);
+    typedef int i32x4u __attribute__((ext_vector_type(4), aligned(4)));
+    const int quads = hh.PR / 4;                                         // quads of a ROW (flat order: PR = PP; block-native: RowWs<NB>::PR)
+    const int blocks_per_obj = ws_finalize_blocks(hh.PR, kFinQuads);
     if (blockIdx.x == gridDim.x - 1) {
         finalize_loss(a);
         return;
@@ -375,18 +449,30 @@ __global__ __launch_bounds__(PG * kFinQuads) void step_finalize_ws(const Finaliz
     }
     const int ql = threadIdx.x % kFinQuads, rg = threadIdx.x / kFinQuads;
     const int q = min(part * kFinQuads + ql, quads - 1);
-    const bool live = part * kFinQuads + ql < quads && 4 * q < a.P;
     wv::f32x4* red = reinterpret_cast<wv::f32x4*>(wv::lds_base());      // [kFinGroups][kFinQuads]
-    // The update's own operands (moments, parameters, image positions) are requested by the threads that will apply it BEFORE the row
-    // reads: behind the join they were a second, fully exposed memory round trip on 96 of the block's 768 threads (round 5: the row
-    // reads alone take 14.3 us of this kernel's 20-24, tests/tools/fin_layout_probe.hip).
-    const bool tail = rg == 0 && live;
-    const long long s = (long long)obj * hh.PP + 4 * q;
+    // The flat parameters behind this row quad (row_tab; rows in flat order: the quad's own index), -1 = padding.  Only the thread that
+    // applies the update (row group 0) needs them.  Its own operands (moments, parameters, image positions) are requested BEFORE the
+    // row reads: behind the join they were a second, fully exposed memory round trip on 96 of the block's 768 threads (round 5: the
+    // row reads alone take 14.3 us of this kernel's 20-24, tests/tools/fin_layout_probe.hip).
+    int fl[4] = {-1, -1, -1, -1};
+    if (rg == 0 && part * kFinQuads + ql < quads) {
+        if (a.row_tab) {
+            const i32x4 f = *reinterpret_cast<const i32x4*>(a.row_tab + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) fl[e] = f[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) fl[e] = 4 * q + e < a.P ? 4 * q + e : -1;
+        }
+    }
+    const bool tail = (fl[0] & fl[1] & fl[2] & fl[3]) >= 0;             // at least one live element
+    const bool cons = fl[0] >= 0 && fl[1] == fl[0] + 1 && fl[2] == fl[0] + 2 && fl[3] == fl[0] + 3;   // four consecutive flat parameters
+    const long long mb = (long long)obj * hh.PP;                         // this object's moments
     int ten[4] = {0, 0, 0, 0}, off[4] = {0, 0, 0, 0};
     if (tail) {                        // (the other seven row groups' threads have no use for the tensor lookup)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int i = min(4 * q + e, a.P - 1);
+            const int i = max(fl[e], 0);
             int t = 0;
 #pragma unroll
             for (int k = 1; k <= kNFc; ++k) t += i >= a.offs[k];
@@ -397,26 +483,33 @@ __global__ __launch_bounds__(PG * kFinQuads) void step_finalize_ws(const Finaliz
     i32x4 iw = {0, 0, 0, 0}, it = iw;
     float* pp[4] = {nullptr, nullptr, nullptr, nullptr};
     float pv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    const bool pvec = 4 * q + 3 < a.P && ten[0] == ten[3];
+    const bool pvec = cons && ten[0] == ten[3];
     if (tail && a.do_adam) {
-        m4 = *reinterpret_cast<const wv::f32x4*>(hh.m + s);
-        v4 = *reinterpret_cast<const wv::f32x4*>(hh.v + s);
-        iw = *reinterpret_cast<const i32x4*>(hh.img_tab + 4 * q);
-        it = *reinterpret_cast<const i32x4*>(tab_wt + 4 * q);
 #pragma unroll
         for (int e = 0; e < 4; ++e) pp[e] = a.param[ten[e]].p + obj * a.param[ten[e]].stride + off[e];
+        if (cons) {
+            m4 = *reinterpret_cast<const wv::f32x4u*>(hh.m + mb + fl[0]);
+            v4 = *reinterpret_cast<const wv::f32x4u*>(hh.v + mb + fl[0]);
+            iw = *reinterpret_cast<const i32x4u*>(hh.img_tab + fl[0]);
+            it = *reinterpret_cast<const i32x4u*>(tab_wt + fl[0]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (fl[e] >= 0) { m4[e] = hh.m[mb + fl[e]]; v4[e] = hh.v[mb + fl[e]]; iw[e] = hh.img_tab[fl[e]]; it[e] = tab_wt[fl[e]]; }
+        }
         if (pvec) {                    // a quad inside ONE parameter tensor: one 16-byte access at a 4-byte boundary, in and out
             const wv::f32x4 p4 = *reinterpret_cast<const wv::f32x4u*>(pp[0]);
 #pragma unroll
             for (int e = 0; e < 4; ++e) pv[e] = p4[e];
         } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) pv[e] = *pp[e];
+            for (int e = 0; e < 4; ++e)
+                if (fl[e] >= 0) pv[e] = *pp[e];
         }
     }
     {
-        const wv::f32x4* pg = reinterpret_cast<const wv::f32x4*>(hh.part_grad + (long long)obj * hh.NW * hh.PP + 4 * q);
-        const long long qs = hh.PP / 4;
+        const wv::f32x4* pg = reinterpret_cast<const wv::f32x4*>(hh.part_grad + (long long)obj * hh.NW * hh.PR + 4 * q);
+        const long long qs = hh.PR / 4;
         const int per = (hh.NW + kFinGroups - 1) / kFinGroups;
         wv::f32x4 g = {0.0f, 0.0f, 0.0f, 0.0f};
         if constexpr (PG == kFinGroups) {
@@ -457,7 +550,7 @@ __global__ __launch_bounds__(PG * kFinQuads) void step_finalize_ws(const Finaliz
         }
     }
     __syncthreads();
-    if (rg != 0 || !live) return;
+    if (!tail) return;
     static_assert((kFinGroups & (kFinGroups - 1)) == 0 && kFinGroups >= 4 && kFinGroups <= 16, "the join below is a pairwise tree");
     wv::f32x4 jn[kFinGroups];
 #pragma unroll
@@ -470,14 +563,14 @@ __global__ __launch_bounds__(PG * kFinQuads) void step_finalize_ws(const Finaliz
     // the caller's gradient tensors (fwd_bwd, the last step of a frame call, the shared background's step)
 #pragma unroll
     for (int e = 0; e < 4; ++e)
-        if (4 * q + e < a.P && a.grad[ten[e]].p) a.grad[ten[e]].p[obj * a.grad[ten[e]].stride + off[e]] = g[e];
+        if (fl[e] >= 0 && a.grad[ten[e]].p) a.grad[ten[e]].p[obj * a.grad[ten[e]].stride + off[e]] = g[e];
     if (!a.do_adam) return;
     float ss, bc;
     adam_step_consts(a, hh, ss, bc);
     char* image = reinterpret_cast<char*>(hh.wimg) + (long long)obj * ImgWs<NB>::BYTES;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        if (4 * q + e < a.P) {
+        if (fl[e] >= 0) {
             float p = pv[e], m = m4[e], v = v4[e];
             adamw_elem(hh, ss, bc, g[e], p, m, v);
             if (!pvec) *pp[e] = p;
@@ -486,8 +579,14 @@ __global__ __launch_bounds__(PG * kFinQuads) void step_finalize_ws(const Finaliz
         }
     }
     if (pvec) *reinterpret_cast<wv::f32x4u*>(pp[0]) = wv::f32x4{pv[0], pv[1], pv[2], pv[3]};
-    *reinterpret_cast<wv::f32x4*>(hh.m + s) = m4;
-    *reinterpret_cast<wv::f32x4*>(hh.v + s) = v4;
+    if (cons) {
+        *reinterpret_cast<wv::f32x4u*>(hh.m + mb + fl[0]) = m4;
+        *reinterpret_cast<wv::f32x4u*>(hh.v + mb + fl[0]) = v4;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (fl[e] >= 0) { hh.m[mb + fl[e]] = m4[e]; hh.v[mb + fl[e]] = v4[e]; }
+    }
 }
 
 // ---- device helpers of step_main_ws -----------------------------------------------------------------------------------
@@ -499,12 +598,15 @@ __global__ __launch_bounds__(PG * kFinQuads) void step_finalize_ws(const Finaliz
 #define VS_ABLW 0
 #endif
 #define WS_WSTEP(s) (s)
-// block_io of a layer for a runtime (wave-uniform) mode; A / B: the hidden-block / encoding-block form, M = the mode
-#define WS_IO3(mode, is_a, A, B)                                                              \
+#ifndef VK_WS8_AH                /* measurement: dw_layer's AH at hidden 256 (see there) */
+#define VK_WS8_AH 1
+#endif
+// slot_io of a block for a runtime (wave-uniform) mode; M = the mode
+#define WS_IO(mode, A)                                                                        \
     do {                                                                                       \
-        if ((mode) == 0) { constexpr int M = 0; if (is_a) { A; } else { B; } }                  \
-        else if ((mode) == 1) { constexpr int M = 1; if (is_a) { A; } else { B; } }             \
-        else { constexpr int M = 2; if (is_a) { A; } else { B; } }                              \
+        if ((mode) == 0) { constexpr int M = 0; A; }                                           \
+        else if ((mode) == 1) { constexpr int M = 1; A; }                                      \
+        else { constexpr int M = 2; A; }                                                       \
     } while (0)
 // global access as (wave-uniform base) + (32-bit lane offset): the scalar-base form of the global instructions, no per-lane
 // 64-bit address arithmetic
@@ -767,13 +869,26 @@ __device__ __forceinline__ void store_rows(float* ubase, unsigned voff, const f3
     if (first) rows_io<K, 0>(ubase, voff, acc, old);
     else { rows_io<K, 1>(ubase, voff, acc, old); rows_io<K, 2>(ubase, voff, acc, old); }
 }
-// a 32x32 weight-gradient block (lane = column k, register r <-> row phi(r, hi)) -> the partial gradients
-template <int KIND, int K, int MODE>
-__device__ __forceinline__ void block_io(float* out_w, float* out_b, const f32x16& acc, float (&old)[16], int blk, int ncols, int p31, int hi) {
-    int col; bool bias;
-    col_target<KIND>(blk, p31, col, bias);
-    if (col >= 0 && col < ncols) rows_io<K, MODE>(out_w, (unsigned)(col + 4 * hi * K), acc, old);
-    else if (bias) rows_io<1, MODE>(out_b, (unsigned)(4 * hi), acc, old);
+// a 32x32 weight-gradient block (lane = column k, register r <-> row phi(r, hi)) <-> its slot of the workgroup's row (RowWs): register
+// group g of the lane at float g * 256 + lane * 4 - four 16-byte accesses that cover 1 KiB each.  lane4 = 4 * lane.
+// MODE 0: store (a workgroup's first round); 1: read the sums of the earlier rounds into old; 2: store old + acc.
+template <int MODE>
+__device__ __forceinline__ void slot_io(float* slot, unsigned lane4, const f32x16& acc, float (&old)[16]) {
+    if (VS_ABLW & 3) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { asm volatile("" ::"v"(acc[r])); old[r] = 0.0f; }
+        return;
+    }
+    float* q = slot + lane4;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        wv::f32x4* qg = reinterpret_cast<wv::f32x4*>(q + 256 * g);
+        if (MODE == 0) *qg = wv::f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+        else if (MODE == 1) {
+            const wv::f32x4 v = *qg;
+            old[4 * g] = v[0]; old[4 * g + 1] = v[1]; old[4 * g + 2] = v[2]; old[4 * g + 3] = v[3];
+        } else *qg = wv::f32x4{old[4 * g] + acc[4 * g], old[4 * g + 1] + acc[4 * g + 1], old[4 * g + 2] + acc[4 * g + 2], old[4 * g + 3] + acc[4 * g + 3]};
+    }
 }
 __device__ __forceinline__ void store_one(float* q, float v, bool first) {
     if (VS_ABLW & 3) { asm volatile("" ::"v"(v)); return; }
@@ -792,11 +907,13 @@ __device__ __forceinline__ void mask_by(float (&d)[16], const f32x16& v, const u
 // kb + 1 and (later rounds) the global reads of block kb's earlier sums go out, the matrix instructions of block kb run, the
 // stores of block kb - 1 retire.  io(mode, kb, acc, old): block_io of the layer.
 // Blocks kb >= NG come from global memory: ximg returns their wave-uniform base, voff = lane * 16.
-template <int N, int NT = 2, int NG = 99, int ND, class XI, class IO>
+// AH = how far ahead of their use a later round requests a block's earlier sums: 2 = in front of the block's own matrix instructions
+// (two sets of 16 registers in flight), 1 = in front of the NEXT block's (one set: hidden 256, whose waves have 256 registers).
+template <int N, int NT = 2, int NG = 99, int AH = 2, int ND, class XI, class IO>
 __device__ __forceinline__ void dw_layer(const unsigned (&dF)[ND][16], bool first, XI&& ximg, IO&& io, unsigned voff = 0u) {
     FImg x[2];
     f32x16 acc[2];
-    float old[2][16];
+    float old[AH][16];
     { const char* p; int st; ximg(0, p, st); if (0 >= NG) fimg_load_g<NT>(x[0], p, st, voff); else fimg_load<NT>(x[0], p, st); }
 #pragma unroll
     for (int kb = 0; kb < N; ++kb) {
@@ -805,13 +922,15 @@ __device__ __forceinline__ void dw_layer(const unsigned (&dF)[ND][16], bool firs
             ximg(kb + 1, p, st);
             if (kb + 1 >= NG) fimg_load_g<NT>(x[(kb + 1) & 1], p, st, voff); else fimg_load<NT>(x[(kb + 1) & 1], p, st);
         }
-        if (!first) io(1, kb, acc[kb & 1], old[kb & 1]);
+        if (AH == 2) { if (!first) io(1, kb, acc[kb & 1], old[kb & (AH - 1)]); }
+        else if (!first && kb > 0) io(1, kb - 1, acc[(kb - 1) & 1], old[0]);
         wv::sched_fence();
         dw_mm_pair<NT>(acc[kb & 1], dF, x[kb & 1]);
-        if (kb > 0) io(first ? 0 : 2, kb - 1, acc[(kb - 1) & 1], old[(kb - 1) & 1]);
+        if (kb > 0) io(first ? 0 : 2, kb - 1, acc[(kb - 1) & 1], old[(kb - 1) & (AH - 1)]);
         wv::sched_fence();
     }
-    io(first ? 0 : 2, N - 1, acc[(N - 1) & 1], old[(N - 1) & 1]);
+    if (AH == 1 && !first) io(1, N - 1, acc[(N - 1) & 1], old[0]);
+    io(first ? 0 : 2, N - 1, acc[(N - 1) & 1], old[(N - 1) & (AH - 1)]);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -841,7 +960,7 @@ __global__ __launch_bounds__(64 * ws_waves<NB>(), 1) void step_main_ws(const WsA
     const float* SM = reinterpret_cast<const float*>(gimg + I::SMALL_OFF);
     float* loss_cells = reinterpret_cast<float*>(lds + LD::LOSS);
     if (tid_k < NWV * 4) loss_cells[tid_k] = 0.0f;
-    float* out_k = a.part_grad + ((long long)(obj * a.NW + wgo)) * a.PP;
+    float* out_k = a.part_grad + ((long long)(obj * a.NW + wgo)) * a.PR;
     float* cb = reinterpret_cast<float*>(lds + LD::CBO);
     float* hp = reinterpret_cast<float*>(lds + LD::HP);
     const float scale = a.pe_scale.p[obj * a.pe_scale.stride];
@@ -1163,11 +1282,10 @@ __global__ __launch_bounds__(64 * ws_waves<NB>(), 1) void step_main_ws(const WsA
     }
     __syncthreads();                                                     // encoding F images complete; the P-form images are dead
     WS_MARK(8);
-    float* outW_c = out + L.f[10] + (long long)32 * wave * (H + kEmb2);
-    float* outW_m2 = out + L.f[6] + (long long)32 * wave * H;
-    float* outW_cat = out + L.f[4] + (long long)32 * wave * (H + kEmb1);
-    float* outW_m1 = out + L.f[2] + (long long)32 * wave * H;
-    float* outW_in = out + L.f[0] + (long long)32 * wave * kEmb1;
+    using RW = RowWs<NB>;
+    constexpr int AH = NB > 4 ? VK_WS8_AH : 2;                             // dw_layer: hidden 256 keeps ONE set of earlier sums in flight
+    float* outR = out + RW::slot(0, wave, 0);                           // this output block's slots of the workgroup's row
+    const unsigned lane4 = 4u * (unsigned)lane;
     char* dlt_own = lds + LD::DLT + wave * 2 * I::DCH + lo16;
     const char* dltx = lds + LD::DLT + lo16;
     char* xf_own = lds + LD::XF + wave * 4096 + lo16;
@@ -1256,13 +1374,13 @@ __global__ __launch_bounds__(64 * ws_waves<NB>(), 1) void step_main_ws(const WsA
         wv::wave_lds_fence();
         fimg_load<NT>(xi, xf_own, LD::XF_ST);
         dw_mm_pair<NT>(accw, dF, xi);
-        if (hi == 0) store_one(out + L.f[8] + 32 * wave + p31, accw[0], first);
+        if (hi == 0) store_one(out + RW::W_A + 32 * wave + p31, accw[0], first);
         if (wave == 0) {
             f32x16 accb;
             db_pair<NT>(accb, dF);
             if (lane == 0) {
-                store_one(out + L.f[9], accb[0], first);
-                store_one(out + L.f[13] + 0, accb[1], first); store_one(out + L.f[13] + 1, accb[2], first); store_one(out + L.f[13] + 2, accb[3], first);
+                store_one(out + RW::B_A, accb[0], first);
+                store_one(out + RW::B_OC + 0, accb[1], first); store_one(out + RW::B_OC + 1, accb[2], first); store_one(out + RW::B_OC + 2, accb[3], first);
             }
         }
         zero_acc(accw);
@@ -1273,9 +1391,9 @@ __global__ __launch_bounds__(64 * ws_waves<NB>(), 1) void step_main_ws(const WsA
             dw_mm_s(accw, dF[st], x0);
         }
         if (hi == 0) {
-            store_one(out + L.f[12] + 0 * H + 32 * wave + p31, accw[1], first);
-            store_one(out + L.f[12] + 1 * H + 32 * wave + p31, accw[2], first);
-            store_one(out + L.f[12] + 2 * H + 32 * wave + p31, accw[3], first);
+            store_one(out + RW::W_OC + 0 * H + 32 * wave + p31, accw[1], first);
+            store_one(out + RW::W_OC + 1 * H + 32 * wave + p31, accw[2], first);
+            store_one(out + RW::W_OC + 2 * H + 32 * wave + p31, accw[3], first);
         }
     }
     // -- delta 0 = d hc (through the ReLU; ah = hc's hi plane) --
@@ -1303,15 +1421,14 @@ __global__ __launch_bounds__(64 * ws_waves<NB>(), 1) void step_main_ws(const WsA
     if (wave == EC1) enc_fetch(I::CT_C + (NB + 1) * JS, 2, 1);
     WS_DMARK(1);
     if (own)
-        dw_layer<NB + 2, NT, LD::EF2_GLOBAL ? NB : 99>(dF, first,
+        dw_layer<NB + 2, NT, LD::EF2_GLOBAL ? NB : 99, AH>(dF, first,
             [&](int kb, const char*& p, int& st) {
                 if (kb < NB) xf_img(kb, p, st);
                 else if (LD::EF2_GLOBAL) { p = wgs + LD::EF2_OFF + (kb - NB) * 4096; st = 2 * 4096; }
                 else { p = efx + (3 + kb - NB) * 4096; st = LD::EF_ST; }
             },
             [&](int mode, int kb, const f32x16& v, float (&old)[16]) {
-                WS_IO3(mode, kb < NB, (block_io<0, H + kEmb2, M>(outW_c + 32 * kb, nullptr, v, old, 0, 32, p31, hi)),
-                       (block_io<2, H + kEmb2, M>(outW_c + H, out + L.f[11] + 32 * wave, v, old, kb - NB, kEmb2, p31, hi)));
+                WS_IO(mode, (slot_io<M>(outR + RW::slot(RW::S_C, 0, kb), lane4, v, old)));
             }, vlo16);
     WS_DMARK(2);
     if (wave == EC0) dprop_enc(I::CT_C + (NB + 0) * JS, 2, 0);
@@ -1337,12 +1454,12 @@ __global__ __launch_bounds__(64 * ws_waves<NB>(), 1) void step_main_ws(const WsA
     WS_MARK(10);
     // mid2
     if (own) {
-        dw_layer<NB, NT>(dF, first, xf_img, [&](int mode, int kb, const f32x16& v, float (&old)[16]) {
-            WS_IO3(mode, true, (block_io<0, H, M>(outW_m2 + 32 * kb, nullptr, v, old, 0, 32, p31, hi)), (void)0);
+        dw_layer<NB, NT, 99, AH>(dF, first, xf_img, [&](int mode, int kb, const f32x16& v, float (&old)[16]) {
+            WS_IO(mode, (slot_io<M>(outR + RW::slot(RW::S_M2, 0, kb), lane4, v, old)));
         });
         WS_DMARK(10);
         db_pair<NT>(accw, dF);
-        if (p31 == 0) store_rows<1>(out + L.f[7] + 32 * wave, (unsigned)(4 * hi), accw, first);
+        if (p31 == 0) store_rows<1>(out + RW::B_M2 + 32 * wave, (unsigned)(4 * hi), accw, first);
         WS_DMARK(11);
         dprop_hidden(I::CT_M2, false);
         WS_DMARK(12);
@@ -1363,11 +1480,10 @@ __global__ __launch_bounds__(64 * ws_waves<NB>(), 1) void step_main_ws(const WsA
     WS_DMARK(15);
     // cat_layer
     if (own)
-        dw_layer<NB + 3, NT>(dF, first,
+        dw_layer<NB + 3, NT, 99, AH>(dF, first,
             [&](int kb, const char*& p, int& st) { if (kb < NB) xf_img(kb, p, st); else { p = efx + (kb - NB) * 4096; st = LD::EF_ST; } },
             [&](int mode, int kb, const f32x16& v, float (&old)[16]) {
-                WS_IO3(mode, kb < NB, (block_io<0, H + kEmb1, M>(outW_cat + 32 * kb, nullptr, v, old, 0, 32, p31, hi)),
-                       (block_io<1, H + kEmb1, M>(outW_cat + H, out + L.f[5] + 32 * wave, v, old, kb - NB, kEmb1, p31, hi)));
+                WS_IO(mode, (slot_io<M>(outR + RW::slot(RW::S_CAT, 0, kb), lane4, v, old)));
             });
     if (wave == 1) dprop_enc(I::CT_CAT + (NB + 0) * JS, 1, 0);
     if (wave == 2) dprop_enc(I::CT_CAT + (NB + 1) * JS, 1, 1);
@@ -1385,11 +1501,11 @@ __global__ __launch_bounds__(64 * ws_waves<NB>(), 1) void step_main_ws(const WsA
     WS_MARK(12);
     // mid1
     if (own) {
-        dw_layer<NB, NT>(dF, first, xf_img, [&](int mode, int kb, const f32x16& v, float (&old)[16]) {
-            WS_IO3(mode, true, (block_io<0, H, M>(outW_m1 + 32 * kb, nullptr, v, old, 0, 32, p31, hi)), (void)0);
+        dw_layer<NB, NT, 99, AH>(dF, first, xf_img, [&](int mode, int kb, const f32x16& v, float (&old)[16]) {
+            WS_IO(mode, (slot_io<M>(outR + RW::slot(RW::S_M1, 0, kb), lane4, v, old)));
         });
         db_pair<NT>(accw, dF);
-        if (p31 == 0) store_rows<1>(out + L.f[3] + 32 * wave, (unsigned)(4 * hi), accw, first);
+        if (p31 == 0) store_rows<1>(out + RW::B_M1 + 32 * wave, (unsigned)(4 * hi), accw, first);
         dprop_hidden(I::CT_M1, false);
 #pragma unroll
         for (int st = 0; st < NT; ++st) mask_by(dv[st], accd[st], ah[st]);  // delta 4 = d h1
@@ -1403,9 +1519,9 @@ __global__ __launch_bounds__(64 * ws_waves<NB>(), 1) void step_main_ws(const WsA
     WS_MARK(13);
     // in_layer
     if (own)
-        dw_layer<3, NT>(dF, first, [&](int kb, const char*& p, int& st) { p = efx + kb * 4096; st = LD::EF_ST; },
+        dw_layer<3, NT, 99, AH>(dF, first, [&](int kb, const char*& p, int& st) { p = efx + kb * 4096; st = LD::EF_ST; },
                     [&](int mode, int kb, const f32x16& v, float (&old)[16]) {
-                        WS_IO3(mode, true, (block_io<1, kEmb1, M>(outW_in, out + L.f[1] + 32 * wave, v, old, kb, kEmb1, p31, hi)), (void)0);
+                        WS_IO(mode, (slot_io<M>(outR + RW::slot(RW::S_IN, 0, kb), lane4, v, old)));
                     });
     if (wave == 0) dprop_enc(I::CT_IN + 0 * JS, 1, 0);
     if (wave == 2) dprop_enc(I::CT_IN + 1 * JS, 1, 1);
@@ -1439,7 +1555,7 @@ __global__ __launch_bounds__(64 * ws_waves<NB>(), 1) void step_main_ws(const WsA
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int d = hi ? 11 + r : r;                          // row phi(r, hi) <-> direction
-                    if (r < (hi ? 10 : 11)) store_one(out + L.f[14] + 3 * d + (p31 - 24), accw[r], first);
+                    if (r < (hi ? 10 : 11)) store_one(out + RW::PE_B + 3 * d + (p31 - 24), accw[r], first);
                 }
             }
         }
