@@ -77,7 +77,7 @@ __device__ __forceinline__ void dw_layer_half(const unsigned (&dF)[2][16], bool 
             xload(x, kb);
             if (!first) io(1, kb, acc, old);
             wv::sched_fence();
-            dw_mm_pair(acc, dF, x);
+            dw_mm_pair<2, kRowT>(acc, dF, x);
             io(first ? 0 : 2, kb, acc, old);
         }
     }

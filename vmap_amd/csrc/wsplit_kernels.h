@@ -20,6 +20,9 @@
 //     gradients (stored by the first round, added by later ones); W^T comes from a second, transposed image.
 #pragma once
 #include "split_kernels.h"
+#ifndef VS_ABLW                  /* measurement builds only, see "device helpers of step_main_ws" */
+#define VS_ABLW 0
+#endif
 
 namespace vk {
 
@@ -228,6 +231,12 @@ __host__ __device__ inline bool ws_small_source(int i, int& t, int& o) {
 // mid1, in_layer in the order the backward produces them - followed by the small vectors; step_finalize_ws walks the ROW and finds
 // every element's parameter through a table (row position -> flat parameter, -1 for the padding columns of the encoding blocks)
 // that step_prep_ws writes.  The sums, their order and the update do not change: only where a number waits in between.
+#ifndef VK_ROW_T                 /* measurement, 1: the weight-gradient blocks of dw_layer leave TRANSPOSED (dw_mm_pair<., true>: a lane's four
+                                    registers = four consecutive parameters, the finalize's update on 16-byte accesses) - slower: background
+                                    step 0.0876 -> 0.0889 ms, a rank's share of configs[4] 0.196 -> 0.201 ms (profiles/round6d_rows_transposed_ab.jsonl) */
+#define VK_ROW_T 0
+#endif
+constexpr bool kRowT = VK_ROW_T != 0;
 template <int NB>
 struct RowWs {
     static constexpr int H = 32 * NB;
@@ -258,16 +267,17 @@ __host__ __device__ inline bool ws_row_source(int r, int& t, int& o) {
     }
     const int sl = r >> 10, w = r & 1023, g = w >> 8, lane = (w >> 2) & 63, j = w & 3, p31 = lane & 31, hi = lane >> 5;
     const int ob = sl / RW::PER_OB, ls = sl - ob * RW::PER_OB;
-    const int row = 32 * ob + 8 * g + 4 * hi + j;                          // = 32 ob + phi(4 g + j, hi)
+    const int br = 8 * g + 4 * hi + j;                                     // the block's row = phi(4 g + j, hi); its column = p31
+    const int row = 32 * ob + (kRowT ? p31 : br), bc = kRowT ? br : p31;   // output row of the layer; input column inside block kb
     int tw, tb, K, kb, nh, kind, ncols;                                     // weight / bias tensor, its row length, block, hidden blocks, encoding kind
     if (ls < RW::S_M2) { tw = 10; tb = 11; K = H + kEmb2; kb = ls - RW::S_C; nh = NB; kind = 2; ncols = kEmb2; }
     else if (ls < RW::S_CAT) { tw = 6; tb = -1; K = H; kb = ls - RW::S_M2; nh = NB; kind = 0; ncols = 0; }
     else if (ls < RW::S_M1) { tw = 4; tb = 5; K = H + kEmb1; kb = ls - RW::S_CAT; nh = NB; kind = 1; ncols = kEmb1; }
     else if (ls < RW::S_IN) { tw = 2; tb = -1; K = H; kb = ls - RW::S_M1; nh = NB; kind = 0; ncols = 0; }
     else { tw = 0; tb = 1; K = kEmb1; kb = ls - RW::S_IN; nh = 0; kind = 1; ncols = kEmb1; }
-    if (kb < nh) { t = tw; o = row * K + 32 * kb + p31; return true; }
+    if (kb < nh) { t = tw; o = row * K + 32 * kb + bc; return true; }
     int col; bool bias;
-    if (kind == 1) col_target<1>(kb - nh, p31, col, bias); else col_target<2>(kb - nh, p31, col, bias);
+    if (kind == 1) col_target<1>(kb - nh, bc, col, bias); else col_target<2>(kb - nh, bc, col, bias);
     if (col >= 0 && col < ncols) { t = tw; o = row * K + (K - ncols) + col; return true; }
     if (bias) { t = tb; o = row; return true; }
     return false;
@@ -398,6 +408,9 @@ __device__ __forceinline__ void ws_image_store(char* img, int locw, int locwt, f
 #else
 #define VK_FIN_LOAD(p) (*(p))
 #endif
+#ifndef VK_FIN_NARROW
+#define VK_FIN_NARROW 100
+#endif
 #ifndef VK_FIN_QUADS
 #define VK_FIN_QUADS 128
 #endif
@@ -414,7 +427,7 @@ __host__ __device__ inline int ws_finalize_grid(int n_obj, int PP, int fin_quads
 // not fill the chip (the one-object background step: 246 instead of 185 blocks): 0.1035 -> 0.1011 ms per step (round 5, tests/tools/finq_probe.py;
 // the kernel's time is the row reads - with the AdamW update and the image rewrite removed it does not change); otherwise slower (more
 // blocks than compute units: hidden 64 / 256 shapes +0.4 .. 0.8 %).
-constexpr int kFinQuadsNarrow = 96;
+constexpr int kFinQuadsNarrow = VK_FIN_NARROW;
 
 // Gradients to the caller's tensors (if given), AdamW + image rewrite (if do_adam).
 // The partial gradients are NW rows of PP floats per object (one per workgroup of step_main_ws, up to 256): a block covers
@@ -466,7 +479,7 @@ __global__ __launch_bounds__(PG * kFinQuads) void step_finalize_ws(const Finaliz
         }
     }
     const bool tail = (fl[0] & fl[1] & fl[2] & fl[3]) >= 0;             // at least one live element
-    const bool cons = fl[0] >= 0 && fl[1] == fl[0] + 1 && fl[2] == fl[0] + 2 && fl[3] == fl[0] + 3;   // four consecutive flat parameters
+    const bool cons = fl[0] >= 0 && ((VS_ABLW & 128) || (fl[1] == fl[0] + 1 && fl[2] == fl[0] + 2 && fl[3] == fl[0] + 3));   // four consecutive flat parameters (bit 7 of VS_ABLW: measurement, taken as if)
     const long long mb = (long long)obj * hh.PP;                         // this object's moments
     int ten[4] = {0, 0, 0, 0}, off[4] = {0, 0, 0, 0};
     if (tail) {                        // (the other seven row groups' threads have no use for the tensor lookup)
@@ -593,7 +606,9 @@ __global__ __launch_bounds__(PG * kFinQuads) void step_finalize_ws(const Finaliz
 // Measurement builds only (tests/tools/build_variant.py ... -DVS_ABLW=<mask>; results WRONG on purpose - the product never defines it):
 // bit 0: the partial-gradient row stores are skipped (the products stay); bit 1: no weight-gradient products either; bit 2: the
 // activation planes do not travel through the workgroup's scratch (stores skipped, loads replaced by constants); bit 3: no d-prop
-// matrix chains; bit 4: no forward matrix chains; bit 5 / 6: only the scratch stores / only the scratch loads of bit 2
+// matrix chains; bit 4: no forward matrix chains; bit 5 / 6: only the scratch stores / only the scratch loads of bit 2;
+// bit 7 (step_finalize_ws): the update's operands of a row quad fetched as if its four parameters were consecutive (what the element-wise
+// gathers of the block-native rows cost: 17.2 -> 16.3 us on the background step, profiles/round6d_finalize_tail_probe.txt)
 #ifndef VS_ABLW
 #define VS_ABLW 0
 #endif
@@ -813,7 +828,9 @@ __device__ __forceinline__ void put_F_g(char* ubase, unsigned voff, const unsign
     for (int c = 0; c < 4; ++c) *reinterpret_cast<u32x4*>(ubase + c * 1024 + voff) = u32x4{f[4 * c], f[4 * c + 1], f[4 * c + 2], f[4 * c + 3]};
 }
 // one weight-gradient block over the round's two tiles: acc = sum_tiles dY^T X (F-form: c[0..1] hi plane steps, c[2..3] mid)
-template <int NT = 2, int ND>
+// T: the same products with the operands exchanged = the block TRANSPOSED (lane = output row, register r <-> input column phi(r, hi)):
+// a lane's four consecutive registers are then four consecutive parameters of one row of the weight matrix
+template <int NT = 2, bool T = false, int ND>
 __device__ __forceinline__ void dw_mm_pair(f32x16& acc, const unsigned (&dF)[ND][16], const FImg& x) {
     zero_acc(acc);
     if (VS_ABLW & 2) return;
@@ -823,9 +840,15 @@ __device__ __forceinline__ void dw_mm_pair(f32x16& acc, const unsigned (&dF)[ND]
         for (int s = 0; s < 2; ++s) {
             const u32x4 ah = u32x4{dF[st][4 * s], dF[st][4 * s + 1], dF[st][4 * s + 2], dF[st][4 * s + 3]};
             const u32x4 am = u32x4{dF[st][8 + 4 * s], dF[st][8 + 4 * s + 1], dF[st][8 + 4 * s + 2], dF[st][8 + 4 * s + 3]};
-            acc = wv::mfma_bf16(ah, x.c[st][2 + s], acc);
-            acc = wv::mfma_bf16(am, x.c[st][s], acc);
-            acc = wv::mfma_bf16(ah, x.c[st][s], acc);
+            if (T) {
+                acc = wv::mfma_bf16(x.c[st][2 + s], ah, acc);
+                acc = wv::mfma_bf16(x.c[st][s], am, acc);
+                acc = wv::mfma_bf16(x.c[st][s], ah, acc);
+            } else {
+                acc = wv::mfma_bf16(ah, x.c[st][2 + s], acc);
+                acc = wv::mfma_bf16(am, x.c[st][s], acc);
+                acc = wv::mfma_bf16(ah, x.c[st][s], acc);
+            }
         }
 }
 // bias gradient of a layer without constant-1 input column: dY^T . ones
@@ -925,7 +948,7 @@ __device__ __forceinline__ void dw_layer(const unsigned (&dF)[ND][16], bool firs
         if (AH == 2) { if (!first) io(1, kb, acc[kb & 1], old[kb & (AH - 1)]); }
         else if (!first && kb > 0) io(1, kb - 1, acc[(kb - 1) & 1], old[0]);
         wv::sched_fence();
-        dw_mm_pair<NT>(acc[kb & 1], dF, x[kb & 1]);
+        dw_mm_pair<NT, kRowT>(acc[kb & 1], dF, x[kb & 1]);
         if (kb > 0) io(first ? 0 : 2, kb - 1, acc[(kb - 1) & 1], old[(kb - 1) & (AH - 1)]);
         wv::sched_fence();
     }
