@@ -30,6 +30,9 @@
 //   * the biases of in / cat / colour layers ride in a weight column that meets a constant-1 slot of the encoding:
 //     no bias preload in the forward, and the bias gradient is a column of the weight-gradient block.
 #pragma once
+#ifndef VS_ABL                   /* measurement builds only: see below */
+#define VS_ABL 0
+#endif
 #include "step_kernels.h"
 
 // Measurement builds only (tests/tools/build_variant.py ... -DVS_ABL=<mask>; results WRONG on purpose - the product never defines it):
@@ -38,6 +41,10 @@
 // bit 2: only the P->F transposes of the weight-gradient operands are skipped (tile_put / tile_get);
 // bit 0: the backward without its weight-gradient products (no matrix instructions in mm_dw_il, no P->F transposes, no staging /
 // finishing of blocks) = the d-prop critical chain alone; bit 1: without the backward's workgroup barriers.
+// The front half (round 6d): bit 8: no LDS-DMA of the parameter image (LDS holds whatever it held); bit 9: the sample point is a function of the lane
+// (no loads of pcs / z); bit 10: the per-ray ground truth and the per-object normalisers are constants (no loads); bit 11: no compositing
+// (barriers kept); bit 12: the encoding's sincos + octave recurrence replaced by a copy; inside the compositing (step_kernels.h):
+// bit 13: no sequential scans (T, D, V, suffix); bit 14: no square root / divisions; bit 15: no loss sums.
 #ifndef VS_ABL
 #define VS_ABL 0
 #endif
@@ -860,9 +867,10 @@ __device__ __forceinline__ void step_main_s32_body(const StepArgs& a) {
     const int smp = valid ? pt - lray * a.S : 0;
     const int ray = ray0 + lray;
     float px3[3] = {0.0f, 0.0f, 0.0f};
-    if (valid) load_point(a, obj, ray, smp, px3[0], px3[1], px3[2]);
+    if (VS_ABL & 512) { px3[0] = 0.01f * (float)lane; px3[1] = 0.02f * (float)wave; px3[2] = 0.003f * (float)(lane + wave); }
+    else if (valid) load_point(a, obj, ray, smp, px3[0], px3[1], px3[2]);
     // ---- asynchronous copy of the parameter image into LDS (issued behind the loads of the sample point, whose latency its 20 instructions cover; lands during the encoding) ----
-    if (grp == wgo) {
+    if (grp == wgo && !(VS_ABL & 256)) {
         const char* src = gimg + wave * 1024 + lane * 16;
 #pragma unroll
         for (int c = 0; c < I::ROUNDS; ++c)
@@ -892,7 +900,8 @@ __device__ __forceinline__ void step_main_s32_body(const StepArgs& a) {
         for (int i = 0; i < 11; ++i) {
             float s[6], c[6];
             const float a0 = proj[i] * kPi;            // fl32(proj * fl32(pi)); the octaves 2^f * a0 are exact
-            if (__builtin_expect(fast, 1)) octave_sincos<false>(a0, s, c);
+            if (VS_ABL & 4096) { for (int f = 0; f < 6; ++f) { s[f] = a0; c[f] = proj[i]; } }
+            else if (__builtin_expect(fast, 1)) octave_sincos<false>(a0, s, c);
             else octave_sincos<true>(a0, s, c);
             const bool own = i < 10 || hi == 0;        // the eleventh direction of the hi = 1 lanes is a dummy
 #pragma unroll
@@ -914,7 +923,9 @@ __device__ __forceinline__ void step_main_s32_body(const StepArgs& a) {
     __syncthreads();        // parameter image landed (the barrier drains the LDS-DMA), composite buffer zeroed
     // ground truth of the ray this lane composites: its six vector loads fly during the MLP forward (at the compositing they
     // cost a full memory round trip of an otherwise idle workgroup)
-    const RayMeta rays_meta = load_ray_meta_rays(a, obj, ray0 + min(4 * wave + (lane >> 4), nrays - 1));
+    RayMeta rays_meta;
+    if (VS_ABL & 1024) { rays_meta.sem = 1; rays_meta.dm = 1; rays_meta.gtd = 1.5f; rays_meta.q0 = 0.2f; rays_meta.q1 = 0.3f; rays_meta.q2 = 0.4f; rays_meta.inv_dd = rays_meta.inv_o = rays_meta.inv_s = 0.01f; }
+    else rays_meta = load_ray_meta_rays(a, obj, ray0 + min(4 * wave + (lane >> 4), nrays - 1));
     wv::sched_fence();
 
     // ---- field MLP forward (model.py:59-83) ----
@@ -963,7 +974,7 @@ __device__ __forceinline__ void step_main_s32_body(const StepArgs& a) {
         ra += SM[I::B_A]; r0 += SM[I::B_OC]; r1 += SM[I::B_OC + 1]; r2 += SM[I::B_OC + 2];
         if (valid && hi == 0) {
             float* row = cb + pt * 8;
-            row[6] = a.z[obj * a.z_so + ray * a.z_sr + smp * a.z_ss];
+            row[6] = (VS_ABL & 512) ? 1.0f + 0.1f * (float)smp : a.z[obj * a.z_so + ray * a.z_sr + smp * a.z_ss];
             row[0] = sigmoidf_acc(ra * 10.0f);                   // :77 raw*10 ; render_rays.py:6 sigmoid
             row[1] = sigmoidf_acc(r0);                           // :83 sigmoid(raw_color)
             row[2] = sigmoidf_acc(r1);
@@ -980,8 +991,9 @@ __device__ __forceinline__ void step_main_s32_body(const StepArgs& a) {
     VS_MARK(5);
     {
         const StepArgs& al = wv::kernarg_late(a);
+        if (!(VS_ABL & 2048))
         composite_phase<BWD>(al, cb, loss_cells, obj, ray0, nrays, wave, lane, tid,
-                             finish_ray_meta(al, obj, rays_meta));
+                             (VS_ABL & 1024) ? rays_meta : finish_ray_meta(al, obj, rays_meta));
     }
     __syncthreads();
     VS_MARK(6);

@@ -28,6 +28,9 @@
 #pragma once
 #include <wave_ops.h>   // resolved through -I: csrc/ (device) or tests/sim/ (CPU SIMT executor)
 
+#ifndef VS_ABL                   /* measurement builds only (split_kernels.h) */
+#define VS_ABL 0
+#endif
 namespace vk {
 
 using wv::f32x16;
@@ -715,22 +718,28 @@ __device__ __forceinline__ void composite_phase(const StepArgs& a, float* cb, fl
             // exact ones / zeros and leaves the sequential result over the S samples unchanged.
             float T = 1.0f;
 #define VK_T(J) { const float fj = wv::row_bcast<J>(f); T = J < i ? T * fj : T; }
+            if (!(VS_ABL & 8192)) {
             VK_T(0) VK_T(1) VK_T(2) VK_T(3) VK_T(4) VK_T(5) VK_T(6) VK_T(7)
             VK_T(8) VK_T(9) VK_T(10) VK_T(11) VK_T(12) VK_T(13) VK_T(14)
+            }
 #undef VK_T
             const float w = o * T;                                     // render_rays.py:32
             const float wz = w * zi;
             float D = 0.0f;
 #define VK_D(J) D += wv::row_bcast<J>(wz);
+            if (VS_ABL & 8192) D = wz; else {
             VK_D(0) VK_D(1) VK_D(2) VK_D(3) VK_D(4) VK_D(5) VK_D(6) VK_D(7)
             VK_D(8) VK_D(9) VK_D(10) VK_D(11) VK_D(12) VK_D(13) VK_D(14) VK_D(15)           // loss.py:27
+            }
 #undef VK_D
             const float dz = zi - D;
             const float wd = w * (dz * dz);
             float V = 0.0f;
 #define VK_V(J) V += wv::row_bcast<J>(wd);
+            if (VS_ABL & 8192) V = wd; else {
             VK_V(0) VK_V(1) VK_V(2) VK_V(3) VK_V(4) VK_V(5) VK_V(6) VK_V(7)
             VK_V(8) VK_V(9) VK_V(10) VK_V(11) VK_V(12) VK_V(13) VK_V(14) VK_V(15)           // loss.py:28-29 (detached)
+            }
 #undef VK_V
             const float O = wv::row_sum16(w);                           // loss.py:31
             const float C0 = wv::row_sum16(w * c0), C1 = wv::row_sum16(w * c1), C2 = wv::row_sum16(w * c2);   // loss.py:30
@@ -740,15 +749,17 @@ __device__ __forceinline__ void composite_phase(const StepArgs& a, float* cb, fl
             const float m_dd = (dm != 0 && s != 0) ? 1.0f : 0.0f;                     // loss.py:37
             const float gtd = mt.gtd, q0 = mt.q0, q1 = mt.q1, q2 = mt.q2;
             const float inv_dd = mt.inv_dd, inv_o = mt.inv_o, inv_s = mt.inv_s;
-            const float info = 1.0f / (sqrtf(V) + 1e-4f);                             // render_rays.py:75-79
+            const float info = (VS_ABL & 16384) ? V + 1e-4f : 1.0f / (sqrtf(V) + 1e-4f);   // render_rays.py:75-79
             const float rd = D - gtd, rc0 = C0 - q0, rc1 = C1 - q1, rc2 = C2 - q2, ro = O - m_o;
             const bool lead = g < nrays && i == 0;
             float ld = lead ? fabsf(rd) * m_dd * info * inv_dd : 0.0f;
             float lc = lead ? (fabsf(rc0) + fabsf(rc1) + fabsf(rc2)) * m_o * inv_o : 0.0f;
             float lo = lead ? fabsf(ro) * m_s * inv_s : 0.0f;
+            if (!(VS_ABL & 32768)) {
             ld += wv::shfl(ld, lane ^ 16); lc += wv::shfl(lc, lane ^ 16); lo += wv::shfl(lo, lane ^ 16);
             ld += wv::swap_half(ld); lc += wv::swap_half(lc); lo += wv::swap_half(lo);
-            if (lane == 0) {                                           // this wave's private loss partials
+            }
+            if (lane == 0 && !(VS_ABL & 32768)) {                      // this wave's private loss partials
                 loss_cells[wave * 4 + 0] += ld;
                 loss_cells[wave * 4 + 1] += lc;
                 loss_cells[wave * 4 + 2] += lo;
@@ -773,10 +784,12 @@ __device__ __forceinline__ void composite_phase(const StepArgs& a, float* cb, fl
                 // that difference cancels catastrophically and is then divided by f, which can be 1e-10)
                 float suffix = 0.0f;
 #define VK_S(J) { const float gj = wv::row_bcast<J>(gww); suffix = J > i ? suffix + gj : suffix; }
+                if (!(VS_ABL & 8192)) {
                 VK_S(15) VK_S(14) VK_S(13) VK_S(12) VK_S(11) VK_S(10) VK_S(9) VK_S(8)
                 VK_S(7) VK_S(6) VK_S(5) VK_S(4) VK_S(3) VK_S(2) VK_S(1)
+                }
 #undef VK_S
-                const float d_occ = gw * T - suffix / f;               // cumprod backward: reverse-cumsum / input
+                const float d_occ = (VS_ABL & 16384) ? gw * T - suffix * f : gw * T - suffix / f;               // cumprod backward: reverse-cumsum / input
                 if (on) {
                     row[0] = 10.0f * (d_occ * o * (1.0f - o));         // through sigmoid and the *10 (model.py:77)
                     row[1] = w * gC0 * c0 * (1.0f - c0);               // through the colour sigmoid (model.py:83)
