@@ -170,6 +170,19 @@ extern "C" int vmsim_sample(const vs::SampleObject* objs, int n_obj, int W, int 
     sl::sample(a, n_obj, (long long)F * P);
     return 0;
 }
+// the row table of step_main_ws / _wp (RowWs<NB>, wsplit_kernels.h): out[r] = flat parameter behind row element r, or -1; returns the row length
+// (out == nullptr: only the length)
+extern "C" int vmsim_row_table(int H, int* out) {
+    if (H != 64 && H != 128 && H != 256) return -1;
+    const vk::GenLayout L = vk::gen_layout(H);
+    const int PR = vk::ws_row_floats(H);
+    for (int r = 0; out && r < PR; ++r) {
+        int t = 0, o = 0;
+        const bool live = H == 256 ? vk::ws_row_source<8>(r, t, o) : H == 128 ? vk::ws_row_source<4>(r, t, o) : vk::ws_row_source<2>(r, t, o);
+        out[r] = live ? L.f[t] + o : -1;
+    }
+    return PR;
+}
 extern "C" int vmsim_sample_object_size() { return (int)sizeof(vs::SampleObject); }
 
 // query: pack the image of one object then run the query kernel of that width (host pointers)

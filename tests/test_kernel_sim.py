@@ -444,3 +444,27 @@ def test_ray_handoff_equals_points_on_the_simulator(H, wide, split, n, R, S):
     b0 = simlib.sim_step(fc, B, sc, dict(batch, pcs=((o[:, :, None, :] + d[:, :, None, :] * z[..., None])).astype(np.float32)), wide=wide, split=split, rays=(o, d, None), G=G)
     a0 = simlib.sim_step(fc, B, sc, dict(batch, pcs=((o[:, :, None, :] + d[:, :, None, :] * z[..., None])).astype(np.float32)), wide=wide, split=split, G=G)
     assert np.array_equal(a0["grads_flat"], b0["grads_flat"]) and a0["loss"] == b0["loss"]          # centres omitted = zeros
+
+
+@pytest.mark.parametrize("H", [64, 128, 256])
+def test_block_native_gradient_row_holds_every_parameter_exactly_once(H):
+    """The row of partial gradients of step_main_ws / _wp is a sequence of 32 x 32 blocks as they leave the matrix pipe + the small
+    vectors (RowWs<NB>, wsplit_kernels.h); step_finalize_ws finds the parameter behind a row element through the table step_prep_ws
+    writes from ws_row_source.  That table must be a bijection between the live row elements and the flat parameters - a parameter
+    missing from it would never be trained, one named twice would take two gradients."""
+    import ctypes
+    from vmap_amd import layout
+    L = simlib.lib()
+    L.vmsim_row_table.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+    PR = L.vmsim_row_table(H, None)
+    tab = np.full(PR, -7, dtype=np.int32)
+    assert L.vmsim_row_table(H, tab.ctypes.data_as(ctypes.POINTER(ctypes.c_int))) == PR
+    P = layout.param_count(H)
+    live = tab[tab >= 0]
+    assert PR % 64 == 0 and tab.min() == -1
+    assert live.size == P and np.array_equal(np.sort(live), np.arange(P))
+    # the blocks come first, 1024 floats each; the padding columns of the encoding blocks are the only holes in front of the small vectors
+    nb = H // 32
+    blocks = nb * (4 * nb + 8)
+    assert PR - 64 < blocks * 1024 + 6 * H + 67 <= PR
+    assert (tab[blocks * 1024:blocks * 1024 + 6 * H + 67] >= 0).all() and (tab[blocks * 1024 + 6 * H + 67:] == -1).all()

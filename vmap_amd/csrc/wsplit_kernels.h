@@ -408,8 +408,8 @@ __device__ __forceinline__ void ws_image_store(char* img, int locw, int locwt, f
 #else
 #define VK_FIN_LOAD(p) (*(p))
 #endif
-#ifndef VK_FIN_NARROW
-#define VK_FIN_NARROW 100
+#ifndef VK_FIN_NARROW            /* quads per block of the narrow finalize form (see kFinQuadsNarrow) */
+#define VK_FIN_NARROW 96
 #endif
 #ifndef VK_FIN_QUADS
 #define VK_FIN_QUADS 128
@@ -427,6 +427,9 @@ __host__ __device__ inline int ws_finalize_grid(int n_obj, int PP, int fin_quads
 // not fill the chip (the one-object background step: 246 instead of 185 blocks): 0.1035 -> 0.1011 ms per step (round 5, tests/tools/finq_probe.py;
 // the kernel's time is the row reads - with the AdamW update and the image rewrite removed it does not change); otherwise slower (more
 // blocks than compute units: hidden 64 / 256 shapes +0.4 .. 0.8 %).
+// Round 6d: with block-native rows (PR = 99 200 at hidden 128) the 96-quad form needs 259 blocks and is no longer taken for the background
+// step; a 100-quad form (248 blocks) measures the same alone (1.747-1.752 ms per 20 steps) and WORSE next to the objects' stream
+// (two-stream frame 2.04 vs 1.99-2.03 ms, profiles/round6d_frame_ab.jsonl): the 128-quad form it is.
 constexpr int kFinQuadsNarrow = VK_FIN_NARROW;
 
 // Gradients to the caller's tensors (if given), AdamW + image rewrite (if do_adam).
