@@ -205,7 +205,7 @@ __global__ __launch_bounds__(128 * NB, 2) void step_main_wp(const WsArgs ga) {
         const bool fast = !wv::wave_any(!(amax * (32.0f * kPi) < kSinCosFastLimit));
         char* e1img = eimg + est * LD::E_ST + evo;
         char* e2img = e1img + LD::E2_OFF;
-        float* cf_out = cfs + est * 66 * 64 + lane;
+        float* cf_out = cfs + est * kCfTile;
 #pragma unroll
         for (int ii = 0; ii < SL; ++ii) {
             const int i = SL * dq + ii;
@@ -223,8 +223,10 @@ __global__ __launch_bounds__(128 * NB, 2) void step_main_wp(const WsArgs ga) {
                 v1[0] = hi ? 0.0f : t[0]; v1[1] = hi ? 0.0f : t[1]; v1[2] = hi ? 0.0f : t[2]; v1[3] = hi ? 0.0f : 1.0f;
                 v2[0] = hi ? 0.0f : 1.0f; v2[1] = 0.0f;
             } else if (BWD) {
+                float cv[6];
 #pragma unroll
-                for (int f = 0; f < 6; ++f) cf_out[(6 * i + f) * 64] = own ? c[f] * (kPi * (float)(1 << f)) : 0.0f;
+                for (int f = 0; f < 6; ++f) cv[f] = own ? c[f] * (kPi * (float)(1 << f)) : 0.0f;
+                cf_store(cf_out, i, lane, cv);
             }
             unsigned h1[2], m1[2], l1[2], h2[1], m2[1], l2[1];
             split_planes<4, 3>(v1, h1, m1, l1);
@@ -463,16 +465,13 @@ __global__ __launch_bounds__(128 * NB, 2) void step_main_wp(const WsArgs ga) {
         bwd_run<W3, JS>(acce, tpe, enc_ptr(ct_chunk), vlo16, dltx, LD::DLT_ST);
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
-            const char* cfu = reinterpret_cast<const char*>(cfs + st * 66 * 64);
+            float cf[16];
+            cf_load(cf, cfs + st * kCfTile, group, blk, lane);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int R = 16 * blk + r;
-                const int idx = group == 1 ? (R < 44 ? 6 * (R >> 2) + (R & 3) : -1) : (R < 22 ? 6 * (R >> 1) + 4 + (R & 1) : -1);
-                if (idx >= 0) {
-                    const float cf = *reinterpret_cast<const float*>(cfu + idx * 256 + (unsigned)lane * 4u);
-                    if (group == 1) dproj[st][R >> 2] = fmaf(acce[st][r], cf, dproj[st][R >> 2]);
-                    else dproj[st][R >> 1] = fmaf(acce[st][r], cf, dproj[st][R >> 1]);
-                }
+                if (group == 1) { if (R < 44) dproj[st][R >> 2] = fmaf(acce[st][r], cf[r], dproj[st][R >> 2]); }
+                else { if (R < 22) dproj[st][R >> 1] = fmaf(acce[st][r], cf[r], dproj[st][R >> 1]); }
             }
         }
     };

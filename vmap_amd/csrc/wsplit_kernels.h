@@ -26,6 +26,46 @@
 
 namespace vk {
 
+// Cos factors of the encoding (cos(2^f a) pi 2^f: what the backward multiplies d(sin) by) wait in the workgroup's scratch; step_main_wp: per tile and
+// direction slot 0..10 as [64 lanes][4 floats] (octaves 0..3 = the first encoding group) followed by [64 lanes][2 floats] (octaves 4, 5 =
+// the second group): a lane's factors of one direction are ONE 16-byte and ONE 8-byte access, and a wave's access covers 1 KiB / 512 B
+// without a gap.  Round 6d: as [66][64 lanes] floats they were 6 four-byte stores per direction and 16 four-byte loads per encoding
+// block and tile; as [lane][8 floats] (32-byte lane pitch, half of every line touched) the kernels got SLOWER (background 70.3 -> 74.5 us,
+// hidden 64 +12 %: profiles/round6d_cos_factor_layout_ab.jsonl) - what the memory system wants is whole lines per wave access.  Kept for
+// step_main_wp (a rank's share of configs[4] 167.4 -> 164.5 us); step_main_ws stays with [66][64 lanes] (same tile size), see enc_fetch.
+constexpr int kCfDir = 64 * 6;                                            // floats per direction slot
+constexpr int kCfTile = 11 * kCfDir;                                      // floats per tile
+__device__ __forceinline__ void cf_store(float* cf_tile, int i, int lane, const float (&v)[6]) {
+    float* q = cf_tile + i * kCfDir;
+    *reinterpret_cast<wv::f32x4*>(q + lane * 4) = wv::f32x4{v[0], v[1], v[2], v[3]};
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    *reinterpret_cast<f32x2*>(q + 256 + lane * 2) = f32x2{v[4], v[5]};
+}
+// the 16 factors a lane needs for encoding block blk of group 1 (R = 16 blk + r <-> direction R >> 2, octave R & 3; R >= 44: none) or
+// group 2 (direction R >> 1, octave 4 + (R & 1); R >= 22: none)
+__device__ __forceinline__ void cf_load(float (&cf)[16], const float* cf_tile, int group, int blk, int lane) {
+    if (group == 1) {
+        const float* q = cf_tile + lane * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = 4 * blk + j;
+            wv::f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (i < 11) v = *reinterpret_cast<const wv::f32x4*>(q + i * kCfDir);
+            cf[4 * j] = v[0]; cf[4 * j + 1] = v[1]; cf[4 * j + 2] = v[2]; cf[4 * j + 3] = v[3];
+        }
+    } else {
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const float* q = cf_tile + 256 + lane * 2;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = 8 * blk + j;
+            f32x2 v = {0.0f, 0.0f};
+            if (i < 11) v = *reinterpret_cast<const f32x2*>(q + i * kCfDir);
+            cf[2 * j] = v[0]; cf[2 * j + 1] = v[1];
+        }
+    }
+}
+
 template <int NB>
 struct ImgWs {
     static constexpr int H = 32 * NB;
@@ -44,10 +84,10 @@ struct ImgWs {
     static constexpr int B_M1 = 0, B_M2 = H, W_A = 2 * H, W_OC = 3 * H, B_A = 6 * H, B_OC = 6 * H + 4, PE_B = 6 * H + 8, SMALL_N = 6 * H + 72;
     static constexpr long long BYTES = (SMALL_OFF + SMALL_N * 4 + 4095) / 4096 * 4096;
     static constexpr int W_ELEMS = CW_N * 512, WT_ELEMS = CT_N * 512;     // bf16 elements per plane
-    // scratch per workgroup (global memory, L2-resident): cos factors of the encoding [tile][66][lane]; then the hi / mid planes of
+    // scratch per workgroup (global memory, L2-resident): cos factors of the encoding [tile][11 directions][384] (cf_store); then the hi / mid planes of
     // the five activations of the wave's block [layer][tile][plane][step][256 threads][16 B] (ReLU masks and weight-gradient
     // operands of the backward pass: 160 registers a thread cannot afford next to the operand prefetch rings)
-    static constexpr int CF_BYTES = 2 * 66 * 64 * 4;
+    static constexpr int CF_BYTES = 2 * kCfTile * 4;
     static constexpr int ACTS_OFF = (CF_BYTES + 4095) / 4096 * 4096;
     static constexpr int WG_SCRATCH = ACTS_OFF + 5 * 2 * 2 * 2 * 4096;
     // ---- LDS map (bytes) ----
@@ -113,10 +153,10 @@ struct LdsWs {
     static_assert(WIDE3 || NB > 4 || (EIM == I::EIM && SCRT == I::SCRT && LOSS == I::LOSS && LDS_BYTES == I::LDS_BYTES), "NT <= 2: the map of ImgWs");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
     static constexpr int kPts = 32 * TT;                                   // sample-point slots of a round's composite buffer
-    // scratch per workgroup: cos factors [tile][66][lane]; activation planes [layer][tile][plane][step][threads][16 B];
+    // scratch per workgroup: cos factors [tile][11][384] (cf_store); activation planes [layer][tile][plane][step][threads][16 B];
     // (three-tile rounds) F-form images of the second encoding group [tile][2][4 KiB]
     static constexpr int CHUNK = NTH * 16;                                 // one 16-deep step of an activation plane, all threads
-    static constexpr int CF_BYTES = TT * 66 * 64 * 4;
+    static constexpr int CF_BYTES = TT * kCfTile * 4;
     static constexpr int ACTS_OFF = (CF_BYTES + 4095) / 4096 * 4096;
     static constexpr int EF2_OFF = ACTS_OFF + 5 * TT * 2 * 2 * CHUNK;
     static constexpr int WG_SCRATCH = EF2_OFF + (EF2_GLOBAL ? TT * 2 * 4096 : 0);
@@ -1059,7 +1099,7 @@ __global__ __launch_bounds__(64 * ws_waves<NB>(), 1) void step_main_ws(const WsA
         const bool fast = !wv::wave_any(!(amax * (32.0f * kPi) < kSinCosFastLimit));
         char* e1img = lds + LD::EIM + est * LD::E_ST + lo16;
         char* e2img = e1img + LD::E2_OFF;
-        float* cf_out = cfs + est * 66 * 64 + lane;
+        float* cf_out = cfs + est * kCfTile + lane;
 #pragma unroll
         for (int ii = 0; ii < 6; ++ii) {
             const int i = 6 * dhalf + ii;
@@ -1366,7 +1406,9 @@ __global__ __launch_bounds__(64 * ws_waves<NB>(), 1) void step_main_ws(const WsA
         tpre_load<W3>(tpe, enc_ptr(ct_chunk), vlo16);
 #pragma unroll
         for (int st = 0; st < NT; ++st) {
-            const char* cfu = reinterpret_cast<const char*>(cfs + st * 66 * 64);
+            // (this kernel keeps the [66][64 lanes] form of the tile: the vector form - cf_load, step_main_wp - costs it registers and time,
+            // background 69.0 -> 71.9 us: profiles/round6d_cos_factor_layout_ab.jsonl)
+            const char* cfu = reinterpret_cast<const char*>(cfs + st * kCfTile);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int R = 16 * blk + r;
