@@ -44,7 +44,8 @@
 // The front half (round 6d): bit 8: no LDS-DMA of the parameter image (LDS holds whatever it held); bit 9: the sample point is a function of the lane
 // (no loads of pcs / z); bit 10: the per-ray ground truth and the per-object normalisers are constants (no loads); bit 11: no compositing
 // (barriers kept); bit 12: the encoding's sincos + octave recurrence replaced by a copy; inside the compositing (step_kernels.h):
-// bit 13: no sequential scans (T, D, V, suffix); bit 14: no square root / divisions; bit 15: no loss sums.
+// bit 13: no sequential scans (T, D, V, suffix); bit 14: no square root / divisions; bit 15: no loss sums; bit 16: no workgroup barriers
+// around the compositing (what a wave-local compositing - whole rays per wave - could save at most).
 #ifndef VS_ABL
 #define VS_ABL 0
 #endif
@@ -987,7 +988,7 @@ __device__ __forceinline__ void step_main_s32_body(const StepArgs& a) {
         }
     }
     VS_MARK(4);
-    __syncthreads();
+    if (!(VS_ABL & 65536)) __syncthreads();
     VS_MARK(5);
     {
         const StepArgs& al = wv::kernarg_late(a);
@@ -995,7 +996,7 @@ __device__ __forceinline__ void step_main_s32_body(const StepArgs& a) {
         composite_phase<BWD>(al, cb, loss_cells, obj, ray0, nrays, wave, lane, tid,
                              (VS_ABL & 1024) ? rays_meta : finish_ray_meta(al, obj, rays_meta));
     }
-    __syncthreads();
+    if (!(VS_ABL & 65536)) __syncthreads();
     VS_MARK(6);
     if (BWD) {
     // ---- backward ----
