@@ -90,7 +90,6 @@ __global__ __launch_bounds__(128 * NB, 2) void step_main_wp(const WsArgs ga) {
     using LD = LdsWp<NB>;
     constexpr int H = I::H, JS = I::JS, NWV = LD::NWV, NTH = LD::NTH;
     const StepArgs& a = ga.s;
-    const GenLayout L = gen_layout(H);
     char* lds = reinterpret_cast<char*>(wv::lds_base());
     const int tid_k = threadIdx.x;
     // xcd_affine (the launcher's choice, from eight objects on): an object's workgroups all on ONE XCD (block b runs on XCD b % 8), so the

@@ -16,8 +16,9 @@
 //     an L2-resident scratch area of the workgroup;
 //   * backward, per layer: the wave's delta block -> P-form image (d-prop operand of everybody) + F-form registers (its own
 //     weight-gradient operand); its block of the layer input -> F-form image in LDS (weight-gradient operand of everybody);
-//     weight-gradient blocks accumulate over the round's two tiles in registers and go straight to the workgroup's partial
-//     gradients (stored by the first round, added by later ones); W^T comes from a second, transposed image.
+//     weight-gradient blocks accumulate over the round's two tiles in registers and go straight to the workgroup's row of partial
+//     gradients, each into its own 4 KiB slot as it stands (RowWs; stored by the first round, added by later ones); W^T comes from a
+//     second, transposed image.
 #pragma once
 #include "split_kernels.h"
 #ifndef VS_ABLW                  /* measurement builds only, see "device helpers of step_main_ws" */
@@ -1018,7 +1019,6 @@ __global__ __launch_bounds__(64 * ws_waves<NB>(), 1) void step_main_ws(const WsA
     constexpr int NWV = LD::NWV, NTH = LD::NTH;
     constexpr int H = I::H, JS = I::JS;
     const StepArgs& a = ga.s;
-    const GenLayout L = gen_layout(H);
     char* lds = reinterpret_cast<char*>(wv::lds_base());
     const int tid_k = threadIdx.x;
     const int obj = blockIdx.x / a.NW, wgo = blockIdx.x - obj * a.NW;
