@@ -205,6 +205,7 @@ __global__ __launch_bounds__(128 * NB, 2) void step_main_wp(const WsArgs ga) {
         char* e1img = eimg + est * LD::E_ST + evo;
         char* e2img = e1img + LD::E2_OFF;
         float* cf_out = cfs + est * kCfTile;
+        unsigned p1[3][4], p2[3][SL];                                    // (SL == 6) planes of a slot pair of group 1 / of the wave's slots of group 2
 #pragma unroll
         for (int ii = 0; ii < SL; ++ii) {
             const int i = SL * dq + ii;
@@ -230,14 +231,43 @@ __global__ __launch_bounds__(128 * NB, 2) void step_main_wp(const WsArgs ga) {
             unsigned h1[2], m1[2], l1[2], h2[1], m2[1], l2[1];
             split_planes<4, 3>(v1, h1, m1, l1);
             split_planes<2, 3>(v2, h2, m2, l2);
-            char* q1 = e1img + (i >> 1) * I::XCH + (i & 1) * 8;
-            *reinterpret_cast<u32x2*>(q1) = u32x2{h1[0], h1[1]};
-            *reinterpret_cast<u32x2*>(q1 + 1024) = u32x2{m1[0], m1[1]};
-            *reinterpret_cast<u32x2*>(q1 + 2048) = u32x2{l1[0], l1[1]};
-            char* q2 = e2img + (i >> 2) * I::XCH + (i & 3) * 4;
-            *reinterpret_cast<unsigned*>(q2) = h2[0];
-            *reinterpret_cast<unsigned*>(q2 + 1024) = m2[0];
-            *reinterpret_cast<unsigned*>(q2 + 2048) = l2[0];
+            if constexpr (SL == 6) {
+                // A lane's 16 bytes of a chunk hold two slots of the first group / four of the second.  Six slots per wave (hidden 64, where
+                // these images live in the L2-side scratch): the slots are gathered and leave as whole 16-byte pieces (8 bytes where the
+                // wave owns half of a lane's sixteen) - a wave store that leaves gaps in its lines costs the memory system twice (round 6d).
+                p1[0][2 * (ii & 1)] = h1[0]; p1[0][2 * (ii & 1) + 1] = h1[1];
+                p1[1][2 * (ii & 1)] = m1[0]; p1[1][2 * (ii & 1) + 1] = m1[1];
+                p1[2][2 * (ii & 1)] = l1[0]; p1[2][2 * (ii & 1) + 1] = l1[1];
+                if (ii & 1) {                                            // (a wave's first slot is even)
+                    char* q1 = e1img + (i >> 1) * I::XCH;
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(q1 + pl * 1024) = u32x4{p1[pl][0], p1[pl][1], p1[pl][2], p1[pl][3]};
+                }
+                p2[0][ii] = h2[0]; p2[1][ii] = m2[0]; p2[2][ii] = l2[0];
+            } else {
+                char* q1 = e1img + (i >> 1) * I::XCH + (i & 1) * 8;
+                *reinterpret_cast<u32x2*>(q1) = u32x2{h1[0], h1[1]};
+                *reinterpret_cast<u32x2*>(q1 + 1024) = u32x2{m1[0], m1[1]};
+                *reinterpret_cast<u32x2*>(q1 + 2048) = u32x2{l1[0], l1[1]};
+                char* q2 = e2img + (i >> 2) * I::XCH + (i & 3) * 4;
+                *reinterpret_cast<unsigned*>(q2) = h2[0];
+                *reinterpret_cast<unsigned*>(q2 + 1024) = m2[0];
+                *reinterpret_cast<unsigned*>(q2 + 2048) = l2[0];
+            }
+        }
+        if constexpr (SL == 6) {
+            // second group: slots 0..3 | 4, 5 (dq = 0) or 6, 7 | 8..11 (dq = 1) = chunk 0 whole + the first half of chunk 1, or the second
+            // half of chunk 1 + chunk 2 whole
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                if (dq == 0) {
+                    *reinterpret_cast<u32x4*>(e2img + pl * 1024) = u32x4{p2[pl][0], p2[pl][1], p2[pl][2], p2[pl][3]};
+                    *reinterpret_cast<u32x2*>(e2img + I::XCH + pl * 1024) = u32x2{p2[pl][4], p2[pl][5]};
+                } else {
+                    *reinterpret_cast<u32x2*>(e2img + I::XCH + 8 + pl * 1024) = u32x2{p2[pl][0], p2[pl][1]};
+                    *reinterpret_cast<u32x4*>(e2img + 2 * I::XCH + pl * 1024) = u32x4{p2[pl][2], p2[pl][3], p2[pl][4], p2[pl][5]};
+                }
+            }
         }
     }
     __syncthreads();
