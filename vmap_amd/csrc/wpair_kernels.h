@@ -62,7 +62,7 @@ __device__ __forceinline__ void acc_recv_add(f32x16& a, const char* slot) {
     }
 }
 // weight-gradient blocks kb = kh, kh + 2, ... < N of one layer; xload(img, kb) fills the block's two F images, io(mode, kb, acc,
-// old): block_io of the layer.  One block at a time (the partner wave on the SIMD covers the LDS round trip; registers are
+// old): slot_io of the block.  One block at a time (the partner wave on the SIMD covers the LDS round trip; registers are
 // 256 per wave here); later rounds read the earlier sums in front of the matrix instructions.
 template <int N, class XL, class IO>
 __device__ __forceinline__ void dw_layer_half(const unsigned (&dF)[2][16], bool first, int kh, XL&& xload, IO&& io) {

@@ -972,7 +972,7 @@ __device__ __forceinline__ void mask_by(float (&d)[16], const f32x16& v, const u
 }
 // weight-gradient blocks of one layer: N input blocks (images at ximg(kb), tile 1: + xst(kb)).  Stage kb: LDS reads of block
 // kb + 1 and (later rounds) the global reads of block kb's earlier sums go out, the matrix instructions of block kb run, the
-// stores of block kb - 1 retire.  io(mode, kb, acc, old): block_io of the layer.
+// stores of block kb - 1 retire.  io(mode, kb, acc, old): slot_io of the block (its slot of the row).
 // Blocks kb >= NG come from global memory: ximg returns their wave-uniform base, voff = lane * 16.
 // AH = how far ahead of their use a later round requests a block's earlier sums: 2 = in front of the block's own matrix instructions
 // (two sets of 16 registers in flight), 1 = in front of the NEXT block's (one set: hidden 256, whose waves have 256 registers).
